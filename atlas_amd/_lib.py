@@ -1,0 +1,113 @@
+"""ctypes loader for the C-ABI shared library (include/atlas_amd.h).
+
+The library is the product: there is NO Python/NumPy fallback for any compute path.  If the shared object is
+missing this module raises at import time; if no HIP device is visible, constructing a Trans raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libatlas_amd.so")
+
+
+class AtlasAmdError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C atlas_amd/csrc`).  atlas_amd has no pure-Python fallback.")
+    return C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+
+lib = _load()
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+c_void_p = C.c_void_p
+
+
+def _sig(name, restype, *argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+    return fn
+
+
+last_error = _sig("atlas_amd__last_error", C.c_char_p)
+version = _sig("atlas_amd__version", C.c_char_p)
+device_count = _sig("atlas_amd__device_count", C.c_int)
+
+Grid_new_gaussian = _sig("atlas_amd__Grid__new_gaussian", c_void_p, C.c_char_p)
+Grid_new_structured = _sig("atlas_amd__Grid__new_structured", c_void_p, C.c_int, c_void_p, c_void_p)
+Grid_delete = _sig("atlas_amd__Grid__delete", None, c_void_p)
+Grid_ny = _sig("atlas_amd__Grid__ny", C.c_int, c_void_p)
+Grid_nxmax = _sig("atlas_amd__Grid__nxmax", C.c_int, c_void_p)
+Grid_size = _sig("atlas_amd__Grid__size", C.c_int64, c_void_p)
+Grid_regular = _sig("atlas_amd__Grid__regular", C.c_int, c_void_p)
+Grid_nx = _sig("atlas_amd__Grid__nx", C.c_int, c_void_p, c_void_p)
+Grid_y = _sig("atlas_amd__Grid__y", C.c_int, c_void_p, c_void_p)
+gaussian_latitudes_npole_spole = _sig("atlas_amd__gaussian_latitudes_npole_spole", C.c_int, C.c_int, c_void_p)
+
+Trans_new = _sig("atlas_amd__Trans__new", c_void_p, c_void_p, C.c_int)
+Trans_new_config = _sig("atlas_amd__Trans__new_config", c_void_p, c_void_p, C.c_int, C.c_char_p, c_void_p, C.c_size_t)
+Trans_delete = _sig("atlas_amd__Trans__delete", None, c_void_p)
+Trans_truncation = _sig("atlas_amd__Trans__truncation", C.c_int, c_void_p)
+Trans_nb_gridpoints = _sig("atlas_amd__Trans__nb_gridpoints", C.c_int64, c_void_p)
+Trans_nb_gridpoints_global = _sig("atlas_amd__Trans__nb_gridpoints_global", C.c_int64, c_void_p)
+Trans_nb_spectral_coefficients = _sig("atlas_amd__Trans__nb_spectral_coefficients", C.c_int64, c_void_p)
+Trans_invtrans_scalar = _sig("atlas_amd__Trans__invtrans_scalar", C.c_int, c_void_p, C.c_int, c_void_p, c_void_p)
+Trans_invtrans = _sig("atlas_amd__Trans__invtrans", C.c_int, c_void_p, C.c_int, c_void_p, C.c_int, c_void_p,
+                      c_void_p, c_void_p)
+Trans_invtrans_vordiv2wind = _sig("atlas_amd__Trans__invtrans_vordiv2wind", C.c_int, c_void_p, C.c_int, c_void_p,
+                                  c_void_p, c_void_p)
+Trans_invtrans_scalar_device = _sig("atlas_amd__Trans__invtrans_scalar_device", C.c_int, c_void_p, C.c_int, c_void_p,
+                                    c_void_p)
+Trans_invtrans_device = _sig("atlas_amd__Trans__invtrans_device", C.c_int, c_void_p, C.c_int, c_void_p, C.c_int,
+                             c_void_p, c_void_p, c_void_p)
+Trans_dirtrans_scalar = _sig("atlas_amd__Trans__dirtrans_scalar", C.c_int, c_void_p, C.c_int, c_void_p, c_void_p)
+Trans_dirtrans_wind2vordiv = _sig("atlas_amd__Trans__dirtrans_wind2vordiv", C.c_int, c_void_p, C.c_int, c_void_p,
+                                  c_void_p, c_void_p)
+Trans_invtrans_adj_scalar = _sig("atlas_amd__Trans__invtrans_adj_scalar", C.c_int, c_void_p, C.c_int, c_void_p,
+                                 c_void_p)
+Trans_stream = _sig("atlas_amd__Trans__stream", c_void_p, c_void_p)
+Trans_set_stream = _sig("atlas_amd__Trans__set_stream", C.c_int, c_void_p, c_void_p)
+Trans_synchronize = _sig("atlas_amd__Trans__synchronize", C.c_int, c_void_p)
+Trans_legendre_cache_size = _sig("atlas_amd__Trans__legendre_cache_size", C.c_size_t, c_void_p)
+Trans_legendre_cache_export = _sig("atlas_amd__Trans__legendre_cache_export", C.c_int, c_void_p, c_void_p, C.c_size_t)
+Trans_fourier_row_pitch = _sig("atlas_amd__Trans__fourier_row_pitch", C.c_int, c_void_p, C.c_int)
+Trans_fourier_size = _sig("atlas_amd__Trans__fourier_size", C.c_int64, c_void_p, C.c_int)
+Trans_owned_wavenumbers = _sig("atlas_amd__Trans__owned_wavenumbers", C.c_int, c_void_p)
+Trans_bands = _sig("atlas_amd__Trans__bands", C.c_int, c_void_p, c_void_p)
+Trans_legendre_device = _sig("atlas_amd__Trans__legendre_device", C.c_int, c_void_p, C.c_int, C.c_int, c_void_p,
+                             c_void_p)
+Trans_fourier_device = _sig("atlas_amd__Trans__fourier_device", C.c_int, c_void_p, C.c_int, C.c_int, c_void_p,
+                            c_void_p, c_void_p)
+Trans_nlat0 = _sig("atlas_amd__Trans__nlat0", C.c_int, c_void_p, c_void_p)
+Trans_legendre_flops = _sig("atlas_amd__Trans__legendre_flops", C.c_double, c_void_p, C.c_int)
+Trans_legendre_table_bytes = _sig("atlas_amd__Trans__legendre_table_bytes", C.c_int64, c_void_p)
+Trans_timings = _sig("atlas_amd__Trans__timings", C.c_int, c_void_p, c_void_p, C.c_int)
+Trans_set_profile = _sig("atlas_amd__Trans__set_profile", C.c_int, c_void_p, C.c_int)
+
+fourier_truncation = _sig("atlas_amd__fourier_truncation", C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                          C.c_int)
+legendre_reference_sizes = _sig("atlas_amd__legendre_reference_sizes", C.c_int, c_void_p, C.c_int,
+                                C.POINTER(C.c_size_t), C.POINTER(C.c_size_t))
+legendre_reference_tables = _sig("atlas_amd__legendre_reference_tables", C.c_int, c_void_p, C.c_int, c_void_p,
+                                 C.c_size_t, c_void_p, C.c_size_t)
+fft_host_row = _sig("atlas_amd__fft_host_row", C.c_int, C.c_int, c_void_p, C.c_int, c_void_p)
+
+
+def check(rc):
+    if rc != 0:
+        msg = last_error().decode("utf-8", "replace")
+        if msg.startswith("Not implemented"):
+            raise NotImplementedError(msg)
+        raise AtlasAmdError(msg)
+
+
+def check_ptr(p):
+    if not p:
+        raise AtlasAmdError(last_error().decode("utf-8", "replace"))
+    return p

@@ -1,0 +1,357 @@
+// extern "C" layer of include/atlas_amd.h (Grid + Trans part).  No exception crosses this boundary.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/atlas_amd.h"
+#include "fft_plan.h"
+#include "gaussian.h"
+#include "legendre_host.h"
+#include "trans.h"
+#include "trans_plan.h"
+
+using namespace atlas_amd;
+
+struct atlas_amd_Grid {
+    grid::StructuredGrid g;
+};
+struct atlas_amd_Trans {
+    trans::Trans* impl;
+};
+
+namespace atlas_amd {
+thread_local std::string g_last_error;
+void set_last_error(const std::string& s) {
+    g_last_error = s;
+}
+}  // namespace atlas_amd
+
+#define AA_TRY try {
+#define AA_CATCH_INT                                 \
+    }                                                \
+    catch (const std::exception& e) {                \
+        atlas_amd::set_last_error(e.what());         \
+        return 1;                                    \
+    }                                                \
+    catch (...) {                                    \
+        atlas_amd::set_last_error("unknown error");  \
+        return 1;                                    \
+    }                                                \
+    return 0;
+#define AA_CATCH_PTR                                 \
+    }                                                \
+    catch (const std::exception& e) {                \
+        atlas_amd::set_last_error(e.what());         \
+        return nullptr;                              \
+    }                                                \
+    catch (...) {                                    \
+        atlas_amd::set_last_error("unknown error");  \
+        return nullptr;                              \
+    }
+
+static std::map<std::string, std::string> parse_config(const char* cfg) {
+    std::map<std::string, std::string> kv;
+    if (!cfg) {
+        return kv;
+    }
+    std::stringstream ss(cfg);
+    std::string item;
+    while (std::getline(ss, item, ';')) {
+        if (item.empty()) {
+            continue;
+        }
+        auto eq = item.find('=');
+        if (eq == std::string::npos) {
+            throw std::invalid_argument("config item without '=': " + item);
+        }
+        kv[item.substr(0, eq)] = item.substr(eq + 1);
+    }
+    return kv;
+}
+
+extern "C" {
+
+const char* atlas_amd__last_error(void) {
+    return atlas_amd::g_last_error.c_str();
+}
+const char* atlas_amd__version(void) {
+    return "atlas_amd 0.1.0 (gfx950; TransLocal invtrans + HaloExchange of ecmwf/atlas 0.44.1)";
+}
+int atlas_amd__device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------- Grid
+atlas_amd_Grid* atlas_amd__Grid__new_gaussian(const char* name) {
+    AA_TRY
+    if (!name) {
+        throw std::invalid_argument("grid name is NULL");
+    }
+    return new atlas_amd_Grid{grid::make_gaussian_grid(name)};
+    AA_CATCH_PTR
+}
+atlas_amd_Grid* atlas_amd__Grid__new_structured(int ny, const int nx[], const double lat_deg[]) {
+    AA_TRY
+    if (ny <= 0 || !nx || !lat_deg) {
+        throw std::invalid_argument("Grid__new_structured: bad arguments");
+    }
+    grid::StructuredGrid g;
+    g.nx.assign(nx, nx + ny);
+    g.y.assign(lat_deg, lat_deg + ny);
+    g.regular = true;
+    for (int j = 1; j < ny; ++j) {
+        g.regular = g.regular && (nx[j] == nx[0]);
+    }
+    g.name = "structured";
+    return new atlas_amd_Grid{g};
+    AA_CATCH_PTR
+}
+void atlas_amd__Grid__delete(atlas_amd_Grid* g) {
+    delete g;
+}
+int atlas_amd__Grid__ny(const atlas_amd_Grid* g) {
+    return g->g.ny();
+}
+int atlas_amd__Grid__nxmax(const atlas_amd_Grid* g) {
+    return g->g.nxmax();
+}
+int64_t atlas_amd__Grid__size(const atlas_amd_Grid* g) {
+    return g->g.size();
+}
+int atlas_amd__Grid__regular(const atlas_amd_Grid* g) {
+    return g->g.regular ? 1 : 0;
+}
+int atlas_amd__Grid__nx(const atlas_amd_Grid* g, int nx_out[]) {
+    std::memcpy(nx_out, g->g.nx.data(), sizeof(int) * g->g.nx.size());
+    return 0;
+}
+int atlas_amd__Grid__y(const atlas_amd_Grid* g, double y_out[]) {
+    std::memcpy(y_out, g->g.y.data(), sizeof(double) * g->g.y.size());
+    return 0;
+}
+int atlas_amd__gaussian_latitudes_npole_spole(int N, double lats_out[]) {
+    AA_TRY
+    grid::gaussian_latitudes_npole_spole(N, lats_out);
+    AA_CATCH_INT
+}
+
+// ---------------------------------------------------------------- Trans
+atlas_amd_Trans* atlas_amd__Trans__new_config(const atlas_amd_Grid* grid, int truncation, const char* config,
+                                              const void* legendre_cache, size_t legendre_cache_size) {
+    AA_TRY
+    if (!grid) {
+        throw std::invalid_argument("grid is NULL");
+    }
+    trans::TransConfig cfg;
+    for (auto& kv : parse_config(config)) {
+        if (kv.first == "profile") {
+            cfg.profile = std::stoi(kv.second) != 0;
+        }
+        else if (kv.first == "nparts") {
+            cfg.nparts = std::stoi(kv.second);
+        }
+        else if (kv.first == "part") {
+            cfg.part = std::stoi(kv.second);
+        }
+        else if (kv.first == "type") {
+            // atlas option::type: this library IS the "local" implementation (TransLocal.cc:57)
+            if (kv.second != "local" && kv.second != "mi355x") {
+                throw std::invalid_argument("unsupported trans type '" + kv.second + "'");
+            }
+        }
+        else {
+            throw std::invalid_argument("unknown config key '" + kv.first + "'");
+        }
+    }
+    cfg.legendre_cache      = legendre_cache;
+    cfg.legendre_cache_size = legendre_cache_size;
+    return new atlas_amd_Trans{new trans::Trans(grid->g, truncation, cfg)};
+    AA_CATCH_PTR
+}
+atlas_amd_Trans* atlas_amd__Trans__new(const atlas_amd_Grid* grid, int truncation) {
+    return atlas_amd__Trans__new_config(grid, truncation, nullptr, nullptr, 0);
+}
+void atlas_amd__Trans__delete(atlas_amd_Trans* t) {
+    if (t) {
+        delete t->impl;
+        delete t;
+    }
+}
+int atlas_amd__Trans__truncation(const atlas_amd_Trans* t) {
+    return t->impl->truncation();
+}
+int64_t atlas_amd__Trans__nb_gridpoints(const atlas_amd_Trans* t) {
+    return t->impl->nb_gridpoints();
+}
+int64_t atlas_amd__Trans__nb_gridpoints_global(const atlas_amd_Trans* t) {
+    return t->impl->nb_gridpoints_global();
+}
+int64_t atlas_amd__Trans__nb_spectral_coefficients(const atlas_amd_Trans* t) {
+    return (int64_t)t->impl->nb_spectral_coefficients();
+}
+
+int atlas_amd__Trans__invtrans_scalar(atlas_amd_Trans* t, int nb_fields, const double sp[], double gp[]) {
+    AA_TRY
+    t->impl->invtrans(nb_fields, sp, gp);
+    AA_CATCH_INT
+}
+int atlas_amd__Trans__invtrans_scalar_device(atlas_amd_Trans* t, int nb_fields, const double* sp, double* gp) {
+    AA_TRY
+    t->impl->invtrans_uv_device(t->impl->truncation(), nb_fields, 0, sp, gp);
+    AA_CATCH_INT
+}
+int atlas_amd__Trans__invtrans(atlas_amd_Trans* t, int nb_scalar, const double sp[], int nb_vordiv,
+                               const double vor[], const double div[], double gp[]) {
+    AA_TRY
+    t->impl->invtrans(nb_scalar, sp, nb_vordiv, vor, div, gp);
+    AA_CATCH_INT
+}
+int atlas_amd__Trans__invtrans_device(atlas_amd_Trans* t, int nb_scalar, const double* sp, int nb_vordiv,
+                                      const double* vor, const double* div, double* gp) {
+    AA_TRY
+    t->impl->invtrans_device(nb_scalar, sp, nb_vordiv, vor, div, gp);
+    AA_CATCH_INT
+}
+int atlas_amd__Trans__invtrans_vordiv2wind(atlas_amd_Trans* t, int nb_fields, const double vor[],
+                                           const double div[], double wind[]) {
+    AA_TRY
+    // TransLocal.cc:1486-1490: invtrans(0, nullptr, nb_vordiv, vor, div, gp)
+    t->impl->invtrans(0, nullptr, nb_fields, vor, div, wind);
+    AA_CATCH_INT
+}
+static int not_implemented(const char* what) {
+    atlas_amd::set_last_error(std::string("Not implemented: ") + what +
+                              " (TransLocal does not implement it either, TransLocal.cc:848-857,899-927,1599-1685)");
+    return 2;
+}
+int atlas_amd__Trans__dirtrans_scalar(atlas_amd_Trans*, int, const double[], double[]) {
+    return not_implemented("dirtrans");
+}
+int atlas_amd__Trans__dirtrans_wind2vordiv(atlas_amd_Trans*, int, const double[], double[], double[]) {
+    return not_implemented("dirtrans_wind2vordiv");
+}
+int atlas_amd__Trans__invtrans_adj_scalar(atlas_amd_Trans*, int, const double[], double[]) {
+    return not_implemented("invtrans_adj");
+}
+
+void* atlas_amd__Trans__stream(atlas_amd_Trans* t) {
+    return (void*)t->impl->stream();
+}
+int atlas_amd__Trans__set_stream(atlas_amd_Trans* t, void* s) {
+    AA_TRY
+    t->impl->set_stream((hipStream_t)s);
+    AA_CATCH_INT
+}
+int atlas_amd__Trans__synchronize(atlas_amd_Trans* t) {
+    AA_TRY
+    t->impl->synchronize();
+    AA_CATCH_INT
+}
+size_t atlas_amd__Trans__legendre_cache_size(const atlas_amd_Trans* t) {
+    return t->impl->legendre_cache_bytes();
+}
+int atlas_amd__Trans__legendre_cache_export(const atlas_amd_Trans* t, void* buffer, size_t size) {
+    AA_TRY
+    if (size != t->impl->legendre_cache_bytes()) {
+        throw std::invalid_argument("legendre_cache_export: wrong buffer size");
+    }
+    t->impl->export_legendre_cache(buffer);
+    AA_CATCH_INT
+}
+int atlas_amd__Trans__fourier_row_pitch(const atlas_amd_Trans* t, int nb_fields) {
+    return t->impl->fourier_row_pitch(nb_fields);
+}
+int64_t atlas_amd__Trans__fourier_size(const atlas_amd_Trans* t, int nb_fields) {
+    return (int64_t)t->impl->fourier_doubles(nb_fields);
+}
+int atlas_amd__Trans__owned_wavenumbers(const atlas_amd_Trans* t) {
+    return t->impl->owned_wavenumbers();
+}
+int atlas_amd__Trans__bands(const atlas_amd_Trans* t, int out[]) {
+    const auto& b = t->impl->bands();
+    std::memcpy(out, b.data(), sizeof(int) * b.size());
+    return 0;
+}
+int atlas_amd__Trans__legendre_device(atlas_amd_Trans* t, int trc_in, int nb_fields, const double* sp,
+                                      double* fourier) {
+    AA_TRY
+    t->impl->legendre_device(trc_in, nb_fields, sp, fourier);
+    AA_CATCH_INT
+}
+int atlas_amd__Trans__fourier_device(atlas_amd_Trans* t, int nb_fields, int nb_vordiv,
+                                     const double* const part_base[], const int part_cnt[], double* gp) {
+    AA_TRY
+    t->impl->fourier_device(nb_fields, nb_vordiv, part_base, part_cnt, gp);
+    AA_CATCH_INT
+}
+int atlas_amd__Trans__nlat0(const atlas_amd_Trans* t, int out[]) {
+    const auto& v = t->impl->geometry().nlat0;
+    std::memcpy(out, v.data(), sizeof(int) * v.size());
+    return 0;
+}
+double atlas_amd__Trans__legendre_flops(const atlas_amd_Trans* t, int nb_fields) {
+    return trans::legendre_flops(t->impl->geometry(), nb_fields);
+}
+int64_t atlas_amd__Trans__legendre_table_bytes(const atlas_amd_Trans* t) {
+    return t->impl->legendre_work().table_doubles * 8;
+}
+int atlas_amd__Trans__timings(atlas_amd_Trans* t, double out[4], int reset) {
+    AA_TRY
+    trans::StageTimings s = t->impl->timings();
+    out[0]                = s.legendre_ms;
+    out[1]                = s.legendre_calls;
+    out[2]                = s.fourier_ms;
+    out[3]                = s.fourier_calls;
+    if (reset) {
+        t->impl->reset_timings();
+    }
+    AA_CATCH_INT
+}
+int atlas_amd__Trans__set_profile(atlas_amd_Trans* t, int on) {
+    AA_TRY
+    t->impl->synchronize();
+    t->impl->set_profile(on != 0);
+    AA_CATCH_INT
+}
+
+// ---------------------------------------------------------------- host-only helpers
+int atlas_amd__fourier_truncation(int truncation, int nx, int nxmax, int ndgl, double lat_rad, int fullgrid) {
+    return trans::fourier_truncation(truncation, nx, nxmax, ndgl, lat_rad, fullgrid != 0);
+}
+int atlas_amd__legendre_reference_sizes(const atlas_amd_Grid* grid, int truncation, size_t* size_sym,
+                                        size_t* size_asym) {
+    AA_TRY
+    trans::TransGeometry geo = trans::make_geometry(grid->g, truncation);
+    *size_sym                = geo.size_sym();
+    *size_asym               = geo.size_asym();
+    AA_CATCH_INT
+}
+int atlas_amd__legendre_reference_tables(const atlas_amd_Grid* grid, int truncation, double* leg_sym,
+                                         size_t size_sym, double* leg_asym, size_t size_asym) {
+    AA_TRY
+    trans::TransGeometry geo = trans::make_geometry(grid->g, truncation);
+    if (size_sym != geo.size_sym() || size_asym != geo.size_asym()) {
+        throw std::invalid_argument("legendre_reference_tables: wrong sizes");
+    }
+    std::memset(leg_sym, 0, size_sym * sizeof(double));
+    std::memset(leg_asym, 0, size_asym * sizeof(double));
+    trans::compute_legendre_tables_reference_layout(geo, leg_sym, leg_asym);
+    AA_CATCH_INT
+}
+int atlas_amd__fft_host_row(int n, const double* modes, int mmax, double* out) {
+    AA_TRY
+    fft::FftPlanSet ps = fft::make_fft_plans({n});
+    fft::host_execute_row(ps, 0, reinterpret_cast<const fft::cplx*>(modes), mmax, out);
+    AA_CATCH_INT
+}
+
+}  // extern "C"

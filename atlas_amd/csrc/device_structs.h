@@ -1,0 +1,59 @@
+// Plain structs passed by value to the HIP kernels (shared between the host launch code and the kernels).
+#pragma once
+#include <cstdint>
+
+#include "fft_core.h"
+#include "fft_plan.h"
+
+namespace atlas_amd {
+namespace trans {
+
+constexpr int LEG_BN_DEV = 64;  // must equal trans_plan.h: LEG_BN
+constexpr int LEG_KB_DEV = 8;   // must equal trans_plan.h: LEG_KB
+
+struct LegendreItemDev {  // mirrors trans_plan.h: LegendreItem
+    int m;
+    int tile;
+    int nrows;
+    int kpad;
+    long long p_off;
+};
+
+struct LegendreParams {
+    const double* P;               // tile-blocked Legendre table
+    const double* sp;              // spectra, layout of TransLocal.cc:970-987 with truncation trc_in
+    double* F;                     // Fourier intermediate F[(lat*(T+1)+m)*RP + r]
+    const LegendreItemDev* items;  // launch-ordered work items
+    const int* nlat0;              // [T+1]
+    int T;
+    int trc_in;  // truncation of the input layout (T, or T+1 on the vor/div path)
+    int nf;
+    int RP;
+    int nlats;
+    int m_div;   // m-sharding: this device owns wavenumbers m with m % m_div == part; local index m / m_div
+    int m_cnt;   // number of owned wavenumbers == m-extent of F:  F[(lat*m_cnt + m/m_div)*RP + r]
+};
+
+struct FourierParams {
+    const double* part_base[fft::MAX_PARTS];  // Fourier intermediate pieces, one per m-owner (see fft_core.h: RowIO)
+    int part_cnt[fft::MAX_PARTS];
+    int nparts;
+    int lat0;                         // first row of the local latitude band
+    double* gp;                       // gp[f*npts + (rowoff[lat]-rowoff[lat0]) + i], npts = points of the local band
+    const fft::FftRowPlan* plans;     // device copy of the plan structs
+    const fft::cplx* table;           // device copy of all FFT tables
+    const int* row_plan;              // [nlats] plan index of each row
+    const int* row_mmax;              // [nlats] highest kept wavenumber of each row (-1: none)
+    const long long* rowoff;          // [nlats+1]
+    const int* rows;                  // rows handled by this launch (size class)
+    int nrows;
+    int T;
+    int RP;
+    int nf;
+    long long npts;
+    int scale_uv_fields;              // first 2*nb_vordiv fields are multiplied by 1/cos(lat) (TransLocal.cc:1443-1469)
+    const double* coslatinv;          // [nlats]
+};
+
+}  // namespace trans
+}  // namespace atlas_amd

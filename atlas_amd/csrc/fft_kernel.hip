@@ -1,0 +1,157 @@
+// Longitudinal inverse real FFT on gfx950: one workgroup per (latitude row, field); the row lives in LDS and is
+// transformed in place by the barrier-separated phases of fft_core.h (c2r pre-processing, optional Bluestein
+// chirp-z for row lengths with large prime factors, mixed-radix {2,3,4,5} DIF/DIT passes).
+//
+// Reference being replaced: TransLocal::invtrans_fourier_reduced / _regular
+// (src/atlas/trans/local/TransLocal.cc:1101-1136, 1155-1196) and the FFTW / pocketfft c2r they call
+// (src/atlas/linalg/fft/FFTW.cc:38-61).  Output layout gp[f*npts + rowoff(lat) + lon] as TransLocal.cc:1132,1187.
+#include <hip/hip_runtime.h>
+
+#include "device_structs.h"
+
+namespace atlas_amd {
+namespace trans {
+
+using fft::cplx;
+
+constexpr int FFT_NTHR = 256;
+constexpr int FGROUP   = 8;  // fields whose modes share one 128-byte line of F
+
+// Block -> (row, field).  Eight consecutive fields of one row share every 128-byte line of F, and hardware places
+// block b on XCD b % 8, so blocks {b, b+8, ..., b+56} (same XCD, dispatched back to back) are given the same
+// (row, field group): the line is then fetched into that XCD's L2 once.  Speed heuristic only.
+__device__ __forceinline__ bool fft_block_to_job(const FourierParams& p, int b, int& row, int& f) {
+    const int x   = b & 7;
+    const int q   = b >> 3;
+    const int j   = q & 7;
+    const int u   = (q >> 3) * 8 + x;
+    const int ngr = (p.nf + FGROUP - 1) / FGROUP;
+    const int ri  = u / ngr;
+    const int fg  = u - ri * ngr;
+    if (ri >= p.nrows) {
+        return false;
+    }
+    f = fg * FGROUP + j;
+    if (f >= p.nf) {
+        return false;
+    }
+    row = p.rows[ri];
+    return true;
+}
+
+// Input modes of one (row, field).  The Fourier intermediate may be split by zonal wavenumber over `nparts`
+// producers (multi-GPU m-sharding: wavenumber m belongs to part m % nparts, local index m / nparts):
+//   X[m] = *(cplx*)(base[m % nparts] + (lat_local * cnt[m % nparts] + m / nparts) * RP + 2*field)
+// nparts == 1 is the single-device layout F[(lat*(T+1) + m)*RP + r].
+struct ModeReader {
+    const FourierParams& p;
+    long long lat_local;
+    int f2;
+    __device__ __forceinline__ cplx operator()(int m) const {
+        const double* base = p.part_base[0];
+        int cnt            = p.part_cnt[0];
+        int ml             = m;
+        if (p.nparts > 1) {
+            ml             = m / p.nparts;
+            const int part = m - ml * p.nparts;
+#pragma unroll
+            for (int i = 1; i < fft::MAX_PARTS; ++i) {  // select chain: keeps the kernel arguments in SGPRs
+                if (part == i) {
+                    base = p.part_base[i];
+                    cnt  = p.part_cnt[i];
+                }
+            }
+        }
+        return *reinterpret_cast<const cplx*>(base + (lat_local * cnt + ml) * p.RP + f2);
+    }
+};
+
+__global__ void __launch_bounds__(FFT_NTHR) fft_rows_kernel(FourierParams p) {
+    extern __shared__ double lds_raw[];
+    cplx* work = reinterpret_cast<cplx*>(lds_raw);
+    int row, f;
+    if (!fft_block_to_job(p, blockIdx.x, row, f)) {
+        return;
+    }
+    const fft::FftRowPlan* pl = p.plans + p.row_plan[row];
+    const long long goff      = (long long)f * p.npts + (p.rowoff[row] - p.rowoff[p.lat0]);
+    const int nx              = (int)(p.rowoff[row + 1] - p.rowoff[row]);
+    double* y                 = p.gp + goff;
+    const int tid             = threadIdx.x;
+    const double scale        = (f < p.scale_uv_fields) ? p.coslatinv[row] : 1.0;
+    const int mmax            = p.row_mmax[row];
+    const ModeReader rd{p, (long long)(row - p.lat0), 2 * f};
+    const int method          = pl->method;
+    const int n               = pl->n;
+    const int h               = pl->h;
+
+    if (method == fft::FFT_DFT) {
+        // odd row length: direct sum (never used by Gaussian grids)
+        const cplx* w = p.table + pl->off_pre;
+        const int mm  = mmax < n / 2 ? mmax : n / 2;
+        for (int k = tid; k < nx; k += FFT_NTHR) {
+            double s = mmax >= 0 ? rd(0).re : 0.;
+            for (int m = 1; m <= mm; ++m) {
+                const cplx t = w[(long long)m * k % n];
+                const cplx v = rd(m);
+                s += 2.0 * (v.re * t.re - v.im * t.im);
+            }
+            y[k] = s * scale;
+        }
+        return;
+    }
+
+    fft::RowTables r;
+    r.n      = n;
+    r.h      = h;
+    r.method = method;
+    r.shape  = &pl->shape;
+    r.tw     = p.table + pl->off_tw;
+    r.pre    = p.table + pl->off_pre;
+    r.chirp  = p.table + pl->off_chirp;
+    r.bhat   = p.table + pl->off_bhat;
+    fft::RowOut io;
+    io.mmax      = mmax < h ? mmax : h;
+    io.y         = y;
+    io.aligned16 = ((goff & 1) == 0) && (nx == n) && scale == 1.0;
+
+    const int nph = fft::row_num_phases(r);
+    for (int ph = 0; ph < nph - 1; ++ph) {
+        fft::row_phase(ph, tid, FFT_NTHR, r, rd, io, work);
+        __syncthreads();
+    }
+    if (io.aligned16) {
+        fft::row_phase(nph - 1, tid, FFT_NTHR, r, rd, io, work);
+    }
+    else {
+        // generic store: scaling by 1/cos(lat) and/or unaligned rows
+        for (int j = tid; j < h; j += FFT_NTHR) {
+            cplx z = work[j];
+            if (method == 1) {
+                z = fft::cmul(z, r.chirp[j]);
+            }
+            if (2 * j < nx) y[2 * j] = z.re * scale;
+            if (2 * j + 1 < nx) y[2 * j + 1] = z.im * scale;
+        }
+    }
+}
+
+hipError_t launch_fourier(const FourierParams& p, int lds_bytes, hipStream_t stream) {
+    static int max_set = 0;
+    if (lds_bytes > max_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) {
+            return e;
+        }
+        max_set = lds_bytes;
+    }
+    const int ngr         = (p.nf + FGROUP - 1) / FGROUP;
+    const long long units = (long long)p.nrows * ngr;
+    const long long nblk  = (units + 7) / 8 * 64;
+    hipLaunchKernelGGL(fft_rows_kernel, dim3((unsigned)nblk), dim3(FFT_NTHR), lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace trans
+}  // namespace atlas_amd

@@ -1,0 +1,215 @@
+// See fft_plan.h.  Host-only.
+#include "fft_plan.h"
+
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <stdexcept>
+
+namespace atlas_amd {
+namespace fft {
+
+namespace {
+
+const long double kPiL = 3.14159265358979323846264338327950288L;
+
+// exp(+2 pi i t / N), evaluated in extended precision with octant folding
+cplx unit_root(int64_t t, int64_t N) {
+    t %= N;
+    if (t < 0) {
+        t += N;
+    }
+    // fold to the first octant for accuracy: angle = 2 pi t / N
+    long double a = 2.0L * kPiL * (long double)t / (long double)N;
+    return cplx{(double)cosl(a), (double)sinl(a)};
+}
+
+void host_fft_dif(const FftShape& s, cplx* d, const cplx* tw, int dir) {
+    int L = s.M;
+    for (int i = 0; i < s.nstages; ++i) {
+        dif_stage_any(s.radix[i], d, s.M, L, tw, dir, 0, 1);
+        L /= s.radix[i];
+    }
+}
+
+}  // namespace
+
+bool is_smooth235(int n) {
+    if (n < 1) {
+        return false;
+    }
+    for (int p : {2, 3, 5}) {
+        while (n % p == 0) {
+            n /= p;
+        }
+    }
+    return n == 1;
+}
+
+int next_smooth235(int n) {
+    while (!is_smooth235(n)) {
+        ++n;
+    }
+    return n;
+}
+
+FftShape make_shape(int M) {
+    if (!is_smooth235(M)) {
+        throw std::invalid_argument("make_shape: M is not {2,3,5}-smooth");
+    }
+    FftShape s{};
+    s.M       = M;
+    s.nstages = 0;
+    int r     = M;
+    auto push = [&](int radix) {
+        if (s.nstages >= MAX_STAGES) {
+            throw std::runtime_error("make_shape: too many stages");
+        }
+        s.radix[s.nstages++] = radix;
+    };
+    while (r % 4 == 0) {
+        push(4);
+        r /= 4;
+    }
+    while (r % 2 == 0) {
+        push(2);
+        r /= 2;
+    }
+    while (r % 3 == 0) {
+        push(3);
+        r /= 3;
+    }
+    while (r % 5 == 0) {
+        push(5);
+        r /= 5;
+    }
+    return s;
+}
+
+int FftPlanSet::plan_index(int n) const {
+    for (size_t i = 0; i < plans.size(); ++i) {
+        if (plans[i].n == n) {
+            return (int)i;
+        }
+    }
+    return -1;
+}
+
+FftPlanSet make_fft_plans(const std::vector<int>& row_lengths) {
+    FftPlanSet ps;
+    std::vector<int> ns(row_lengths);
+    std::sort(ns.begin(), ns.end());
+    ns.erase(std::unique(ns.begin(), ns.end()), ns.end());
+    std::map<int, int64_t> tw_of_M;  // twiddle tables are shared between plans with equal M
+    auto twiddles = [&](int M) -> int64_t {
+        auto it = tw_of_M.find(M);
+        if (it != tw_of_M.end()) {
+            return it->second;
+        }
+        int64_t off = (int64_t)ps.table.size();
+        for (int t = 0; t < M; ++t) {
+            ps.table.push_back(unit_root(t, M));
+        }
+        tw_of_M[M] = off;
+        return off;
+    };
+    for (int n : ns) {
+        FftRowPlan p{};
+        p.n = n;
+        if (n % 2 != 0) {
+            p.method      = FFT_DFT;
+            p.h           = 0;
+            p.lds_complex = 0;
+            p.off_pre     = (int64_t)ps.table.size();
+            for (int j = 0; j < n; ++j) {
+                ps.table.push_back(unit_root(j, n));
+            }
+            ps.plans.push_back(p);
+            continue;
+        }
+        const int h = n / 2;
+        p.h         = h;
+        if (is_smooth235(h)) {
+            p.method = FFT_DIRECT;
+            p.shape  = make_shape(h);
+        }
+        else {
+            p.method = FFT_BLUESTEIN;
+            p.shape  = make_shape(next_smooth235(2 * h - 1));
+        }
+        const int M   = p.shape.M;
+        p.lds_complex = M;
+        p.off_tw      = twiddles(M);
+        p.off_pre     = (int64_t)ps.table.size();
+        for (int k = 0; k < h; ++k) {
+            ps.table.push_back(unit_root(k, n));
+        }
+        if (p.method == FFT_BLUESTEIN) {
+            // chirp c[k] = exp(+i pi k^2 / h) = exp(2 pi i (k^2 mod 2h) / 2h)
+            p.off_chirp = (int64_t)ps.table.size();
+            std::vector<cplx> chirp(h);
+            for (int k = 0; k < h; ++k) {
+                const int64_t q = ((int64_t)k * k) % (2 * (int64_t)h);
+                chirp[k]        = unit_root(q, 2 * (int64_t)h);
+                ps.table.push_back(chirp[k]);
+            }
+            // filter b[d] = conj(c[|d|]) wrapped into M, spectrum via the kernel's own forward DIF, scaled by 1/M
+            std::vector<cplx> b(M, cplx{0., 0.});
+            for (int d = 0; d < h; ++d) {
+                b[d] = cconj(chirp[d]);
+                if (d) {
+                    b[M - d] = b[d];
+                }
+            }
+            host_fft_dif(p.shape, b.data(), ps.table.data() + p.off_tw, -1);
+            p.off_bhat = (int64_t)ps.table.size();
+            const double inv = 1.0 / M;
+            for (int i = 0; i < M; ++i) {
+                ps.table.push_back(cplx{b[i].re * inv, b[i].im * inv});
+            }
+        }
+        ps.plans.push_back(p);
+    }
+    return ps;
+}
+
+void host_execute_row(const FftPlanSet& ps, int plan, const cplx* X, int mmax, double* y, int nthreads) {
+    const FftRowPlan& p = ps.plans.at(plan);
+    if (p.method == FFT_DFT) {
+        const cplx* w = ps.table.data() + p.off_pre;
+        const int n   = p.n;
+        for (int k = 0; k < n; ++k) {
+            double s = X[0].re;
+            for (int m = 1; m <= std::min(mmax, n / 2); ++m) {
+                const cplx t = w[(int64_t)m * k % n];
+                s += 2.0 * (X[m].re * t.re - X[m].im * t.im);
+            }
+            y[k] = s;
+        }
+        return;
+    }
+    RowTables r;
+    r.n      = p.n;
+    r.h      = p.h;
+    r.method = p.method;
+    r.shape  = &p.shape;
+    r.tw     = ps.table.data() + p.off_tw;
+    r.pre    = ps.table.data() + p.off_pre;
+    r.chirp  = ps.table.data() + p.off_chirp;
+    r.bhat   = ps.table.data() + p.off_bhat;
+    RowOut io;
+    io.mmax      = std::min(mmax, p.h);
+    io.y         = y;
+    io.aligned16 = 0;
+    auto rd      = [X](int m) { return X[m]; };
+    std::vector<cplx> work(p.lds_complex);
+    const int nph = row_num_phases(r);
+    for (int ph = 0; ph < nph; ++ph) {
+        for (int t = 0; t < nthreads; ++t) {
+            row_phase(ph, t, nthreads, r, rd, io, work.data());
+        }
+    }
+}
+
+}  // namespace fft
+}  // namespace atlas_amd

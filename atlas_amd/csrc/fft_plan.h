@@ -1,0 +1,49 @@
+// Host planner for the longitudinal inverse real FFT (one plan per distinct row length n).
+//
+// Reference call sites: TransLocal.cc:652-686 (one FFTW/pocketfft plan per distinct row length),
+// :1101-1136 (regular grids, inverse_c2r_many) and :1155-1196 (reduced grids, inverse_c2r per row).
+//
+// Method per row length n (h = n/2):
+//   DIRECT    n even, h is {2,3,5}-smooth : half-length complex FFT (c2r pre-processing + in-place DIT)
+//   BLUESTEIN n even otherwise            : half-length chirp-z with a {2,3,5}-smooth M >= 2h-1
+//   DFT       n odd                       : O(n*modes) direct sum (never hit by Gaussian grids)
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "fft_core.h"
+
+namespace atlas_amd {
+namespace fft {
+
+enum FftMethod : int { FFT_DIRECT = 0, FFT_BLUESTEIN = 1, FFT_DFT = 2 };
+
+struct FftRowPlan {
+    int n;              // row length (number of longitudes of the global row)
+    int h;              // n/2 (DIRECT/BLUESTEIN)
+    int method;         // FftMethod
+    int lds_complex;    // LDS footprint in complex elements (M)
+    FftShape shape;     // M-point shape (M = h for DIRECT)
+    int64_t off_tw;     // [M]  exp(+2 pi i t / M)
+    int64_t off_pre;    // [h]  exp(+2 pi i k / n)        (DFT method: [n] exp(+2 pi i j / n))
+    int64_t off_chirp;  // [h]  exp(+i pi k^2 / h)        (BLUESTEIN)
+    int64_t off_bhat;   // [M]  DFT_M(conj chirp, wrapped) / M in DIF order (BLUESTEIN)
+};
+
+struct FftPlanSet {
+    std::vector<FftRowPlan> plans;   // one per distinct n
+    std::vector<cplx> table;         // all tables, concatenated (uploaded once)
+    int plan_index(int n) const;
+};
+
+bool is_smooth235(int n);
+int next_smooth235(int n);
+FftShape make_shape(int M);  // M must be {2,3,5}-smooth
+FftPlanSet make_fft_plans(const std::vector<int>& row_lengths);
+
+// Host execution of one row with exactly the kernel's algorithm (used by CPU tests; NOT a product fallback:
+// nothing in the invtrans path calls it).  X: h+1 (or n/2+1) complex modes (zero beyond mmax); y: n reals.
+void host_execute_row(const FftPlanSet& ps, int plan, const cplx* X, int mmax, double* y, int nthreads = 256);
+
+}  // namespace fft
+}  // namespace atlas_amd

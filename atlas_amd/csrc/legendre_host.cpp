@@ -1,0 +1,252 @@
+// See legendre_host.h.  Host-only; compiled with -ffp-contract=off so that every operation rounds exactly once,
+// in the order the reference writes it.
+#include "legendre_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace atlas_amd {
+namespace trans {
+
+LegendreEvaluator::LegendreEvaluator(int trc): trc_(trc), tri_(size_t(trc + 2) * size_t(trc + 1) / 2) {
+    const size_t ld = size_t(trc) + 1;
+    zfn_.assign(ld * ld, 0.);
+    // compute_zfn (LegendrePolynomials.cc:24-45)
+    zfn_[0] = 2.;
+    for (int jn = 1; jn <= trc; ++jn) {
+        double zfnn = zfn_[0];
+        for (int jgl = 1; jgl <= jn; ++jgl) {
+            zfnn *= std::sqrt(1. - 0.25 / (double(jgl) * double(jgl)));
+        }
+        const int iodd      = jn % 2;
+        zfn_[jn * ld + jn]  = zfnn;
+        for (int jgl = 2; jgl <= jn - iodd; jgl += 2) {
+            const double zfjn       = ((jgl - 1.) * (2. * jn - jgl + 2.));
+            const double zfjd       = (jgl * (2. * jn - jgl + 1.));
+            zfn_[jn * ld + jn - jgl] = zfn_[jn * ld + jn - jgl + 2] * zfjn / zfjd;
+        }
+    }
+    // side effect of the odd-n branch of compute_legendre_polynomials_lat (:102)
+    for (int jn = 1; jn <= trc; jn += 2) {
+        zfn_[jn * ld + 0] = 0.;
+    }
+    sq1_.assign(ld, 0.);
+    diag_.assign(ld, 0.);
+    for (int jn = 1; jn <= trc; ++jn) {
+        sq1_[jn]  = 1. / std::sqrt(jn * (jn + 1.));
+        diag_[jn] = std::sqrt((2. * jn + 1.) / (2. * jn));
+    }
+    // Belousov (17) coefficients (:136-149); independent of latitude
+    ca_.assign(tri_, 0.);
+    cb_.assign(tri_, 0.);
+    cc_.assign(tri_, 0.);
+    for (int jn = 3; jn <= trc; ++jn) {
+        for (int jm = 2; jm < jn; ++jm) {
+            const double cn = ((2. * jn + 1.) * (jn + jm - 3.) * (jn + jm - 1.));
+            const double cd = ((2. * jn - 3.) * (jn + jm - 2.) * (jn + jm));
+            const double dn = ((2. * jn + 1.) * (jn - jm + 1.) * (jn + jm - 1.));
+            const double dd = ((2. * jn - 1.) * (jn + jm - 2.) * (jn + jm));
+            const double en = ((2. * jn + 1.) * (jn - jm));
+            const double ed = ((2. * jn - 1.) * (jn + jm));
+            const size_t i  = idxmn(trc, jm, jn);
+            ca_[i]          = std::sqrt(cn / cd);
+            cb_[i]          = std::sqrt(dn / dd);
+            cc_[i]          = std::sqrt(en / ed);
+        }
+    }
+}
+
+void LegendreEvaluator::evaluate(double lat, double* legpol, double* scratch) const {
+    const int trc   = trc_;
+    const size_t ld = size_t(trc) + 1;
+    double* vsin    = scratch;
+    double* vcos    = scratch + ld;
+    // 1. first two columns (:58-115)
+    const double zdlx1       = (M_PI_2 - lat);
+    double zdlx              = std::cos(zdlx1);
+    volatile double zdlsita  = std::sqrt(1. - zdlx * zdlx);
+    legpol[idxmn(trc, 0, 0)] = 1.;
+    for (int j = 1; j <= trc; j++) {
+        vsin[j] = std::sin(j * zdlx1);
+        vcos[j] = std::cos(j * zdlx1);
+    }
+    double zdl1sita = 0.;
+    if (std::abs(zdlsita) <= std::sqrt(std::numeric_limits<double>::epsilon())) {
+        zdlx    = 1.;
+        zdlsita = 0.;
+    }
+    else {
+        zdl1sita = 1. / zdlsita;
+    }
+    for (int jn = 2; jn <= trc; jn += 2) {
+        const double* z = &zfn_[jn * ld];
+        double zdlk     = 0.5 * z[0];
+        double zdlldn   = 0.0;
+        const double sq = sq1_[jn];
+        for (int jk = 2; jk <= jn; jk += 2) {
+            zdlk   = zdlk + z[jk] * vcos[jk];
+            zdlldn = zdlldn + sq * z[jk] * jk * vsin[jk];
+        }
+        legpol[idxmn(trc, 0, jn)] = zdlk;
+        legpol[idxmn(trc, 1, jn)] = zdlldn;
+    }
+    for (int jn = 1; jn <= trc; jn += 2) {
+        const double* z = &zfn_[jn * ld];
+        double zdlk     = 0.;
+        double zdlldn   = 0.0;
+        const double sq = sq1_[jn];
+        for (int jk = 1; jk <= jn; jk += 2) {
+            zdlk   = zdlk + z[jk] * vcos[jk];
+            zdlldn = zdlldn + sq * z[jk] * jk * vsin[jk];
+        }
+        legpol[idxmn(trc, 0, jn)] = zdlk;
+        legpol[idxmn(trc, 1, jn)] = zdlldn;
+    }
+    // 2. diagonal (:122-130)
+    const double zdls = zdl1sita * std::numeric_limits<double>::min();
+    const double sint = zdlsita;
+    for (int jn = 2; jn <= trc; ++jn) {
+        double v = legpol[idxmn(trc, jn - 1, jn - 1)] * sint * diag_[jn];
+        if (std::abs(v) < zdls) {
+            v = 0.0;
+        }
+        legpol[idxmn(trc, jn, jn)] = v;
+    }
+    // 3. general recurrence (:136-149).  The reference iterates n outer / m inner; the data dependencies
+    //    (m-2,n-2), (m-2,n-1), (m,n-1) allow m outer / n inner, which is contiguous in the packed triangle and
+    //    performs the identical operations on identical operands.
+    for (int jm = 2; jm < trc; ++jm) {
+        const size_t base   = idxmn(trc, jm, jm);      // (jm, jm)
+        const size_t basem2 = idxmn(trc, jm - 2, jm - 2);  // (jm-2, jm-2)
+        double* p           = legpol + base;           // p[n-jm]
+        const double* q     = legpol + basem2;         // q[n-(jm-2)]
+        const double* a     = ca_.data() + base;
+        const double* b     = cb_.data() + base;
+        const double* c     = cc_.data() + base;
+        for (int jn = std::max(3, jm + 1); jn <= trc; ++jn) {
+            const int i = jn - jm;
+            // (m-2, n-2) -> q[n-2-(m-2)] = q[i];  (m-2, n-1) -> q[i+1];  (m, n-1) -> p[i-1]
+            p[i] = a[i] * q[i] - b[i] * q[i + 1] * zdlx + c[i] * p[i - 1] * zdlx;
+        }
+    }
+}
+
+void compute_legendre_tables_reference_layout(const TransGeometry& geo, double* leg_sym, double* leg_asym) {
+    const int trc   = geo.T + 1;
+    const int nlats = geo.nlatsLeg;
+    LegendreEvaluator ev(trc);
+#pragma omp parallel
+    {
+        std::vector<double> legpol(ev.triangle_size());
+        std::vector<double> scratch(2 * size_t(trc + 1));
+#pragma omp for schedule(dynamic, 1)
+        for (int jlat = 0; jlat < nlats; ++jlat) {
+            ev.evaluate(geo.lats_leg[jlat], legpol.data(), scratch.data());
+            for (int jm = 0; jm <= trc; ++jm) {
+                const size_t is1 = num_n(trc, jm, true), ia1 = num_n(trc, jm, false);
+                size_t is2 = 0, ia2 = 0;
+                for (int jn = trc; jn >= jm; --jn) {  // n descending (:195-205)
+                    const double v = legpol[LegendreEvaluator::idxmn(trc, jm, jn)];
+                    if ((jn - jm) % 2 == 0) {
+                        leg_sym[geo.begin_sym[jm] + is1 * size_t(jlat) + is2++] = v;
+                    }
+                    else {
+                        leg_asym[geo.begin_asym[jm] + ia1 * size_t(jlat) + ia2++] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+namespace {
+// destination of P(m, n) for Legendre row jlat in the tiled table
+inline void tiled_store(const TransGeometry& geo, const LegendreWork& work, double* table, int m, int jlat0, int nl,
+                        const double* const* legpols) {
+    // rows jlat0 .. jlat0+nl-1 (all >= nlat0[m])
+    const int trc  = geo.T + 1;
+    const int c0   = jlat0 - geo.nlat0[m];
+    const int ntop[2] = {trc - ((trc - m) & 1), trc - 1 + ((trc - m) & 1)};  // largest n<=trc with (n-m)%2 == p
+    for (int l = 0; l < nl; ++l) {
+        const int c          = c0 + l;
+        const LegendreItem& it = work.items_by_m[work.first_item_of_m[m] + c / LEG_BN];
+        const int col        = c % LEG_BN;
+        double* blk          = table + it.p_off + col;
+        const double* lp     = legpols[l] + LegendreEvaluator::idxmn(trc, m, m);  // lp[n-m]
+        for (int p = 0; p < 2; ++p) {
+            double* dst = blk + size_t(p) * it.kpad * LEG_BN;
+            int k       = 0;
+            for (int n = ntop[p]; n >= m; n -= 2, ++k) {
+                dst[size_t(k) * LEG_BN] = lp[n - m];
+            }
+        }
+    }
+}
+}  // namespace
+
+void compute_legendre_table_tiled(const TransGeometry& geo, const LegendreWork& work, double* table) {
+    const int trc   = geo.T + 1;
+    const int nlats = geo.nlatsLegR;
+    LegendreEvaluator ev(trc);
+    constexpr int LB = 8;  // latitudes per block: keeps the strided scatter within one cache line per (m,n)
+    const int nblk   = (nlats + LB - 1) / LB;
+    // NB: `table` must be zero-initialised by the caller: padded k rows / latitude columns stay zero
+#pragma omp parallel
+    {
+        std::vector<std::vector<double>> legpol(LB, std::vector<double>(ev.triangle_size()));
+        std::vector<double> scratch(2 * size_t(trc + 1));
+#pragma omp for schedule(dynamic, 1)
+        for (int b = 0; b < nblk; ++b) {
+            const int j0 = b * LB;
+            const int nl = std::min(LB, nlats - j0);
+            for (int l = 0; l < nl; ++l) {
+                ev.evaluate(geo.lats_leg[j0 + l], legpol[l].data(), scratch.data());
+            }
+            for (int m = 0; m <= geo.T; ++m) {
+                if (work.first_item_of_m[m + 1] == work.first_item_of_m[m]) {
+                    continue;  // no rows for this m, or m owned by another device
+                }
+                // sub-range of this block that lies at or south of nlat0[m]
+                const int lo = std::max(j0, geo.nlat0[m]);
+                if (lo >= j0 + nl) {
+                    continue;
+                }
+                const double* ptrs[LB];
+                for (int l = lo; l < j0 + nl; ++l) {
+                    ptrs[l - lo] = legpol[l - j0].data();
+                }
+                tiled_store(geo, work, table, m, lo, j0 + nl - lo, ptrs);
+            }
+        }
+    }
+}
+
+void retile_legendre_tables(const TransGeometry& geo, const LegendreWork& work, const double* leg_sym,
+                            const double* leg_asym, double* table) {
+    const int trc = geo.T + 1;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int m = 0; m <= geo.T; ++m) {
+        if (work.first_item_of_m[m + 1] == work.first_item_of_m[m]) {
+            continue;
+        }
+        const size_t ks = num_n(trc, m, true), ka = num_n(trc, m, false);
+        for (int jlat = geo.nlat0[m]; jlat < geo.nlatsLegR; ++jlat) {
+            const int c            = jlat - geo.nlat0[m];
+            const LegendreItem& it = work.items_by_m[work.first_item_of_m[m] + c / LEG_BN];
+            double* blk            = table + it.p_off + (c % LEG_BN);
+            const double* s        = leg_sym + geo.begin_sym[m] + ks * size_t(jlat);
+            const double* a        = leg_asym + geo.begin_asym[m] + ka * size_t(jlat);
+            for (size_t k = 0; k < ks; ++k) {
+                blk[k * LEG_BN] = s[k];
+            }
+            for (size_t k = 0; k < ka; ++k) {
+                blk[(size_t(it.kpad) + k) * LEG_BN] = a[k];
+            }
+        }
+    }
+}
+
+}  // namespace trans
+}  // namespace atlas_amd

@@ -1,0 +1,46 @@
+// Host computation of the normalised associated Legendre functions used by TransLocal
+// (reference: src/atlas/trans/local/LegendrePolynomials.cc:24-209).  Arithmetic follows the reference
+// operation by operation (same series, same recurrences, same evaluation order) so that the tables are the
+// ones TransLocal would build; the recurrence coefficients are hoisted out of the latitude loop (they do not
+// depend on latitude), which leaves every product/sum bit-identical.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "trans_plan.h"
+
+namespace atlas_amd {
+namespace trans {
+
+class LegendreEvaluator {
+public:
+    explicit LegendreEvaluator(int trc);
+    int trc() const { return trc_; }
+    size_t triangle_size() const { return tri_; }
+    static size_t idxmn(int trc, int m, int n) { return size_t(2 * trc + 3 - m) * size_t(m) / 2 + size_t(n - m); }
+    // legpol: packed triangle of size triangle_size(); scratch: 2*(trc+1) doubles
+    void evaluate(double lat_rad, double* legpol, double* scratch) const;
+
+private:
+    int trc_;
+    size_t tri_;
+    std::vector<double> zfn_;            // (trc+1)^2, odd-n rows have zfn(n,0)=0 (LegendrePolynomials.cc:102)
+    std::vector<double> ca_, cb_, cc_;   // recurrence coefficients per packed (m,n)
+    std::vector<double> diag_;           // sqrt((2n+1)/(2n))
+    std::vector<double> sq1_;            // 1/sqrt(n(n+1))
+};
+
+// Reference (cache-file) layout: block m at begin[m], column-major K x nlatsLeg, n descending.
+// (LegendrePolynomials.cc:154-209, TransLocal.cc:592-637)
+void compute_legendre_tables_reference_layout(const TransGeometry& geo, double* leg_sym, double* leg_asym);
+
+// Tile-blocked device layout (see trans_plan.h / DESIGN.md): item block = [parity][kpad][LEG_BN].
+void compute_legendre_table_tiled(const TransGeometry& geo, const LegendreWork& work, double* table);
+
+// reference layout -> tiled layout (used when importing a Legendre cache blob)
+void retile_legendre_tables(const TransGeometry& geo, const LegendreWork& work, const double* leg_sym,
+                            const double* leg_asym, double* table);
+
+}  // namespace trans
+}  // namespace atlas_amd

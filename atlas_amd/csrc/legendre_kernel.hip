@@ -1,0 +1,236 @@
+// Inverse Legendre transform on gfx950 (MI355X): batched fp64 MFMA contraction of the associated-Legendre
+// table against the spectral coefficients, with the spectral parity split, the two GEMMs per zonal wavenumber and
+// the hemisphere merge of the reference fused into one kernel.
+//
+// Reference being replaced: TransLocal::invtrans_legendre, src/atlas/trans/local/TransLocal.cc:939-1097
+//   * "Legendre split"     :970-1003  -> rows of the spectral array are addressed in place (n descending, by parity)
+//   * 2 x matrix_multiply  :1007-1023 -> v_mfma_f64_16x16x4_f64, both parities accumulated side by side
+//   * "merge spheres"      :1031-1080 -> epilogue: north = sym + asym, south = sym - asym
+//
+// Work decomposition (trans_plan.h): one workgroup (8 waves) per (m, tile of 64 latitudes); it streams its
+// contiguous P block [parity][kpad][64] from HBM exactly once and multiplies it with ALL (field, re/im) columns,
+// which it re-reads from L2 (every tile of one m is placed on the same XCD).
+//
+// MFMA operand roles (layout verified on hardware, tools/probe):
+//   A (16 x 4)  = P^T  : lane l holds P[k = 4*ks + (l>>4)][lat = 16*lt + (l&15)]
+//   B (4 x 16)  = S    : lane l holds S[k = 4*ks + (l>>4)][r   = 16*rt + (l&15)]     r = 2*field + imag
+//   D (16 x 16)        : lane l, reg g holds D[lat = (l>>4) + 4*g][r = l&15]
+// so 16 consecutive lanes store 16 consecutive r (128 B) of one latitude.
+//
+// Output ("Fourier intermediate", own layout -- the reference's scl_fourier is internal to TransLocal):
+//   F[(lat * m_cnt + m / m_div) * RP + r],  lat = 0..nlats-1 north->south, r = 2*field + imag, RP = 16*ceil(2*nf/16)
+//   (single device: m_div = 1, m_cnt = T+1; multi-GPU m-sharding: this device owns m with m % m_div == part).
+// Entries with m above the row's Fourier truncation are never written and never read (fft_kernel.hip).
+#include <hip/hip_runtime.h>
+
+#include "device_structs.h"
+
+namespace atlas_amd {
+namespace trans {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int KB   = LEG_KB_DEV;  // 8 total wavenumbers per stage
+constexpr int BN   = LEG_BN_DEV;  // 64 latitudes per item
+constexpr int PSTR = BN + 16;     // LDS row stride of the P stage (== 16 mod 32 doubles: conflict-free ds_read_b64)
+constexpr int NTHR = 512;
+
+template <int RTW>
+struct LegLds {
+    static constexpr int SSTR   = 32 * RTW + 16;  // == 16 mod 32
+    static constexpr int P_ELEM = 2 * KB * PSTR;
+    static constexpr int S_ELEM = 2 * KB * SSTR;
+    static constexpr int STAGE  = P_ELEM + S_ELEM;
+    static constexpr int BYTES  = 2 * STAGE * 8;  // double buffered
+};
+
+template <int RTW>
+__global__ void __launch_bounds__(NTHR) legendre_kernel(LegendreParams p) {
+    using L = LegLds<RTW>;
+    extern __shared__ double lds[];
+
+    const LegendreItemDev it = p.items[blockIdx.x];
+    if (it.m < 0) {
+        return;
+    }
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int lt   = wave & 3;   // latitude tile of this wave
+    const int rg   = wave >> 2;  // r-tile group of this wave
+    const int m    = it.m;
+    const int T    = p.T;
+    const int nf   = p.nf;
+    const int trc  = p.trc_in;
+    const int r0   = blockIdx.y * (32 * RTW);  // first interleaved column of this chunk
+    const int TL   = T + 1;                    // truncation of the table
+    // largest n <= T+1 of each parity (n-m even: sym)
+    const int ntop0 = TL - ((TL - m) & 1);
+    const int ntop1 = TL - 1 + ((TL - m) & 1);
+    const int nmax  = trc < TL ? trc : TL;  // highest n present in the input spectra
+    const bool m_ok = m < trc;              // TransLocal.cc:982  (jm < truncation)
+    const long long ioff = (long long)(2 * trc + 3 - m) * m / 2 * nf * 2;
+    const double* __restrict__ sp = p.sp + ioff;
+    const double* __restrict__ Pb = p.P + it.p_off;
+    const int nstage = it.kpad / KB;
+
+    d4 acc[2][RTW];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < RTW; ++j) acc[q][j] = d4{0., 0., 0., 0.};
+
+    // ---- staging: registers for one stage ----
+    double2 preg;       // P: 2 doubles per thread (1024 doubles per stage)
+    double sreg[RTW];   // S: RTW doubles per thread (512*RTW doubles per stage)
+    // P element ids 2*tid, 2*tid+1:  parity = e / 512, k = (e % 512) / 64, c = e % 64
+    const int pe   = 2 * tid;
+    const int ppar = pe >> 9, pk = (pe & 511) >> 6, pc = pe & 63;
+    const double* pg = Pb + (long long)ppar * it.kpad * BN + pk * BN + pc;
+    const int plds   = ppar * (KB * PSTR) + pk * PSTR + pc;
+
+    auto load_stage = [&](int s) {
+        preg = *reinterpret_cast<const double2*>(pg + (long long)s * KB * BN);
+#pragma unroll
+        for (int i = 0; i < RTW; ++i) {
+            const int q    = tid + NTHR * i;
+            const int row  = q / (32 * RTW);  // 0..15 : parity*8 + k
+            const int col  = q - row * (32 * RTW);
+            const int par  = row >> 3;
+            const int k    = s * KB + (row & 7);
+            const int n    = (par ? ntop1 : ntop0) - 2 * k;
+            const int r    = r0 + col;
+            const int f    = r >> 1, im = r & 1;
+            double v       = 0.;
+            if (m_ok && n >= m && n <= nmax && f < nf) {
+                v = sp[(long long)(n - m) * 2 * nf + im * nf + f];
+            }
+            sreg[i] = v;
+        }
+    };
+    auto store_stage = [&](int buf) {
+        double* base = lds + buf * L::STAGE;
+        *reinterpret_cast<double2*>(base + plds) = preg;
+        double* sb = base + L::P_ELEM;
+#pragma unroll
+        for (int i = 0; i < RTW; ++i) {
+            const int q   = tid + NTHR * i;
+            const int row = q / (32 * RTW);
+            const int col = q - row * (32 * RTW);
+            sb[row * L::SSTR + col] = sreg[i];
+        }
+    };
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+
+    const int a_off = (lane >> 4) * PSTR + lt * 16 + (lane & 15);
+    const int b_off = (lane >> 4) * L::SSTR + rg * RTW * 16 + (lane & 15);
+
+    for (int s = 0; s < nstage; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nstage) {
+            load_stage(s + 1);
+        }
+        const double* base = lds + buf * L::STAGE;
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const double* pb = base + par * (KB * PSTR) + a_off;
+            const double* sb = base + L::P_ELEM + par * (KB * L::SSTR) + b_off;
+#pragma unroll
+            for (int ks = 0; ks < KB / 4; ++ks) {
+                const double a = pb[ks * 4 * PSTR];
+#pragma unroll
+                for (int j = 0; j < RTW; ++j) {
+                    const double b = sb[ks * 4 * L::SSTR + j * 16];
+                    acc[par][j]    = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[par][j], 0, 0, 0);
+                }
+            }
+        }
+        if (s + 1 < nstage) {
+            store_stage(buf ^ 1);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: merge hemispheres and store ----
+    const int nlats  = p.nlats;
+    const int jleg0  = p.nlat0[m] + it.tile * BN;
+    const long long RP = p.RP;
+    const int ml       = m / p.m_div;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int c = lt * 16 + (lane >> 4) + 4 * g;
+        if (c < it.nrows) {
+            const int jn = jleg0 + c;
+            const int js = nlats - 1 - jn;
+            double* fn   = p.F + ((long long)jn * p.m_cnt + ml) * RP;
+            double* fs   = p.F + ((long long)js * p.m_cnt + ml) * RP;
+#pragma unroll
+            for (int j = 0; j < RTW; ++j) {
+                const int r = r0 + (rg * RTW + j) * 16 + (lane & 15);
+                if (r < RP) {
+                    double sy = acc[0][j][g], as = acc[1][j][g];
+                    if (m == 0 && (r & 1)) {  // n_imag = 1 for m = 0 (TransLocal.cc:953)
+                        sy = 0.;
+                        as = 0.;
+                    }
+                    if (jn != js) {
+                        fn[r] = sy + as;
+                    }
+                    fs[r] = sy - as;  // for an equator row the southern value wins (TransLocal.cc:1056-1068 runs last)
+                }
+            }
+        }
+    }
+}
+
+template <int RTW>
+static hipError_t launch_rtw(const LegendreParams& p, int nitems, int nchunks, hipStream_t stream) {
+    using L = LegLds<RTW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&legendre_kernel<RTW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES);
+        if (e != hipSuccess) {
+            return e;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(legendre_kernel<RTW>, dim3(nitems, nchunks), dim3(NTHR), L::BYTES, stream, p);
+    return hipGetLastError();
+}
+
+// r tiles per wave for a given number of fields: two wave groups cover 2*RTW tiles (32*RTW columns) per chunk
+int legendre_rtw(int nf) {
+    const int rt = (2 * nf + 15) / 16;
+    int rtw      = (rt + 1) / 2;
+    if (rtw > 9) {
+        // several chunks: balance the chunk width
+        const int nchunk = (rt + 17) / 18;
+        rtw              = ((rt + nchunk - 1) / nchunk + 1) / 2;
+    }
+    return rtw < 1 ? 1 : rtw;
+}
+
+hipError_t launch_legendre(const LegendreParams& p, int nitems, hipStream_t stream) {
+    const int rt      = (2 * p.nf + 15) / 16;
+    const int rtw     = legendre_rtw(p.nf);
+    const int nchunks = (rt + 2 * rtw - 1) / (2 * rtw);
+    switch (rtw) {
+        case 1: return launch_rtw<1>(p, nitems, nchunks, stream);
+        case 2: return launch_rtw<2>(p, nitems, nchunks, stream);
+        case 3: return launch_rtw<3>(p, nitems, nchunks, stream);
+        case 4: return launch_rtw<4>(p, nitems, nchunks, stream);
+        case 5: return launch_rtw<5>(p, nitems, nchunks, stream);
+        case 6: return launch_rtw<6>(p, nitems, nchunks, stream);
+        case 7: return launch_rtw<7>(p, nitems, nchunks, stream);
+        case 8: return launch_rtw<8>(p, nitems, nchunks, stream);
+        case 9: return launch_rtw<9>(p, nitems, nchunks, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace trans
+}  // namespace atlas_amd

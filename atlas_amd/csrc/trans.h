@@ -1,0 +1,150 @@
+// atlas_amd::trans::Trans -- MI355X implementation of the TransLocal inverse transform for global structured
+// grids.  Mirrors the subset of atlas::trans::TransImpl that TransLocal implements
+// (reference: src/atlas/trans/detail/TransImpl.h:116-181, src/atlas/trans/local/TransLocal.cc:818-934,1409-1597):
+//   invtrans(nb_scalar, sp, gp), invtrans(nb_scalar, sp, nb_vordiv, vor, div, gp), invtrans(nb_vordiv, vor, div, gp),
+//   truncation(), nb_spectral_coefficients(), grid size;  dirtrans / adjoints are "not implemented" there as well
+//   (TransLocal.cc:848-857,899-927,1599-1685).
+// Host-pointer overloads stage through device memory; *_device overloads take device pointers and are
+// asynchronous on the object's stream.  One in-flight call per object (as for TransLocal, SURVEY 8b "Threading").
+//
+// Multi-GPU (new capability; TransLocal itself refuses mpi::size()>1, TransLocal.cc:338-340): an object created
+// with (nparts, part) owns the zonal wavenumbers m % nparts == part for the Legendre stage and the latitude band
+// latitude_bands()[part] .. [part+1] for the Fourier stage; the caller exchanges the Fourier intermediate
+// (all-to-all, one contiguous slab per peer) between legendre_device() and fourier_device().
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "fft_plan.h"
+#include "gaussian.h"
+#include "legendre_host.h"
+#include "trans_plan.h"
+
+namespace atlas_amd {
+namespace trans {
+
+struct TransConfig {
+    bool profile               = false;    // record HIP events around the two stages
+    const void* legendre_cache = nullptr;  // optional Legendre cache blob (reference layout: sym ++ asym)
+    size_t legendre_cache_size = 0;
+    int nparts                 = 1;  // m-sharding / latitude-band decomposition
+    int part                   = 0;
+};
+
+struct StageTimings {
+    double legendre_ms = 0, fourier_ms = 0;
+    int legendre_calls = 0, fourier_calls = 0;
+};
+
+class Trans {
+public:
+    Trans(const grid::StructuredGrid& grid, int truncation, const TransConfig& cfg = TransConfig());
+    ~Trans();
+    Trans(const Trans&)            = delete;
+    Trans& operator=(const Trans&) = delete;
+
+    int truncation() const { return geo_.T; }
+    int64_t nb_gridpoints() const { return geo_.rowoff[band_end()] - geo_.rowoff[band_begin()]; }
+    int64_t nb_gridpoints_global() const { return geo_.npts; }
+    size_t nb_spectral_coefficients() const { return size_t(geo_.T + 1) * size_t(geo_.T + 2); }  // TransLocal.h:90
+    const TransGeometry& geometry() const { return geo_; }
+    const LegendreWork& legendre_work() const { return work_; }
+    const fft::FftPlanSet& fft_plans() const { return fftplans_; }
+    int nparts() const { return cfg_.nparts; }
+    int part() const { return cfg_.part; }
+    int band_begin() const { return bands_[cfg_.part]; }
+    int band_end() const { return bands_[cfg_.part + 1]; }
+    const std::vector<int>& bands() const { return bands_; }
+    int owned_wavenumbers() const { return m_cnt_; }
+    hipStream_t stream() const { return stream_; }
+    void set_stream(hipStream_t s);
+    void synchronize() const;
+
+    // ---- device-pointer API (asynchronous on stream()) ----
+    // TransLocal::invtrans_uv (TransLocal.cc:1409-1484); the first 2*nb_vordiv fields are scaled by 1/cos(lat)
+    void invtrans_uv_device(int trc_in, int nb_fields, int nb_vordiv, const double* sp_dev, double* gp_dev);
+    // the two stages separately (multi-GPU driver, stage-level parity tests)
+    void legendre_device(int trc_in, int nb_fields, const double* sp_dev, double* fourier_dev);
+    void fourier_device(int nb_fields, int nb_vordiv, const double* fourier_dev, double* gp_dev);
+    void fourier_device(int nb_fields, int nb_vordiv, const double* const* part_base, const int* part_cnt,
+                        double* gp_dev);
+    size_t fourier_doubles(int nb_fields) const;  // local Fourier intermediate: nlats * owned m * RP
+    int fourier_row_pitch(int nb_fields) const;   // RP = 16*ceil(2*nb_fields/16)
+    double* fourier_buffer(int nb_fields);        // scratch intermediate owned by the object (grown on demand)
+
+    // TransLocal::invtrans(nb_scalar, sp, nb_vordiv, vor, div, gp) (TransLocal.cc:1523-1597): gp holds
+    // [u fields][v fields][scalar fields]; vor/div -> U,V in spectral space, truncation extended to T+1
+    void invtrans_device(int nb_scalar_fields, const double* sp_dev, int nb_vordiv_fields, const double* vor_dev,
+                         const double* div_dev, double* gp_dev);
+
+    // ---- host-pointer API (synchronous) : TransLocal.cc:931-934, 1486-1490, 1523-1597 ----
+    void invtrans(int nb_scalar_fields, const double scalar_spectra[], double gp_fields[]);
+    void invtrans(int nb_scalar_fields, const double scalar_spectra[], int nb_vordiv_fields,
+                  const double vorticity_spectra[], const double divergence_spectra[], double gp_fields[]);
+
+    // Legendre cache, byte-compatible with TransLocal's write_legendre file (TransLocal.cc:638-647)
+    size_t legendre_cache_bytes() const { return (geo_.size_sym() + geo_.size_asym()) * sizeof(double); }
+    void export_legendre_cache(void* buffer) const;
+
+    StageTimings timings();
+    void reset_timings() {
+        collect_timings();
+        timings_ = StageTimings();
+    }
+    void set_profile(bool on) { profile_ = on; }
+
+private:
+    void upload();
+    void collect_timings();
+    void timed_begin(int kind);
+    void timed_end();
+
+    TransGeometry geo_;
+    TransConfig cfg_;
+    LegendreWork work_;
+    fft::FftPlanSet fftplans_;
+    std::vector<int> bands_;
+    int m_cnt_          = 0;
+    bool profile_       = false;
+    hipStream_t stream_ = nullptr;
+    bool own_stream_    = false;
+
+    // device state
+    double* d_P_         = nullptr;
+    void* d_items_       = nullptr;
+    int* d_nlat0_        = nullptr;
+    void* d_fftplans_    = nullptr;
+    void* d_ffttable_    = nullptr;
+    int* d_row_plan_     = nullptr;
+    int* d_row_mmax_     = nullptr;
+    long long* d_rowoff_ = nullptr;
+    double* d_coslatinv_ = nullptr;
+    struct SizeClass {
+        int lds_bytes;
+        int nrows;
+        int* d_rows;
+    };
+    std::vector<SizeClass> classes_;
+    double* d_fourier_  = nullptr;
+    size_t fourier_cap_ = 0;
+    double* d_sp_       = nullptr;
+    size_t sp_cap_      = 0;
+    double* d_gp_       = nullptr;
+    size_t gp_cap_      = 0;
+    double* d_all_      = nullptr;  // combined (U,V,scalar) spectra of the vor/div path
+    size_t all_cap_     = 0;
+    double* d_vd_       = nullptr;  // host-API staging of vor ++ div
+    size_t vd_cap_      = 0;
+    void ensure(double*& ptr, size_t& cap, size_t n);
+    std::vector<hipEvent_t> events_;  // pairs (begin, end)
+    std::vector<int> ev_kind_;        // 0 legendre, 1 fourier, per pair
+    size_t ev_used_ = 0;
+    StageTimings timings_;
+};
+
+}  // namespace trans
+}  // namespace atlas_amd

@@ -1,0 +1,435 @@
+// See trans.h.  Host code of the MI355X TransLocal replacement: builds the plan, uploads the tables once,
+// launches the two kernels per call on the object's HIP stream.
+#include "trans.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+
+#include "device_structs.h"
+
+namespace atlas_amd {
+namespace trans {
+
+hipError_t launch_legendre(const LegendreParams& p, int nitems, hipStream_t stream);
+hipError_t launch_fourier(const FourierParams& p, int lds_bytes, hipStream_t stream);
+hipError_t launch_spectra_prepare(const double* vor, const double* div, const double* sp, double* out, int T, int nvd,
+                                  int ns, hipStream_t stream);
+
+namespace {
+void hip_check(hipError_t e, const char* what, const char* file, int line) {
+    if (e != hipSuccess) {
+        std::ostringstream ss;
+        ss << "HIP error '" << hipGetErrorString(e) << "' in " << what << " (" << file << ":" << line << ")";
+        throw std::runtime_error(ss.str());
+    }
+}
+#define HIP_CHECK(x) hip_check((x), #x, __FILE__, __LINE__)
+
+template <typename T>
+T* dev_upload(const T* host, size_t n) {
+    T* d = nullptr;
+    if (n == 0) {
+        n = 1;
+        HIP_CHECK(hipMalloc((void**)&d, sizeof(T)));
+        return d;
+    }
+    HIP_CHECK(hipMalloc((void**)&d, n * sizeof(T)));
+    HIP_CHECK(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
+    return d;
+}
+}  // namespace
+
+Trans::Trans(const grid::StructuredGrid& grid, int truncation, const TransConfig& cfg):
+    geo_(make_geometry(grid, truncation)), cfg_(cfg), profile_(cfg.profile) {
+    if (cfg.nparts < 1 || cfg.nparts > fft::MAX_PARTS || cfg.part < 0 || cfg.part >= cfg.nparts) {
+        throw std::invalid_argument("Trans: invalid (nparts, part)");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        throw std::runtime_error(
+            "atlas_amd::Trans needs a HIP device (MI355X / gfx950); there is no CPU fallback for the transform");
+    }
+    work_ = make_legendre_work(geo_, cfg.nparts, cfg.part);
+    bands_ = latitude_bands(geo_, cfg.nparts);
+    m_cnt_ = 0;
+    for (int m = cfg.part; m <= geo_.T; m += cfg.nparts) {
+        m_cnt_++;
+    }
+    std::vector<int> lengths;
+    if (geo_.regular) {
+        lengths.push_back(geo_.nxmax);
+    }
+    else {
+        lengths = geo_.nx;
+    }
+    fftplans_ = fft::make_fft_plans(lengths);
+    HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    own_stream_ = true;
+    upload();
+}
+
+Trans::~Trans() {
+    (void)hipStreamSynchronize(stream_);
+    auto fr = [](void* p) {
+        if (p) {
+            (void)hipFree(p);
+        }
+    };
+    fr(d_P_);
+    fr(d_items_);
+    fr(d_nlat0_);
+    fr(d_fftplans_);
+    fr(d_ffttable_);
+    fr(d_row_plan_);
+    fr(d_row_mmax_);
+    fr(d_rowoff_);
+    fr(d_coslatinv_);
+    for (auto& c : classes_) {
+        fr(c.d_rows);
+    }
+    fr(d_fourier_);
+    fr(d_sp_);
+    fr(d_gp_);
+    fr(d_all_);
+    fr(d_vd_);
+    for (auto& e : events_) {
+        (void)hipEventDestroy(e);
+    }
+    if (own_stream_ && stream_) {
+        (void)hipStreamDestroy(stream_);
+    }
+}
+
+void Trans::set_stream(hipStream_t s) {
+    synchronize();
+    if (own_stream_ && stream_) {
+        (void)hipStreamDestroy(stream_);
+    }
+    stream_     = s;
+    own_stream_ = false;
+}
+
+void Trans::synchronize() const {
+    HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Trans::upload() {
+    // ---- Legendre table (tile-blocked), owned wavenumbers only ----
+    {
+        const size_t n = (size_t)work_.table_doubles;
+        double* host   = (double*)calloc(std::max<size_t>(n, 1), sizeof(double));
+        if (!host) {
+            throw std::runtime_error("out of host memory for the Legendre table");
+        }
+        if (cfg_.legendre_cache) {
+            // TransLocal.cc:608-614: sym then asym, size must match exactly
+            if (cfg_.legendre_cache_size != legendre_cache_bytes()) {
+                free(host);
+                throw std::invalid_argument("Legendre cache has the wrong size for this (grid, truncation)");
+            }
+            const double* sym  = (const double*)cfg_.legendre_cache;
+            const double* asym = sym + geo_.size_sym();
+            retile_legendre_tables(geo_, work_, sym, asym, host);
+        }
+        else {
+            compute_legendre_table_tiled(geo_, work_, host);
+        }
+        d_P_ = dev_upload(host, n);
+        free(host);
+    }
+    {
+        std::vector<LegendreItemDev> items(work_.items.size());
+        for (size_t i = 0; i < items.size(); ++i) {
+            const LegendreItem& it = work_.items[i];
+            items[i]               = LegendreItemDev{it.m, it.tile, it.nrows, it.kpad, (long long)it.p_off};
+        }
+        d_items_ = dev_upload(items.data(), items.size());
+    }
+    d_nlat0_ = dev_upload(geo_.nlat0.data(), geo_.nlat0.size());
+    // ---- FFT plans / tables ----
+    d_fftplans_ = dev_upload(fftplans_.plans.data(), fftplans_.plans.size());
+    d_ffttable_ = dev_upload(fftplans_.table.data(), fftplans_.table.size());
+    std::vector<int> row_plan(geo_.nlats), row_mmax(geo_.nlats);
+    std::vector<double> coslatinv(geo_.nlats);
+    for (int j = 0; j < geo_.nlats; ++j) {
+        const int n    = geo_.regular ? geo_.nxmax : geo_.nx[j];
+        row_plan[j]    = fftplans_.plan_index(n);
+        const int jleg = j < geo_.nlatsNH ? j : geo_.nlats - 1 - j;
+        row_mmax[j]    = geo_.mmax_leg[jleg];
+        double lat     = std::max(std::min(geo_.lat_deg[j], kLatPole), -kLatPole);  // TransLocal.cc:1449-1456
+        coslatinv[j]   = 1. / std::cos(lat * (M_PI / 180.));
+    }
+    d_row_plan_  = dev_upload(row_plan.data(), row_plan.size());
+    d_row_mmax_  = dev_upload(row_mmax.data(), row_mmax.size());
+    d_coslatinv_ = dev_upload(coslatinv.data(), coslatinv.size());
+    std::vector<long long> rowoff(geo_.rowoff.begin(), geo_.rowoff.end());
+    d_rowoff_ = dev_upload(rowoff.data(), rowoff.size());
+    // ---- LDS size classes for the rows of the local latitude band ----
+    const int class_bytes[] = {8 << 10, 16 << 10, 32 << 10, 48 << 10, 64 << 10, 96 << 10, 128 << 10, 160 << 10};
+    std::map<int, std::vector<int>> by_class;
+    for (int j = band_begin(); j < band_end(); ++j) {
+        const fft::FftRowPlan& pl = fftplans_.plans[row_plan[j]];
+        const int need            = pl.lds_complex * 16;
+        int cls                   = -1;
+        for (int c : class_bytes) {
+            if (need <= c) {
+                cls = c;
+                break;
+            }
+        }
+        if (cls < 0) {
+            throw std::runtime_error("row length " + std::to_string(pl.n) + " does not fit in LDS (160 KiB)");
+        }
+        by_class[cls].push_back(j);
+    }
+    // big classes first (longest blocks start first)
+    for (auto it = by_class.rbegin(); it != by_class.rend(); ++it) {
+        SizeClass c;
+        c.lds_bytes = std::max(it->first, 16);
+        c.nrows     = (int)it->second.size();
+        // within a class: longest rows first
+        std::sort(it->second.begin(), it->second.end(), [&](int a, int b) {
+            const int na = fftplans_.plans[row_plan[a]].lds_complex, nb = fftplans_.plans[row_plan[b]].lds_complex;
+            return na > nb || (na == nb && a < b);
+        });
+        c.d_rows = dev_upload(it->second.data(), it->second.size());
+        classes_.push_back(c);
+    }
+}
+
+int Trans::fourier_row_pitch(int nb_fields) const {
+    return (2 * nb_fields + 15) / 16 * 16;
+}
+
+size_t Trans::fourier_doubles(int nb_fields) const {
+    return size_t(geo_.nlats) * size_t(m_cnt_) * size_t(fourier_row_pitch(nb_fields));
+}
+
+double* Trans::fourier_buffer(int nb_fields) {
+    const size_t need = fourier_doubles(nb_fields);
+    if (need > fourier_cap_) {
+        synchronize();
+        if (d_fourier_) {
+            HIP_CHECK(hipFree(d_fourier_));
+            d_fourier_ = nullptr;
+        }
+        HIP_CHECK(hipMalloc((void**)&d_fourier_, need * sizeof(double)));
+        fourier_cap_ = need;
+    }
+    return d_fourier_;
+}
+
+void Trans::timed_begin(int kind) {
+    if (!profile_) {
+        return;
+    }
+    while (events_.size() < ev_used_ + 2) {
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreate(&e));
+        events_.push_back(e);
+    }
+    ev_kind_.push_back(kind);
+    HIP_CHECK(hipEventRecord(events_[ev_used_], stream_));
+}
+
+void Trans::timed_end() {
+    if (!profile_) {
+        return;
+    }
+    HIP_CHECK(hipEventRecord(events_[ev_used_ + 1], stream_));
+    ev_used_ += 2;
+}
+
+void Trans::legendre_device(int trc_in, int nb_fields, const double* sp_dev, double* fourier_dev) {
+    if (nb_fields <= 0) {
+        return;
+    }
+    if (trc_in != geo_.T && trc_in != geo_.T + 1) {
+        throw std::invalid_argument("legendre_device: input truncation must be T or T+1");
+    }
+    LegendreParams p;
+    p.P      = d_P_;
+    p.sp     = sp_dev;
+    p.F      = fourier_dev;
+    p.items  = (const LegendreItemDev*)d_items_;
+    p.nlat0  = d_nlat0_;
+    p.T      = geo_.T;
+    p.trc_in = trc_in;
+    p.nf     = nb_fields;
+    p.RP     = fourier_row_pitch(nb_fields);
+    p.nlats  = geo_.nlats;
+    p.m_div  = cfg_.nparts;
+    p.m_cnt  = m_cnt_;
+    timed_begin(0);
+    if (!work_.items.empty()) {
+        HIP_CHECK(launch_legendre(p, (int)work_.items.size(), stream_));
+    }
+    timed_end();
+}
+
+void Trans::fourier_device(int nb_fields, int nb_vordiv, const double* const* part_base, const int* part_cnt,
+                           double* gp_dev) {
+    if (nb_fields <= 0) {
+        return;
+    }
+    FourierParams p;
+    for (int i = 0; i < fft::MAX_PARTS; ++i) {
+        p.part_base[i] = i < cfg_.nparts ? part_base[i] : nullptr;
+        p.part_cnt[i]  = i < cfg_.nparts ? part_cnt[i] : 0;
+    }
+    p.nparts          = cfg_.nparts;
+    p.lat0            = band_begin();
+    p.gp              = gp_dev;
+    p.plans           = (const fft::FftRowPlan*)d_fftplans_;
+    p.table           = (const fft::cplx*)d_ffttable_;
+    p.row_plan        = d_row_plan_;
+    p.row_mmax        = d_row_mmax_;
+    p.rowoff          = d_rowoff_;
+    p.T               = geo_.T;
+    p.RP              = fourier_row_pitch(nb_fields);
+    p.nf              = nb_fields;
+    p.npts            = geo_.rowoff[band_end()] - geo_.rowoff[band_begin()];
+    p.scale_uv_fields = std::min(2 * nb_vordiv, nb_fields);
+    p.coslatinv       = d_coslatinv_;
+    timed_begin(1);
+    for (const SizeClass& c : classes_) {
+        p.rows  = c.d_rows;
+        p.nrows = c.nrows;
+        HIP_CHECK(launch_fourier(p, c.lds_bytes, stream_));
+    }
+    timed_end();
+}
+
+void Trans::fourier_device(int nb_fields, int nb_vordiv, const double* fourier_dev, double* gp_dev) {
+    if (cfg_.nparts != 1) {
+        throw std::logic_error("single-buffer fourier_device needs nparts == 1");
+    }
+    const double* base[1] = {fourier_dev};
+    int cnt[1]            = {m_cnt_};
+    fourier_device(nb_fields, nb_vordiv, base, cnt, gp_dev);
+}
+
+void Trans::invtrans_uv_device(int trc_in, int nb_fields, int nb_vordiv, const double* sp_dev, double* gp_dev) {
+    if (nb_fields <= 0) {
+        return;
+    }
+    if (cfg_.nparts != 1) {
+        throw std::logic_error("invtrans_uv_device on a sharded Trans: use legendre_device / exchange / fourier_device");
+    }
+    double* F = fourier_buffer(nb_fields);
+    legendre_device(trc_in, nb_fields, sp_dev, F);
+    fourier_device(nb_fields, nb_vordiv, F, gp_dev);
+}
+
+void Trans::collect_timings() {
+    if (ev_used_ == 0) {
+        return;
+    }
+    synchronize();
+    for (size_t i = 0; i + 1 < ev_used_; i += 2) {
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, events_[i], events_[i + 1]));
+        if (ev_kind_[i / 2] == 0) {
+            timings_.legendre_ms += ms;
+            timings_.legendre_calls++;
+        }
+        else {
+            timings_.fourier_ms += ms;
+            timings_.fourier_calls++;
+        }
+    }
+    ev_used_ = 0;
+    ev_kind_.clear();
+}
+
+StageTimings Trans::timings() {
+    collect_timings();
+    return timings_;
+}
+
+void Trans::invtrans(int nb_scalar_fields, const double scalar_spectra[], double gp_fields[]) {
+    // TransLocal.cc:931-934
+    if (nb_scalar_fields <= 0) {
+        return;
+    }
+    if (cfg_.nparts != 1) {
+        throw std::logic_error("host invtrans needs nparts == 1");
+    }
+    const size_t nsp = nb_spectral_coefficients() * (size_t)nb_scalar_fields;
+    const size_t ngp = (size_t)geo_.npts * (size_t)nb_scalar_fields;
+    ensure(d_sp_, sp_cap_, nsp);
+    ensure(d_gp_, gp_cap_, ngp);
+    HIP_CHECK(hipMemcpyAsync(d_sp_, scalar_spectra, nsp * sizeof(double), hipMemcpyHostToDevice, stream_));
+    invtrans_uv_device(geo_.T, nb_scalar_fields, 0, d_sp_, d_gp_);
+    HIP_CHECK(hipMemcpyAsync(gp_fields, d_gp_, ngp * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    synchronize();
+}
+
+void Trans::ensure(double*& ptr, size_t& cap, size_t n) {
+    if (n > cap) {
+        synchronize();
+        if (ptr) {
+            HIP_CHECK(hipFree(ptr));
+            ptr = nullptr;
+        }
+        HIP_CHECK(hipMalloc((void**)&ptr, n * sizeof(double)));
+        cap = n;
+    }
+}
+
+void Trans::invtrans_device(int nb_scalar, const double* sp_dev, int nb_vordiv, const double* vor_dev,
+                            const double* div_dev, double* gp_dev) {
+    if (cfg_.nparts != 1) {
+        throw std::logic_error("invtrans_device on a sharded Trans: use the stage API");
+    }
+    if (nb_vordiv > 0) {
+        const int T       = geo_.T;
+        const int nall    = 2 * nb_vordiv + nb_scalar;
+        const size_t nout = size_t(T + 2) * size_t(T + 3) * size_t(nall);
+        ensure(d_all_, all_cap_, nout);
+        HIP_CHECK(launch_spectra_prepare(vor_dev, div_dev, sp_dev, d_all_, T, nb_vordiv, nb_scalar, stream_));
+        invtrans_uv_device(T + 1, nall, nb_vordiv, d_all_, gp_dev);  // TransLocal.cc:1590
+    }
+    else if (nb_scalar > 0) {
+        invtrans_uv_device(geo_.T, nb_scalar, 0, sp_dev, gp_dev);  // TransLocal.cc:1593-1595
+    }
+}
+
+void Trans::invtrans(int nb_scalar, const double sp[], int nb_vordiv, const double vor[], const double div[],
+                     double gp[]) {
+    if (nb_vordiv <= 0) {
+        invtrans(nb_scalar, sp, gp);
+        return;
+    }
+    nb_scalar          = std::max(nb_scalar, 0);
+    const size_t ncoef = nb_spectral_coefficients();
+    const size_t nvd   = ncoef * (size_t)nb_vordiv;
+    const size_t nsp   = ncoef * (size_t)nb_scalar;
+    const size_t ngp   = (size_t)geo_.npts * (size_t)(2 * nb_vordiv + nb_scalar);
+    ensure(d_vd_, vd_cap_, 2 * nvd);
+    ensure(d_sp_, sp_cap_, std::max<size_t>(nsp, 1));
+    ensure(d_gp_, gp_cap_, ngp);
+    HIP_CHECK(hipMemcpyAsync(d_vd_, vor, nvd * sizeof(double), hipMemcpyHostToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(d_vd_ + nvd, div, nvd * sizeof(double), hipMemcpyHostToDevice, stream_));
+    if (nsp) {
+        HIP_CHECK(hipMemcpyAsync(d_sp_, sp, nsp * sizeof(double), hipMemcpyHostToDevice, stream_));
+    }
+    invtrans_device(nb_scalar, d_sp_, nb_vordiv, d_vd_, d_vd_ + nvd, d_gp_);
+    HIP_CHECK(hipMemcpyAsync(gp, d_gp_, ngp * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    synchronize();
+}
+
+void Trans::export_legendre_cache(void* buffer) const {
+    double* sym  = (double*)buffer;
+    double* asym = sym + geo_.size_sym();
+    std::memset(buffer, 0, legendre_cache_bytes());
+    compute_legendre_tables_reference_layout(geo_, sym, asym);
+}
+
+}  // namespace trans
+}  // namespace atlas_amd

@@ -1,0 +1,112 @@
+// Spectral vorticity/divergence -> U,V (= u,v * cos(lat)) and assembly of the combined spectral array that
+// TransLocal feeds to invtrans_uv on the vor/div path.
+//
+// Reference being replaced (all three fused into one elementwise kernel):
+//   extend_truncation          TransLocal.cc:1496-1519   T -> T+1, new row/column zero
+//   vd2uv                      VorDivToUVLocal.cc:62-184  Temperton (1991) eq. 2.12/2.13, scaled by 1/a
+//   "merge all spectra"        TransLocal.cc:1567-1581   per (m,n,imag): [U fields][V fields][scalar fields]
+//
+// With eps(m,n) = sqrt((n^2-m^2)/(4n^2-1)), lap(n) = -a^2/(n(n+1)) (lap(0)=0), for m <= n <= T+1:
+//   chi  = m * lap(n),  psiM = (n-1) * eps(m,n) * lap(n-1),  psiP = (n+2) * eps(m,n+1) * lap(n+1)
+//   U_re = -chi*div_im(n) + psiM*vor_re(n-1) - psiP*vor_re(n+1)       U_im = +chi*div_re(n) + psiM*vor_im(n-1) - psiP*vor_im(n+1)
+//   V_re = -chi*vor_im(n) - psiM*div_re(n-1) + psiP*div_re(n+1)       V_im = +chi*vor_re(n) - psiM*div_im(n-1) + psiP*div_im(n+1)
+// (m = 0: real parts only, no chi terms; imaginary parts are 0), vor/div taken as 0 outside m <= n <= T.
+#include <hip/hip_runtime.h>
+
+#include "device_structs.h"
+
+namespace atlas_amd {
+namespace trans {
+
+constexpr double kEarthRadius = 6371229.;  // util::Earth::radius(), src/atlas/util/Earth.h:23
+
+struct PrepareParams {
+    const double* vor;  // [(T+1)(T+2)] x nvd, truncation T layout
+    const double* div;
+    const double* sp;   // scalars, truncation T layout, ns fields (may be null if ns == 0)
+    double* out;        // [(T+2)(T+3)] x (2*nvd + ns), truncation T+1 layout
+    int T;
+    int nvd;
+    int ns;
+};
+
+__device__ __forceinline__ double dev_eps(int m, int n) {
+    if (n < m || (m == 0 && n == 0)) {
+        return 0.;
+    }
+    return sqrt(((double)n * n - (double)m * m) / (4. * (double)n * n - 1.));
+}
+__device__ __forceinline__ double dev_lap(int n) {
+    if (n <= 0) {
+        return 0.;
+    }
+    return -kEarthRadius * kEarthRadius / (n * (n + 1.));
+}
+
+__global__ void __launch_bounds__(256) spectra_prepare_kernel(PrepareParams p) {
+    const int m    = blockIdx.y;
+    const int T    = p.T;
+    const int TE   = T + 1;
+    const int nall = 2 * p.nvd + p.ns;
+    const int len  = (TE - m + 1) * 2 * nall;  // (n - m, imag, fld) for this m
+    const long long obase = (long long)(2 * TE + 3 - m) * m / 2 * 2 * nall;
+    const long long ibase = (long long)(2 * T + 3 - m) * m / 2 * 2;  // x nf of the respective input
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < len; e += gridDim.x * blockDim.x) {
+        const int fld  = e % nall;
+        const int rest = e / nall;
+        const int imag = rest & 1;
+        const int n    = m + (rest >> 1);
+        double v       = 0.;
+        if (fld >= 2 * p.nvd) {
+            // scalar field, zero-extended (TransLocal.cc:1507-1513)
+            const int f = fld - 2 * p.nvd;
+            if (n <= T && m <= T) {
+                v = p.sp[(ibase + 2 * (n - m) + imag) * p.ns + f];
+            }
+        }
+        else if (m <= T || n <= T) {
+            const bool isV = fld >= p.nvd;
+            const int f    = isV ? fld - p.nvd : fld;
+            auto get = [&](const double* a, int nn, int im) -> double {
+                if (nn < m || nn > T || m > T) {
+                    return 0.;
+                }
+                return a[(ibase + 2 * (nn - m) + im) * p.nvd + f];
+            };
+            const double chi  = m * dev_lap(n);
+            const double psiM = (n - 1) * dev_eps(m, n) * dev_lap(n - 1);
+            const double psiP = (n + 2) * dev_eps(m, n + 1) * dev_lap(n + 1);
+            const double* A   = isV ? p.div : p.vor;  // the field the psi terms act on
+            const double* B   = isV ? p.vor : p.div;  // the field the chi term acts on
+            const double sg   = isV ? -1. : 1.;
+            double r;
+            if (m == 0) {
+                r = imag ? 0. : sg * (psiM * get(A, n - 1, 0) - psiP * get(A, n + 1, 0));
+            }
+            else if (imag == 0) {
+                r = -chi * get(B, n, 1) + sg * (psiM * get(A, n - 1, 0) - psiP * get(A, n + 1, 0));
+            }
+            else {
+                r = +chi * get(B, n, 0) + sg * (psiM * get(A, n - 1, 1) - psiP * get(A, n + 1, 1));
+            }
+            v = r * (1. / kEarthRadius);
+        }
+        p.out[obase + e] = v;
+    }
+}
+
+hipError_t launch_spectra_prepare(const double* vor, const double* div, const double* sp, double* out, int T, int nvd,
+                                  int ns, hipStream_t stream) {
+    PrepareParams p{vor, div, sp, out, T, nvd, ns};
+    const int nall = 2 * nvd + ns;
+    const int len0 = (T + 2) * 2 * nall;
+    dim3 grid((len0 + 255) / 256, T + 2);
+    if (grid.x > 64) {
+        grid.x = 64;
+    }
+    hipLaunchKernelGGL(spectra_prepare_kernel, grid, dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace trans
+}  // namespace atlas_amd

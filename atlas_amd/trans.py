@@ -1,0 +1,184 @@
+"""Host-side mirror of atlas::trans::Trans for type "local"
+(reference: src/atlas/trans/Trans.h:42-189, src/atlas/trans/local/TransLocal.cc:818-934,1409-1597).
+
+All arithmetic happens in the HIP library behind the C ABI (include/atlas_amd.h); this class only checks shapes
+and forwards pointers.  NumPy arrays go through the host-pointer entry points, torch CUDA tensors (or anything with
+`data_ptr()` and `is_cuda`) through the device-pointer entry points, asynchronously on the Trans stream."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .grid import StructuredGrid
+
+
+def _is_device(a):
+    return hasattr(a, "data_ptr") and bool(getattr(a, "is_cuda", False))
+
+
+def _ptr(a, n=None, name="array", writable=False):
+    """pointer of a contiguous float64 array/tensor with at least n elements"""
+    if a is None:
+        return None
+    if _is_device(a):
+        import torch
+        if a.dtype != torch.float64 or not a.is_contiguous():
+            raise TypeError(f"{name}: need a contiguous float64 tensor")
+        if n is not None and a.numel() < n:
+            raise ValueError(f"{name}: {a.numel()} elements, need {n}")
+        return a.data_ptr()
+    if not isinstance(a, np.ndarray) or a.dtype != np.float64 or not a.flags.c_contiguous:
+        raise TypeError(f"{name}: need a C-contiguous float64 numpy array")
+    if writable and not a.flags.writeable:
+        raise TypeError(f"{name}: not writable")
+    if n is not None and a.size < n:
+        raise ValueError(f"{name}: {a.size} elements, need {n}")
+    return a.ctypes.data
+
+
+class Trans:
+    """trans::Trans(grid, truncation, config) with option::type("local") semantics, running on an MI355X."""
+
+    def __init__(self, grid, truncation, profile=False, nparts=1, part=0, legendre_cache=None):
+        if isinstance(grid, str):
+            grid = StructuredGrid(name=grid)
+        self.grid = grid
+        cfg = f"profile={int(bool(profile))};nparts={int(nparts)};part={int(part)}"
+        cache_ptr, cache_size = None, 0
+        if legendre_cache is not None:
+            self._cache = np.ascontiguousarray(np.frombuffer(legendre_cache, dtype=np.uint8))
+            cache_ptr, cache_size = self._cache.ctypes.data, self._cache.size
+        self._h = _lib.check_ptr(_lib.Trans_new_config(grid._h, int(truncation), cfg.encode(), cache_ptr, cache_size))
+        self.nparts, self.part = int(nparts), int(part)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.Trans_delete(h)
+            self._h = None
+
+    # ---- atlas::trans::TransImpl accessors (TransImpl.h:38-60) ----
+    def truncation(self):
+        return _lib.Trans_truncation(self._h)
+
+    def nb_spectral_coefficients(self):
+        return _lib.Trans_nb_spectral_coefficients(self._h)
+
+    def nb_spectral_coefficients_global(self):
+        return _lib.Trans_nb_spectral_coefficients(self._h)
+
+    def nb_gridpoints(self):
+        return _lib.Trans_nb_gridpoints(self._h)
+
+    def nb_gridpoints_global(self):
+        return _lib.Trans_nb_gridpoints_global(self._h)
+
+    # ---- inverse transforms ----
+    def invtrans(self, nb_scalar_fields, scalar_spectra, *args):
+        """invtrans(nb_scalar, sp, gp)                                    TransLocal.cc:931-934
+           invtrans(nb_scalar, sp, nb_vordiv, vor, div, gp)               TransLocal.cc:1523-1597"""
+        ncoef = self.nb_spectral_coefficients()
+        npts = self.nb_gridpoints_global()
+        if len(args) == 1:
+            (gp,) = args
+            nf = int(nb_scalar_fields)
+            dev = _is_device(gp)
+            if dev != _is_device(scalar_spectra):
+                raise TypeError("spectra and grid-point arrays must both be host or both be device")
+            sp_p = _ptr(scalar_spectra, ncoef * nf, "scalar_spectra")
+            gp_p = _ptr(gp, npts * nf, "gp_fields", writable=True)
+            fn = _lib.Trans_invtrans_scalar_device if dev else _lib.Trans_invtrans_scalar
+            _lib.check(fn(self._h, nf, sp_p, gp_p))
+            return gp
+        if len(args) == 4:
+            nvd, vor, div, gp = args
+            ns, nvd = int(nb_scalar_fields), int(nvd)
+            dev = _is_device(gp)
+            sp_p = _ptr(scalar_spectra, ncoef * ns, "scalar_spectra") if ns > 0 else None
+            vor_p = _ptr(vor, ncoef * nvd, "vorticity_spectra") if nvd > 0 else None
+            div_p = _ptr(div, ncoef * nvd, "divergence_spectra") if nvd > 0 else None
+            gp_p = _ptr(gp, npts * (ns + 2 * nvd), "gp_fields", writable=True)
+            fn = _lib.Trans_invtrans_device if dev else _lib.Trans_invtrans
+            _lib.check(fn(self._h, ns, sp_p, nvd, vor_p, div_p, gp_p))
+            return gp
+        raise TypeError("invtrans(nb_scalar, sp, gp) or invtrans(nb_scalar, sp, nb_vordiv, vor, div, gp)")
+
+    def invtrans_vordiv2wind(self, nb_fields, vorticity_spectra, divergence_spectra, wind_fields):
+        """TransLocal.cc:1486-1490 (pointer API)"""
+        return self.invtrans(0, None, nb_fields, vorticity_spectra, divergence_spectra, wind_fields)
+
+    # ---- not implemented by TransLocal (TransLocal.cc:848-857,899-927,1599-1685) ----
+    def dirtrans(self, nb_fields, scalar_fields, scalar_spectra):
+        _lib.check(_lib.Trans_dirtrans_scalar(self._h, nb_fields, None, None))
+
+    def dirtrans_wind2vordiv(self, nb_fields, wind, vor, div):
+        _lib.check(_lib.Trans_dirtrans_wind2vordiv(self._h, nb_fields, None, None, None))
+
+    def invtrans_adj(self, nb_fields, gp, sp):
+        _lib.check(_lib.Trans_invtrans_adj_scalar(self._h, nb_fields, None, None))
+
+    # ---- streams / profiling ----
+    def synchronize(self):
+        _lib.check(_lib.Trans_synchronize(self._h))
+
+    def stream(self):
+        return _lib.Trans_stream(self._h)
+
+    def set_stream(self, hip_stream):
+        _lib.check(_lib.Trans_set_stream(self._h, hip_stream))
+
+    def use_torch_stream(self):
+        """run on torch's current CUDA(HIP) stream so that torch tensors are stream-ordered with the transform"""
+        import torch
+        self.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def set_profile(self, on):
+        _lib.check(_lib.Trans_set_profile(self._h, int(bool(on))))
+
+    def timings(self, reset=False):
+        out = (C.c_double * 4)()
+        _lib.check(_lib.Trans_timings(self._h, out, int(reset)))
+        return {"legendre_ms": out[0], "legendre_calls": int(out[1]), "fourier_ms": out[2],
+                "fourier_calls": int(out[3])}
+
+    # ---- Legendre cache (TransLocal.cc:608-647) ----
+    def legendre_cache(self):
+        n = _lib.Trans_legendre_cache_size(self._h)
+        buf = np.zeros(n, dtype=np.uint8)
+        _lib.check(_lib.Trans_legendre_cache_export(self._h, buf.ctypes.data, n))
+        return buf
+
+    # ---- stage API (multi-GPU driver, stage-level parity tests) ----
+    def fourier_row_pitch(self, nf):
+        return _lib.Trans_fourier_row_pitch(self._h, nf)
+
+    def fourier_size(self, nf):
+        return _lib.Trans_fourier_size(self._h, nf)
+
+    def owned_wavenumbers(self):
+        return _lib.Trans_owned_wavenumbers(self._h)
+
+    def bands(self):
+        out = np.zeros(self.nparts + 1, dtype=np.int32)
+        _lib.Trans_bands(self._h, out.ctypes.data)
+        return out
+
+    def nlat0(self):
+        out = np.zeros(self.truncation() + 1, dtype=np.int32)
+        _lib.Trans_nlat0(self._h, out.ctypes.data)
+        return out
+
+    def legendre_flops(self, nf):
+        return _lib.Trans_legendre_flops(self._h, nf)
+
+    def legendre_table_bytes(self):
+        return _lib.Trans_legendre_table_bytes(self._h)
+
+    def legendre_device(self, truncation_in, nf, spectra, fourier):
+        _lib.check(_lib.Trans_legendre_device(self._h, truncation_in, nf, _ptr(spectra), _ptr(fourier)))
+
+    def fourier_device(self, nf, nb_vordiv, parts, part_cnt, gp):
+        n = len(parts)
+        bases = (C.c_void_p * n)(*[_ptr(p) for p in parts])
+        cnts = (C.c_int * n)(*[int(c) for c in part_cnt])
+        _lib.check(_lib.Trans_fourier_device(self._h, nf, nb_vordiv, bases, cnts, _ptr(gp)))

@@ -1,0 +1,146 @@
+/*
+ * atlas_amd -- C ABI of the MI355X-native TransLocal inverse spherical-harmonics transform and HaloExchange.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ / torch types.  Every entry point names the
+ * reference (ecmwf/atlas 0.44.1) interface it replaces.  INTEGRATION.md shows the adapter a maintainer adds on
+ * the Atlas side (a TransImpl subclass registered with TransBuilderGrid, and a HaloExchange shim).
+ *
+ * Conventions
+ *   - functions returning int return 0 on success, non-zero on error; atlas_amd__last_error() gives the message
+ *     (the reference throws eckit::Exception through its extern "C" layer, TransInterface.cc:43-283; a C ABI
+ *     cannot, so the adapter re-throws).
+ *   - "_device" variants take device pointers and are asynchronous on the object's HIP stream;
+ *     the others take host pointers and are synchronous.
+ *   - layouts are exactly those of the reference (SURVEY.md section 8 "Layout cheat-sheet"):
+ *       spectra   sp[(2*pos(m,n) + imag)*nf + fld],  pos(m,n) = (2T+3-m)*m/2 + (n-m)     (TransLocal.cc:970-987)
+ *       gridpoint gp[fld*npts + rowoffset(jlat) + jlon]                                   (TransLocal.cc:1132,1187)
+ */
+#ifndef ATLAS_AMD_H
+#define ATLAS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct atlas_amd_Grid atlas_amd_Grid;
+typedef struct atlas_amd_Trans atlas_amd_Trans;
+typedef struct atlas_amd_HaloExchange atlas_amd_HaloExchange;
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * errors / library info
+ * ------------------------------------------------------------------------------------------------------------- */
+const char* atlas_amd__last_error(void);
+const char* atlas_amd__version(void);
+/* number of visible HIP devices (0: the transform cannot run; there is no CPU fallback) */
+int atlas_amd__device_count(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Grid description.  Replaces the `const Grid::Implementation*` argument of atlas__Trans__new
+ * (src/atlas/trans/detail/TransInterface.h:52-54): the adapter passes ny, nx(j), y(j) of its StructuredGrid.
+ * ------------------------------------------------------------------------------------------------------------- */
+/* "F<N>" regular Gaussian / "O<N>" octahedral Gaussian (src/atlas/grid/detail/grid/Gaussian.cc:111-177) */
+atlas_amd_Grid* atlas_amd__Grid__new_gaussian(const char* name);
+/* any global structured grid: ny latitudes (degrees, north to south), nx[j] points per latitude, xmin = 0 */
+atlas_amd_Grid* atlas_amd__Grid__new_structured(int ny, const int nx[], const double lat_deg[]);
+void atlas_amd__Grid__delete(atlas_amd_Grid* g);
+int atlas_amd__Grid__ny(const atlas_amd_Grid* g);
+int atlas_amd__Grid__nxmax(const atlas_amd_Grid* g);
+int64_t atlas_amd__Grid__size(const atlas_amd_Grid* g);
+int atlas_amd__Grid__regular(const atlas_amd_Grid* g);
+int atlas_amd__Grid__nx(const atlas_amd_Grid* g, int nx_out[]);
+int atlas_amd__Grid__y(const atlas_amd_Grid* g, double lat_deg_out[]);
+/* Gaussian latitudes north pole -> south pole, 2N values
+ * (src/atlas/grid/detail/spacing/gaussian/Latitudes.cc:41-67) */
+int atlas_amd__gaussian_latitudes_npole_spole(int N, double lats_out[]);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Trans.  Replaces atlas__Trans__* (src/atlas/trans/detail/TransInterface.h:44-107) for type "local".
+ * ------------------------------------------------------------------------------------------------------------- */
+/* atlas__Trans__new(grid, truncation)                                        TransInterface.h:52 */
+atlas_amd_Trans* atlas_amd__Trans__new(const atlas_amd_Grid* grid, int truncation);
+/* atlas__Trans__new_config(grid, truncation, config).  `config` is "key=value;key=value" with keys
+ *   profile=0|1          record HIP events around the two stages (atlas_amd__Trans__timings)
+ *   nparts=P;part=p      multi-GPU decomposition: this object owns wavenumbers m%P==p and latitude band p
+ * legendre_cache / size: optional Legendre cache blob in TransLocal's file layout (TransLocal.cc:608-614), or NULL */
+atlas_amd_Trans* atlas_amd__Trans__new_config(const atlas_amd_Grid* grid, int truncation, const char* config,
+                                              const void* legendre_cache, size_t legendre_cache_size);
+void atlas_amd__Trans__delete(atlas_amd_Trans* t);                           /* atlas__Trans__delete      :55 */
+int atlas_amd__Trans__truncation(const atlas_amd_Trans* t);                  /* atlas__Trans__truncation  :99 */
+int64_t atlas_amd__Trans__nb_gridpoints(const atlas_amd_Trans* t);           /* local band (== global for nparts=1) */
+int64_t atlas_amd__Trans__nb_gridpoints_global(const atlas_amd_Trans* t);
+int64_t atlas_amd__Trans__nb_spectral_coefficients(const atlas_amd_Trans* t); /* (T+1)(T+2), TransLocal.h:90 */
+
+/* atlas__Trans__invtrans_scalar(t, nb_fields, sp, gp)                         TransInterface.h:77 */
+int atlas_amd__Trans__invtrans_scalar(atlas_amd_Trans* t, int nb_fields, const double scalar_spectra[],
+                                      double scalar_fields[]);
+/* atlas__Trans__invtrans(t, nb_scalar, sp, nb_vordiv, vor, div, gp, config)   TransInterface.h:74
+ * gp holds [u fields][v fields][scalar fields] (TransLocal.cc:1567-1596) */
+int atlas_amd__Trans__invtrans(atlas_amd_Trans* t, int nb_scalar_fields, const double scalar_spectra[],
+                               int nb_vordiv_fields, const double vorticity_spectra[],
+                               const double divergence_spectra[], double gp_fields[]);
+/* atlas__Trans__invtrans_vordiv2wind(t, nb_fields, vor, div, wind)            TransInterface.h:79 */
+int atlas_amd__Trans__invtrans_vordiv2wind(atlas_amd_Trans* t, int nb_fields, const double vorticity_spectra[],
+                                           const double divergence_spectra[], double wind_fields[]);
+/* device-pointer variants (asynchronous on the Trans stream) */
+int atlas_amd__Trans__invtrans_scalar_device(atlas_amd_Trans* t, int nb_fields, const double* scalar_spectra_dev,
+                                             double* scalar_fields_dev);
+int atlas_amd__Trans__invtrans_device(atlas_amd_Trans* t, int nb_scalar_fields, const double* scalar_spectra_dev,
+                                      int nb_vordiv_fields, const double* vorticity_spectra_dev,
+                                      const double* divergence_spectra_dev, double* gp_fields_dev);
+/* direct transforms and adjoints: not implemented by TransLocal either (TransLocal.cc:848-857,899-927,1599-1685);
+ * these return an error whose message starts with "Not implemented" */
+int atlas_amd__Trans__dirtrans_scalar(atlas_amd_Trans* t, int nb_fields, const double scalar_fields[],
+                                      double scalar_spectra[]);
+int atlas_amd__Trans__dirtrans_wind2vordiv(atlas_amd_Trans* t, int nb_fields, const double wind_fields[],
+                                           double vorticity_spectra[], double divergence_spectra[]);
+int atlas_amd__Trans__invtrans_adj_scalar(atlas_amd_Trans* t, int nb_fields, const double gp_fields[],
+                                          double scalar_spectra[]);
+
+/* stream control */
+void* atlas_amd__Trans__stream(atlas_amd_Trans* t);              /* hipStream_t */
+int atlas_amd__Trans__set_stream(atlas_amd_Trans* t, void* hip_stream);
+int atlas_amd__Trans__synchronize(atlas_amd_Trans* t);
+
+/* Legendre cache, byte-compatible with TransLocal's write_legendre / LegendreCache blobs
+ * (TransLocal.cc:638-647, src/atlas/trans/Cache.h:98-136) */
+size_t atlas_amd__Trans__legendre_cache_size(const atlas_amd_Trans* t);
+int atlas_amd__Trans__legendre_cache_export(const atlas_amd_Trans* t, void* buffer, size_t size);
+
+/* the two stages separately: multi-GPU drivers and stage-level parity tests.
+ * Fourier intermediate layout: F[(lat*m_cnt + m/nparts)*RP + 2*fld + imag], RP = fourier_row_pitch */
+int atlas_amd__Trans__fourier_row_pitch(const atlas_amd_Trans* t, int nb_fields);
+int64_t atlas_amd__Trans__fourier_size(const atlas_amd_Trans* t, int nb_fields); /* doubles */
+int atlas_amd__Trans__owned_wavenumbers(const atlas_amd_Trans* t);
+int atlas_amd__Trans__bands(const atlas_amd_Trans* t, int bands_out[] /* nparts+1 */);
+int atlas_amd__Trans__legendre_device(atlas_amd_Trans* t, int truncation_in, int nb_fields,
+                                      const double* spectra_dev, double* fourier_dev);
+int atlas_amd__Trans__fourier_device(atlas_amd_Trans* t, int nb_fields, int nb_vordiv_fields,
+                                     const double* const part_base_dev[], const int part_cnt[], double* gp_dev);
+
+/* introspection used by tests */
+int atlas_amd__Trans__nlat0(const atlas_amd_Trans* t, int nlat0_out[] /* T+1 */);
+double atlas_amd__Trans__legendre_flops(const atlas_amd_Trans* t, int nb_fields);
+int64_t atlas_amd__Trans__legendre_table_bytes(const atlas_amd_Trans* t);
+/* accumulated kernel times from HIP events on the Trans stream (profile=1):
+ * out = {legendre_ms, legendre_calls, fourier_ms, fourier_calls}; reset != 0 clears the accumulators */
+int atlas_amd__Trans__timings(atlas_amd_Trans* t, double out[4], int reset);
+int atlas_amd__Trans__set_profile(atlas_amd_Trans* t, int on);
+
+/* host-only helpers exposed for CPU tests of the host logic (no GPU needed) */
+int atlas_amd__fourier_truncation(int truncation, int nx, int nxmax, int ndgl, double lat_rad, int fullgrid);
+/* Legendre tables in the reference layout for (grid, truncation): sizes via *_size, then fill */
+int atlas_amd__legendre_reference_tables(const atlas_amd_Grid* grid, int truncation, double* leg_sym,
+                                         size_t size_sym, double* leg_asym, size_t size_asym);
+int atlas_amd__legendre_reference_sizes(const atlas_amd_Grid* grid, int truncation, size_t* size_sym,
+                                        size_t* size_asym);
+/* run ONE row of the c2r transform on the host with the kernel's own phase code (fft_core.h); modes: n/2+1
+ * interleaved complex values; out: n reals.  Test hook only -- the product never computes on the CPU. */
+int atlas_amd__fft_host_row(int n, const double* modes, int mmax, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,175 @@
+"""ctypes front-end of oracle/translocal_oracle.c (TEST INFRASTRUCTURE ONLY)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("translocal_oracle.c", "halo_oracle.c")]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        vp, i, d, sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
+        L.orc_fourier_truncation.restype = i
+        L.orc_fourier_truncation.argtypes = [i, i, i, i, d, i]
+        L.orc_num_n.restype = sz
+        L.orc_num_n.argtypes = [i, i, i]
+        L.orc_compute_zfn.argtypes = [i, vp]
+        L.orc_legendre_lat.argtypes = [i, d, vp, vp, vp, vp]
+        L.orc_plan_create.restype = vp
+        L.orc_plan_create.argtypes = [i, i, vp, vp, i, i]
+        L.orc_plan_destroy.argtypes = [vp]
+        L.orc_plan_nlat0.restype = i
+        L.orc_plan_nlat0.argtypes = [vp, i]
+        L.orc_plan_nlats_leg.restype = i
+        L.orc_plan_nlats_leg.argtypes = [vp]
+        L.orc_plan_nlats_legr.restype = i
+        L.orc_plan_nlats_legr.argtypes = [vp]
+        L.orc_plan_npts.restype = C.c_int64
+        L.orc_plan_npts.argtypes = [vp]
+        for f in ("orc_plan_size_sym", "orc_plan_size_asym"):
+            getattr(L, f).restype = sz
+            getattr(L, f).argtypes = [vp]
+        for f in ("orc_plan_leg_sym", "orc_plan_leg_asym"):
+            getattr(L, f).restype = vp
+            getattr(L, f).argtypes = [vp]
+        for f in ("orc_plan_begin_sym", "orc_plan_begin_asym"):
+            getattr(L, f).restype = sz
+            getattr(L, f).argtypes = [vp, i]
+        L.orc_invtrans.argtypes = [vp, i, vp, vp, i]
+        L.orc_invtrans_uv.argtypes = [vp, i, i, i, vp, vp, i]
+        L.orc_invtrans_legendre_only.argtypes = [vp, i, i, vp, vp]
+        L.orc_invtrans_fourier.argtypes = [vp, i, vp, vp, i]
+        L.orc_invtrans_rows.argtypes = [vp, i, i, vp, i, vp, vp, i]
+        L.orc_c2r_direct.argtypes = [i, vp, vp]
+        L.orc_c2r_fft.argtypes = [i, vp, vp]
+        _lib = L
+    return _lib
+
+
+def fourier_truncation(truncation, nx, nxmax, ndgl, lat_rad, fullgrid):
+    return lib().orc_fourier_truncation(truncation, nx, nxmax, ndgl, float(lat_rad), int(bool(fullgrid)))
+
+
+def legendre_lat(trc, lat_rad):
+    """packed triangle legpol[idx(m,n)], idx = (2*trc+3-m)*m/2 + n-m  (LegendrePolynomials.cc:47-151)"""
+    L = lib()
+    zfn = np.zeros((trc + 1) * (trc + 1))
+    L.orc_compute_zfn(trc, zfn.ctypes.data)
+    legpol = np.zeros((trc + 2) * (trc + 1) // 2)
+    vs, vc = np.zeros(trc + 1), np.zeros(trc + 1)
+    L.orc_legendre_lat(trc, float(lat_rad), legpol.ctypes.data, zfn.ctypes.data, vs.ctypes.data, vc.ctypes.data)
+    return legpol
+
+
+def c2r_direct(n, half_spectrum):
+    x = np.ascontiguousarray(half_spectrum, dtype=np.complex128)
+    assert x.size == n // 2 + 1
+    out = np.zeros(n)
+    lib().orc_c2r_direct(n, x.ctypes.data, out.ctypes.data)
+    return out
+
+
+def c2r_fft(n, half_spectrum):
+    x = np.ascontiguousarray(half_spectrum, dtype=np.complex128)
+    assert x.size == n // 2 + 1
+    out = np.zeros(n)
+    lib().orc_c2r_fft(n, x.ctypes.data, out.ctypes.data)
+    return out
+
+
+class OraclePlan:
+    """TransLocal constructor geometry + tables for a global structured grid (oracle side)."""
+
+    def __init__(self, truncation, nx, lat_deg, regular=None, with_tables=True):
+        self.T = int(truncation)
+        self.nx = np.ascontiguousarray(nx, dtype=np.int32)
+        self.lat = np.ascontiguousarray(lat_deg, dtype=np.float64)
+        self.nlats = len(self.nx)
+        self.regular = bool(np.all(self.nx == self.nx[0])) if regular is None else bool(regular)
+        self._h = lib().orc_plan_create(self.T, self.nlats, self.nx.ctypes.data, self.lat.ctypes.data,
+                                        int(self.regular), int(with_tables))
+        self.npts = int(lib().orc_plan_npts(self._h))
+        self.with_tables = with_tables
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_plan_destroy(self._h)
+            self._h = None
+
+    @property
+    def nlat0(self):
+        return np.array([lib().orc_plan_nlat0(self._h, m) for m in range(self.T + 1)], dtype=np.int32)
+
+    def nspec(self, nf, trc=None):
+        trc = self.T if trc is None else trc
+        return (trc + 1) * (trc + 2) * nf
+
+    def tables(self):
+        L = lib()
+        ns, na = L.orc_plan_size_sym(self._h), L.orc_plan_size_asym(self._h)
+        sym = np.ctypeslib.as_array(C.cast(L.orc_plan_leg_sym(self._h), C.POINTER(C.c_double)), shape=(ns,))
+        asym = np.ctypeslib.as_array(C.cast(L.orc_plan_leg_asym(self._h), C.POINTER(C.c_double)), shape=(na,))
+        return sym, asym
+
+    def begin(self, m):
+        return lib().orc_plan_begin_sym(self._h, m), lib().orc_plan_begin_asym(self._h, m)
+
+    def invtrans(self, nf, sp, use_fft=False):
+        sp = np.ascontiguousarray(sp, dtype=np.float64)
+        assert sp.size == self.nspec(nf)
+        gp = np.zeros(nf * self.npts)
+        lib().orc_invtrans(self._h, nf, sp.ctypes.data, gp.ctypes.data, int(use_fft))
+        return gp
+
+    def invtrans_uv(self, trc, nf, nb_vordiv, sp, use_fft=False):
+        sp = np.ascontiguousarray(sp, dtype=np.float64)
+        assert sp.size == self.nspec(nf, trc)
+        gp = np.zeros(nf * self.npts)
+        lib().orc_invtrans_uv(self._h, trc, nf, nb_vordiv, sp.ctypes.data, gp.ctypes.data, int(use_fft))
+        return gp
+
+    def legendre(self, nf, sp, trc=None):
+        """Fourier intermediate in the reference layout [fld][lat][m][re,im] (TransLocal.h:177-180)"""
+        trc = self.T if trc is None else trc
+        sp = np.ascontiguousarray(sp, dtype=np.float64)
+        out = np.zeros(nf * 2 * self.nlats * (self.T + 1))
+        lib().orc_invtrans_legendre_only(self._h, trc, nf, sp.ctypes.data, out.ctypes.data)
+        return out.reshape(nf, self.nlats, self.T + 1, 2)
+
+    def fourier(self, nf, scl_fourier, use_fft=False):
+        f = np.ascontiguousarray(scl_fourier, dtype=np.float64)
+        gp = np.zeros(nf * self.npts)
+        lib().orc_invtrans_fourier(self._h, nf, f.ctypes.data, gp.ctypes.data, int(use_fft))
+        return gp
+
+    def invtrans_rows(self, nf, sp, rows, trc=None, use_fft=False):
+        """grid-point rows `rows` (all nf fields each) without building tables: list of arrays [nf][nx(row)]"""
+        trc = self.T if trc is None else trc
+        sp = np.ascontiguousarray(sp, dtype=np.float64)
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        total = int(sum(nf * int(self.nx[r]) for r in rows))
+        out = np.zeros(total)
+        lib().orc_invtrans_rows(self._h, trc, nf, sp.ctypes.data, len(rows), rows.ctypes.data, out.ctypes.data,
+                                int(use_fft))
+        res, off = [], 0
+        for r in rows:
+            n = int(self.nx[r])
+            res.append(out[off:off + nf * n].reshape(nf, n))
+            off += nf * n
+        return res

@@ -1,0 +1,750 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- CPU oracle for the atlas::trans::TransLocal inverse spherical-harmonics
+ * transform (global structured Gaussian / lon-lat grids).
+ *
+ * This file is a plain-C restatement of the reference ALGORITHM (not its code).  It exists so that
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg can check / time the HIP path against
+ * an independent implementation.  Nothing under atlas_amd/ may include, link or call it.
+ *
+ * Every function cites the reference file:line (ecmwf/atlas 0.44.1) whose behaviour it follows.
+ * The oracle is pinned by tests/test_oracle_*.py against the reference's own known-answer tests
+ * (analytic spherical harmonics, src/tests/trans/test_transgeneral.cc:80-374,433-449,472-489) and against
+ * independent mpmath / numpy.fft (pocketfft) evaluations -- see oracle/README.md.
+ *
+ * Build: gcc -O2 -fopenmp -shared -fPIC translocal_oracle.c -o liboracle.so -lm
+ */
+#include <math.h>
+#include <float.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_DEG2RAD (M_PI / 180.)
+#define ORC_PIL 3.14159265358979323846264338327950288L
+/* TransLocal.cc:49 : latitudes are clamped to +-89.9999999 deg before use */
+#define ORC_LATPOLE 89.9999999
+
+/* ------------------------------------------------------------------------------------------------
+ * a1  fourier_truncation   (TransLocal.cc:272-300)
+ * ---------------------------------------------------------------------------------------------- */
+int orc_fourier_truncation(int truncation, int nx, int nxmax, int ndgl, double lat_rad, int fullgrid) {
+    (void)nxmax; /* unused in the reference as well (:274) */
+    int trc     = truncation;
+    int trclin  = ndgl - 1;
+    int trcquad = ndgl * 2 / 3 - 1;
+    if (truncation >= trclin || fullgrid) {
+        trc = (nx - 1) / 2; /* linear */
+    }
+    else if (truncation >= trcquad) {
+        /* quadratic: NB the weight is an INTEGER division in the reference (:287) */
+        double weight = (double)(3 * (trclin - truncation) / ndgl);
+        double c      = cos(lat_rad);
+        double sqcos  = pow(c, 2);
+        trc           = (int)((nx - 1) / (2 + weight * sqcos));
+    }
+    else {
+        double c     = cos(lat_rad);
+        double sqcos = pow(c, 2);
+        trc          = (int)((nx - 1) / (2 + sqcos) - 1); /* cubic */
+    }
+    return trc < truncation ? trc : truncation;
+}
+
+/* num_n (TransLocal.cc:183-187): number of total wavenumbers n in [m, trc] with (n-m) even / odd */
+size_t orc_num_n(int trc, int m, int symmetric) {
+    int len = (trc - m + (symmetric ? 2 : 1)) / 2;
+    return (size_t)(len < 0 ? 0 : len);
+}
+
+/* add_padding (TransLocal.cc:236-238): round up to a multiple of 8 doubles */
+static size_t orc_pad8(size_t n) {
+    return (size_t)(ceil(n / 8.)) * 8;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a4  compute_zfn  (LegendrePolynomials.cc:24-45)  Fourier coefficients of the ordinary Legendre
+ *     polynomials (Belousov), IFS normalisation 0.5*int(P^2)=1.   zfn is (trc+1) x (trc+1), row n.
+ * ---------------------------------------------------------------------------------------------- */
+void orc_compute_zfn(int trc, double* zfn) {
+    const size_t ld = (size_t)trc + 1;
+    zfn[0]          = 2.;
+    for (int n = 1; n <= trc; ++n) {
+        double v = zfn[0];
+        for (int j = 1; j <= n; ++j) {
+            v *= sqrt(1. - 0.25 / ((double)j * (double)j));
+        }
+        zfn[(size_t)n * ld + n] = v;
+        int odd                 = n % 2;
+        for (int j = 2; j <= n - odd; j += 2) {
+            double num                    = (j - 1.) * (2. * n - j + 2.);
+            double den                    = j * (2. * n - j + 1.);
+            zfn[(size_t)n * ld + (n - j)] = zfn[(size_t)n * ld + (n - j + 2)] * num / den;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a5  compute_legendre_polynomials_lat (LegendrePolynomials.cc:47-151)
+ *     legpol is the packed triangle: index(m,n) = (2*trc+3-m)*m/2 + n-m, 0<=m<=n<=trc.
+ *     NB: like the reference (:102) this zeroes zfn(n,0) for odd n as a side effect.
+ * ---------------------------------------------------------------------------------------------- */
+static inline size_t orc_idxmn(int trc, int m, int n) {
+    return (size_t)(2 * trc + 3 - m) * (size_t)m / 2 + (size_t)(n - m);
+}
+
+void orc_legendre_lat(int trc, double lat_rad, double* legpol, double* zfn, double* vsin, double* vcos) {
+    const size_t ld      = (size_t)trc + 1;
+    double theta         = M_PI_2 - lat_rad;
+    double x             = cos(theta);
+    volatile double sint = sqrt(1. - x * x); /* :61 sin(theta) computed like the IFS trans library */
+
+    legpol[orc_idxmn(trc, 0, 0)] = 1.;
+    for (int j = 1; j <= trc; ++j) {
+        vsin[j] = sin(j * theta);
+        vcos[j] = cos(j * theta);
+    }
+    double inv_sint = 0.;
+    if (fabs(sint) <= sqrt(DBL_EPSILON)) { /* :72 closer than ~1 m to the pole */
+        x    = 1.;
+        sint = 0.;
+    }
+    else {
+        inv_sint = 1. / sint;
+    }
+    /* m = 0 and m = 1 columns from the cos / sin series (:85-115) */
+    for (int n = 2; n <= trc; n += 2) {
+        double p0 = 0.5 * zfn[(size_t)n * ld + 0];
+        double p1 = 0.;
+        double sq = 1. / sqrt(n * (n + 1.));
+        for (int k = 2; k <= n; k += 2) {
+            p0 = p0 + zfn[(size_t)n * ld + k] * vcos[k];
+            p1 = p1 + sq * zfn[(size_t)n * ld + k] * k * vsin[k];
+        }
+        legpol[orc_idxmn(trc, 0, n)] = p0;
+        legpol[orc_idxmn(trc, 1, n)] = p1;
+    }
+    for (int n = 1; n <= trc; n += 2) {
+        zfn[(size_t)n * ld + 0] = 0.;
+        double p0               = 0.;
+        double p1               = 0.;
+        double sq               = 1. / sqrt(n * (n + 1.));
+        for (int k = 1; k <= n; k += 2) {
+            p0 = p0 + zfn[(size_t)n * ld + k] * vcos[k];
+            p1 = p1 + sq * zfn[(size_t)n * ld + k] * k * vsin[k];
+        }
+        legpol[orc_idxmn(trc, 0, n)] = p0;
+        legpol[orc_idxmn(trc, 1, n)] = p1;
+    }
+    /* diagonal, Belousov (23) with underflow flush (:122-130) */
+    double tiny = inv_sint * DBL_MIN;
+    for (int n = 2; n <= trc; ++n) {
+        double sq = sqrt((2. * n + 1.) / (2. * n));
+        double v  = legpol[orc_idxmn(trc, n - 1, n - 1)] * sint * sq;
+        if (fabs(v) < tiny) {
+            v = 0.0;
+        }
+        legpol[orc_idxmn(trc, n, n)] = v;
+    }
+    /* general recurrence, Belousov (17) (:136-149) */
+    for (int n = 3; n <= trc; ++n) {
+        for (int m = 2; m < n; ++m) {
+            double cn = ((2. * n + 1.) * (n + m - 3.) * (n + m - 1.));
+            double cd = ((2. * n - 3.) * (n + m - 2.) * (n + m));
+            double dn = ((2. * n + 1.) * (n - m + 1.) * (n + m - 1.));
+            double dd = ((2. * n - 1.) * (n + m - 2.) * (n + m));
+            double en = ((2. * n + 1.) * (n - m));
+            double ed = ((2. * n - 1.) * (n + m));
+            legpol[orc_idxmn(trc, m, n)] = sqrt(cn / cd) * legpol[orc_idxmn(trc, m - 2, n - 2)] -
+                                           sqrt(dn / dd) * legpol[orc_idxmn(trc, m - 2, n - 1)] * x +
+                                           sqrt(en / ed) * legpol[orc_idxmn(trc, m, n - 1)] * x;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a3  table offsets (TransLocal.cc:592-606).  trc_leg = T+1.  begin arrays have trc_leg+2 entries.
+ * ---------------------------------------------------------------------------------------------- */
+void orc_legendre_offsets(int trc_leg, int nlats_leg, size_t* begin_sym, size_t* begin_asym) {
+    size_t ss = 0, sa = 0;
+    begin_sym[0]  = 0;
+    begin_asym[0] = 0;
+    for (int m = 0; m <= trc_leg; ++m) {
+        ss += orc_pad8(orc_num_n(trc_leg, m, 1) * (size_t)nlats_leg);
+        sa += orc_pad8(orc_num_n(trc_leg, m, 0) * (size_t)nlats_leg);
+        begin_sym[m + 1]  = ss;
+        begin_asym[m + 1] = sa;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a6  compute_legendre_polynomials (LegendrePolynomials.cc:154-209): scatter each latitude's triangle
+ *     into the symmetric / antisymmetric tables, block m column-major K x nlats, n DESCENDING.
+ * ---------------------------------------------------------------------------------------------- */
+void orc_legendre_tables(int trc, int nlats, const double* lats_rad, double* leg_sym, double* leg_asym,
+                         const size_t* begin_sym, const size_t* begin_asym) {
+    size_t tri   = (size_t)(trc + 2) * (size_t)(trc + 1) / 2;
+    double* zfn0 = (double*)calloc((size_t)(trc + 1) * (trc + 1), sizeof(double));
+    orc_compute_zfn(trc, zfn0);
+#pragma omp parallel
+    {
+        double* legpol = (double*)malloc(tri * sizeof(double));
+        double* zfn    = (double*)malloc((size_t)(trc + 1) * (trc + 1) * sizeof(double));
+        double* vsin   = (double*)malloc((size_t)(trc + 1) * sizeof(double));
+        double* vcos   = (double*)malloc((size_t)(trc + 1) * sizeof(double));
+        memcpy(zfn, zfn0, (size_t)(trc + 1) * (trc + 1) * sizeof(double));
+#pragma omp for schedule(dynamic, 1)
+        for (int jlat = 0; jlat < nlats; ++jlat) {
+            orc_legendre_lat(trc, lats_rad[jlat], legpol, zfn, vsin, vcos);
+            for (int m = 0; m <= trc; ++m) {
+                size_t ks = orc_num_n(trc, m, 1), ka = orc_num_n(trc, m, 0);
+                size_t is = 0, ia = 0;
+                for (int n = trc; n >= m; --n) {
+                    if ((n - m) % 2 == 0) {
+                        leg_sym[begin_sym[m] + ks * (size_t)jlat + is++] = legpol[orc_idxmn(trc, m, n)];
+                    }
+                    else {
+                        leg_asym[begin_asym[m] + ka * (size_t)jlat + ia++] = legpol[orc_idxmn(trc, m, n)];
+                    }
+                }
+            }
+        }
+        free(legpol);
+        free(zfn);
+        free(vsin);
+        free(vcos);
+    }
+    free(zfn0);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Plan: the geometry TransLocal's constructor derives for a GLOBAL structured grid
+ * (TransLocal.cc:371-488, 533-558).  Cropped domains are out of scope.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct orc_plan {
+    int T;          /* truncation_ */
+    int nlats;      /* g.ny() == nlatsGlobal_ */
+    int nlats_nh;   /* nlatsNH_ */
+    int nlats_sh;   /* nlatsSH_ */
+    int nlats_leg;  /* nlatsLeg_ = (nlatsGlobal+1)/2 */
+    int nlats_legr; /* nlatsLegReduced_ (== nlatsLegDomain_ for a global grid) */
+    int regular;    /* RegularGrid(gridGlobal_) */
+    int nxmax;
+    int64_t npts;
+    int* nx;         /* [nlats] */
+    double* lat_deg; /* [nlats] */
+    int* nlat0;      /* [T+1] */
+    size_t* begin_sym;
+    size_t* begin_asym; /* [T+3] */
+    double* leg_sym;
+    double* leg_asym; /* NULL when built without tables */
+    double* lats_leg; /* [nlats_leg] radians, clamped */
+} orc_plan;
+
+static int orc_approx_zero(double v) { /* eckit::types::is_approximately_equal(lat, 0.) default eps */
+    return fabs(v) <= DBL_EPSILON;
+}
+
+orc_plan* orc_plan_create(int T, int nlats, const int* nx, const double* lat_deg, int regular, int with_tables) {
+    orc_plan* p = (orc_plan*)calloc(1, sizeof(orc_plan));
+    p->T        = T;
+    p->nlats    = nlats;
+    p->regular  = regular;
+    p->nx       = (int*)malloc(sizeof(int) * nlats);
+    p->lat_deg  = (double*)malloc(sizeof(double) * nlats);
+    memcpy(p->nx, nx, sizeof(int) * nlats);
+    memcpy(p->lat_deg, lat_deg, sizeof(double) * nlats);
+    int neq = 0;
+    for (int j = 0; j < nlats; ++j) { /* :371-380 */
+        double lat = lat_deg[j];
+        if (orc_approx_zero(lat)) neq++;
+        else if (lat < 0) p->nlats_sh++;
+        else p->nlats_nh++;
+        if (nx[j] > p->nxmax) p->nxmax = nx[j];
+        p->npts += nx[j];
+    }
+    if (neq > 0) { /* :381-384 */
+        p->nlats_nh++;
+        p->nlats_sh++;
+    }
+    int nlats_leg_domain = p->nlats_nh >= p->nlats_sh ? p->nlats_nh : p->nlats_sh; /* :385-390 */
+    p->nlats_leg         = (nlats + 1) / 2;                                         /* :435 */
+    int jlat_min_leg     = 0; /* global grid: jlatMin_ = 0 and NH>=SH, so jlatMinLeg_ = 0 (:441-457) */
+    p->nlats_legr        = jlat_min_leg + nlats_leg_domain; /* :459 */
+
+    /* nlat0 (:462-488) */
+    p->nlat0  = (int*)malloc(sizeof(int) * (T + 1));
+    int nmen0 = -1;
+    for (int jlat = 0; jlat < nlats / 2; ++jlat) {
+        double lat = lat_deg[jlat] * ORC_DEG2RAD;
+        int nmen   = orc_fourier_truncation(T, nx[jlat], p->nxmax, nlats, lat, regular);
+        if (nmen0 > nmen) nmen = nmen0;
+        int ndgluj = jlat_min_leg > jlat ? jlat_min_leg : jlat;
+        for (int j = nmen0 + 1; j <= nmen; ++j) p->nlat0[j] = ndgluj;
+        nmen0 = nmen;
+    }
+    for (int j = nmen0 + 1; j <= T; ++j) p->nlat0[j] = p->nlats_leg;
+
+    /* latitudes of the Legendre rows, clamped, radians (:533-545) */
+    p->lats_leg = (double*)malloc(sizeof(double) * p->nlats_leg);
+    for (int j = 0; j < p->nlats_leg; ++j) {
+        double lat = lat_deg[j];
+        if (lat > ORC_LATPOLE) lat = ORC_LATPOLE;
+        if (lat < -ORC_LATPOLE) lat = -ORC_LATPOLE;
+        p->lats_leg[j] = lat * ORC_DEG2RAD;
+    }
+    p->begin_sym  = (size_t*)malloc(sizeof(size_t) * (T + 3));
+    p->begin_asym = (size_t*)malloc(sizeof(size_t) * (T + 3));
+    orc_legendre_offsets(T + 1, p->nlats_leg, p->begin_sym, p->begin_asym);
+    if (with_tables) {
+        p->leg_sym  = (double*)calloc(p->begin_sym[T + 2], sizeof(double));
+        p->leg_asym = (double*)calloc(p->begin_asym[T + 2], sizeof(double));
+        orc_legendre_tables(T + 1, p->nlats_leg, p->lats_leg, p->leg_sym, p->leg_asym, p->begin_sym, p->begin_asym);
+    }
+    return p;
+}
+
+void orc_plan_destroy(orc_plan* p) {
+    if (!p) return;
+    free(p->nx);
+    free(p->lat_deg);
+    free(p->nlat0);
+    free(p->begin_sym);
+    free(p->begin_asym);
+    free(p->leg_sym);
+    free(p->leg_asym);
+    free(p->lats_leg);
+    free(p);
+}
+
+/* accessors for ctypes */
+int orc_plan_nlat0(const orc_plan* p, int m) { return p->nlat0[m]; }
+int orc_plan_nlats_leg(const orc_plan* p) { return p->nlats_leg; }
+int orc_plan_nlats_legr(const orc_plan* p) { return p->nlats_legr; }
+int64_t orc_plan_npts(const orc_plan* p) { return p->npts; }
+size_t orc_plan_size_sym(const orc_plan* p) { return p->begin_sym[p->T + 2]; }
+size_t orc_plan_size_asym(const orc_plan* p) { return p->begin_asym[p->T + 2]; }
+const double* orc_plan_leg_sym(const orc_plan* p) { return p->leg_sym; }
+const double* orc_plan_leg_asym(const orc_plan* p) { return p->leg_asym; }
+size_t orc_plan_begin_sym(const orc_plan* p, int m) { return p->begin_sym[m]; }
+size_t orc_plan_begin_asym(const orc_plan* p, int m) { return p->begin_asym[m]; }
+
+/* posMethod (TransLocal.h:177-180): layout of the Fourier intermediate */
+static inline size_t orc_pos_fourier(const orc_plan* p, int fld, int imag, int jlat, int m) {
+    return (size_t)imag + 2 * ((size_t)m + (size_t)(p->T + 1) * ((size_t)jlat + (size_t)p->nlats * (size_t)fld));
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a8-a10  invtrans_legendre (TransLocal.cc:939-1097): per zonal wavenumber split the spectra by
+ * parity (n descending from T+1), two column-major GEMMs against the tables, merge hemispheres.
+ * `trc` is the CALL's truncation (T for scalars, T+1 on the vor/div path); entries are taken only
+ * if n <= trc && m < trc (:982).  scl_fourier must be zero-initialised by the caller (:1423-1428).
+ * ---------------------------------------------------------------------------------------------- */
+void orc_invtrans_legendre(const orc_plan* p, int trc, int nf, const double* sp, double* scl_fourier) {
+    const int T = p->T;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int m = 0; m <= T; ++m) {
+        size_t ks        = orc_num_n(T + 1, m, 1);
+        size_t ka        = orc_num_n(T + 1, m, 0);
+        const int n_imag = m ? 2 : 1;
+        int L            = p->nlats_legr - p->nlat0[m];
+        int rows         = nf * n_imag;
+        if (rows * L > 0) {
+            double* a_sym  = (double*)malloc(sizeof(double) * rows * (ks ? ks : 1));
+            double* a_asym = (double*)malloc(sizeof(double) * rows * (ka ? ka : 1));
+            double* c_sym  = (double*)calloc((size_t)rows * L, sizeof(double));
+            double* c_asym = (double*)calloc((size_t)rows * L, sizeof(double));
+            /* split (:970-1003) */
+            size_t is = 0, ia = 0;
+            size_t ioff = (size_t)(2 * trc + 3 - m) * m / 2 * nf * 2;
+            for (int n = T + 1; n >= m; --n) {
+                for (int imag = 0; imag < n_imag; ++imag) {
+                    for (int f = 0; f < nf; ++f) {
+                        size_t idx = (size_t)f + (size_t)nf * (imag + 2 * (size_t)(n - m));
+                        double v   = (n <= trc && m < trc) ? sp[idx + ioff] : 0.;
+                        if ((n - m) % 2 == 0) a_sym[is++] = v;
+                        else a_asym[ia++] = v;
+                    }
+                }
+            }
+            /* C(rows x L) = A(rows x K) * B(K x L), all column-major (:1007-1023; eckit "generic" order) */
+            const double* b_sym  = p->leg_sym + p->begin_sym[m] + (size_t)p->nlat0[m] * ks;
+            const double* b_asym = p->leg_asym + p->begin_asym[m] + (size_t)p->nlat0[m] * ka;
+            for (int c = 0; c < L; ++c) {
+                for (size_t k = 0; k < ks; ++k) {
+                    double b = b_sym[(size_t)c * ks + k];
+                    for (int r = 0; r < rows; ++r) c_sym[(size_t)c * rows + r] += a_sym[k * rows + r] * b;
+                }
+                for (size_t k = 0; k < ka; ++k) {
+                    double b = b_asym[(size_t)c * ka + k];
+                    for (int r = 0; r < rows; ++r) c_asym[(size_t)c * rows + r] += a_asym[k * rows + r] * b;
+                }
+            }
+            /* merge hemispheres (:1031-1080); posFourier :955-957 */
+            for (int jlat = 0; jlat < p->nlats_nh; ++jlat) {
+                int c = L - p->nlats_nh + jlat;
+                for (int imag = 0; imag < n_imag; ++imag)
+                    for (int f = 0; f < nf; ++f) {
+                        double v = 0.;
+                        if (c >= 0) {
+                            size_t idx = (size_t)f + (size_t)nf * (imag + (size_t)n_imag * c);
+                            v          = c_sym[idx] + c_asym[idx];
+                        }
+                        scl_fourier[orc_pos_fourier(p, f, imag, jlat, m)] = v;
+                    }
+            }
+            for (int jlat = 0; jlat < p->nlats_sh; ++jlat) {
+                int c     = L - p->nlats_sh + jlat;
+                int jslat = p->nlats - jlat - 1;
+                for (int imag = 0; imag < n_imag; ++imag)
+                    for (int f = 0; f < nf; ++f) {
+                        double v = 0.;
+                        if (c >= 0) {
+                            size_t idx = (size_t)f + (size_t)nf * (imag + (size_t)n_imag * c);
+                            v          = c_sym[idx] - c_asym[idx];
+                        }
+                        scl_fourier[orc_pos_fourier(p, f, imag, jslat, m)] = v;
+                    }
+            }
+            free(a_sym);
+            free(a_asym);
+            free(c_sym);
+            free(c_asym);
+        }
+        else {
+            for (int jlat = 0; jlat < p->nlats; ++jlat)
+                for (int imag = 0; imag < n_imag; ++imag)
+                    for (int f = 0; f < nf; ++f) scl_fourier[orc_pos_fourier(p, f, imag, jlat, m)] = 0.;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a13  linalg::FFT::inverse_c2r contract (FFT.h:27-72, FFTW.cc:38-61, pocketfft.cc:32-60):
+ *      unnormalised Hermitian c2r, in = n/2+1 complex (interleaved), out = n reals.
+ *      The third-party FFT (FFTW3 / pocketfft_hdronly) is absent from /root/reference; the oracle uses
+ *      (a) a direct O(n * nmodes) DFT with table twiddles  [orc_c2r_direct], and
+ *      (b) a mixed-radix + Bluestein FFT                   [orc_c2r_fft, used by the CPU baseline];
+ *      both are pinned against numpy.fft.irfft (pocketfft C) in tests/test_oracle_fft.py.
+ * ---------------------------------------------------------------------------------------------- */
+void orc_c2r_direct(int n, const double* in, double* out) {
+    /* twiddle table in long double, indexed by (m*k) mod n so no phase error accumulates */
+    long double* cs = (long double*)malloc(sizeof(long double) * 2 * n);
+    for (int j = 0; j < n; ++j) {
+        long double ang = 2.0L * ORC_PIL * (long double)j / (long double)n;
+        cs[2 * j]       = cosl(ang);
+        cs[2 * j + 1]   = sinl(ang);
+    }
+    int nc = n / 2 + 1;
+    /* highest non-zero mode (cheap pruning; zeros contribute nothing) */
+    int mtop = nc - 1;
+    while (mtop > 0 && in[2 * mtop] == 0. && in[2 * mtop + 1] == 0.) mtop--;
+    for (int k = 0; k < n; ++k) {
+        long double s = in[0];
+        for (int m = 1; m <= mtop; ++m) {
+            int j = (int)(((int64_t)m * k) % n);
+            if (2 * m == n) {
+                s += (long double)in[2 * m] * cs[2 * j]; /* Nyquist: real part only */
+            }
+            else {
+                s += 2.0L * ((long double)in[2 * m] * cs[2 * j] - (long double)in[2 * m + 1] * cs[2 * j + 1]);
+            }
+        }
+        out[k] = (double)s;
+    }
+    free(cs);
+}
+
+/* ---- plain double-precision complex FFT (recursive mixed radix, generic odd radix, Bluestein) ---- */
+typedef struct { double re, im; } orc_cplx;
+
+static void orc_twiddle(int n, int j, double* c, double* s) {
+    /* exp(+2 pi i j / n) with octant reduction for accuracy */
+    j %= n;
+    if (j < 0) j += n;
+    long double ang = 2.0L * ORC_PIL * (long double)j / (long double)n;
+    *c = (double)cosl(ang);
+    *s = (double)sinl(ang);
+}
+
+static int orc_smallest_factor(int n) {
+    if (n % 4 == 0) return 4;
+    if (n % 2 == 0) return 2;
+    for (int f = 3; (int64_t)f * f <= n; f += 2)
+        if (n % f == 0) return f;
+    return n;
+}
+
+/* out[k] = sum_j in[j*stride] exp(sign 2 pi i jk/n); recursive decimation in time */
+static void orc_fft_rec(int n, int sign, const orc_cplx* in, int stride, orc_cplx* out, orc_cplx* scratch);
+
+static int orc_is_smooth(int n) {
+    while (n % 2 == 0) n /= 2;
+    while (n % 3 == 0) n /= 3;
+    while (n % 5 == 0) n /= 5;
+    while (n % 7 == 0) n /= 7;
+    return n == 1;
+}
+
+static void orc_fft_bluestein(int n, int sign, const orc_cplx* in, int stride, orc_cplx* out) {
+    int M = 1;
+    while (M < 2 * n - 1) M *= 2;
+    orc_cplx* a  = (orc_cplx*)calloc(M, sizeof(orc_cplx));
+    orc_cplx* b  = (orc_cplx*)calloc(M, sizeof(orc_cplx));
+    orc_cplx* fa = (orc_cplx*)malloc(sizeof(orc_cplx) * M);
+    orc_cplx* fb = (orc_cplx*)malloc(sizeof(orc_cplx) * M);
+    orc_cplx* sc = (orc_cplx*)malloc(sizeof(orc_cplx) * M);
+    orc_cplx* w  = (orc_cplx*)malloc(sizeof(orc_cplx) * n);
+    for (int j = 0; j < n; ++j) { /* w_j = exp(sign i pi j^2 / n), j^2 reduced mod 2n */
+        int64_t q = ((int64_t)j * j) % (2 * (int64_t)n);
+        double c, s;
+        orc_twiddle(2 * n, (int)q, &c, &s);
+        w[j].re = c;
+        w[j].im = sign * s;
+    }
+    for (int j = 0; j < n; ++j) {
+        orc_cplx x = in[(size_t)j * stride];
+        a[j].re    = x.re * w[j].re - x.im * w[j].im;
+        a[j].im    = x.re * w[j].im + x.im * w[j].re;
+        b[j].re    = w[j].re;
+        b[j].im    = -w[j].im;
+        if (j) {
+            b[M - j] = b[j];
+        }
+    }
+    orc_fft_rec(M, +1, a, 1, fa, sc);
+    orc_fft_rec(M, +1, b, 1, fb, sc);
+    for (int j = 0; j < M; ++j) {
+        double re = fa[j].re * fb[j].re - fa[j].im * fb[j].im;
+        double im = fa[j].re * fb[j].im + fa[j].im * fb[j].re;
+        a[j].re   = re;
+        a[j].im   = im;
+    }
+    orc_fft_rec(M, -1, a, 1, fa, sc);
+    for (int k = 0; k < n; ++k) {
+        double re = fa[k].re / M, im = fa[k].im / M;
+        out[k].re = re * w[k].re - im * w[k].im;
+        out[k].im = re * w[k].im + im * w[k].re;
+    }
+    free(a);
+    free(b);
+    free(fa);
+    free(fb);
+    free(sc);
+    free(w);
+}
+
+static void orc_fft_rec(int n, int sign, const orc_cplx* in, int stride, orc_cplx* out, orc_cplx* scratch) {
+    if (n == 1) {
+        out[0] = in[0];
+        return;
+    }
+    int r = orc_smallest_factor(n);
+    if (r > 7 && !orc_is_smooth(n)) {
+        /* n has only large prime factors left */
+        orc_fft_bluestein(n, sign, in, stride, out);
+        return;
+    }
+    int m = n / r;
+    /* r sub-transforms of length m on the decimated inputs */
+    for (int q = 0; q < r; ++q) orc_fft_rec(m, sign, in + (size_t)q * stride, stride * r, scratch + (size_t)q * m, out);
+    /* butterflies: out[k + p*m] = sum_q W_n^{q(k+pm)} S_q[k] */
+    orc_cplx t[8];
+    for (int k = 0; k < m; ++k) {
+        for (int q = 0; q < r; ++q) {
+            double c, s;
+            orc_twiddle(n, (int)(((int64_t)q * k) % n), &c, &s);
+            s *= sign;
+            orc_cplx v = scratch[(size_t)q * m + k];
+            t[q].re    = v.re * c - v.im * s;
+            t[q].im    = v.re * s + v.im * c;
+        }
+        for (int pp = 0; pp < r; ++pp) {
+            double re = 0, im = 0;
+            for (int q = 0; q < r; ++q) {
+                double c, s;
+                orc_twiddle(r, (pp * q) % r, &c, &s);
+                s *= sign;
+                re += t[q].re * c - t[q].im * s;
+                im += t[q].re * s + t[q].im * c;
+            }
+            out[k + (size_t)pp * m].re = re;
+            out[k + (size_t)pp * m].im = im;
+        }
+    }
+}
+
+void orc_c2r_fft(int n, const double* in, double* out) {
+    /* expand the Hermitian half spectrum and run a complex inverse (sign +) transform */
+    orc_cplx* x  = (orc_cplx*)malloc(sizeof(orc_cplx) * n);
+    orc_cplx* y  = (orc_cplx*)malloc(sizeof(orc_cplx) * n);
+    orc_cplx* sc = (orc_cplx*)malloc(sizeof(orc_cplx) * n);
+    x[0].re      = in[0];
+    x[0].im      = 0.;
+    for (int m = 1; m <= n / 2; ++m) {
+        double re = in[2 * m], im = in[2 * m + 1];
+        if (2 * m == n) {
+            x[m].re = re;
+            x[m].im = 0.;
+        }
+        else {
+            x[m].re     = re;
+            x[m].im     = im;
+            x[n - m].re = re;
+            x[n - m].im = -im;
+        }
+    }
+    orc_fft_rec(n, +1, x, 1, y, sc);
+    for (int k = 0; k < n; ++k) out[k] = y[k].re;
+    free(x);
+    free(y);
+    free(sc);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a11/a12  invtrans_fourier_reduced / _regular (TransLocal.cc:1101-1196), global grid (jlonMin=0).
+ * use_fft = 0: direct DFT (slow, most accurate);  1: FFT.
+ * ---------------------------------------------------------------------------------------------- */
+void orc_invtrans_fourier(const orc_plan* p, int nf, const double* scl_fourier, double* gp, int use_fft) {
+    const int T = p->T;
+    int64_t* rowoff = (int64_t*)malloc(sizeof(int64_t) * (p->nlats + 1));
+    rowoff[0]       = 0;
+    for (int j = 0; j < p->nlats; ++j) rowoff[j + 1] = rowoff[j] + p->nx[j];
+#pragma omp parallel
+    {
+        double* in  = (double*)malloc(sizeof(double) * 2 * (p->nxmax / 2 + 1));
+        double* out = (double*)malloc(sizeof(double) * p->nxmax);
+#pragma omp for collapse(2) schedule(dynamic, 8)
+        for (int f = 0; f < nf; ++f) {
+            for (int jlat = 0; jlat < p->nlats; ++jlat) {
+                int n  = p->regular ? p->nxmax : p->nx[jlat];
+                int nc = n / 2 + 1;
+                in[0]  = scl_fourier[orc_pos_fourier(p, f, 0, jlat, 0)];
+                in[1]  = 0.;
+                for (int m = 1; m < nc; ++m) {
+                    for (int imag = 0; imag < 2; ++imag) {
+                        in[2 * m + imag] = (m <= T) ? scl_fourier[orc_pos_fourier(p, f, imag, jlat, m)] : 0.;
+                    }
+                }
+                if (use_fft) orc_c2r_fft(n, in, out);
+                else orc_c2r_direct(n, in, out);
+                double* dst = gp + (size_t)f * p->npts + rowoff[jlat];
+                for (int i = 0; i < p->nx[jlat]; ++i) dst[i] = out[i];
+            }
+        }
+        free(in);
+        free(out);
+    }
+    free(rowoff);
+}
+
+/* a7  invtrans_uv, scalar part (TransLocal.cc:1409-1441): zero-fill, Legendre, Fourier */
+void orc_invtrans_uv(const orc_plan* p, int trc, int nf, int nb_vordiv, const double* sp, double* gp, int use_fft) {
+    if (nf <= 0) return;
+    size_t nfour = (size_t)nf * 2 * p->nlats * (p->T + 1);
+    double* four = (double*)calloc(nfour, sizeof(double));
+    orc_invtrans_legendre(p, trc, nf, sp, four);
+    orc_invtrans_fourier(p, nf, four, gp, use_fft);
+    /* a14: u,v from U,V (TransLocal.cc:1443-1469) */
+    if (nb_vordiv > 0) {
+        size_t idx = 0;
+        for (int f = 0; f < 2 * nb_vordiv && f < nf; ++f) {
+            for (int jlat = 0; jlat < p->nlats; ++jlat) {
+                double lat = p->lat_deg[jlat];
+                if (lat > ORC_LATPOLE) lat = ORC_LATPOLE;
+                if (lat < -ORC_LATPOLE) lat = -ORC_LATPOLE;
+                double inv = 1. / cos(lat * ORC_DEG2RAD);
+                for (int i = 0; i < p->nx[jlat]; ++i) gp[idx++] *= inv;
+            }
+        }
+    }
+    free(four);
+}
+
+void orc_invtrans(const orc_plan* p, int nf, const double* sp, double* gp, int use_fft) {
+    orc_invtrans_uv(p, p->T, nf, 0, sp, gp, use_fft); /* TransLocal.cc:931-934 */
+}
+
+/* expose the Fourier intermediate for stage-level parity tests */
+void orc_invtrans_legendre_only(const orc_plan* p, int trc, int nf, const double* sp, double* scl_fourier) {
+    memset(scl_fourier, 0, sizeof(double) * (size_t)nf * 2 * p->nlats * (p->T + 1));
+    orc_invtrans_legendre(p, trc, nf, sp, scl_fourier);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Row-sampled evaluation for FULL-SIZE parity (TL1279): computes gp rows (jlat in rows[], all nf fields)
+ * exactly as the table path would, but evaluating the polynomials of one latitude on the fly, so that
+ * no 8 GB table is needed.  Same split / n-descending summation / merge / c2r as above.
+ * out is [nrows][nf][nx(row)] packed row after row.
+ * ---------------------------------------------------------------------------------------------- */
+void orc_invtrans_rows(const orc_plan* p, int trc, int nf, const double* sp, int nrows, const int* rows, double* out,
+                       int use_fft) {
+    const int T   = p->T;
+    const int TL  = T + 1;
+    size_t tri    = (size_t)(TL + 2) * (size_t)(TL + 1) / 2;
+    double* zfn0  = (double*)calloc((size_t)(TL + 1) * (TL + 1), sizeof(double));
+    orc_compute_zfn(TL, zfn0);
+    int64_t* outoff = (int64_t*)malloc(sizeof(int64_t) * (nrows + 1));
+    outoff[0]       = 0;
+    for (int r = 0; r < nrows; ++r) outoff[r + 1] = outoff[r] + (int64_t)nf * p->nx[rows[r]];
+#pragma omp parallel
+    {
+        double* legpol = (double*)malloc(tri * sizeof(double));
+        double* zfn    = (double*)malloc((size_t)(TL + 1) * (TL + 1) * sizeof(double));
+        double* vsin   = (double*)malloc((size_t)(TL + 1) * sizeof(double));
+        double* vcos   = (double*)malloc((size_t)(TL + 1) * sizeof(double));
+        double* in     = (double*)malloc(sizeof(double) * 2 * (p->nxmax / 2 + 1));
+        double* o      = (double*)malloc(sizeof(double) * p->nxmax);
+        double* four   = (double*)malloc(sizeof(double) * 2 * (size_t)(T + 1) * nf);
+        memcpy(zfn, zfn0, (size_t)(TL + 1) * (TL + 1) * sizeof(double));
+#pragma omp for schedule(dynamic, 1)
+        for (int r = 0; r < nrows; ++r) {
+            int jlat  = rows[r];
+            int south = jlat >= p->nlats_nh; /* pure southern row (global grid, no equator row) */
+            int jleg  = south ? p->nlats - 1 - jlat : jlat;
+            orc_legendre_lat(TL, p->lats_leg[jleg], legpol, zfn, vsin, vcos);
+            for (int m = 0; m <= T; ++m) {
+                const int n_imag = m ? 2 : 1;
+                size_t ioff      = (size_t)(2 * trc + 3 - m) * m / 2 * nf * 2;
+                for (int f = 0; f < nf; ++f) {
+                    for (int imag = 0; imag < 2; ++imag) {
+                        double s = 0., a = 0.;
+                        if (imag < n_imag && jleg >= p->nlat0[m]) {
+                            for (int n = TL; n >= m; --n) {
+                                size_t idx = (size_t)f + (size_t)nf * (imag + 2 * (size_t)(n - m));
+                                double v   = (n <= trc && m < trc) ? sp[idx + ioff] : 0.;
+                                double pl  = legpol[orc_idxmn(TL, m, n)];
+                                if ((n - m) % 2 == 0) s += v * pl;
+                                else a += v * pl;
+                            }
+                        }
+                        four[((size_t)f * (T + 1) + m) * 2 + imag] = south ? s - a : s + a;
+                    }
+                }
+            }
+            int n  = p->regular ? p->nxmax : p->nx[jlat];
+            int nc = n / 2 + 1;
+            for (int f = 0; f < nf; ++f) {
+                const double* ff = four + (size_t)f * (T + 1) * 2;
+                in[0]            = ff[0];
+                in[1]            = 0.;
+                for (int m = 1; m < nc; ++m) {
+                    in[2 * m]     = (m <= T) ? ff[2 * m] : 0.;
+                    in[2 * m + 1] = (m <= T) ? ff[2 * m + 1] : 0.;
+                }
+                if (use_fft) orc_c2r_fft(n, in, o);
+                else orc_c2r_direct(n, in, o);
+                memcpy(out + outoff[r] + (size_t)f * p->nx[jlat], o, sizeof(double) * p->nx[jlat]);
+            }
+        }
+        free(legpol);
+        free(zfn);
+        free(vsin);
+        free(vcos);
+        free(in);
+        free(o);
+        free(four);
+    }
+    free(zfn0);
+    free(outoff);
+}
