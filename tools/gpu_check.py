@@ -91,3 +91,33 @@ if __name__ == "__main__":
         check("O640", 639, 137, full_oracle=False)
     if "huge" in which:
         check("O1280", 1279, 137, full_oracle=False, nrows=8)
+
+
+def timeit(gridname, T, nf, iters=5):
+    g = atlas_amd.Grid(gridname)
+    t0 = time.time()
+    tr = atlas_amd.Trans(g, T, profile=True)
+    print(f"[time {gridname} T{T} nf={nf}] setup {time.time() - t0:.1f}s table {tr.legendre_table_bytes() / 1e9:.2f} GB")
+    sp_d = torch.from_numpy(spectra(T, nf)).cuda()
+    gp_d = torch.zeros(nf * g.size(), dtype=torch.float64, device="cuda")
+    for _ in range(2):
+        tr.invtrans(nf, sp_d, gp_d)
+    tr.synchronize()
+    tr.timings(reset=True)
+    t0 = time.time()
+    for _ in range(iters):
+        tr.invtrans(nf, sp_d, gp_d)
+    tr.synchronize()
+    wall = (time.time() - t0) / iters
+    tm = tr.timings()
+    lm, fm = tm["legendre_ms"] / tm["legendre_calls"], tm["fourier_ms"] / tm["fourier_calls"]
+    fl = tr.legendre_flops(nf)
+    print(f"   wall {wall * 1e3:.2f} ms/call  legendre {lm:.2f} ms ({fl / lm / 1e9:.1f} TF/s)  fourier {fm:.2f} ms "
+          f"({(tr.fourier_size(nf) * 8 * 0.82 + gp_d.numel() * 8) / fm / 1e9:.2f} TB/s alg.)  -> {1 / wall:.1f} transforms/s")
+
+
+if __name__ == "__main__":
+    if "time" in sys.argv[1:]:
+        timeit("O160", 159, 60)
+        timeit("O640", 639, 137)
+        timeit("O1280", 1279, 137)
