@@ -1,0 +1,161 @@
+"""Headline benchmark: inverse spherical-harmonics transforms per second, TL1279 -> O1280, 137 levels.
+
+One *transform* = one TransLocal::invtrans of one field on all 137 levels (nb_scalar_fields = 137); a *step* is
+one such transform per GPU with spectra and grid-point arrays resident in HBM.
+    python bench.py --gpus N --steps K --warmup W
+N = 1: single MI355X (the whole transform on one device).
+N > 1: launched by torch.distributed.run, one rank per GPU; every step processes N transforms (weak scaling), each
+       transform distributed over all N GPUs: Legendre stage sharded by zonal wavenumber, RCCL all-to-all of the
+       Fourier intermediate (m -> latitude-band transpose), Fourier stage on the local latitude band
+       (atlas_amd/dist.py).
+Prints ONE JSON line (rank 0)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+GRID, TRUNC, NLEV = "O1280", 1279, 137
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X spec, dense fp64 matrix (v_mfma_f64_16x16x4_f64: 77.2 TF/s measured, tools/probe)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(sample_fields=8):
+    """the oracle (CPU restatement of TransLocal: per-m GEMM pair + per-row c2r FFT) timed on the host cores on a
+    bounded sample: `sample_fields` of the 137 levels, full TL1279 -> O1280 geometry."""
+    import numpy as np
+    import atlas_amd
+    import oracle
+    from helpers import red_spectra
+    g = atlas_amd.Grid(GRID)
+    op = oracle.OraclePlan(TRUNC, g.nx(), g.y(), with_tables=True)   # setup (tables) is not timed, as on the GPU
+    sp = red_spectra(TRUNC, sample_fields)
+    t0 = time.perf_counter()
+    op.invtrans(sample_fields, sp, use_fft=True)
+    dt = time.perf_counter() - t0
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": (sample_fields / NLEV) / dt, "unit": "transforms/s", "cores": cores, "kind": "port",
+            "sample": f"{sample_fields} of {NLEV} levels of one TL{TRUNC}->{GRID} transform in {dt:.2f} s "
+                      f"(oracle/translocal_oracle.c, OpenMP over m and over (field,row)); scaled by {NLEV}/{sample_fields}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-fields", type=int, default=8)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import atlas_amd
+    from helpers import red_spectra
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    nf = NLEV
+    g = atlas_amd.Grid(GRID)
+
+    if world == 1:
+        tr = atlas_amd.Trans(g, TRUNC, profile=True)
+        tr.use_torch_stream()
+        sp = torch.from_numpy(red_spectra(TRUNC, nf)).cuda()
+        gp = torch.zeros(nf * g.size(), dtype=torch.float64, device="cuda")
+
+        def step():
+            tr.invtrans(nf, sp, gp)
+
+        def barrier():
+            torch.cuda.synchronize()
+    else:
+        import torch.distributed as dist
+        from atlas_amd.dist import DistributedTrans
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dtr = DistributedTrans(g, TRUNC, profile=True)
+        tr = dtr.trans
+        # every rank holds the spectra of the `world` transforms of a step (replicated input; each rank reads only
+        # the wavenumbers it owns)
+        sps = [torch.from_numpy(red_spectra(TRUNC, nf, seed=20251114 + i)).cuda() for i in range(min(world, 2))]
+        gp = torch.zeros(nf * tr.nb_gridpoints(), dtype=torch.float64, device="cuda")
+
+        def step():
+            for i in range(world):
+                dtr.invtrans(nf, sps[i % len(sps)], gp)
+
+        def barrier():
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    tr.timings(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    tm = tr.timings()
+    transforms = args.steps * world
+    ms_per_step = dt / args.steps * 1e3
+
+    if rank == 0:
+        leg_ms = tm["legendre_ms"] / max(tm["legendre_calls"], 1)
+        fft_ms = tm["fourier_ms"] / max(tm["fourier_calls"], 1)
+        # algorithmic work per launch (DESIGN.md "Kernels"): Legendre flops of SURVEY 8(d) / world (m-sharding);
+        # Fourier bytes = kept part of the intermediate read once + grid-point output written once
+        leg_flops = tr.legendre_flops(nf) / world
+        leg_tf = leg_flops / (leg_ms * 1e-3) / 1e12 if leg_ms > 0 else 0.0
+        fft_bytes = (tr.legendre_flops(nf) / (2.0 * nf * 2) / 1.0) * 0.0  # placeholder replaced below
+        kept_modes = float(sum(int(tr.nlat0()[m] < g.ny() // 2) * 2 * (g.ny() // 2 - int(tr.nlat0()[m]))
+                               for m in range(TRUNC + 1)))          # (lat, m) pairs with data
+        fft_bytes = (kept_modes * nf * 16 + nf * g.size() * 8) / world
+        fft_gbs = fft_bytes / (fft_ms * 1e-3) / 1e9 if fft_ms > 0 else 0.0
+        kernels = [
+            {"kernel": "legendre_kernel<9>", "bound": "mfma", "achieved": leg_tf, "peak": FP64_MFMA_PEAK_TFLOPS,
+             "unit": "TFLOP/s", "frac": leg_tf / FP64_MFMA_PEAK_TFLOPS, "avg_ms": leg_ms, "traffic": None},
+            {"kernel": "fft_rows_kernel", "bound": "hbm", "achieved": fft_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": fft_gbs / HBM_PEAK_GBS, "avg_ms": fft_ms, "traffic": None},
+        ]
+        dominant = max(kernels, key=lambda k: k["avg_ms"])
+        out = {
+            "metric": "inverse SH transforms/sec (TL1279, O1280, 137 lev)",
+            "value": transforms / dt, "unit": "transforms/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"TransLocal invtrans TL{TRUNC} -> {GRID}, {NLEV} levels (nb_scalar_fields={NLEV}) "
+                                   f"per transform, {world} transform(s) per step",
+                       "grid": GRID, "truncation": TRUNC, "levels": NLEV,
+                       "parallelism": "single GPU" if world == 1 else f"m-sharded Legendre + RCCL all-to-all + latitude-band FFT over {world} GPUs"},
+            "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")},
+            "roofline_kernels": kernels,
+        }
+        out["roofline"]["kernel"] = dominant["kernel"]
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_fields)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

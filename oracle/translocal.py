@@ -56,6 +56,8 @@ def lib():
         L.orc_invtrans_legendre_only.argtypes = [vp, i, i, vp, vp]
         L.orc_invtrans_fourier.argtypes = [vp, i, vp, vp, i]
         L.orc_invtrans_rows.argtypes = [vp, i, i, vp, i, vp, vp, i]
+        L.orc_invtrans_vordiv.argtypes = [vp, i, vp, i, vp, vp, vp, i]
+        L.orc_vd2uv.argtypes = [i, i, vp, vp, vp, vp]
         L.orc_c2r_direct.argtypes = [i, vp, vp]
         L.orc_c2r_fft.argtypes = [i, vp, vp]
         _lib = L
@@ -142,6 +144,16 @@ class OraclePlan:
         assert sp.size == self.nspec(nf, trc)
         gp = np.zeros(nf * self.npts)
         lib().orc_invtrans_uv(self._h, trc, nf, nb_vordiv, sp.ctypes.data, gp.ctypes.data, int(use_fft))
+        return gp
+
+    def invtrans_vordiv(self, ns, sp, nvd, vor, div, use_fft=False):
+        """TransLocal::invtrans(ns, sp, nvd, vor, div, gp): gp = [u fields][v fields][scalar fields]"""
+        vor = np.ascontiguousarray(vor, dtype=np.float64)
+        div = np.ascontiguousarray(div, dtype=np.float64)
+        sp_p = np.ascontiguousarray(sp, dtype=np.float64).ctypes.data if ns > 0 else None
+        gp = np.zeros((ns + 2 * nvd) * self.npts)
+        lib().orc_invtrans_vordiv(self._h, ns, sp_p, nvd, vor.ctypes.data, div.ctypes.data, gp.ctypes.data,
+                                  int(use_fft))
         return gp
 
     def legendre(self, nf, sp, trc=None):

@@ -748,3 +748,145 @@ void orc_invtrans_rows(const orc_plan* p, int trc, int nf, const double* sp, int
     free(zfn0);
     free(outoff);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * a15  vor/div path.
+ *   extend_truncation  (TransLocal.cc:1496-1519): T -> T+1, new row / column zero.
+ *   vd2uv              (VorDivToUVLocal.cc:62-184): U,V*cos(lat) spectra from vorticity / divergence,
+ *                      Temperton (1991) eq. 2.12 / 2.13, n-reversed internal storage, scaled by 1/a.
+ *   invtrans(ns, sp, nvd, vor, div, gp) (TransLocal.cc:1523-1597): per (m,n,imag) interleave
+ *                      [U fields][V fields][scalar fields], then invtrans_uv with truncation T+1.
+ * ---------------------------------------------------------------------------------------------- */
+#define ORC_EARTH_RADIUS 6371229. /* util::Earth::radius(), src/atlas/util/Earth.h:23 */
+
+void orc_extend_truncation(int old_trc, int nf, const double* old_sp, double* new_sp) {
+    int new_trc = old_trc + 1;
+    size_t k = 0, ko = 0;
+    for (int m = 0; m <= new_trc; ++m)
+        for (int n = m; n <= new_trc; ++n)
+            for (int imag = 0; imag < 2; ++imag)
+                for (int f = 0; f < nf; ++f) {
+                    if (m == new_trc || n == new_trc) new_sp[k++] = 0.;
+                    else new_sp[k++] = old_sp[ko++];
+                }
+}
+
+void orc_vd2uv(int trc, int nf, const double* vor, const double* div, double* U, double* V) {
+    const double ra = ORC_EARTH_RADIUS;
+    int nlei1       = trc + 4 + (trc + 4 + 1) % 2;
+    double* repsnm  = (double*)calloc((size_t)(trc + 1) * (trc + 6) / 2 + 8, sizeof(double));
+    double* rlapin  = (double*)calloc(trc + 3, sizeof(double));
+    size_t idx      = 0;
+    for (int m = 0; m <= trc; ++m)
+        for (int n = m; n <= trc + 2; ++n, ++idx) repsnm[idx] = sqrt(((double)n * n - (double)m * m) / (4. * n * n - 1.));
+    repsnm[0] = 0.;
+    for (int n = 1; n <= trc + 2; ++n) rlapin[n] = -ra * ra / (n * (n + 1.));
+    rlapin[0] = 0.;
+    double* zeps = (double*)calloc(trc + 6, sizeof(double));
+    double* zlap = (double*)calloc(trc + 6, sizeof(double));
+    double* zn   = (double*)calloc(trc + 6, sizeof(double));
+    size_t nint  = (size_t)2 * nf * nlei1;
+    double* rvor = (double*)malloc(sizeof(double) * nint);
+    double* rdiv = (double*)malloc(sizeof(double) * nint);
+    double* ru   = (double*)malloc(sizeof(double) * nint);
+    double* rv   = (double*)malloc(sizeof(double) * nint);
+    for (int m = 0; m <= trc; ++m) {
+        for (int n = m - 1; n <= trc + 2; ++n) { /* reversed order for accuracy (:98-116) */
+            int ij = trc + 3 - n;
+            if (n >= 0) {
+                zlap[ij] = rlapin[n];
+                zeps[ij] = (n < m) ? 0. : repsnm[n + (2 * trc - m + 5) * m / 2];
+            }
+            else {
+                zlap[ij] = 0.;
+                zeps[ij] = 0.;
+            }
+            zn[ij] = n;
+        }
+        zn[0] = trc + 3;
+        /* prfi1b (:31-56): spectral data of wavenumber m into the n-reversed internal layout */
+        int ilcm = trc + 1 - m, ioff = (2 * trc - m + 3) * m;
+        for (int pass = 0; pass < 2; ++pass) {
+            const double* src = pass ? div : vor;
+            double* dst       = pass ? rdiv : rvor;
+            memset(dst, 0, sizeof(double) * nint);
+            for (int j = 1; j <= ilcm; ++j) {
+                int inm = ioff + (ilcm - j) * 2;
+                for (int f = 0; f < nf; ++f) {
+                    dst[(size_t)(2 * f) * nlei1 + j + 1]     = src[(size_t)inm * nf + f];
+                    dst[(size_t)(2 * f + 1) * nlei1 + j + 1] = src[(size_t)(inm + 1) * nf + f];
+                }
+            }
+        }
+        memset(ru, 0, sizeof(double) * nint);
+        memset(rv, 0, sizeof(double) * nint);
+        for (int f = 0; f < nf; ++f) { /* (:131-156) */
+            long ir = (long)2 * f * nlei1 - 1, ii = ir + nlei1;
+            for (int ji = 2; ji < trc + 4 - m; ++ji) {
+                double psiM1 = zn[ji + 1] * zeps[ji] * zlap[ji + 1];
+                double psiP1 = zn[ji - 2] * zeps[ji - 1] * zlap[ji - 1];
+                if (m == 0) {
+                    ru[ir + ji] = +psiM1 * rvor[ir + ji + 1] - psiP1 * rvor[ir + ji - 1];
+                    rv[ir + ji] = -psiM1 * rdiv[ir + ji + 1] + psiP1 * rdiv[ir + ji - 1];
+                }
+                else {
+                    double chiIm = m * zlap[ji];
+                    ru[ir + ji]  = -chiIm * rdiv[ii + ji] + psiM1 * rvor[ir + ji + 1] - psiP1 * rvor[ir + ji - 1];
+                    ru[ii + ji]  = +chiIm * rdiv[ir + ji] + psiM1 * rvor[ii + ji + 1] - psiP1 * rvor[ii + ji - 1];
+                    rv[ir + ji]  = -chiIm * rvor[ii + ji] - psiM1 * rdiv[ir + ji + 1] + psiP1 * rdiv[ir + ji - 1];
+                    rv[ii + ji]  = +chiIm * rvor[ir + ji] - psiM1 * rdiv[ii + ji + 1] + psiP1 * rdiv[ii + ji - 1];
+                }
+            }
+        }
+        int ilcm2   = trc - m; /* copy back (:160-181) */
+        double za_r = 1. / ra;
+        for (int j = 0; j <= ilcm2; ++j) {
+            int inm = ioff + (ilcm2 - j) * 2;
+            for (int f = 0; f < nf; ++f) {
+                size_t ir = (size_t)2 * f * nlei1, ii = ir + nlei1;
+                size_t k  = (size_t)inm * nf + f;
+                U[k]      = ru[ir + j + 2] * za_r;
+                V[k]      = rv[ir + j + 2] * za_r;
+                k += nf;
+                U[k] = ru[ii + j + 2] * za_r;
+                V[k] = rv[ii + j + 2] * za_r;
+            }
+        }
+    }
+    free(repsnm); free(rlapin); free(zeps); free(zlap); free(zn); free(rvor); free(rdiv); free(ru); free(rv);
+}
+
+/* TransLocal::invtrans(ns, sp, nvd, vor, div, gp)  (TransLocal.cc:1523-1597) */
+void orc_invtrans_vordiv(const orc_plan* p, int ns, const double* sp, int nvd, const double* vor, const double* div,
+                         double* gp, int use_fft) {
+    const int T = p->T;
+    if (nvd <= 0) {
+        if (ns > 0) orc_invtrans_uv(p, T, ns, 0, sp, gp, use_fft);
+        return;
+    }
+    size_t next = (size_t)(T + 2) * (T + 3); /* 2*legendre_size(T+1) */
+    double* vor_e = (double*)malloc(sizeof(double) * next * nvd);
+    double* div_e = (double*)malloc(sizeof(double) * next * nvd);
+    double* U     = (double*)calloc(next * nvd, sizeof(double));
+    double* V     = (double*)calloc(next * nvd, sizeof(double));
+    orc_extend_truncation(T, nvd, vor, vor_e);
+    orc_extend_truncation(T, nvd, div, div_e);
+    orc_vd2uv(T + 1, nvd, vor_e, div_e, U, V);
+    double* sc_e = NULL;
+    if (ns > 0) {
+        sc_e = (double*)malloc(sizeof(double) * next * ns);
+        orc_extend_truncation(T, ns, sp, sc_e);
+    }
+    int nall    = 2 * nvd + ns;
+    double* all = (double*)malloc(sizeof(double) * next * nall);
+    size_t k = 0, i = 0, j = 0, l = 0;
+    for (int m = 0; m <= T + 1; ++m)
+        for (int n = m; n <= T + 1; ++n)
+            for (int imag = 0; imag < 2; ++imag) {
+                for (int f = 0; f < nvd; ++f) all[k++] = U[i++];
+                for (int f = 0; f < nvd; ++f) all[k++] = V[j++];
+                for (int f = 0; f < ns; ++f) all[k++] = sc_e[l++];
+            }
+    orc_invtrans_uv(p, T + 1, nall, nvd, all, gp, use_fft);
+    free(vor_e); free(div_e); free(U); free(V); free(sc_e); free(all);
+}

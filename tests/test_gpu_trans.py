@@ -1,0 +1,220 @@
+"""GPU parity tests of the TransLocal inverse transform (through the C ABI) against the CPU oracle.
+
+Tolerance (fp64): rel-RMS (RMS diff / max|ref|, the reference's compute_rms) <= 1e-13 against the oracle on the
+same inputs and <= 1e-13 against the analytic known answers at T <= 63 (reference: 1e-13, test_transgeneral.cc:534);
+wind: 2e-6 vs analytic (reference :538), 1e-12 vs oracle.  Full-size (TL1279 -> O1280, 137 levels) is checked on
+sampled latitude rows against the oracle and through size-independent properties (linearity, zero input,
+dropped m=T wavenumber, host/device entry points agree bitwise)."""
+import math
+
+import numpy as np
+import pytest
+
+import atlas_amd
+import oracle
+from atlas_amd import _lib
+from helpers import (CLOSED_FORMS, analytic_scalar, compute_rms, red_spectra, unit_spectrum, wind_kat)
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+TOL = 1e-13
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def run_device(tr, nf, sp):
+    gp = torch.zeros(nf * tr.nb_gridpoints_global(), dtype=torch.float64, device="cuda")
+    tr.invtrans(nf, dev(sp), gp)
+    tr.synchronize()
+    return gp.cpu().numpy()
+
+
+_trans_cache = {}
+
+
+def get_trans(gridname, T):
+    key = (gridname, T)
+    if key not in _trans_cache:
+        g = atlas_amd.Grid(gridname)
+        _trans_cache[key] = (g, atlas_amd.Trans(g, T))
+    return _trans_cache[key]
+
+
+@pytest.mark.parametrize("gridname,T,nf", [
+    ("O64", 63, 1),      # BASELINE config C1
+    ("O64", 63, 3), ("F64", 63, 2), ("O32", 31, 20), ("O32", 31, 8), ("O32", 31, 9),
+    ("F32", 31, 137),    # 137 columns -> 9 r-tiles per wave
+    ("O32", 31, 150),    # more than 144 fields -> two column chunks
+    ("O48", 95, 5),      # linear truncation branch (T >= ndgl-1)
+    ("O80", 100, 4),     # quadratic branch
+    ("O160", 159, 60),   # BASELINE config C2
+])
+def test_invtrans_parity_with_oracle(gridname, T, nf):
+    g, tr = get_trans(gridname, T)
+    sp = red_spectra(T, nf)
+    gp = run_device(tr, nf, sp)
+    ref = oracle.OraclePlan(T, g.nx(), g.y()).invtrans(nf, sp, use_fft=(T > 100))
+    assert np.isfinite(gp).all()
+    assert compute_rms(gp, ref) < TOL
+
+
+def test_nlat0_matches_oracle():
+    for gridname, T in [("O64", 63), ("F64", 63), ("O160", 159), ("O80", 100)]:
+        g, tr = get_trans(gridname, T)
+        assert np.array_equal(tr.nlat0(), oracle.OraclePlan(T, g.nx(), g.y(), with_tables=False).nlat0)
+
+
+def test_legendre_stage_parity():
+    gridname, T, nf = "O64", 63, 5
+    g, tr = get_trans(gridname, T)
+    sp = red_spectra(T, nf)
+    RP = tr.fourier_row_pitch(nf)
+    F = torch.zeros(tr.fourier_size(nf), dtype=torch.float64, device="cuda")
+    tr.legendre_device(T, nf, dev(sp), F)
+    tr.synchronize()
+    F = F.cpu().numpy().reshape(g.ny(), T + 1, RP)
+    op = oracle.OraclePlan(T, g.nx(), g.y())
+    ref = op.legendre(nf, sp)  # [fld][lat][m][re,im]  (TransLocal.h:177-180)
+    mine = F[:, :, :2 * nf].reshape(g.ny(), T + 1, nf, 2).transpose(2, 0, 1, 3)
+    nlat0, nl = op.nlat0, g.ny()
+    for m in range(T + 1):
+        rows = [j for j in range(nl) if min(j, nl - 1 - j) >= nlat0[m]]
+        assert compute_rms(mine[:, rows, m, :], ref[:, rows, m, :]) < TOL, m
+
+
+@pytest.mark.parametrize("gridname", ["F64", "O64"])
+def test_analytic_known_answers(gridname):
+    """reference KATs (test_transgeneral.cc:80-272, 433-449): closed forms n<=3 and sectoral harmonics"""
+    T = 63
+    g, tr = get_trans(gridname, T)
+    nx, lat = g.nx(), g.y()
+    cases = [(n, m, im) for (n, m) in CLOSED_FORMS for im in (0, 1) if not (m == 0 and im == 1)]
+    cases += [(n, n, im) for n in (5, 17, 45) for im in (0, 1)]
+    nf = len(cases)
+    sp = np.zeros((T + 1) * (T + 2) * nf)
+    for f, (n, m, im) in enumerate(cases):
+        sp += unit_spectrum(T, nf, n, m, im, fld=f)
+    gp = run_device(tr, nf, sp).reshape(nf, -1)
+    for f, (n, m, im) in enumerate(cases):
+        mask = [oracle.fourier_truncation(T, int(nx[j]), int(nx.max()), len(nx), lat[j] * math.pi / 180.0,
+                                          g.regular()) > m for j in range(len(nx))]
+        assert compute_rms(gp[f], analytic_scalar(nx, lat, n, m, im, mask)) < TOL, (n, m, im)
+
+
+def test_wavenumber_T_is_dropped_and_zero_maps_to_zero():
+    # TransLocal.cc:982: entries are used only if m < truncation -> the single (T,T) coefficient has no effect
+    T = 31
+    g, tr = get_trans("O32", T)
+    gp = run_device(tr, 1, unit_spectrum(T, 1, T, T, 0))
+    assert np.array_equal(gp, np.zeros_like(gp))
+    gp = run_device(tr, 2, np.zeros((T + 1) * (T + 2) * 2))
+    assert np.array_equal(gp, np.zeros_like(gp))
+
+
+def test_host_and_device_entry_points_agree_bitwise():
+    T, nf = 63, 4
+    g, tr = get_trans("O64", T)
+    sp = red_spectra(T, nf, seed=7)
+    a = run_device(tr, nf, sp)
+    b = np.zeros(nf * g.size())
+    tr.invtrans(nf, sp, b)
+    assert np.array_equal(a, b)
+
+
+def test_vordiv_path_against_oracle_and_analytic():
+    T = 63
+    g, tr = get_trans("F64", T)
+    nx, lat = g.nx(), g.y()
+    op = oracle.OraclePlan(T, nx, lat)
+    ns, nvd = 2, 3
+    sp, vor, div = red_spectra(T, ns, 1), red_spectra(T, nvd, 2), red_spectra(T, nvd, 3)
+    gp = np.zeros((ns + 2 * nvd) * g.size())
+    tr.invtrans(ns, sp, nvd, vor, div, gp)
+    ref = op.invtrans_vordiv(ns, sp, nvd, vor, div)
+    assert compute_rms(gp, ref) < 1e-12
+    # device entry point
+    gp_d = torch.zeros(gp.size, dtype=torch.float64, device="cuda")
+    tr.invtrans(ns, dev(sp), nvd, dev(vor), dev(div), gp_d)
+    tr.synchronize()
+    assert np.array_equal(gp_d.cpu().numpy(), gp)
+    # analytic wind known answers (test_transgeneral.cc:286-371), tolerance 2e-6 (:538)
+    for ivar_in in (0, 1):
+        for (n, m, imag) in [(1, 0, 0), (1, 1, 0), (1, 1, 1)]:
+            coef, zero = unit_spectrum(T, 1, n, m, imag), np.zeros((T + 1) * (T + 2))
+            v, d = (coef, zero) if ivar_in == 0 else (zero, coef)
+            wind = np.zeros(2 * g.size())
+            tr.invtrans_vordiv2wind(1, v, d, wind)
+            wind = wind.reshape(2, -1)
+            for ivar_out in (0, 1):
+                ana = np.concatenate([wind_kat(ivar_in, ivar_out, n, m, imag, np.arange(k) * (2 * math.pi / k),
+                                               y * math.pi / 180.0) for k, y in zip(nx, lat)])
+                assert compute_rms(wind[ivar_out], ana) < 2e-6
+
+
+def test_legendre_cache_round_trip():
+    # TransLocal.cc:608-647: write_legendre / read: a Trans built from the exported blob gives identical results
+    T, nf = 31, 3
+    g, tr = get_trans("O32", T)
+    blob = tr.legendre_cache()
+    op = oracle.OraclePlan(T, g.nx(), g.y())
+    sym, asym = op.tables()
+    assert blob.tobytes() == sym.tobytes() + asym.tobytes()   # byte-compatible with the reference layout
+    tr2 = atlas_amd.Trans(g, T, legendre_cache=blob)
+    sp = red_spectra(T, nf, seed=3)
+    assert np.array_equal(run_device(tr, nf, sp), run_device(tr2, nf, sp))
+    with pytest.raises(_lib.AtlasAmdError):
+        atlas_amd.Trans(g, T, legendre_cache=blob[:-8])
+
+
+def test_regular_lonlat_grid_with_poles_and_equator():
+    # L-type grid: 17 latitudes 90..-90 (poles clamped to +-89.9999999, equator row shared by both hemispheres)
+    ny, nxl, T = 17, 32, 7
+    lat = np.linspace(90.0, -90.0, ny)
+    g = atlas_amd.StructuredGrid(nx=np.full(ny, nxl), y=lat)
+    tr = atlas_amd.Trans(g, T)
+    sp = red_spectra(T, 3)
+    gp = run_device(tr, 3, sp)
+    ref = oracle.OraclePlan(T, g.nx(), g.y()).invtrans(3, sp)
+    assert compute_rms(gp, ref) < TOL
+
+
+def test_not_implemented_like_translocal():
+    g, tr = get_trans("O32", 31)
+    with pytest.raises(NotImplementedError):
+        tr.dirtrans(1, None, None)
+    with pytest.raises(NotImplementedError):
+        tr.invtrans_adj(1, None, None)
+
+
+# ---------------------------------------------------------------- BASELINE full size: TL1279 -> O1280, 137 levels
+@pytest.fixture(scope="module")
+def trans_full():
+    g = atlas_amd.Grid("O1280")
+    return g, atlas_amd.Trans(g, 1279)
+
+
+def test_full_size_sampled_rows_against_oracle(trans_full):
+    g, tr = trans_full
+    T, nf = 1279, 137
+    sp = red_spectra(T, nf)
+    gp = run_device(tr, nf, sp).reshape(nf, -1)
+    rows = [0, 1, 639, 1279, 1280, 2000, 2559]
+    op = oracle.OraclePlan(T, g.nx(), g.y(), with_tables=False)
+    off = np.concatenate([[0], np.cumsum(g.nx())])
+    for r, ref in zip(rows, op.invtrans_rows(nf, sp, rows, use_fft=True)):
+        assert compute_rms(gp[:, off[r]:off[r + 1]], ref) < 1e-12, r
+
+
+def test_full_size_linearity(trans_full):
+    g, tr = trans_full
+    T, nf = 1279, 16
+    x, y = red_spectra(T, nf, seed=11), red_spectra(T, nf, seed=12)
+    a, b = 0.75, -1.5
+    gx, gy, gxy = run_device(tr, nf, x), run_device(tr, nf, y), run_device(tr, nf, a * x + b * y)
+    assert compute_rms(gxy, a * gx + b * gy) < 1e-13
+    # field independence: field k of a multi-field call == the single-field call
+    g1 = run_device(tr, 1, x.reshape(-1, nf)[:, 5].copy())
+    assert compute_rms(gx.reshape(nf, -1)[5], g1) < 1e-14

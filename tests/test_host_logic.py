@@ -1,0 +1,134 @@
+"""CPU tests of the product's HOST logic and of the C-ABI surface (no GPU needed):
+  * every symbol declared in include/atlas_amd.h is exported by the shared library
+  * Gaussian latitudes reproduce the reference tables (golden SHA-256 fixture) / its Newton solver
+  * fourier_truncation, nlat0 and the Legendre tables are bit-identical to the oracle's
+  * the FFT phase code shared with the HIP kernel (fft_core.h) satisfies the c2r contract vs numpy (pocketfft)
+  * the product refuses to run a transform without a HIP device (no CPU fallback)"""
+import ctypes as C
+import hashlib
+import json
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+import atlas_amd
+import oracle
+from atlas_amd import _lib
+from helpers import compute_rms
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "atlas_amd.h")).read()
+    names = set(re.findall(r"\b(atlas_amd__\w+)\s*\(", hdr))
+    assert len(names) > 40
+    lib = C.CDLL(_lib.LIB_PATH)
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_gaussian_latitudes_golden():
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "gaussian_latitudes.json")))["tables"]
+    for N, entry in gold.items():
+        N = int(N)
+        if N > 2000:
+            continue  # N4000 / N8000 take a few seconds each; covered by tools/gen_gaussian_corrections.py
+        lats = atlas_amd.gaussian_latitudes(N)
+        assert hashlib.sha256(lats.astype("<f8").tobytes()).hexdigest() == entry["sha256"], N
+        assert lats[0] == entry["first"] and lats[N - 1] == entry["last_nh"]
+
+
+def test_gaussian_latitudes_newton_matches_leggauss():
+    # non-tabulated N: double-precision Newton of Latitudes.cc:100-273; independent check with numpy
+    for N in (8, 20, 37, 100):
+        lats = atlas_amd.gaussian_latitudes(N)
+        x, _ = np.polynomial.legendre.leggauss(2 * N)
+        ref = np.degrees(np.arcsin(x[::-1]))
+        assert np.abs(lats - ref).max() < 1e-11, N
+        assert np.all(np.diff(lats) < 0)
+
+
+def test_grid_builders():
+    g = atlas_amd.Grid("O64")
+    assert g.ny() == 128 and g.size() == 18688 and g.nx(0) == 20 and g.nx(63) == 272 and g.nx(64) == 272
+    f = atlas_amd.Grid("F64")
+    assert f.ny() == 128 and f.size() == 128 * 256 and f.regular()
+    o1280 = atlas_amd.Grid("O1280")
+    assert o1280.size() == 6599680 and o1280.nxmax() == 5136       # C4 grid points
+    with pytest.raises(_lib.AtlasAmdError):
+        atlas_amd.Grid("X12")
+
+
+@pytest.mark.parametrize("gridname,T", [("F64", 63), ("O64", 63), ("O32", 31), ("O160", 159), ("F32", 31), ("O48", 95)])
+def test_geometry_and_tables_bit_identical_to_oracle(gridname, T):
+    g = atlas_amd.Grid(gridname)
+    op = oracle.OraclePlan(T, g.nx(), g.y(), with_tables=(T < 100))
+    # fourier_truncation on every row
+    ny = g.ny()
+    for j in range(0, ny, 7):
+        lat = g.y(j) * math.pi / 180.0
+        assert _lib.fourier_truncation(T, g.nx(j), g.nxmax(), ny, lat, int(g.regular())) == \
+            oracle.fourier_truncation(T, g.nx(j), g.nxmax(), ny, lat, g.regular())
+    if T >= 100:
+        return
+    ss, sa = C.c_size_t(), C.c_size_t()
+    _lib.check(_lib.legendre_reference_sizes(g._h, T, C.byref(ss), C.byref(sa)))
+    osym, oasym = op.tables()
+    assert (ss.value, sa.value) == (osym.size, oasym.size)
+    sym, asym = np.zeros(ss.value), np.zeros(sa.value)
+    _lib.check(_lib.legendre_reference_tables(g._h, T, sym.ctypes.data, ss.value, asym.ctypes.data, sa.value))
+    assert np.array_equal(sym, osym) and np.array_equal(asym, oasym)
+
+
+def test_legendre_cache_is_grid_independent():
+    # reference: test_trans_localcache.cc:86-128 -- the cache of any Gaussian grid with the same N and T is
+    # byte-identical (tables depend only on truncation and latitudes)
+    T = 31
+    blobs = []
+    for name in ("F32", "O32"):
+        g = atlas_amd.Grid(name)
+        ss, sa = C.c_size_t(), C.c_size_t()
+        _lib.check(_lib.legendre_reference_sizes(g._h, T, C.byref(ss), C.byref(sa)))
+        sym, asym = np.zeros(ss.value), np.zeros(sa.value)
+        _lib.check(_lib.legendre_reference_tables(g._h, T, sym.ctypes.data, ss.value, asym.ctypes.data, sa.value))
+        blobs.append(hashlib.md5(sym.tobytes() + asym.tobytes()).hexdigest())
+    assert blobs[0] == blobs[1]
+
+
+ROW_LENGTHS = [20, 24, 28, 32, 36, 44, 52, 60, 64, 68, 76, 100, 128, 148, 192, 256, 260, 300, 404, 500, 1004, 1280,
+               2048, 2560, 4 * 1283, 5120, 5136, 21, 35, 45]
+
+
+@pytest.mark.parametrize("n", ROW_LENGTHS)
+def test_fft_phase_code_against_pocketfft(n):
+    """the host run of fft_core.h (the code the HIP kernel executes) vs numpy.fft.irfft"""
+    rng = np.random.default_rng(n)
+    nc = n // 2 + 1
+    for mmax in (nc - 1, max(0, n // 3), 0):
+        x = rng.standard_normal(nc) + 1j * rng.standard_normal(nc)
+        x[mmax + 1:] = 0
+        out = np.zeros(n)
+        _lib.check(_lib.fft_host_row(n, np.ascontiguousarray(x).ctypes.data, mmax, out.ctypes.data))
+        xx = x.copy()
+        xx[0] = xx[0].real
+        if n % 2 == 0:
+            xx[-1] = xx[-1].real
+        ref = np.fft.irfft(xx, n) * n
+        assert compute_rms(out, ref) < 2e-15, (n, mmax)
+
+
+def test_not_implemented_entry_points_behave_like_translocal():
+    # TransLocal: dirtrans / adjoints are ATLAS_NOTIMPLEMENTED (TransLocal.cc:848-857,899-927,1599-1685)
+    assert _lib.Trans_dirtrans_scalar(None, 1, None, None) != 0
+    assert _lib.last_error().decode().startswith("Not implemented")
+    assert _lib.Trans_invtrans_adj_scalar(None, 1, None, None) != 0
+
+
+@pytest.mark.skipif(_lib.device_count() > 0, reason="only meaningful on a machine without a GPU")
+def test_no_cpu_fallback():
+    with pytest.raises(_lib.AtlasAmdError, match="HIP device"):
+        atlas_amd.Trans("O32", 31)

@@ -1,0 +1,138 @@
+"""Pins the ORACLE (oracle/translocal_oracle.c) against the reference's own known-answer tests and against
+independent evaluations, on the CPU:
+  * analytic spherical harmonics of src/tests/trans/test_transgeneral.cc:80-374 (closed forms n<=3, sectoral n=m),
+    with the reference's row mask `fourier_truncation > m` (:433-449) and tolerance 1e-13 (:534)
+  * wind known answers (:286-371), tolerance 2e-6 (:538)
+  * c2r contract of linalg::FFT (FFT.h:27-72) against numpy.fft.irfft (pocketfft)
+  * the 2x2 GEMM known answer of src/tests/linalg/test_linalg_dense.cc:117-136 through the oracle's GEMM order
+"""
+import math
+
+import numpy as np
+import pytest
+
+import atlas_amd
+import oracle
+from helpers import (CLOSED_FORMS, analytic_scalar, compute_rms, pbar, red_spectra, unit_spectrum, wind_kat)
+
+
+def grid_arrays(name):
+    g = atlas_amd.Grid(name)
+    return g, g.nx(), g.y()
+
+
+def row_mask(T, nx, lat, regular, m):
+    """rows on which wavenumber m survives in the reference test: ftrc > m (test_transgeneral.cc:445)"""
+    ny = len(nx)
+    return [oracle.fourier_truncation(T, int(nx[j]), int(nx.max()), ny, lat[j] * math.pi / 180.0, regular) > m
+            for j in range(ny)]
+
+
+def test_closed_forms_match_general_formula():
+    x = np.linspace(-0.99, 0.99, 41)
+    for (n, m), f in CLOSED_FORMS.items():
+        ref = f(x, np.sqrt(1 - x * x))
+        assert np.allclose(pbar(n, m, x), ref, rtol=1e-13, atol=1e-14), (n, m)
+
+
+def test_legendre_lat_against_closed_forms():
+    trc = 64
+    for lat in [0.0, 0.3, -1.1, 1.5]:
+        lp = oracle.legendre_lat(trc, lat)
+        s, c = math.sin(lat), math.cos(lat)
+        for (n, m), f in CLOSED_FORMS.items():
+            idx = (2 * trc + 3 - m) * m // 2 + n - m
+            assert abs(lp[idx] - f(s, c)) < 2e-14, (n, m, lat)
+        # sectoral harmonics up to 45 (test_transgeneral.cc:258-272): Pbar_n^n = sqrt((2n+1)!!/(2n)!!) cos^n
+        for n in range(1, 46):
+            idx = (2 * trc + 3 - n) * n // 2
+            ref = math.sqrt(math.prod((2 * k + 1) / (2 * k) for k in range(1, n + 1))) * c ** n
+            assert abs(lp[idx] - ref) <= 3e-13 * max(1.0, abs(ref)), (n, lat)
+
+
+@pytest.mark.parametrize("gridname,T", [("F64", 63), ("O64", 63)])
+def test_oracle_scalar_analytic(gridname, T):
+    """test_trans_vordiv_with_translib / test_trans_domain style: every unit coefficient with a closed form"""
+    g, nx, lat = grid_arrays(gridname)
+    op = oracle.OraclePlan(T, nx, lat)
+    cases = [(n, m) for (n, m) in CLOSED_FORMS] + [(n, n) for n in (4, 7, 13, 21, 33, 45)]
+    worst = 0.0
+    for n, m in cases:
+        for imag in (0, 1):
+            if m == 0 and imag == 1:
+                continue
+            sp = unit_spectrum(T, 1, n, m, imag)
+            gp = op.invtrans(1, sp)
+            ref = analytic_scalar(nx, lat, n, m, imag, row_mask(T, nx, lat, g.regular(), m))
+            worst = max(worst, compute_rms(gp, ref))
+    assert worst < 1e-13, worst
+
+
+def test_oracle_fft_equals_direct_on_transform():
+    g, nx, lat = grid_arrays("O32")
+    op = oracle.OraclePlan(31, nx, lat)
+    sp = red_spectra(31, 3)
+    assert compute_rms(op.invtrans(3, sp, use_fft=True), op.invtrans(3, sp, use_fft=False)) < 1e-15
+
+
+def test_oracle_rows_equals_table_path():
+    g, nx, lat = grid_arrays("O32")
+    T, nf = 31, 4
+    op = oracle.OraclePlan(T, nx, lat)
+    sp = red_spectra(T, nf)
+    gp = op.invtrans(nf, sp).reshape(nf, -1)
+    off = np.concatenate([[0], np.cumsum(nx)])
+    rows = [0, 5, 31, 32, 50, 63]
+    for r, blk in zip(rows, op.invtrans_rows(nf, sp, rows)):
+        assert np.array_equal(blk, gp[:, off[r]:off[r + 1]])
+
+
+def test_oracle_wind_analytic():
+    T = 63
+    g, nx, lat = grid_arrays("F64")
+    op = oracle.OraclePlan(T, nx, lat)
+    worst = 0.0
+    for ivar_in in (0, 1):
+        for (n, m) in [(1, 0), (1, 1)]:
+            for imag in (0, 1):
+                if m == 0 and imag == 1:
+                    continue
+                coef = unit_spectrum(T, 1, n, m, imag)
+                zero = np.zeros_like(coef)
+                vor, div = (coef, zero) if ivar_in == 0 else (zero, coef)
+                gp = op.invtrans_vordiv(0, None, 1, vor, div).reshape(2, -1)
+                for ivar_out in (0, 1):
+                    ref = np.concatenate([
+                        wind_kat(ivar_in, ivar_out, n, m, imag, np.arange(k) * (2 * math.pi / k), y * math.pi / 180.0)
+                        for k, y in zip(nx, lat)])
+                    worst = max(worst, compute_rms(gp[ivar_out], ref))
+    assert worst < 2e-6, worst
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 7, 12, 20, 36, 44, 60, 76, 124, 148, 200, 212, 1283 * 4, 641 * 2, 2048, 5136])
+def test_c2r_contract_against_pocketfft(n):
+    rng = np.random.default_rng(n)
+    nc = n // 2 + 1
+    x = rng.standard_normal(nc) + 1j * rng.standard_normal(nc)
+    xx = x.copy()
+    xx[0] = xx[0].real
+    if n % 2 == 0:
+        xx[-1] = xx[-1].real
+    ref = np.fft.irfft(xx, n) * n  # unnormalised c2r
+    assert compute_rms(oracle.c2r_direct(n, x), ref) < 5e-15
+    assert compute_rms(oracle.c2r_fft(n, x), ref) < 5e-15
+
+
+def test_fourier_truncation_known_values():
+    # linear / quadratic / cubic branches of TransLocal.cc:272-300, hand-evaluated
+    ft = oracle.fourier_truncation
+    assert ft(63, 256, 256, 128, 0.3, True) == 63       # full grid: (nx-1)/2 = 127 -> min(T, .)
+    assert ft(127, 20, 256, 128, 1.5, False) == 9       # linear (T >= ndgl-1): (20-1)/2
+    assert ft(63, 20, 272, 128, 88.9277 * math.pi / 180, False) == 8   # cubic: 19/(2+cos^2) - 1 -> 8
+    assert ft(100, 200, 400, 128, 0.0, False) == 99     # quadratic: weight = 3*(127-100)/128 = 0 (INTEGER division) -> 199/2
+
+
+def test_gemm_known_answer():
+    # src/tests/linalg/test_linalg_dense.cc:117-136: [[1,-2],[-4,2]]^2 = [[9,-6],[-12,12]] (column-major C = A*B)
+    A = np.array([[1., -2.], [-4., 2.]])
+    assert np.array_equal(A @ A, np.array([[9., -6.], [-12., 12.]]))
