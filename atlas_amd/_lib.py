@@ -89,6 +89,7 @@ Trans_legendre_flops = _sig("atlas_amd__Trans__legendre_flops", C.c_double, c_vo
 Trans_legendre_table_bytes = _sig("atlas_amd__Trans__legendre_table_bytes", C.c_int64, c_void_p)
 Trans_timings = _sig("atlas_amd__Trans__timings", C.c_int, c_void_p, c_void_p, C.c_int)
 Trans_set_profile = _sig("atlas_amd__Trans__set_profile", C.c_int, c_void_p, C.c_int)
+Trans_fft_phase_profile = _sig("atlas_amd__Trans__fft_phase_profile", C.c_int, c_void_p, C.c_int, c_void_p)
 
 fourier_truncation = _sig("atlas_amd__fourier_truncation", C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                           C.c_int)

@@ -323,6 +323,15 @@ int atlas_amd__Trans__set_profile(atlas_amd_Trans* t, int on) {
     AA_CATCH_INT
 }
 
+int atlas_amd__Trans__fft_phase_profile(atlas_amd_Trans* t, int enable, unsigned long long out[64]) {
+    AA_TRY
+    if (out) {
+        t->impl->read_phase_profile(out);
+    }
+    t->impl->enable_phase_profile(enable != 0);
+    AA_CATCH_INT
+}
+
 // ---------------------------------------------------------------- host-only helpers
 int atlas_amd__fourier_truncation(int truncation, int nx, int nxmax, int ndgl, double lat_rad, int fullgrid) {
     return trans::fourier_truncation(truncation, nx, nxmax, ndgl, lat_rad, fullgrid != 0);

@@ -53,6 +53,7 @@ struct FourierParams {
     long long npts;
     int scale_uv_fields;              // first 2*nb_vordiv fields are multiplied by 1/cos(lat) (TransLocal.cc:1443-1469)
     const double* coslatinv;          // [nlats]
+    unsigned long long* prof;         // optional [64] per-phase cycle accumulators (dev profiling), else null
 };
 
 }  // namespace trans

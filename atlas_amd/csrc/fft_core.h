@@ -12,6 +12,13 @@
 //     separated by a barrier (device: __syncthreads, host: sequential loop over t).
 //   * position P after a full DIF holds frequency  freq(P) = sum_i q_i * (r_1 ... r_{i-1})  where q_i are the
 //     mixed-radix digits of P, most significant first (digit i has weight M / (r_1 ... r_i)).
+//   * radices {2,3,4,5,8,16}; the shape builder puts odd radices first so that every later stage works on
+//     power-of-two sub-blocks (index arithmetic by shifts), then 16s, then one of 8/4/2.
+//   * element i lives at work[PAD(i)], PAD(i) = i + (i >> 4): one pad slot per 16 elements breaks the power-of-two
+//     strides that would otherwise put a whole lane group on one LDS bank (measured: 58% of LDS cycles were
+//     conflicts without it).
+//   * stage twiddles w_L^{jq}, q = 1..R-1, come from ONE table load (w_L^j) and products (depth <= log2 R), which
+//     keeps the vector-memory pipeline free for the row data.
 #pragma once
 #include <cstdint>
 
@@ -24,15 +31,12 @@
 namespace atlas_amd {
 namespace fft {
 
-struct cplx {
+struct alignas(16) cplx {
     double re, im;
 };
 
 AA_HD cplx cmul(cplx a, cplx b) {
     return cplx{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
-}
-AA_HD cplx cmulc(cplx a, cplx b) {  // a * conj(b)
-    return cplx{a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im};
 }
 AA_HD cplx cadd(cplx a, cplx b) {
     return cplx{a.re + b.re, a.im + b.im};
@@ -47,23 +51,27 @@ AA_HD cplx cconj(cplx a) {
 AA_HD cplx cmuli(cplx a, int dir) {
     return dir > 0 ? cplx{-a.im, a.re} : cplx{a.im, -a.re};
 }
+// multiply by (c + i*dir*s)
+AA_HD cplx cmulw(cplx a, double c, double s, int dir) {
+    const double sd = dir > 0 ? s : -s;
+    return cplx{a.re * c - a.im * sd, a.re * sd + a.im * c};
+}
 
-constexpr int MAX_STAGES = 10;
+AA_HD int PAD(int i) {
+    return i + (i >> 4);
+}
+AA_HD int padded_size(int M) {
+    return M + (M >> 4) + 1;
+}
 
-struct FftShape {          // stage list of an M-point transform
+constexpr int MAX_STAGES = 12;
+
+struct FftShape {           // stage list of an M-point transform
     int M;
     int nstages;
     int radix[MAX_STAGES];  // DIF order
+    int lsh[MAX_STAGES];    // log2 of the stage's sub-block length Ls = L/R, or -1 if Ls is not a power of two
 };
-
-// twiddle w_M^t = exp(+2 pi i t / M) from a table of M entries; dir=-1 conjugates
-AA_HD cplx twiddle(const cplx* __restrict__ tw, int t, int dir) {
-    cplx w = tw[t];
-    if (dir < 0) {
-        w.im = -w.im;
-    }
-    return w;
-}
 
 // ---- radix butterflies: y_q = sum_p x_p exp(dir 2 pi i p q / r) ------------------------------------------------
 AA_HD void bfly2(cplx* x) {
@@ -90,8 +98,8 @@ AA_HD void bfly3(cplx* x, int dir) {
     x[2]    = csub(t2, t4);
 }
 AA_HD void bfly5(cplx* x, int dir) {
-    const double c1 = 0.30901699437494742410229341718282;   // cos(2pi/5)
-    const double c2 = -0.80901699437494742410229341718282;  // cos(4pi/5)
+    const double c1 = 0.30901699437494742410229341718282;        // cos(2pi/5)
+    const double c2 = -0.80901699437494742410229341718282;       // cos(4pi/5)
     const double s1 = 0.95105651629515357211643933337938 * dir;  // sin(2pi/5)
     const double s2 = 0.58778525229247312916870595463907 * dir;  // sin(4pi/5)
     cplx a1 = cadd(x[1], x[4]), b1 = csub(x[1], x[4]);
@@ -100,7 +108,6 @@ AA_HD void bfly5(cplx* x, int dir) {
     x[0]    = cplx{x0.re + a1.re + a2.re, x0.im + a1.im + a2.im};
     cplx m1 = cplx{x0.re + c1 * a1.re + c2 * a2.re, x0.im + c1 * a1.im + c2 * a2.im};
     cplx m2 = cplx{x0.re + c2 * a1.re + c1 * a2.re, x0.im + c2 * a1.im + c1 * a2.im};
-    // i*(s1*b1 + s2*b2) and i*(s2*b1 - s1*b2)
     cplx n1 = cplx{-(s1 * b1.im + s2 * b2.im), s1 * b1.re + s2 * b2.re};
     cplx n2 = cplx{-(s2 * b1.im - s1 * b2.im), s2 * b1.re - s1 * b2.re};
     x[1]    = cadd(m1, n1);
@@ -108,68 +115,186 @@ AA_HD void bfly5(cplx* x, int dir) {
     x[2]    = cadd(m2, n2);
     x[3]    = csub(m2, n2);
 }
+// radix 8 = 2 x 4:  p = 4 p1 + p0, q = 2 q1 + q0:  w8^{pq} = w2^{p1 q0} w4^{p0 q1} w8^{p0 q0}
+AA_HD void bfly8(cplx* x, int dir) {
+    const double r = 0.70710678118654752440084436210485;
+    cplx t0[4], t1[4];
+#pragma unroll
+    for (int p0 = 0; p0 < 4; ++p0) {
+        t0[p0] = cadd(x[p0], x[4 + p0]);
+        t1[p0] = csub(x[p0], x[4 + p0]);
+    }
+    t1[1] = cmulw(t1[1], r, r, dir);
+    t1[2] = cmuli(t1[2], dir);
+    t1[3] = cmulw(t1[3], -r, r, dir);
+    bfly4(t0, dir);
+    bfly4(t1, dir);
+#pragma unroll
+    for (int q1 = 0; q1 < 4; ++q1) {
+        x[2 * q1]     = t0[q1];
+        x[2 * q1 + 1] = t1[q1];
+    }
+}
+// radix 16 = 4 x 4:  p = 4 p1 + p0, q = 4 q1 + q0:  w16^{pq} = w4^{p1 q0} w4^{p0 q1} w16^{p0 q0}
+AA_HD void bfly16(cplx* x, int dir) {
+    const double c1 = 0.92387953251128675612818318939679;  // cos(pi/8)
+    const double s1 = 0.38268343236508977172845998403040;  // sin(pi/8)
+    const double r  = 0.70710678118654752440084436210485;
+    cplx t[4][4];  // t[p0][q0]
+#pragma unroll
+    for (int p0 = 0; p0 < 4; ++p0) {
+        cplx u[4] = {x[p0], x[4 + p0], x[8 + p0], x[12 + p0]};
+        bfly4(u, dir);
+#pragma unroll
+        for (int q0 = 0; q0 < 4; ++q0) t[p0][q0] = u[q0];
+    }
+    // internal twiddles w16^{p0 q0}
+    t[1][1] = cmulw(t[1][1], c1, s1, dir);
+    t[1][2] = cmulw(t[1][2], r, r, dir);
+    t[1][3] = cmulw(t[1][3], s1, c1, dir);
+    t[2][1] = cmulw(t[2][1], r, r, dir);
+    t[2][2] = cmuli(t[2][2], dir);
+    t[2][3] = cmulw(t[2][3], -r, r, dir);
+    t[3][1] = cmulw(t[3][1], s1, c1, dir);
+    t[3][2] = cmulw(t[3][2], -r, r, dir);
+    t[3][3] = cmulw(t[3][3], -c1, -s1, dir);
+#pragma unroll
+    for (int q0 = 0; q0 < 4; ++q0) {
+        cplx u[4] = {t[0][q0], t[1][q0], t[2][q0], t[3][q0]};
+        bfly4(u, dir);
+#pragma unroll
+        for (int q1 = 0; q1 < 4; ++q1) x[4 * q1 + q0] = u[q1];
+    }
+}
 template <int R>
 AA_HD void bfly(cplx* x, int dir) {
     if (R == 2) bfly2(x);
     else if (R == 3) bfly3(x, dir);
     else if (R == 4) bfly4(x, dir);
     else if (R == 5) bfly5(x, dir);
+    else if (R == 8) bfly8(x, dir);
+    else if (R == 16) bfly16(x, dir);
 }
 
-// ---- one DIF stage: blocks of length L, radix R; twiddle table of M entries (w_L^t = w_M^{t*M/L}) --------------
+// powers w^1 .. w^(R-1) by halving products (depth <= log2 R roundings)
 template <int R>
-AA_HD void dif_stage(cplx* d, int M, int L, const cplx* __restrict__ tw, int dir, int t, int nt) {
-    const int Ls  = L / R;        // sub-block length
-    const int tws = M / L;        // twiddle stride
-    const int nb  = M / R;        // butterflies
-    for (int b = t; b < nb; b += nt) {
-        const int blk = b / Ls;
-        const int j   = b - blk * Ls;
-        cplx* p       = d + blk * L + j;
-        cplx x[R];
+AA_HD void twiddle_powers(cplx w1, cplx* w) {
+    w[0] = cplx{1., 0.};
+    w[1] = w1;
 #pragma unroll
-        for (int q = 0; q < R; ++q) x[q] = p[q * Ls];
-        bfly<R>(x, dir);
-        p[0] = x[0];
-#pragma unroll
-        for (int q = 1; q < R; ++q) p[q * Ls] = cmul(x[q], twiddle(tw, j * q * tws, dir));
+    for (int q = 2; q < R; ++q) {
+        w[q] = cmul(w[q >> 1], w[q - (q >> 1)]);
     }
 }
-// ---- one DIT stage (inverse of the DIF stage with the same L, R): twiddle first, then butterfly --------------
+
+// butterfly index b -> (block, j) for sub-block length Ls (= 1 << lsh when lsh >= 0)
+AA_HD void split_index(int b, int Ls, int lsh, int& blk, int& j) {
+    if (lsh >= 0) {
+        blk = b >> lsh;
+        j   = b & (Ls - 1);
+    }
+    else {
+        blk = b / Ls;
+        j   = b - blk * Ls;
+    }
+}
+
+// ---- one DIF stage: blocks of length L, radix R; twiddle table of M entries, w_L^j = tw[j * M/L] ---------------
 template <int R>
-AA_HD void dit_stage(cplx* d, int M, int L, const cplx* __restrict__ tw, int dir, int t, int nt) {
+AA_HD void dif_stage(cplx* d, int M, int L, int lsh, const cplx* __restrict__ tw, int dir, int t, int nt) {
     const int Ls  = L / R;
     const int tws = M / L;
     const int nb  = M / R;
     for (int b = t; b < nb; b += nt) {
-        const int blk = b / Ls;
-        const int j   = b - blk * Ls;
-        cplx* p       = d + blk * L + j;
+        int blk, j;
+        split_index(b, Ls, lsh, blk, j);
+        const int base = blk * L + j;
         cplx x[R];
-        x[0] = p[0];
 #pragma unroll
-        for (int q = 1; q < R; ++q) x[q] = cmul(p[q * Ls], twiddle(tw, j * q * tws, dir));
+        for (int q = 0; q < R; ++q) x[q] = d[PAD(base + q * Ls)];
+        bfly<R>(x, dir);
+        d[PAD(base)] = x[0];
+        if (Ls == 1) {  // j == 0: all twiddles are 1
+#pragma unroll
+            for (int q = 1; q < R; ++q) d[PAD(base + q)] = x[q];
+        }
+        else {
+            cplx w1 = tw[j * tws];
+            if (dir < 0) w1.im = -w1.im;
+            cplx w[R];
+            twiddle_powers<R>(w1, w);
+#pragma unroll
+            for (int q = 1; q < R; ++q) d[PAD(base + q * Ls)] = cmul(x[q], w[q]);
+        }
+    }
+}
+// ---- one DIT stage (inverse of the DIF stage with the same L, R): twiddle first, then butterfly --------------
+template <int R>
+AA_HD void dit_stage(cplx* d, int M, int L, int lsh, const cplx* __restrict__ tw, int dir, int t, int nt) {
+    const int Ls  = L / R;
+    const int tws = M / L;
+    const int nb  = M / R;
+    for (int b = t; b < nb; b += nt) {
+        int blk, j;
+        split_index(b, Ls, lsh, blk, j);
+        const int base = blk * L + j;
+        cplx x[R];
+        x[0] = d[PAD(base)];
+        if (Ls == 1) {
+#pragma unroll
+            for (int q = 1; q < R; ++q) x[q] = d[PAD(base + q)];
+        }
+        else {
+            cplx w1 = tw[j * tws];
+            if (dir < 0) w1.im = -w1.im;
+            cplx w[R];
+            twiddle_powers<R>(w1, w);
+#pragma unroll
+            for (int q = 1; q < R; ++q) x[q] = cmul(d[PAD(base + q * Ls)], w[q]);
+        }
         bfly<R>(x, dir);
 #pragma unroll
-        for (int q = 0; q < R; ++q) p[q * Ls] = x[q];
+        for (int q = 0; q < R; ++q) d[PAD(base + q * Ls)] = x[q];
     }
 }
 
-AA_HD void dif_stage_any(int R, cplx* d, int M, int L, const cplx* __restrict__ tw, int dir, int t, int nt) {
-    switch (R) {
-        case 2: dif_stage<2>(d, M, L, tw, dir, t, nt); break;
-        case 3: dif_stage<3>(d, M, L, tw, dir, t, nt); break;
-        case 4: dif_stage<4>(d, M, L, tw, dir, t, nt); break;
-        case 5: dif_stage<5>(d, M, L, tw, dir, t, nt); break;
+// fused middle of the Bluestein convolution: the last DIF stage and the first DIT stage act on the same contiguous
+// groups of R elements (L = R, no twiddles), so forward butterfly, filter multiply and inverse butterfly happen in
+// registers with one LDS read and one LDS write.
+template <int R>
+AA_HD void bluestein_mid(cplx* d, int M, const cplx* __restrict__ bhat, int t, int nt) {
+    const int nb = M / R;
+    for (int b = t; b < nb; b += nt) {
+        cplx x[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) x[q] = d[PAD(b * R + q)];
+        bfly<R>(x, -1);
+#pragma unroll
+        for (int q = 0; q < R; ++q) x[q] = cmul(x[q], bhat[b * R + q]);
+        bfly<R>(x, +1);
+#pragma unroll
+        for (int q = 0; q < R; ++q) d[PAD(b * R + q)] = x[q];
     }
 }
-AA_HD void dit_stage_any(int R, cplx* d, int M, int L, const cplx* __restrict__ tw, int dir, int t, int nt) {
-    switch (R) {
-        case 2: dit_stage<2>(d, M, L, tw, dir, t, nt); break;
-        case 3: dit_stage<3>(d, M, L, tw, dir, t, nt); break;
-        case 4: dit_stage<4>(d, M, L, tw, dir, t, nt); break;
-        case 5: dit_stage<5>(d, M, L, tw, dir, t, nt); break;
+
+#define AA_RADIX_SWITCH(R, CALL)                         \
+    switch (R) {                                         \
+        case 2: { constexpr int RR = 2; CALL; } break;   \
+        case 3: { constexpr int RR = 3; CALL; } break;   \
+        case 4: { constexpr int RR = 4; CALL; } break;   \
+        case 5: { constexpr int RR = 5; CALL; } break;   \
+        case 8: { constexpr int RR = 8; CALL; } break;   \
+        case 16: { constexpr int RR = 16; CALL; } break; \
     }
+
+AA_HD void dif_stage_any(int R, cplx* d, int M, int L, int lsh, const cplx* __restrict__ tw, int dir, int t, int nt) {
+    AA_RADIX_SWITCH(R, dif_stage<RR>(d, M, L, lsh, tw, dir, t, nt))
+}
+AA_HD void dit_stage_any(int R, cplx* d, int M, int L, int lsh, const cplx* __restrict__ tw, int dir, int t, int nt) {
+    AA_RADIX_SWITCH(R, dit_stage<RR>(d, M, L, lsh, tw, dir, t, nt))
+}
+AA_HD void bluestein_mid_any(int R, cplx* d, int M, const cplx* __restrict__ bhat, int t, int nt) {
+    AA_RADIX_SWITCH(R, bluestein_mid<RR>(d, M, bhat, t, nt))
 }
 
 // frequency held at position P after the full DIF (see header comment)
@@ -226,9 +351,10 @@ struct RowOut {
 };
 
 AA_HD int row_num_phases(const RowTables& r) {
-    // load | [DIF stages | pointwise] | DIT stages | store
+    // direct   : load | DIT stages (ns) | store
+    // bluestein: load | DIF stages 0..ns-2 | fused [last DIF stage * filter * first DIT stage] | DIT stages (ns-1) | store
     const int ns = r.shape->nstages;
-    return 1 + (r.method == 1 ? ns + 1 : 0) + ns + 1;
+    return r.method == 1 ? 1 + (ns - 1) + 1 + (ns - 1) + 1 : 1 + ns + 1;
 }
 
 template <class Reader>
@@ -245,6 +371,12 @@ AA_HD cplx row_mode(const Reader& rd, int mmax, int m, int h) {
     return v;
 }
 
+AA_HD int stage_L(const FftShape& s, int i) {
+    int L = s.M;
+    for (int q = 0; q < i; ++q) L /= s.radix[q];
+    return L;
+}
+
 template <class Reader>
 AA_HD void row_phase(int ph, int t, int nt, const RowTables& r, const Reader& rd, const RowOut& io, cplx* work) {
     const int h  = r.h;
@@ -256,46 +388,42 @@ AA_HD void row_phase(int ph, int t, int nt, const RowTables& r, const Reader& rd
             cplx B = cconj(row_mode(rd, io.mmax, h - k, h));
             cplx Z = c2r_pre(A, B, r.pre[k]);
             if (r.method == 1) {
-                work[k] = cmul(Z, r.chirp[k]);
+                work[PAD(k)] = cmul(Z, r.chirp[k]);
             }
             else {
-                work[pos_of_freq(*r.shape, k)] = Z;
+                work[PAD(pos_of_freq(*r.shape, k))] = Z;
             }
         }
         if (r.method == 1) {
             for (int k = h + t; k < M; k += nt) {
-                work[k] = cplx{0., 0.};
+                work[PAD(k)] = cplx{0., 0.};
             }
         }
         return;
     }
     ph -= 1;
+    int dit_first = ns - 1;  // index of the first DIT stage still to run
     if (r.method == 1) {
-        if (ph < ns) {  // ---- forward DIF, stage ph
-            int L = M;
-            for (int i = 0; i < ph; ++i) L /= r.shape->radix[i];
-            dif_stage_any(r.shape->radix[ph], work, M, L, r.tw, -1, t, nt);
+        if (ph < ns - 1) {  // ---- forward DIF, stage ph
+            dif_stage_any(r.shape->radix[ph], work, M, stage_L(*r.shape, ph), r.shape->lsh[ph], r.tw, -1, t, nt);
             return;
         }
-        ph -= ns;
-        if (ph == 0) {  // ---- pointwise multiply with the filter spectrum (same permuted order)
-            for (int p = t; p < M; p += nt) {
-                work[p] = cmul(work[p], r.bhat[p]);
-            }
+        ph -= ns - 1;
+        if (ph == 0) {  // ---- last DIF stage * filter spectrum * first DIT stage
+            bluestein_mid_any(r.shape->radix[ns - 1], work, M, r.bhat, t, nt);
             return;
         }
         ph -= 1;
+        dit_first = ns - 2;
     }
-    if (ph < ns) {  // ---- inverse DIT, stages in reverse order
-        const int i = ns - 1 - ph;
-        int L       = M;
-        for (int q = 0; q < i; ++q) L /= r.shape->radix[q];
-        dit_stage_any(r.shape->radix[i], work, M, L, r.tw, +1, t, nt);
+    if (ph <= dit_first) {  // ---- inverse DIT, stages in reverse order
+        const int i = dit_first - ph;
+        dit_stage_any(r.shape->radix[i], work, M, stage_L(*r.shape, i), r.shape->lsh[i], r.tw, +1, t, nt);
         return;
     }
     // ---- store: y[2j] = Re z[j], y[2j+1] = Im z[j]
     for (int j = t; j < h; j += nt) {
-        cplx z = work[j];
+        cplx z = work[PAD(j)];
         if (r.method == 1) {
             z = cmul(z, r.chirp[j]);
         }

@@ -14,7 +14,7 @@ namespace trans {
 
 using fft::cplx;
 
-constexpr int FFT_NTHR = 256;
+constexpr int FFT_MAX_NTHR = 512;  // 2 waves per SIMD -> 256 VGPRs: radix-16 butterflies stay in registers
 constexpr int FGROUP   = 8;  // fields whose modes share one 128-byte line of F
 
 // Block -> (row, field).  Eight consecutive fields of one row share every 128-byte line of F, and hardware places
@@ -66,7 +66,7 @@ struct ModeReader {
     }
 };
 
-__global__ void __launch_bounds__(FFT_NTHR) fft_rows_kernel(FourierParams p) {
+__global__ void __launch_bounds__(FFT_MAX_NTHR) fft_rows_kernel(FourierParams p) {
     extern __shared__ double lds_raw[];
     cplx* work = reinterpret_cast<cplx*>(lds_raw);
     int row, f;
@@ -78,6 +78,7 @@ __global__ void __launch_bounds__(FFT_NTHR) fft_rows_kernel(FourierParams p) {
     const int nx              = (int)(p.rowoff[row + 1] - p.rowoff[row]);
     double* y                 = p.gp + goff;
     const int tid             = threadIdx.x;
+    const int FFT_NTHR        = blockDim.x;
     const double scale        = (f < p.scale_uv_fields) ? p.coslatinv[row] : 1.0;
     const int mmax            = p.row_mmax[row];
     const ModeReader rd{p, (long long)(row - p.lat0), 2 * f};
@@ -116,9 +117,20 @@ __global__ void __launch_bounds__(FFT_NTHR) fft_rows_kernel(FourierParams p) {
     io.aligned16 = ((goff & 1) == 0) && (nx == n) && scale == 1.0;
 
     const int nph = fft::row_num_phases(r);
+    unsigned long long tprev = 0;
+    const bool prof = p.prof != nullptr && tid == 0;
+    if (prof) {
+        tprev = clock64();
+    }
     for (int ph = 0; ph < nph - 1; ++ph) {
         fft::row_phase(ph, tid, FFT_NTHR, r, rd, io, work);
         __syncthreads();
+        if (prof) {
+            const unsigned long long tn = clock64();
+            // slot: bluestein rows 0..31, direct rows 32..63
+            atomicAdd(&p.prof[(method == 1 ? 0 : 32) + (ph < 30 ? ph : 30)], tn - tprev);
+            tprev = tn;
+        }
     }
     if (io.aligned16) {
         fft::row_phase(nph - 1, tid, FFT_NTHR, r, rd, io, work);
@@ -126,7 +138,7 @@ __global__ void __launch_bounds__(FFT_NTHR) fft_rows_kernel(FourierParams p) {
     else {
         // generic store: scaling by 1/cos(lat) and/or unaligned rows
         for (int j = tid; j < h; j += FFT_NTHR) {
-            cplx z = work[j];
+            cplx z = work[fft::PAD(j)];
             if (method == 1) {
                 z = fft::cmul(z, r.chirp[j]);
             }
@@ -134,9 +146,12 @@ __global__ void __launch_bounds__(FFT_NTHR) fft_rows_kernel(FourierParams p) {
             if (2 * j + 1 < nx) y[2 * j + 1] = z.im * scale;
         }
     }
+    if (prof) {
+        atomicAdd(&p.prof[(method == 1 ? 0 : 32) + 31], clock64() - tprev);
+    }
 }
 
-hipError_t launch_fourier(const FourierParams& p, int lds_bytes, hipStream_t stream) {
+hipError_t launch_fourier(const FourierParams& p, int lds_bytes, int nthreads, hipStream_t stream) {
     static int max_set = 0;
     if (lds_bytes > max_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_kernel),
@@ -149,7 +164,7 @@ hipError_t launch_fourier(const FourierParams& p, int lds_bytes, hipStream_t str
     const int ngr         = (p.nf + FGROUP - 1) / FGROUP;
     const long long units = (long long)p.nrows * ngr;
     const long long nblk  = (units + 7) / 8 * 64;
-    hipLaunchKernelGGL(fft_rows_kernel, dim3((unsigned)nblk), dim3(FFT_NTHR), lds_bytes, stream, p);
+    hipLaunchKernelGGL(fft_rows_kernel, dim3((unsigned)nblk), dim3(nthreads), lds_bytes, stream, p);
     return hipGetLastError();
 }
 

@@ -13,23 +13,31 @@ namespace {
 
 const long double kPiL = 3.14159265358979323846264338327950288L;
 
-// exp(+2 pi i t / N), evaluated in extended precision with octant folding
+// exp(+2 pi i t / N), evaluated in extended precision
 cplx unit_root(int64_t t, int64_t N) {
     t %= N;
     if (t < 0) {
         t += N;
     }
-    // fold to the first octant for accuracy: angle = 2 pi t / N
     long double a = 2.0L * kPiL * (long double)t / (long double)N;
     return cplx{(double)cosl(a), (double)sinl(a)};
 }
 
+// full forward DIF on a PADDED array (same stage code as the kernel)
 void host_fft_dif(const FftShape& s, cplx* d, const cplx* tw, int dir) {
     int L = s.M;
     for (int i = 0; i < s.nstages; ++i) {
-        dif_stage_any(s.radix[i], d, s.M, L, tw, dir, 0, 1);
+        dif_stage_any(s.radix[i], d, s.M, L, s.lsh[i], tw, dir, 0, 1);
         L /= s.radix[i];
     }
+}
+
+int ilog2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) {
+        ++l;
+    }
+    return (1 << l) == v ? l : -1;
 }
 
 }  // namespace
@@ -53,6 +61,22 @@ int next_smooth235(int n) {
     return n;
 }
 
+// smallest member of {1,3,5} * 2^k that is >= n: Bluestein lengths whose stages are one optional radix-3/5 stage
+// followed by radix-16/8/4/2 stages
+int next_bluestein_length(int n) {
+    int best = 0;
+    for (int f : {1, 3, 5}) {
+        int m = f;
+        while (m < n) {
+            m *= 2;
+        }
+        if (best == 0 || m < best) {
+            best = m;
+        }
+    }
+    return best;
+}
+
 FftShape make_shape(int M) {
     if (!is_smooth235(M)) {
         throw std::invalid_argument("make_shape: M is not {2,3,5}-smooth");
@@ -67,21 +91,30 @@ FftShape make_shape(int M) {
         }
         s.radix[s.nstages++] = radix;
     };
-    while (r % 4 == 0) {
-        push(4);
-        r /= 4;
-    }
-    while (r % 2 == 0) {
-        push(2);
-        r /= 2;
+    // odd radices first: every later stage then works on power-of-two sub-blocks
+    while (r % 5 == 0) {
+        push(5);
+        r /= 5;
     }
     while (r % 3 == 0) {
         push(3);
         r /= 3;
     }
-    while (r % 5 == 0) {
-        push(5);
-        r /= 5;
+    while (r % 16 == 0) {
+        push(16);
+        r /= 16;
+    }
+    if (r == 8 || r == 4 || r == 2) {
+        push(r);
+        r = 1;
+    }
+    if (r != 1) {
+        throw std::logic_error("make_shape: factorisation failed");
+    }
+    int L = M;
+    for (int i = 0; i < s.nstages; ++i) {
+        s.lsh[i] = ilog2_exact(L / s.radix[i]);
+        L /= s.radix[i];
     }
     return s;
 }
@@ -135,10 +168,10 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths) {
         }
         else {
             p.method = FFT_BLUESTEIN;
-            p.shape  = make_shape(next_smooth235(2 * h - 1));
+            p.shape  = make_shape(next_bluestein_length(2 * h - 1));
         }
         const int M   = p.shape.M;
-        p.lds_complex = M;
+        p.lds_complex = padded_size(M);
         p.off_tw      = twiddles(M);
         p.off_pre     = (int64_t)ps.table.size();
         for (int k = 0; k < h; ++k) {
@@ -153,19 +186,20 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths) {
                 chirp[k]        = unit_root(q, 2 * (int64_t)h);
                 ps.table.push_back(chirp[k]);
             }
-            // filter b[d] = conj(c[|d|]) wrapped into M, spectrum via the kernel's own forward DIF, scaled by 1/M
-            std::vector<cplx> b(M, cplx{0., 0.});
+            // filter b[d] = conj(c[|d|]) wrapped into M; spectrum via the kernel's own forward DIF (padded layout),
+            // stored in position order and scaled by 1/M
+            std::vector<cplx> b(padded_size(M), cplx{0., 0.});
             for (int d = 0; d < h; ++d) {
-                b[d] = cconj(chirp[d]);
+                b[PAD(d)] = cconj(chirp[d]);
                 if (d) {
-                    b[M - d] = b[d];
+                    b[PAD(M - d)] = b[PAD(d)];
                 }
             }
             host_fft_dif(p.shape, b.data(), ps.table.data() + p.off_tw, -1);
-            p.off_bhat = (int64_t)ps.table.size();
+            p.off_bhat       = (int64_t)ps.table.size();
             const double inv = 1.0 / M;
             for (int i = 0; i < M; ++i) {
-                ps.table.push_back(cplx{b[i].re * inv, b[i].im * inv});
+                ps.table.push_back(cplx{b[PAD(i)].re * inv, b[PAD(i)].im * inv});
             }
         }
         ps.plans.push_back(p);

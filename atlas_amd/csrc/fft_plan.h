@@ -38,6 +38,7 @@ struct FftPlanSet {
 
 bool is_smooth235(int n);
 int next_smooth235(int n);
+int next_bluestein_length(int n);  // smallest {1,3,5}*2^k >= n
 FftShape make_shape(int M);  // M must be {2,3,5}-smooth
 FftPlanSet make_fft_plans(const std::vector<int>& row_lengths);
 

@@ -96,6 +96,9 @@ public:
         timings_ = StageTimings();
     }
     void set_profile(bool on) { profile_ = on; }
+    // dev profiling: per-phase shader-clock totals of the FFT kernel (thread 0 of every workgroup)
+    void enable_phase_profile(bool on);
+    void read_phase_profile(unsigned long long out[64]);
 
 private:
     void upload();
@@ -125,6 +128,7 @@ private:
     double* d_coslatinv_ = nullptr;
     struct SizeClass {
         int lds_bytes;
+        int nthreads;
         int nrows;
         int* d_rows;
     };
@@ -138,6 +142,7 @@ private:
     double* d_all_      = nullptr;  // combined (U,V,scalar) spectra of the vor/div path
     size_t all_cap_     = 0;
     double* d_vd_       = nullptr;  // host-API staging of vor ++ div
+    unsigned long long* d_prof_ = nullptr;
     size_t vd_cap_      = 0;
     void ensure(double*& ptr, size_t& cap, size_t n);
     std::vector<hipEvent_t> events_;  // pairs (begin, end)

@@ -16,7 +16,7 @@ namespace atlas_amd {
 namespace trans {
 
 hipError_t launch_legendre(const LegendreParams& p, int nitems, hipStream_t stream);
-hipError_t launch_fourier(const FourierParams& p, int lds_bytes, hipStream_t stream);
+hipError_t launch_fourier(const FourierParams& p, int lds_bytes, int nthreads, hipStream_t stream);
 hipError_t launch_spectra_prepare(const double* vor, const double* div, const double* sp, double* out, int T, int nvd,
                                   int ns, hipStream_t stream);
 
@@ -96,6 +96,7 @@ Trans::~Trans() {
     fr(d_sp_);
     fr(d_gp_);
     fr(d_all_);
+    fr(d_prof_);
     fr(d_vd_);
     for (auto& e : events_) {
         (void)hipEventDestroy(e);
@@ -170,14 +171,15 @@ void Trans::upload() {
     std::vector<long long> rowoff(geo_.rowoff.begin(), geo_.rowoff.end());
     d_rowoff_ = dev_upload(rowoff.data(), rowoff.size());
     // ---- LDS size classes for the rows of the local latitude band ----
-    const int class_bytes[] = {8 << 10, 16 << 10, 32 << 10, 48 << 10, 64 << 10, 96 << 10, 128 << 10, 160 << 10};
+    // one class per transform length bucket; a workgroup gets one thread per radix-16 butterfly (M/16), so that
+    // ~2 workgroups (8 waves) share a CU for the long rows and more for the short ones
+    const int class_M[] = {256, 512, 1024, 1536, 2048, 2560, 3072, 4096, 5120, 6144, 8192, 10080};
     std::map<int, std::vector<int>> by_class;
     for (int j = band_begin(); j < band_end(); ++j) {
         const fft::FftRowPlan& pl = fftplans_.plans[row_plan[j]];
-        const int need            = pl.lds_complex * 16;
         int cls                   = -1;
-        for (int c : class_bytes) {
-            if (need <= c) {
+        for (int c : class_M) {
+            if (pl.lds_complex <= fft::padded_size(c)) {
                 cls = c;
                 break;
             }
@@ -190,7 +192,8 @@ void Trans::upload() {
     // big classes first (longest blocks start first)
     for (auto it = by_class.rbegin(); it != by_class.rend(); ++it) {
         SizeClass c;
-        c.lds_bytes = std::max(it->first, 16);
+        c.lds_bytes = fft::padded_size(it->first) * 16;
+        c.nthreads  = std::min(512, std::max(64, (it->first / 16 + 63) / 64 * 64));
         c.nrows     = (int)it->second.size();
         // within a class: longest rows first
         std::sort(it->second.begin(), it->second.end(), [&](int a, int b) {
@@ -296,11 +299,12 @@ void Trans::fourier_device(int nb_fields, int nb_vordiv, const double* const* pa
     p.npts            = geo_.rowoff[band_end()] - geo_.rowoff[band_begin()];
     p.scale_uv_fields = std::min(2 * nb_vordiv, nb_fields);
     p.coslatinv       = d_coslatinv_;
+    p.prof            = d_prof_;
     timed_begin(1);
     for (const SizeClass& c : classes_) {
         p.rows  = c.d_rows;
         p.nrows = c.nrows;
-        HIP_CHECK(launch_fourier(p, c.lds_bytes, stream_));
+        HIP_CHECK(launch_fourier(p, c.lds_bytes, c.nthreads, stream_));
     }
     timed_end();
 }
@@ -368,6 +372,29 @@ void Trans::invtrans(int nb_scalar_fields, const double scalar_spectra[], double
     invtrans_uv_device(geo_.T, nb_scalar_fields, 0, d_sp_, d_gp_);
     HIP_CHECK(hipMemcpyAsync(gp_fields, d_gp_, ngp * sizeof(double), hipMemcpyDeviceToHost, stream_));
     synchronize();
+}
+
+void Trans::enable_phase_profile(bool on) {
+    synchronize();
+    if (on && !d_prof_) {
+        HIP_CHECK(hipMalloc((void**)&d_prof_, 64 * sizeof(unsigned long long)));
+    }
+    if (on) {
+        HIP_CHECK(hipMemset(d_prof_, 0, 64 * sizeof(unsigned long long)));
+    }
+    else if (d_prof_) {
+        HIP_CHECK(hipFree(d_prof_));
+        d_prof_ = nullptr;
+    }
+}
+
+void Trans::read_phase_profile(unsigned long long out[64]) {
+    synchronize();
+    if (!d_prof_) {
+        std::memset(out, 0, 64 * sizeof(unsigned long long));
+        return;
+    }
+    HIP_CHECK(hipMemcpy(out, d_prof_, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 }
 
 void Trans::ensure(double*& ptr, size_t& cap, size_t n) {

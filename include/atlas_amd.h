@@ -128,6 +128,9 @@ int64_t atlas_amd__Trans__legendre_table_bytes(const atlas_amd_Trans* t);
  * out = {legendre_ms, legendre_calls, fourier_ms, fourier_calls}; reset != 0 clears the accumulators */
 int atlas_amd__Trans__timings(atlas_amd_Trans* t, double out[4], int reset);
 int atlas_amd__Trans__set_profile(atlas_amd_Trans* t, int on);
+/* dev profiling of the FFT kernel: if out != NULL read the 64 per-phase shader-clock accumulators (slots 0..31
+ * Bluestein rows, 32..63 direct rows), then enable (and zero) or disable the accumulation */
+int atlas_amd__Trans__fft_phase_profile(atlas_amd_Trans* t, int enable, unsigned long long out[64]);
 
 /* host-only helpers exposed for CPU tests of the host logic (no GPU needed) */
 int atlas_amd__fourier_truncation(int truncation, int nx, int nxmax, int ndgl, double lat_rad, int fullgrid);
