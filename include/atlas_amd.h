@@ -143,6 +143,72 @@ int atlas_amd__legendre_reference_sizes(const atlas_amd_Grid* grid, int truncati
  * interleaved complex values; out: n reals.  Test hook only -- the product never computes on the CPU. */
 int atlas_amd__fft_host_row(int n, const double* modes, int mmax, double* out);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * HaloExchange.  Replaces atlas__HaloExchange__* (src/atlas/parallel/HaloExchange.h:429-456).
+ * dtype codes: 0 int, 1 long, 2 float, 3 double (the four types Atlas instantiates, detail/Packer.cc:71-95).
+ * ------------------------------------------------------------------------------------------------------------- */
+atlas_amd_HaloExchange* atlas_amd__HaloExchange__new(void);                 /* atlas__HaloExchange__new    :430 */
+void atlas_amd__HaloExchange__delete(atlas_amd_HaloExchange* h);            /* atlas__HaloExchange__delete :431 */
+/* atlas__HaloExchange__setup(This, part, remote_idx, base, size)  :432 -- one process (periodic / pole duplicates are
+ * exchanged with the same rank) */
+int atlas_amd__HaloExchange__setup(atlas_amd_HaloExchange* h, const int part[], const int remote_idx[], int base,
+                                   int size);
+/* HaloExchange::setup(part, remote_idx, base, parsize, halo_begin)  (HaloExchange.cc:70-72) */
+int atlas_amd__HaloExchange__setup_halo_begin(atlas_amd_HaloExchange* h, const int part[], const int remote_idx[],
+                                              int base, int size, int halo_begin);
+/* multi-process setup in two phases around the caller's allToAll(recvcounts -> sendcounts) and
+ * allToAllv(send_requests -> recv_requests)  (HaloExchange.cc:118,156-159): begin computes recvcounts, recvmap and
+ * send_requests; finish stores sendcounts and sendmap */
+int atlas_amd__HaloExchange__setup_begin(atlas_amd_HaloExchange* h, int nproc, int myproc, const int part[],
+                                         const int remote_idx[], int base, int size, int halo_begin);
+/* same with part / remote_idx in device memory: ghost list built by wavefront-ballot compaction */
+int atlas_amd__HaloExchange__setup_begin_device(atlas_amd_HaloExchange* h, int nproc, int myproc,
+                                                const int* part_dev, const int* remote_idx_dev, int base, int size,
+                                                int halo_begin);
+int atlas_amd__HaloExchange__setup_finish(atlas_amd_HaloExchange* h, const int sendcounts[],
+                                          const int recv_requests[]);
+int atlas_amd__HaloExchange__nproc(const atlas_amd_HaloExchange* h);
+int atlas_amd__HaloExchange__sendcnt(const atlas_amd_HaloExchange* h);
+int atlas_amd__HaloExchange__recvcnt(const atlas_amd_HaloExchange* h);
+/* what: "sendcounts" | "recvcounts" | "senddispls" | "recvdispls" (nproc ints), "sendmap" (sendcnt),
+ *       "recvmap" | "send_requests" (recvcnt) */
+int atlas_amd__HaloExchange__get(const atlas_amd_HaloExchange* h, const char* what, int out[]);
+/* atlas__HaloExchange__execute_strided_<T>(This, field, var_strides, var_shape, var_rank)   :433-440
+ * host arrays, one process; parallel dimension slowest with stride var_shape[0]*var_strides[0] */
+int atlas_amd__HaloExchange__execute_strided_int(atlas_amd_HaloExchange* h, int field[], const int var_strides[],
+                                                 const int var_shape[], int var_rank);
+int atlas_amd__HaloExchange__execute_strided_long(atlas_amd_HaloExchange* h, long field[], const int var_strides[],
+                                                  const int var_shape[], int var_rank);
+int atlas_amd__HaloExchange__execute_strided_float(atlas_amd_HaloExchange* h, float field[], const int var_strides[],
+                                                   const int var_shape[], int var_rank);
+int atlas_amd__HaloExchange__execute_strided_double(atlas_amd_HaloExchange* h, double field[],
+                                                    const int var_strides[], const int var_shape[], int var_rank);
+/* atlas__HaloExchange__execute_adjoint_strided_<T>   :445-452 */
+int atlas_amd__HaloExchange__execute_adjoint_strided_int(atlas_amd_HaloExchange* h, int field[],
+                                                         const int var_strides[], const int var_shape[],
+                                                         int var_rank);
+int atlas_amd__HaloExchange__execute_adjoint_strided_long(atlas_amd_HaloExchange* h, long field[],
+                                                          const int var_strides[], const int var_shape[],
+                                                          int var_rank);
+int atlas_amd__HaloExchange__execute_adjoint_strided_float(atlas_amd_HaloExchange* h, float field[],
+                                                           const int var_strides[], const int var_shape[],
+                                                           int var_rank);
+int atlas_amd__HaloExchange__execute_adjoint_strided_double(atlas_amd_HaloExchange* h, double field[],
+                                                            const int var_strides[], const int var_shape[],
+                                                            int var_rank);
+/* (atlas__HaloExchange__execute_<T>(This, field, var_rank), :441-443/:453-455, are declared but never defined in the
+ * reference, so they have no counterpart.) */
+/* general form of HaloExchange::execute<T,RANK,ParallelDim> / the pack and unpack stages (HaloExchange.h:151-290):
+ * op 0 execute, 1 execute_adjoint (both: one process), 2 pack(sendmap), 3 unpack(recvmap), 4 pack_adjoint(recvmap),
+ * 5 unpack_adjoint(+= at sendmap), 6 zero_halos.  Buffers hold sendcnt*var_size (ops 2,5) or recvcnt*var_size
+ * (ops 3,4) elements.  on_device != 0: device pointers, asynchronous on the object's stream. */
+int atlas_amd__HaloExchange__field_op(atlas_amd_HaloExchange* h, int op, int dtype, void* field, int rank,
+                                      const int shape[], const long long strides[], int parallel_dim, void* buffer,
+                                      int on_device);
+void* atlas_amd__HaloExchange__stream(atlas_amd_HaloExchange* h);
+int atlas_amd__HaloExchange__set_stream(atlas_amd_HaloExchange* h, void* hip_stream);
+int atlas_amd__HaloExchange__synchronize(atlas_amd_HaloExchange* h);
+
 #ifdef __cplusplus
 }
 #endif
