@@ -8,6 +8,7 @@
 #include <string>
 
 #include "../../include/atlas_amd.h"
+#include "capi_types.h"
 #include "fft_plan.h"
 #include "gaussian.h"
 #include "legendre_host.h"
@@ -16,12 +17,6 @@
 
 using namespace atlas_amd;
 
-struct atlas_amd_Grid {
-    grid::StructuredGrid g;
-};
-struct atlas_amd_Trans {
-    trans::Trans* impl;
-};
 
 namespace atlas_amd {
 thread_local std::string g_last_error;

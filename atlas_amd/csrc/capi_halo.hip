@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/atlas_amd.h"
+#include "capi_types.h"
 #include "halo_exchange.h"
 
 namespace atlas_amd {
@@ -16,9 +17,6 @@ void set_last_error(const std::string& s);
 using atlas_amd::parallel::HaloExchange;
 using atlas_amd::parallel::HaloFieldDesc;
 
-struct atlas_amd_HaloExchange {
-    HaloExchange impl;
-};
 
 #define HX_TRY try {
 #define HX_CATCH                                    \

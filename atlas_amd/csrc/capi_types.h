@@ -1,0 +1,20 @@
+// Opaque handle types of include/atlas_amd.h (internal definitions shared by the capi_*.hip translation units).
+#pragma once
+#include "gaussian.h"
+#include "halo_exchange.h"
+
+namespace atlas_amd {
+namespace trans {
+class Trans;
+}
+}  // namespace atlas_amd
+
+struct atlas_amd_Grid {
+    atlas_amd::grid::StructuredGrid g;
+};
+struct atlas_amd_Trans {
+    atlas_amd::trans::Trans* impl;
+};
+struct atlas_amd_HaloExchange {
+    atlas_amd::parallel::HaloExchange impl;
+};

@@ -1,0 +1,175 @@
+"""Host-side mirror of atlas::functionspace::StructuredColumns for global structured grids with band distributions
+(reference: src/atlas/functionspace/StructuredColumns.h, detail/StructuredColumns.cc:811-911 haloExchange dispatch)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .grid import StructuredGrid
+from .parallel import HaloExchange, _describe
+
+c_void_p, c_int = C.c_void_p, C.c_int
+_sig = _lib._sig
+SC_new = _sig("atlas_amd__StructuredColumns__new", c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int)
+SC_delete = _sig("atlas_amd__StructuredColumns__delete", None, c_void_p)
+SC_size_owned = _sig("atlas_amd__StructuredColumns__size_owned", c_int, c_void_p)
+SC_size_halo = _sig("atlas_amd__StructuredColumns__size_halo", c_int, c_void_p)
+SC_bounds = _sig("atlas_amd__StructuredColumns__bounds", c_int, c_void_p, c_void_p)
+SC_row_bounds = _sig("atlas_amd__StructuredColumns__row_bounds", c_int, c_void_p, c_int, c_void_p)
+SC_index = _sig("atlas_amd__StructuredColumns__index", c_int, c_void_p, c_int, c_int, c_void_p)
+SC_get_int = _sig("atlas_amd__StructuredColumns__get_int", c_int, c_void_p, C.c_char_p, c_void_p)
+SC_npole = _sig("atlas_amd__StructuredColumns__nb_pole_row_nodes", c_int, c_void_p)
+SC_glb = _sig("atlas_amd__StructuredColumns__global_index", c_int, c_void_p, c_void_p)
+SC_xy = _sig("atlas_amd__StructuredColumns__xy", c_int, c_void_p, c_void_p)
+SC_setup_hx = _sig("atlas_amd__StructuredColumns__setup_halo_exchange", c_int, c_void_p, c_void_p, c_int, c_int)
+SC_fixup = _sig("atlas_amd__StructuredColumns__fixup_halo_for_vectors", c_int, c_void_p, c_int, c_void_p, c_int,
+                C.c_longlong, C.c_longlong, C.c_longlong, c_void_p)
+
+
+class StructuredColumns:
+    """functionspace::StructuredColumns(grid, distribution, halo=..., periodic_points=...)"""
+
+    def __init__(self, grid, halo=0, periodic_points=False, nparts=1, part=0, distribution="equal_bands"):
+        if isinstance(grid, str):
+            grid = StructuredGrid(name=grid)
+        self.grid = grid
+        if distribution == "equal_bands":
+            bs = 1
+        elif distribution == "regular_bands":
+            if not grid.regular():
+                raise ValueError("regular_bands needs a regular grid")   # RegularBandsPartitioner
+            bs = grid.nxmax()
+        else:
+            raise NotImplementedError(f"distribution '{distribution}' (supported: equal_bands, regular_bands)")
+        self.nparts, self.part = int(nparts), int(part)
+        self._h = _lib.check_ptr(SC_new(grid._h, int(halo), int(bool(periodic_points)), self.nparts, self.part, bs))
+        self._halo_exchange = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h and SC_delete is not None:
+            SC_delete(h)
+            self._h = None
+
+    def sizeOwned(self):
+        return SC_size_owned(self._h)
+
+    def sizeHalo(self):
+        return SC_size_halo(self._h)
+
+    size = sizeHalo
+
+    def _bounds(self):
+        out = (c_int * 4)()
+        SC_bounds(self._h, out)
+        return list(out)
+
+    def j_begin(self):
+        return self._bounds()[0]
+
+    def j_end(self):
+        return self._bounds()[1]
+
+    def j_begin_halo(self):
+        return self._bounds()[2]
+
+    def j_end_halo(self):
+        return self._bounds()[3]
+
+    def _row(self, j):
+        out = (c_int * 4)()
+        _lib.check(SC_row_bounds(self._h, int(j), out))
+        return list(out)
+
+    def i_begin(self, j):
+        return self._row(j)[0]
+
+    def i_end(self, j):
+        return self._row(j)[1]
+
+    def i_begin_halo(self, j):
+        return self._row(j)[2]
+
+    def i_end_halo(self, j):
+        return self._row(j)[3]
+
+    def index(self, i, j):
+        out = c_int()
+        _lib.check(SC_index(self._h, int(i), int(j), C.byref(out)))
+        return out.value
+
+    def _ints(self, what, n=None):
+        out = np.zeros(max(self.sizeHalo() if n is None else n, 1), dtype=np.int32)
+        _lib.check(SC_get_int(self._h, what.encode(), out.ctypes.data))
+        return out[:self.sizeHalo() if n is None else n]
+
+    def partition(self):
+        return self._ints("partition")
+
+    def ghost(self):
+        return self._ints("ghost")
+
+    def index_i(self):
+        return self._ints("index_i")
+
+    def index_j(self):
+        return self._ints("index_j")
+
+    def remote_index(self):
+        return self._ints("remote_idx")
+
+    def pole_row_nodes(self):
+        return self._ints("pole_row_nodes", SC_npole(self._h))
+
+    def global_index(self):
+        out = np.zeros(self.sizeHalo(), dtype=np.int64)
+        SC_glb(self._h, out.ctypes.data)
+        return out
+
+    def xy(self):
+        out = np.zeros((self.sizeHalo(), 2))
+        SC_xy(self._h, out.ctypes.data)
+        return out
+
+    # ---- halo exchange (StructuredColumns.cc:104-152, 811-911)
+    def halo_exchange(self):
+        if self._halo_exchange is None:
+            if self.nparts != 1:
+                raise RuntimeError("multi-partition function space: use begin_halo_exchange() on every partition, then "
+                                   "HaloExchange.finish_emulated([...]) or a distributed setup")
+            hx = HaloExchange()
+            _lib.check(SC_setup_hx(self._h, hx._h, 1, 0))
+            hx._is_setup = True
+            self._halo_exchange = hx
+        return self._halo_exchange
+
+    def begin_halo_exchange(self):
+        hx = HaloExchange()
+        _lib.check(SC_setup_hx(self._h, hx._h, self.nparts, self.part))
+        self._halo_exchange = hx
+        return hx
+
+    def fixup_halo_for_vectors(self, field, stream=None):
+        """field(n, var) or field(n, lev, var) on the device; negates var 0,1 beyond the poles"""
+        dt, ptr, rank, shape, strides, on_dev, _ = _describe(field)
+        if not on_dev:
+            raise TypeError("fixup_halo_for_vectors needs a device tensor")
+        if rank == 2:
+            lev, sn, sk, sv = 1, strides[0], 0, strides[1]
+        elif rank == 3:
+            lev, sn, sk, sv = shape[1], strides[0], strides[1], strides[2]
+        else:
+            raise NotImplementedError("vector fields must have rank 2 or 3")   # StructuredColumns.cc:735-741
+        _lib.check(SC_fixup(self._h, dt, ptr, lev, sn, sk, sv, stream))
+
+    def haloExchange(self, field, vector=False):
+        """fs.haloExchange(field): exchange + pole fix-up for fields whose metadata type is 'vector'"""
+        hx = self.halo_exchange()
+        hx.execute(field)
+        if vector:
+            if hasattr(field, "is_cuda") and field.is_cuda:
+                from .parallel import HX_stream
+                self.fixup_halo_for_vectors(field, HX_stream(hx._h))
+            else:
+                raise TypeError("vector fix-up is implemented for device tensors")
+        return field

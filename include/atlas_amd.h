@@ -28,6 +28,7 @@ extern "C" {
 typedef struct atlas_amd_Grid atlas_amd_Grid;
 typedef struct atlas_amd_Trans atlas_amd_Trans;
 typedef struct atlas_amd_HaloExchange atlas_amd_HaloExchange;
+typedef struct atlas_amd_StructuredColumns atlas_amd_StructuredColumns;
 
 /* ---------------------------------------------------------------------------------------------------------------
  * errors / library info
@@ -208,6 +209,39 @@ int atlas_amd__HaloExchange__field_op(atlas_amd_HaloExchange* h, int op, int dty
 void* atlas_amd__HaloExchange__stream(atlas_amd_HaloExchange* h);
 int atlas_amd__HaloExchange__set_stream(atlas_amd_HaloExchange* h, void* hip_stream);
 int atlas_amd__HaloExchange__synchronize(atlas_amd_HaloExchange* h);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * functionspace::StructuredColumns (global structured grids, band distributions): halo index construction
+ * (src/atlas/functionspace/detail/StructuredColumns_setup.cc:88-663, _create_remote_index.cc:37-255) and the
+ * halo-exchange dispatch of atlas__FunctionSpace__halo_exchange_field (FunctionSpaceInterface.h:40-43 ->
+ * StructuredColumns.cc:811-911).  blocksize: 1 = "equal_bands", nx = "regular_bands"
+ * (src/atlas/grid/detail/distribution/BandsDistribution.h:32-34).  Indices are 0-based.
+ * ------------------------------------------------------------------------------------------------------------- */
+atlas_amd_StructuredColumns* atlas_amd__StructuredColumns__new(const atlas_amd_Grid* grid, int halo,
+                                                               int periodic_points, int nparts, int part,
+                                                               int blocksize);
+void atlas_amd__StructuredColumns__delete(atlas_amd_StructuredColumns* fs);
+int atlas_amd__StructuredColumns__size_owned(const atlas_amd_StructuredColumns* fs);
+int atlas_amd__StructuredColumns__size_halo(const atlas_amd_StructuredColumns* fs);
+/* out = {j_begin, j_end, j_begin_halo, j_end_halo} */
+int atlas_amd__StructuredColumns__bounds(const atlas_amd_StructuredColumns* fs, int out[4]);
+/* out = {i_begin(j), i_end(j), i_begin_halo(j), i_end_halo(j)} */
+int atlas_amd__StructuredColumns__row_bounds(const atlas_amd_StructuredColumns* fs, int j, int out[4]);
+int atlas_amd__StructuredColumns__index(const atlas_amd_StructuredColumns* fs, int i, int j, int* out);
+/* what: "partition" | "ghost" | "index_i" | "index_j" | "remote_idx" (size_halo ints) | "pole_row_nodes" */
+int atlas_amd__StructuredColumns__get_int(const atlas_amd_StructuredColumns* fs, const char* what, int out[]);
+int atlas_amd__StructuredColumns__nb_pole_row_nodes(const atlas_amd_StructuredColumns* fs);
+int atlas_amd__StructuredColumns__global_index(const atlas_amd_StructuredColumns* fs, int64_t out[]); /* 1-based */
+int atlas_amd__StructuredColumns__xy(const atlas_amd_StructuredColumns* fs, double out[]);           /* [n][2] */
+/* HaloExchange::setup(partition, remote_index, base, sizeHalo, sizeOwned) (StructuredColumns.cc:145-148): complete
+ * setup for nparts == 1, local phase (atlas_amd__HaloExchange__setup_begin) otherwise */
+int atlas_amd__StructuredColumns__setup_halo_exchange(const atlas_amd_StructuredColumns* fs,
+                                                      atlas_amd_HaloExchange* hx, int nparts, int part);
+/* FixupHaloForVectors (StructuredColumns.cc:732-808): negate components 0,1 of field(n,[k,]var) in the halo rows
+ * beyond the poles; strides in elements; device pointer, asynchronous on hip_stream */
+int atlas_amd__StructuredColumns__fixup_halo_for_vectors(atlas_amd_StructuredColumns* fs, int dtype, void* field_dev,
+                                                         int levels, long long stride_n, long long stride_k,
+                                                         long long stride_v, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,64 @@
+"""CPU tests: the product's StructuredColumns host logic is identical to the oracle's (all index fields, bitwise xy)
+and reproduces the sizes asserted by the reference tests."""
+import numpy as np
+import pytest
+
+import atlas_amd
+from atlas_amd.functionspace import StructuredColumns
+from oracle.structured_columns import StructuredColumnsOracle
+
+
+def lonlat_grid(nxl, nyl):
+    y = np.array([90.0 - j * 180.0 / (nyl - 1) for j in range(nyl)])
+    return atlas_amd.StructuredGrid(nx=np.full(nyl, nxl), y=y)
+
+
+def compare(fs, orc):
+    assert (fs.sizeOwned(), fs.sizeHalo()) == (orc.size_owned, orc.size_halo)
+    assert np.array_equal(fs.partition(), orc.partition_f)
+    assert np.array_equal(fs.ghost(), orc.ghost)
+    assert np.array_equal(fs.global_index(), orc.glb_idx)
+    assert np.array_equal(fs.index_i(), orc.index_i) and np.array_equal(fs.index_j(), orc.index_j)
+    assert np.array_equal(fs.remote_index(), orc.remote_idx)
+    assert np.array_equal(fs.xy(), orc.xy)
+    assert np.array_equal(fs.pole_row_nodes(), orc.pole_rows_nodes())
+    assert (fs.j_begin(), fs.j_end(), fs.j_begin_halo(), fs.j_end_halo()) == \
+        (orc.j_begin, orc.j_end, orc.j_begin_halo, orc.j_end_halo)
+    for j in range(orc.j_begin_halo, orc.j_end_halo):
+        assert (fs.i_begin_halo(j), fs.i_end_halo(j)) == (orc.i_begin_halo[j], orc.i_end_halo[j])
+        for i in (orc.i_begin_halo[j], orc.i_end_halo[j] - 1):
+            assert fs.index(i, j) == orc.index(i, j)
+
+
+def test_reference_sizes():
+    # src/tests/functionspace/test_structuredcolumns_haloexchange.cc:70-75, 101-112
+    g = lonlat_grid(400, 200)
+    assert StructuredColumns(g, halo=1, periodic_points=True).sizeHalo() == 81406
+    assert StructuredColumns(g, halo=1).sizeHalo() == 81204
+    g = lonlat_grid(400, 201)
+    assert StructuredColumns(g, halo=1).sizeHalo() == 81606
+    owned, halo = [20400, 20000, 20000, 20000], [21306, 20904, 20904, 20904]
+    for r in range(4):
+        fs = StructuredColumns(g, halo=1, nparts=4, part=r, distribution="regular_bands")
+        assert (fs.sizeOwned(), fs.sizeHalo()) == (owned[r], halo[r])
+
+
+@pytest.mark.parametrize("gridname,halo,pp,nparts", [("O8", 2, True, 1), ("O8", 1, False, 3), ("O16", 3, True, 4),
+                                                     ("F8", 2, True, 2), ("O32", 1, False, 8)])
+def test_identical_to_oracle_gaussian(gridname, halo, pp, nparts):
+    g = atlas_amd.Grid(gridname)
+    for part in range(nparts):
+        fs = StructuredColumns(g, halo=halo, periodic_points=pp, nparts=nparts, part=part)
+        orc = StructuredColumnsOracle(g.nx(), g.y(), halo=halo, periodic_points=pp, nparts=nparts, part=part)
+        compare(fs, orc)
+
+
+def test_identical_to_oracle_lonlat_with_poles():
+    g = lonlat_grid(36, 19)
+    for nparts, bs in ((1, 1), (3, 36)):
+        for part in range(nparts):
+            fs = StructuredColumns(g, halo=2, periodic_points=True, nparts=nparts, part=part,
+                                   distribution="regular_bands" if bs > 1 else "equal_bands")
+            orc = StructuredColumnsOracle(g.nx(), g.y(), halo=2, periodic_points=True, nparts=nparts, part=part,
+                                          blocksize=bs)
+            compare(fs, orc)
