@@ -218,3 +218,42 @@ def test_full_size_linearity(trans_full):
     # field independence: field k of a multi-field call == the single-field call
     g1 = run_device(tr, 1, x.reshape(-1, nf)[:, 5].copy())
     assert compute_rms(gx.reshape(nf, -1)[5], g1) < 1e-14
+
+
+# ---------------------------------------------------------------- multi-GPU decomposition, emulated on one device
+@pytest.mark.parametrize("gridname,T,nf,nparts", [("O64", 63, 5, 2), ("O64", 63, 3, 3), ("F32", 31, 4, 4),
+                                                  ("O160", 159, 9, 8)])
+def test_sharded_stages_reproduce_single_device_result(gridname, T, nf, nparts):
+    """P objects with (nparts=P, part=p) in one process: m-sharded Legendre stage, the all-to-all replaced by device
+    copies that follow atlas_amd.dist.transpose_plan, latitude-band Fourier stage.  Must equal the single-object
+    result bit for bit (same arithmetic per (m, latitude) and per row)."""
+    from atlas_amd.dist import transpose_plan
+    g, tr1 = get_trans(gridname, T)
+    sp = red_spectra(T, nf, seed=5)
+    ref = run_device(tr1, nf, sp).reshape(nf, -1)
+    sp_d = dev(sp)
+    trs = [atlas_amd.Trans(g, T, nparts=nparts, part=p) for p in range(nparts)]
+    bands = trs[0].bands()
+    RP = trs[0].fourier_row_pitch(nf)
+    plans = [transpose_plan(g.ny(), T, RP, bands, nparts, p) for p in range(nparts)]
+    F = []
+    for p, tr in enumerate(trs):
+        assert tr.owned_wavenumbers() == plans[p]["cnt"][p]
+        f = torch.zeros(tr.fourier_size(nf), dtype=torch.float64, device="cuda")
+        tr.legendre_device(T, nf, sp_d, f)
+        tr.synchronize()
+        F.append(f)
+    off = np.concatenate([[0], np.cumsum(g.nx())])
+    for q, tr in enumerate(trs):
+        R = torch.zeros(sum(plans[q]["out_splits"]), dtype=torch.float64, device="cuda")
+        for p in range(nparts):   # what all_to_all_single delivers to rank q from rank p
+            src0 = sum(plans[p]["in_splits"][:q])
+            n = plans[p]["in_splits"][q]
+            assert n == plans[q]["out_splits"][p]
+            R[plans[q]["out_offsets"][p]:plans[q]["out_offsets"][p] + n] = F[p][src0:src0 + n]
+        gp = torch.zeros(nf * tr.nb_gridpoints(), dtype=torch.float64, device="cuda")
+        tr.fourier_device(nf, 0, [R[o:] for o in plans[q]["out_offsets"]], plans[q]["cnt"], gp)
+        tr.synchronize()
+        lo, hi = off[bands[q]], off[bands[q + 1]]
+        assert tr.nb_gridpoints() == hi - lo
+        assert np.array_equal(gp.cpu().numpy().reshape(nf, -1), ref[:, lo:hi]), q
