@@ -357,5 +357,11 @@ int atlas_amd__fft_host_row(int n, const double* modes, int mmax, double* out) {
     fft::host_execute_row(ps, 0, reinterpret_cast<const fft::cplx*>(modes), mmax, out);
     AA_CATCH_INT
 }
+int atlas_amd__fft_host_row_generic(int n, const double* modes, int mmax, double* out) {
+    AA_TRY
+    fft::FftPlanSet ps = fft::make_fft_plans({n});
+    fft::host_execute_row(ps, 0, reinterpret_cast<const fft::cplx*>(modes), mmax, out, 256, false);
+    AA_CATCH_INT
+}
 
 }  // extern "C"

@@ -21,6 +21,7 @@
 //     keeps the vector-memory pipeline free for the row data.
 #pragma once
 #include <cstdint>
+#include <type_traits>
 
 #if defined(__HIPCC__)
 #define AA_HD __host__ __device__ __forceinline__
@@ -347,7 +348,8 @@ struct RowTables {
 struct RowOut {
     int mmax;                // highest non-zero mode, mmax <= h
     double* y;               // n reals
-    int aligned16;           // y is 16-byte aligned
+    int aligned16;           // y is 16-byte aligned and scale == 1: store complex pairs directly
+    double scale;            // 1/cos(lat) for the u,v fields of the vor/div path (TransLocal.cc:1443-1469), else 1
 };
 
 AA_HD int row_num_phases(const RowTables& r) {
@@ -436,6 +438,178 @@ AA_HD void row_phase(int ph, int t, int nt, const RowTables& r, const Reader& rd
         }
     }
 }
+
+
+// ======================================================================================================
+// Compile-time specialised Bluestein rows: M = F * 2^K (F in {1,3,5}).  Same stage primitives as above, but the
+// stage list is a template parameter so every stride / shift folds to a constant, the load + c2r pre-processing +
+// chirp is fused into DIF stage 0 (whose inputs k >= h are the zero padding) and the chirp post-multiply + store is
+// fused into the last DIT stage (whose outputs k >= h are not needed): 2*NS-1 phases, 2*NS-2 barriers, 4 LDS round
+// trips for a 3-stage length instead of 6.  The filter spectrum is read through a [q][butterfly] transposed copy so
+// that the lanes of one load instruction are contiguous.
+template <int F_, int K_>
+struct CtShape {
+    static constexpr int F   = F_;
+    static constexpr int K   = K_;
+    static constexpr int M   = F_ << K_;
+    static constexpr int N16 = K_ / 4;
+    static constexpr int REM = 1 << (K_ % 4);
+    static constexpr int NS  = (F_ > 1 ? 1 : 0) + N16 + (REM > 1 ? 1 : 0);
+    static constexpr int radix(int i) {
+        if (F_ > 1) {
+            if (i == 0) return F_;
+            i -= 1;
+        }
+        return i < N16 ? 16 : REM;
+    }
+    static constexpr int L(int i) {
+        int l = M;
+        for (int q = 0; q < i; ++q) l /= radix(q);
+        return l;
+    }
+    static constexpr int lsh(int i) {
+        int ls = L(i) / radix(i), s = 0;
+        while ((1 << s) < ls) ++s;
+        return (1 << s) == ls ? s : -1;
+    }
+};
+
+struct RowTablesCt {
+    int n, h;
+    const cplx* tw;       // [M]
+    const cplx* pre;      // [h]
+    const cplx* chirp;    // [h]
+    const cplx* bhat_t;   // [R_last][M / R_last]  filter spectrum, transposed for the fused middle stage
+};
+
+template <class S, int I, class Fn>
+AA_HD void ct_stage_dispatch(int i, Fn&& fn) {
+    if constexpr (I < S::NS) {
+        if (i == I) {
+            fn(std::integral_constant<int, I>{});
+        }
+        else {
+            ct_stage_dispatch<S, I + 1>(i, fn);
+        }
+    }
+}
+
+template <class S>
+AA_HD constexpr int row_num_phases_ct() {
+    return 2 * S::NS - 1;
+}
+
+template <class S, class Reader>
+AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCt& r, const Reader& rd, const RowOut& io,
+                        cplx* work) {
+    constexpr int M   = S::M;
+    constexpr int NS  = S::NS;
+    constexpr int R0  = S::radix(0);
+    constexpr int Ls0 = M / R0;
+    constexpr int RL  = S::radix(NS - 1);
+    const int h       = r.h;
+    if (ph == 0) {
+        // ---- fused: load + c2r pre-processing + chirp + DIF stage 0 (L = M, one block)
+        for (int b = t; b < Ls0; b += nt) {
+            cplx x[R0];
+#pragma unroll
+            for (int q = 0; q < R0; ++q) {
+                const int k = b + q * Ls0;
+                if (k < h) {
+                    cplx A = row_mode(rd, io.mmax, k, h);
+                    cplx B = cconj(row_mode(rd, io.mmax, h - k, h));
+                    x[q]   = cmul(c2r_pre(A, B, r.pre[k]), r.chirp[k]);
+                }
+                else {
+                    x[q] = cplx{0., 0.};
+                }
+            }
+            bfly<R0>(x, -1);
+            cplx w1 = r.tw[b];
+            w1.im   = -w1.im;
+            cplx w[R0];
+            twiddle_powers<R0>(w1, w);
+            work[PAD(b)] = x[0];
+#pragma unroll
+            for (int q = 1; q < R0; ++q) work[PAD(b + q * Ls0)] = cmul(x[q], w[q]);
+        }
+        return;
+    }
+    if (ph < NS - 1) {  // ---- forward DIF stages 1 .. NS-2
+        ct_stage_dispatch<S, 1>(ph, [&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            if constexpr (I >= 1 && I <= NS - 2) {
+                dif_stage<S::radix(I)>(work, M, S::L(I), S::lsh(I), r.tw, -1, t, nt);
+            }
+        });
+        return;
+    }
+    if (ph == NS - 1) {  // ---- fused middle: last DIF stage * filter * first DIT stage (L = RL, no twiddles)
+        constexpr int nb = M / RL;
+        for (int b = t; b < nb; b += nt) {
+            cplx x[RL];
+#pragma unroll
+            for (int q = 0; q < RL; ++q) x[q] = work[PAD(b * RL + q)];
+            bfly<RL>(x, -1);
+#pragma unroll
+            for (int q = 0; q < RL; ++q) x[q] = cmul(x[q], r.bhat_t[q * nb + b]);
+            bfly<RL>(x, +1);
+#pragma unroll
+            for (int q = 0; q < RL; ++q) work[PAD(b * RL + q)] = x[q];
+        }
+        return;
+    }
+    if (ph < 2 * NS - 2) {  // ---- inverse DIT stages NS-2 .. 1
+        const int i = 2 * NS - 2 - ph;  // ph = NS -> i = NS-2 ; ph = 2NS-3 -> i = 1
+        ct_stage_dispatch<S, 1>(i, [&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            if constexpr (I >= 1 && I <= NS - 2) {
+                dit_stage<S::radix(I)>(work, M, S::L(I), S::lsh(I), r.tw, +1, t, nt);
+            }
+        });
+        return;
+    }
+    // ---- fused: DIT stage 0 + chirp + store (outputs k >= h are padding)
+    for (int b = t; b < Ls0; b += nt) {
+        cplx w1 = r.tw[b];
+        cplx w[R0];
+        twiddle_powers<R0>(w1, w);
+        cplx x[R0];
+        x[0] = work[PAD(b)];
+#pragma unroll
+        for (int q = 1; q < R0; ++q) x[q] = cmul(work[PAD(b + q * Ls0)], w[q]);
+        bfly<R0>(x, +1);
+#pragma unroll
+        for (int q = 0; q < R0; ++q) {
+            const int k = b + q * Ls0;
+            if (k < h) {
+                const cplx z = cmul(x[q], r.chirp[k]);
+                if (io.aligned16) {
+                    *reinterpret_cast<cplx*>(io.y + 2 * (int64_t)k) = z;
+                }
+                else {
+                    io.y[2 * (int64_t)k]     = z.re * io.scale;
+                    io.y[2 * (int64_t)k + 1] = z.im * io.scale;
+                }
+            }
+        }
+    }
+}
+
+// the (F, K) instances that exist (kernel and host emulation use the same list)
+AA_HD constexpr bool ct_supported(int f, int k) {
+    return (f == 1 && k >= 8 && k <= 13) || (f == 3 && k >= 7 && k <= 11) || (f == 5 && k >= 6 && k <= 10);
+}
+#define AA_CT_CASE(FF, KK, CALL)                         \
+    if (ctf == FF && ctk == KK) {                        \
+        using S = ::atlas_amd::fft::CtShape<FF, KK>;     \
+        CALL;                                            \
+    }
+#define AA_CT_DISPATCH(ctf, ctk, CALL)                                                                          \
+    AA_CT_CASE(1, 8, CALL) AA_CT_CASE(1, 9, CALL) AA_CT_CASE(1, 10, CALL) AA_CT_CASE(1, 11, CALL)               \
+    AA_CT_CASE(1, 12, CALL) AA_CT_CASE(1, 13, CALL) AA_CT_CASE(3, 7, CALL) AA_CT_CASE(3, 8, CALL)               \
+    AA_CT_CASE(3, 9, CALL) AA_CT_CASE(3, 10, CALL) AA_CT_CASE(3, 11, CALL) AA_CT_CASE(5, 6, CALL)               \
+    AA_CT_CASE(5, 7, CALL) AA_CT_CASE(5, 8, CALL) AA_CT_CASE(5, 9, CALL) AA_CT_CASE(5, 10, CALL)
 
 }  // namespace fft
 }  // namespace atlas_amd

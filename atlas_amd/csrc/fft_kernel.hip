@@ -115,6 +115,7 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR) fft_rows_kernel(FourierParams p)
     io.mmax      = mmax < h ? mmax : h;
     io.y         = y;
     io.aligned16 = ((goff & 1) == 0) && (nx == n) && scale == 1.0;
+    io.scale     = scale;
 
     const int nph = fft::row_num_phases(r);
     unsigned long long tprev = 0;
@@ -149,6 +150,68 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR) fft_rows_kernel(FourierParams p)
     if (prof) {
         atomicAdd(&p.prof[(method == 1 ? 0 : 32) + 31], clock64() - tprev);
     }
+}
+
+// ---- compile-time specialised Bluestein rows (fft_core.h: row_phase_ct) -------------------------------------------
+template <class S>
+__global__ void __launch_bounds__(FFT_MAX_NTHR) fft_rows_ct_kernel(FourierParams p) {
+    extern __shared__ double lds_raw[];
+    cplx* work = reinterpret_cast<cplx*>(lds_raw);
+    int row, f;
+    if (!fft_block_to_job(p, blockIdx.x, row, f)) {
+        return;
+    }
+    const fft::FftRowPlan* pl = p.plans + p.row_plan[row];
+    const long long goff      = (long long)f * p.npts + (p.rowoff[row] - p.rowoff[p.lat0]);
+    const int tid             = threadIdx.x;
+    const int nt              = blockDim.x;
+    const double scale        = (f < p.scale_uv_fields) ? p.coslatinv[row] : 1.0;
+    const int mmax            = p.row_mmax[row];
+    const ModeReader rd{p, (long long)(row - p.lat0), 2 * f};
+    fft::RowTablesCt r;
+    r.n      = pl->n;
+    r.h      = pl->h;
+    r.tw     = p.table + pl->off_tw;
+    r.pre    = p.table + pl->off_pre;
+    r.chirp  = p.table + pl->off_chirp;
+    r.bhat_t = p.table + pl->off_bhat_t;
+    fft::RowOut io;
+    io.mmax      = mmax < r.h ? mmax : r.h;
+    io.y         = p.gp + goff;
+    io.aligned16 = ((goff & 1) == 0) && scale == 1.0;
+    io.scale     = scale;
+    constexpr int NPH = fft::row_num_phases_ct<S>();
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+        fft::row_phase_ct<S>(ph, tid, nt, r, rd, io, work);
+        if (ph < NPH - 1) {
+            __syncthreads();
+        }
+    }
+}
+
+template <class S>
+static hipError_t launch_ct(const FourierParams& p, int lds_bytes, int nthreads, unsigned nblk, hipStream_t stream) {
+    static int max_set = 0;
+    if (lds_bytes > max_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_ct_kernel<S>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) {
+            return e;
+        }
+        max_set = lds_bytes;
+    }
+    hipLaunchKernelGGL(fft_rows_ct_kernel<S>, dim3(nblk), dim3(nthreads), lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_fourier_ct(const FourierParams& p, int ctf, int ctk, int lds_bytes, int nthreads,
+                             hipStream_t stream) {
+    const int ngr         = (p.nf + FGROUP - 1) / FGROUP;
+    const long long units = (long long)p.nrows * ngr;
+    const unsigned nblk   = (unsigned)((units + 7) / 8 * 64);
+    AA_CT_DISPATCH(ctf, ctk, return launch_ct<S>(p, lds_bytes, nthreads, nblk, stream))
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_fourier(const FourierParams& p, int lds_bytes, int nthreads, hipStream_t stream) {

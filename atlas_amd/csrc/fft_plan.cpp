@@ -148,7 +148,8 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths) {
     };
     for (int n : ns) {
         FftRowPlan p{};
-        p.n = n;
+        p.n    = n;
+        p.ct_k = -1;
         if (n % 2 != 0) {
             p.method      = FFT_DFT;
             p.h           = 0;
@@ -201,13 +202,37 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths) {
             for (int i = 0; i < M; ++i) {
                 ps.table.push_back(cplx{b[PAD(i)].re * inv, b[PAD(i)].im * inv});
             }
+            // transposed copy [q][butterfly] for the specialised kernel's fused middle stage
+            const int RL = p.shape.radix[p.shape.nstages - 1];
+            const int nb = M / RL;
+            p.off_bhat_t = (int64_t)ps.table.size();
+            for (int q = 0; q < RL; ++q) {
+                for (int bb = 0; bb < nb; ++bb) {
+                    ps.table.push_back(ps.table[p.off_bhat + (int64_t)bb * RL + q]);
+                }
+            }
+            // M = F * 2^K with a specialised instance?
+            p.ct_k = -1;
+            for (int f : {1, 3, 5}) {
+                if (M % f == 0) {
+                    const int k = ilog2_exact(M / f);
+                    if (k >= 0 && ct_supported(f, k)) {
+                        p.ct_f = f;
+                        p.ct_k = k;
+                    }
+                }
+            }
+        }
+        else {
+            p.ct_k = -1;
         }
         ps.plans.push_back(p);
     }
     return ps;
 }
 
-void host_execute_row(const FftPlanSet& ps, int plan, const cplx* X, int mmax, double* y, int nthreads) {
+void host_execute_row(const FftPlanSet& ps, int plan, const cplx* X, int mmax, double* y, int nthreads,
+                      bool use_specialised) {
     const FftRowPlan& p = ps.plans.at(plan);
     if (p.method == FFT_DFT) {
         const cplx* w = ps.table.data() + p.off_pre;
@@ -235,8 +260,31 @@ void host_execute_row(const FftPlanSet& ps, int plan, const cplx* X, int mmax, d
     io.mmax      = std::min(mmax, p.h);
     io.y         = y;
     io.aligned16 = 0;
+    io.scale     = 1.0;
     auto rd      = [X](int m) { return X[m]; };
     std::vector<cplx> work(p.lds_complex);
+    if (use_specialised && p.method == FFT_BLUESTEIN && p.ct_k >= 0) {
+        RowTablesCt rc;
+        rc.n      = p.n;
+        rc.h      = p.h;
+        rc.tw     = r.tw;
+        rc.pre    = r.pre;
+        rc.chirp  = r.chirp;
+        rc.bhat_t = ps.table.data() + p.off_bhat_t;
+        const int ctf = p.ct_f, ctk = p.ct_k;
+        bool done = false;
+        AA_CT_DISPATCH(ctf, ctk, {
+            for (int ph = 0; ph < row_num_phases_ct<S>(); ++ph) {
+                for (int t = 0; t < nthreads; ++t) {
+                    row_phase_ct<S>(ph, t, nthreads, rc, rd, io, work.data());
+                }
+            }
+            done = true;
+        })
+        if (done) {
+            return;
+        }
+    }
     const int nph = row_num_phases(r);
     for (int ph = 0; ph < nph; ++ph) {
         for (int t = 0; t < nthreads; ++t) {

@@ -28,6 +28,8 @@ struct FftRowPlan {
     int64_t off_pre;    // [h]  exp(+2 pi i k / n)        (DFT method: [n] exp(+2 pi i j / n))
     int64_t off_chirp;  // [h]  exp(+i pi k^2 / h)        (BLUESTEIN)
     int64_t off_bhat;   // [M]  DFT_M(conj chirp, wrapped) / M in DIF order (BLUESTEIN)
+    int64_t off_bhat_t; // [R_last][M/R_last] the same, transposed for the compile-time specialised kernel
+    int ct_f, ct_k;     // M = ct_f << ct_k handled by a specialised kernel instance (ct_k < 0: generic kernel)
 };
 
 struct FftPlanSet {
@@ -44,7 +46,8 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths);
 
 // Host execution of one row with exactly the kernel's algorithm (used by CPU tests; NOT a product fallback:
 // nothing in the invtrans path calls it).  X: h+1 (or n/2+1) complex modes (zero beyond mmax); y: n reals.
-void host_execute_row(const FftPlanSet& ps, int plan, const cplx* X, int mmax, double* y, int nthreads = 256);
+void host_execute_row(const FftPlanSet& ps, int plan, const cplx* X, int mmax, double* y, int nthreads = 256,
+                      bool use_specialised = true);
 
 }  // namespace fft
 }  // namespace atlas_amd

@@ -113,6 +113,7 @@ private:
     std::vector<int> bands_;
     int m_cnt_          = 0;
     bool profile_       = false;
+    bool use_ct_        = true;  // ATLAS_AMD_FFT_GENERIC=1 forces the generic FFT kernel (A/B comparisons)
     hipStream_t stream_ = nullptr;
     bool own_stream_    = false;
 
@@ -129,6 +130,7 @@ private:
     struct SizeClass {
         int lds_bytes;
         int nthreads;
+        int ct_f, ct_k;  // specialised kernel instance, or ct_k < 0
         int nrows;
         int* d_rows;
     };

@@ -17,6 +17,8 @@ namespace trans {
 
 hipError_t launch_legendre(const LegendreParams& p, int nitems, hipStream_t stream);
 hipError_t launch_fourier(const FourierParams& p, int lds_bytes, int nthreads, hipStream_t stream);
+hipError_t launch_fourier_ct(const FourierParams& p, int ctf, int ctk, int lds_bytes, int nthreads,
+                             hipStream_t stream);
 hipError_t launch_spectra_prepare(const double* vor, const double* div, const double* sp, double* out, int T, int nvd,
                                   int ns, hipStream_t stream);
 
@@ -53,6 +55,9 @@ Trans::Trans(const grid::StructuredGrid& grid, int truncation, const TransConfig
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         throw std::runtime_error(
             "atlas_amd::Trans needs a HIP device (MI355X / gfx950); there is no CPU fallback for the transform");
+    }
+    if (const char* e = std::getenv("ATLAS_AMD_FFT_GENERIC")) {
+        use_ct_ = !(e[0] == '1');
     }
     work_ = make_legendre_work(geo_, cfg.nparts, cfg.part);
     bands_ = latitude_bands(geo_, cfg.nparts);
@@ -170,14 +175,18 @@ void Trans::upload() {
     d_coslatinv_ = dev_upload(coslatinv.data(), coslatinv.size());
     std::vector<long long> rowoff(geo_.rowoff.begin(), geo_.rowoff.end());
     d_rowoff_ = dev_upload(rowoff.data(), rowoff.size());
-    // ---- LDS size classes for the rows of the local latitude band ----
-    // one class per transform length bucket; a workgroup gets one thread per radix-16 butterfly (M/16), so that
-    // ~2 workgroups (8 waves) share a CU for the long rows and more for the short ones
+    // ---- launch classes for the rows of the local latitude band ----
+    // Bluestein rows whose length M = F*2^K has a compile-time specialised kernel instance form one class per M;
+    // everything else (short rows, {2,3,5}-smooth rows, odd rows) goes to the generic kernel, bucketed by LDS need.
     const int class_M[] = {256, 512, 1024, 1536, 2048, 2560, 3072, 4096, 5120, 6144, 8192, 10080};
-    std::map<int, std::vector<int>> by_class;
+    std::map<std::pair<int, int>, std::vector<int>> by_class;  // (specialised ? 1 : 0, M bucket)
     for (int j = band_begin(); j < band_end(); ++j) {
         const fft::FftRowPlan& pl = fftplans_.plans[row_plan[j]];
-        int cls                   = -1;
+        if (pl.method == fft::FFT_BLUESTEIN && pl.ct_k >= 0) {
+            by_class[{1, pl.shape.M}].push_back(j);
+            continue;
+        }
+        int cls = -1;
         for (int c : class_M) {
             if (pl.lds_complex <= fft::padded_size(c)) {
                 cls = c;
@@ -187,17 +196,24 @@ void Trans::upload() {
         if (cls < 0) {
             throw std::runtime_error("row length " + std::to_string(pl.n) + " does not fit in LDS (160 KiB)");
         }
-        by_class[cls].push_back(j);
+        by_class[{0, cls}].push_back(j);
     }
     // big classes first (longest blocks start first)
     for (auto it = by_class.rbegin(); it != by_class.rend(); ++it) {
         SizeClass c;
-        c.lds_bytes = fft::padded_size(it->first) * 16;
-        c.nthreads  = std::min(512, std::max(64, (it->first / 16 + 63) / 64 * 64));
+        const int M = it->first.second;
+        c.lds_bytes = fft::padded_size(M) * 16;
+        c.nthreads  = std::min(512, std::max(64, (M / 16 + 63) / 64 * 64));
         c.nrows     = (int)it->second.size();
+        c.ct_f = c.ct_k = -1;
+        if (it->first.first == 1) {
+            const fft::FftRowPlan& pl = fftplans_.plans[row_plan[it->second[0]]];
+            c.ct_f                    = pl.ct_f;
+            c.ct_k                    = pl.ct_k;
+        }
         // within a class: longest rows first
         std::sort(it->second.begin(), it->second.end(), [&](int a, int b) {
-            const int na = fftplans_.plans[row_plan[a]].lds_complex, nb = fftplans_.plans[row_plan[b]].lds_complex;
+            const int na = fftplans_.plans[row_plan[a]].n, nb = fftplans_.plans[row_plan[b]].n;
             return na > nb || (na == nb && a < b);
         });
         c.d_rows = dev_upload(it->second.data(), it->second.size());
@@ -304,7 +320,12 @@ void Trans::fourier_device(int nb_fields, int nb_vordiv, const double* const* pa
     for (const SizeClass& c : classes_) {
         p.rows  = c.d_rows;
         p.nrows = c.nrows;
-        HIP_CHECK(launch_fourier(p, c.lds_bytes, c.nthreads, stream_));
+        if (c.ct_k >= 0 && use_ct_) {
+            HIP_CHECK(launch_fourier_ct(p, c.ct_f, c.ct_k, c.lds_bytes, c.nthreads, stream_));
+        }
+        else {
+            HIP_CHECK(launch_fourier(p, c.lds_bytes, c.nthreads, stream_));
+        }
     }
     timed_end();
 }

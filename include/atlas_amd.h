@@ -143,6 +143,8 @@ int atlas_amd__legendre_reference_sizes(const atlas_amd_Grid* grid, int truncati
 /* run ONE row of the c2r transform on the host with the kernel's own phase code (fft_core.h); modes: n/2+1
  * interleaved complex values; out: n reals.  Test hook only -- the product never computes on the CPU. */
 int atlas_amd__fft_host_row(int n, const double* modes, int mmax, double* out);
+/* same through the generic (run-time shape) phase code even where a compile-time specialised instance exists */
+int atlas_amd__fft_host_row_generic(int n, const double* modes, int mmax, double* out);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * HaloExchange.  Replaces atlas__HaloExchange__* (src/atlas/parallel/HaloExchange.h:429-456).
