@@ -58,12 +58,27 @@ AA_HD cplx cmulw(cplx a, double c, double s, int dir) {
     return cplx{a.re * c - a.im * sd, a.re * sd + a.im * c};
 }
 
+#ifndef AA_FFT_LDS_SWIZZLE
+#define AA_FFT_LDS_SWIZZLE 1
+#endif
+#if AA_FFT_LDS_SWIZZLE
+// XOR swizzle of the low 4 index bits with the next 4: a bijection inside every aligned block of 256 elements, so
+// the footprint stays exactly M (two M = 5120 rows fit the 160 KiB of a CU) while the power-of-two strides of the
+// radix-16/8/4 stages still spread over the 16-byte LDS slots.
+AA_HD int PAD(int i) {
+    return i ^ ((i >> 4) & 15);
+}
+AA_HD int padded_size(int M) {
+    return (M + 255) / 256 * 256;
+}
+#else
 AA_HD int PAD(int i) {
     return i + (i >> 4);
 }
 AA_HD int padded_size(int M) {
     return M + (M >> 4) + 1;
 }
+#endif
 
 constexpr int MAX_STAGES = 12;
 
@@ -362,11 +377,14 @@ AA_HD int row_num_phases(const RowTables& r) {
 template <class Reader>
 AA_HD cplx row_mode(const Reader& rd, int mmax, int m, int h) {
     // X[m] with the c2r conventions of the reference call site (TransLocal.cc:1166-1178):
-    // imaginary part of m=0 is dropped; the Nyquist mode m=h contributes its real part only.
-    if (m > mmax) {
-        return cplx{0., 0.};
+    // imaginary part of m=0 is dropped; the Nyquist mode m=h contributes its real part only; modes above mmax are 0.
+    // Branch-free (clamped address + select) so that the gathers of one phase can all be in flight together.
+    const int mc = m > mmax ? (mmax < 0 ? 0 : mmax) : m;
+    cplx v       = rd(mc);
+    if (m > mmax || mmax < 0) {
+        v.re = 0.;
+        v.im = 0.;
     }
-    cplx v = rd(m);
     if (m == 0 || m == h) {
         v.im = 0.;
     }

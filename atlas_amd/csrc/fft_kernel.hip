@@ -181,11 +181,21 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR) fft_rows_ct_kernel(FourierParams
     io.aligned16 = ((goff & 1) == 0) && scale == 1.0;
     io.scale     = scale;
     constexpr int NPH = fft::row_num_phases_ct<S>();
+    unsigned long long tprev = 0;
+    const bool prof = p.prof != nullptr && tid == 0;
+    if (prof) {
+        tprev = clock64();
+    }
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) {
         fft::row_phase_ct<S>(ph, tid, nt, r, rd, io, work);
         if (ph < NPH - 1) {
             __syncthreads();
+        }
+        if (prof) {
+            const unsigned long long tn = clock64();
+            atomicAdd(&p.prof[ph], tn - tprev);
+            tprev = tn;
         }
     }
 }

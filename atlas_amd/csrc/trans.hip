@@ -203,7 +203,11 @@ void Trans::upload() {
         SizeClass c;
         const int M = it->first.second;
         c.lds_bytes = fft::padded_size(M) * 16;
-        c.nthreads  = std::min(512, std::max(64, (M / 16 + 63) / 64 * 64));
+        int ntdiv   = 16;
+        if (const char* e = std::getenv("ATLAS_AMD_FFT_NT_DIV")) {
+            ntdiv = std::max(1, atoi(e));
+        }
+        c.nthreads  = std::min(512, std::max(64, (M / ntdiv + 63) / 64 * 64));
         c.nrows     = (int)it->second.size();
         c.ct_f = c.ct_k = -1;
         if (it->first.first == 1) {
