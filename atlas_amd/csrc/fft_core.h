@@ -12,7 +12,7 @@
 //     separated by a barrier (device: __syncthreads, host: sequential loop over t).
 //   * position P after a full DIF holds frequency  freq(P) = sum_i q_i * (r_1 ... r_{i-1})  where q_i are the
 //     mixed-radix digits of P, most significant first (digit i has weight M / (r_1 ... r_i)).
-//   * radices {2,3,4,5,8,16}; the shape builder puts odd radices first so that every later stage works on
+//   * radices {2,3,4,5,8,9,16}; the shape builder puts odd radices first so that every later stage works on
 //     power-of-two sub-blocks (index arithmetic by shifts), then 16s, then one of 8/4/2.
 //   * element i lives at work[PAD(i)], PAD(i) = i + (i >> 4): one pad slot per 16 elements breaks the power-of-two
 //     strides that would otherwise put a whole lane group on one LDS bank (measured: 58% of LDS cycles were
@@ -182,9 +182,35 @@ AA_HD void bfly16(cplx* x, int dir) {
         for (int q1 = 0; q1 < 4; ++q1) x[4 * q1 + q0] = u[q1];
     }
 }
+// radix 9 = 3 x 3:  p = 3 p1 + p0, q = 3 q1 + q0:  w9^{pq} = w3^{p1 q0} w9^{p0 q0} w3^{p0 q1}
+AA_HD void bfly9(cplx* x, int dir) {
+    const double c1 = 0.76604444311897803520239265055542, s1 = 0.64278760968653932632264340990726;   // 40 deg
+    const double c2 = 0.17364817766693034885171662676931, s2 = 0.98480775301220805936674302458952;   // 80 deg
+    const double c4 = -0.93969262078590838405410927732473, s4 = 0.34202014332566873304409961468226;  // 160 deg
+    cplx t[3][3];  // t[p0][q0]
+#pragma unroll
+    for (int p0 = 0; p0 < 3; ++p0) {
+        cplx u[3] = {x[p0], x[3 + p0], x[6 + p0]};
+        bfly3(u, dir);
+#pragma unroll
+        for (int q0 = 0; q0 < 3; ++q0) t[p0][q0] = u[q0];
+    }
+    t[1][1] = cmulw(t[1][1], c1, s1, dir);
+    t[1][2] = cmulw(t[1][2], c2, s2, dir);
+    t[2][1] = cmulw(t[2][1], c2, s2, dir);
+    t[2][2] = cmulw(t[2][2], c4, s4, dir);
+#pragma unroll
+    for (int q0 = 0; q0 < 3; ++q0) {
+        cplx u[3] = {t[0][q0], t[1][q0], t[2][q0]};
+        bfly3(u, dir);
+#pragma unroll
+        for (int q1 = 0; q1 < 3; ++q1) x[3 * q1 + q0] = u[q1];
+    }
+}
 template <int R>
 AA_HD void bfly(cplx* x, int dir) {
     if (R == 2) bfly2(x);
+    else if (R == 9) bfly9(x, dir);
     else if (R == 3) bfly3(x, dir);
     else if (R == 4) bfly4(x, dir);
     else if (R == 5) bfly5(x, dir);
@@ -300,6 +326,7 @@ AA_HD void bluestein_mid(cplx* d, int M, const cplx* __restrict__ bhat, int t, i
         case 4: { constexpr int RR = 4; CALL; } break;   \
         case 5: { constexpr int RR = 5; CALL; } break;   \
         case 8: { constexpr int RR = 8; CALL; } break;   \
+        case 9: { constexpr int RR = 9; CALL; } break;   \
         case 16: { constexpr int RR = 16; CALL; } break; \
     }
 
@@ -616,7 +643,8 @@ AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCt& r, const Reade
 
 // the (F, K) instances that exist (kernel and host emulation use the same list)
 AA_HD constexpr bool ct_supported(int f, int k) {
-    return (f == 1 && k >= 8 && k <= 13) || (f == 3 && k >= 7 && k <= 11) || (f == 5 && k >= 6 && k <= 10);
+    return (f == 1 && k >= 8 && k <= 13) || (f == 3 && k >= 7 && k <= 11) || (f == 5 && k >= 6 && k <= 10) ||
+           (f == 9 && k >= 5 && k <= 9);
 }
 #define AA_CT_CASE(FF, KK, CALL)                         \
     if (ctf == FF && ctk == KK) {                        \
@@ -627,7 +655,9 @@ AA_HD constexpr bool ct_supported(int f, int k) {
     AA_CT_CASE(1, 8, CALL) AA_CT_CASE(1, 9, CALL) AA_CT_CASE(1, 10, CALL) AA_CT_CASE(1, 11, CALL)               \
     AA_CT_CASE(1, 12, CALL) AA_CT_CASE(1, 13, CALL) AA_CT_CASE(3, 7, CALL) AA_CT_CASE(3, 8, CALL)               \
     AA_CT_CASE(3, 9, CALL) AA_CT_CASE(3, 10, CALL) AA_CT_CASE(3, 11, CALL) AA_CT_CASE(5, 6, CALL)               \
-    AA_CT_CASE(5, 7, CALL) AA_CT_CASE(5, 8, CALL) AA_CT_CASE(5, 9, CALL) AA_CT_CASE(5, 10, CALL)
+    AA_CT_CASE(5, 7, CALL) AA_CT_CASE(5, 8, CALL) AA_CT_CASE(5, 9, CALL) AA_CT_CASE(5, 10, CALL)               \
+    AA_CT_CASE(9, 5, CALL) AA_CT_CASE(9, 6, CALL) AA_CT_CASE(9, 7, CALL) AA_CT_CASE(9, 8, CALL)                 \
+    AA_CT_CASE(9, 9, CALL)
 
 }  // namespace fft
 }  // namespace atlas_amd

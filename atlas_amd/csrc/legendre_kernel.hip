@@ -23,6 +23,9 @@
 // Entries with m above the row's Fourier truncation are never written and never read (fft_kernel.hip).
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "device_structs.h"
 
 namespace atlas_amd {
@@ -33,23 +36,38 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int KB   = LEG_KB_DEV;  // 8 total wavenumbers per stage
 constexpr int BN   = LEG_BN_DEV;  // 64 latitudes per item
 constexpr int PSTR = BN + 16;     // LDS row stride of the P stage (== 16 mod 32 doubles: conflict-free ds_read_b64)
-constexpr int NTHR = 512;
 
-template <int RTW>
+// RTW = 16-column tiles per wave, NRG = column groups (of RTW tiles) per workgroup; a workgroup has 4*NRG waves:
+// wave w handles latitude tile (w & 3) and column group (w >> 2).
+template <int RTW, int NRG>
 struct LegLds {
-    static constexpr int SSTR   = 32 * RTW + 16;  // == 16 mod 32
+    static constexpr int NTHR   = 256 * NRG;
+    static constexpr int SCOLS  = 16 * RTW * NRG;
+    static constexpr int SSTR   = SCOLS + ((16 - SCOLS % 32) + 32) % 32;  // smallest stride >= SCOLS that is == 16 mod 32
     static constexpr int P_ELEM = 2 * KB * PSTR;
     static constexpr int S_ELEM = 2 * KB * SSTR;
     static constexpr int STAGE  = P_ELEM + S_ELEM;
     static constexpr int BYTES  = 2 * STAGE * 8;  // double buffered
 };
 
-template <int RTW>
-__global__ void __launch_bounds__(NTHR) legendre_kernel(LegendreParams p) {
-    using L = LegLds<RTW>;
+template <int RTW, int NRG>
+__global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel(LegendreParams p) {
+    using L = LegLds<RTW, NRG>;
+    constexpr int NTHR = L::NTHR;
     extern __shared__ double lds[];
 
-    const LegendreItemDev it = p.items[blockIdx.x];
+    // block -> (item, column chunk).  Hardware places block b on XCD b % 8; the chunks of one item are given to
+    // blocks b, b+8, b+16, ... (same XCD, dispatched back to back) so that a later chunk finds the item's P block
+    // in that XCD's L2, and items keep the XCD their list position implies (trans_plan.cpp).  Speed heuristic only.
+    const int nchunks   = p.nchunks;
+    const int bx        = blockIdx.x & 7;
+    const int bq        = blockIdx.x >> 3;
+    const int chunk     = bq % nchunks;
+    const int item_slot = (bq / nchunks) * 8 + bx;
+    if (item_slot >= p.nitems) {
+        return;
+    }
+    const LegendreItemDev it = p.items[item_slot];
     if (it.m < 0) {
         return;
     }
@@ -62,7 +80,7 @@ __global__ void __launch_bounds__(NTHR) legendre_kernel(LegendreParams p) {
     const int T    = p.T;
     const int nf   = p.nf;
     const int trc  = p.trc_in;
-    const int r0   = blockIdx.y * (32 * RTW);  // first interleaved column of this chunk
+    const int r0   = chunk * L::SCOLS;         // first interleaved column of this chunk
     const int TL   = T + 1;                    // truncation of the table
     // largest n <= T+1 of each parity (n-m even: sym)
     const int ntop0 = TL - ((TL - m) & 1);
@@ -81,21 +99,33 @@ __global__ void __launch_bounds__(NTHR) legendre_kernel(LegendreParams p) {
         for (int j = 0; j < RTW; ++j) acc[q][j] = d4{0., 0., 0., 0.};
 
     // ---- staging: registers for one stage ----
-    double2 preg;       // P: 2 doubles per thread (1024 doubles per stage)
-    double sreg[RTW];   // S: RTW doubles per thread (512*RTW doubles per stage)
-    // P element ids 2*tid, 2*tid+1:  parity = e / 512, k = (e % 512) / 64, c = e % 64
-    const int pe   = 2 * tid;
-    const int ppar = pe >> 9, pk = (pe & 511) >> 6, pc = pe & 63;
-    const double* pg = Pb + (long long)ppar * it.kpad * BN + pk * BN + pc;
-    const int plds   = ppar * (KB * PSTR) + pk * PSTR + pc;
+    constexpr int PPT   = NTHR >= 512 ? 1 : 512 / NTHR;  // double2 of P per thread (1024 doubles per stage)
+    const bool p_loader = NTHR <= 512 || tid < 512;      // with more than 512 threads only the first 512 stage P
+    double2 preg[PPT];
+    double sreg[RTW];   // S: RTW doubles per thread (16 rows x SCOLS columns per stage)
+    // P element ids 2*(tid + NTHR*i):  parity = e / 512, k = (e % 512) / 64, c = e % 64
+    const double* pg[PPT];
+    int plds[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int pe   = (2 * (tid + NTHR * i)) & 1023;
+        const int ppar = pe >> 9, pk = (pe & 511) >> 6, pc = pe & 63;
+        pg[i]          = Pb + (long long)ppar * it.kpad * BN + pk * BN + pc;
+        plds[i]        = ppar * (KB * PSTR) + pk * PSTR + pc;
+    }
 
     auto load_stage = [&](int s) {
-        preg = *reinterpret_cast<const double2*>(pg + (long long)s * KB * BN);
+        if (p_loader) {
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                preg[i] = *reinterpret_cast<const double2*>(pg[i] + (long long)s * KB * BN);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < RTW; ++i) {
             const int q    = tid + NTHR * i;
-            const int row  = q / (32 * RTW);  // 0..15 : parity*8 + k
-            const int col  = q - row * (32 * RTW);
+            const int row  = q / L::SCOLS;  // 0..15 : parity*8 + k
+            const int col  = q - row * L::SCOLS;
             const int par  = row >> 3;
             const int k    = s * KB + (row & 7);
             const int n    = (par ? ntop1 : ntop0) - 2 * k;
@@ -110,13 +140,18 @@ __global__ void __launch_bounds__(NTHR) legendre_kernel(LegendreParams p) {
     };
     auto store_stage = [&](int buf) {
         double* base = lds + buf * L::STAGE;
-        *reinterpret_cast<double2*>(base + plds) = preg;
+        if (p_loader) {
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                *reinterpret_cast<double2*>(base + plds[i]) = preg[i];
+            }
+        }
         double* sb = base + L::P_ELEM;
 #pragma unroll
         for (int i = 0; i < RTW; ++i) {
             const int q   = tid + NTHR * i;
-            const int row = q / (32 * RTW);
-            const int col = q - row * (32 * RTW);
+            const int row = q / L::SCOLS;
+            const int col = q - row * L::SCOLS;
             sb[row * L::SSTR + col] = sreg[i];
         }
     };
@@ -186,49 +221,56 @@ __global__ void __launch_bounds__(NTHR) legendre_kernel(LegendreParams p) {
     }
 }
 
-template <int RTW>
-static hipError_t launch_rtw(const LegendreParams& p, int nitems, int nchunks, hipStream_t stream) {
-    using L = LegLds<RTW>;
+template <int RTW, int NRG>
+static hipError_t launch_cfg(LegendreParams p, int nitems, int nchunks, hipStream_t stream) {
+    using L = LegLds<RTW, NRG>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&legendre_kernel<RTW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&legendre_kernel<RTW, NRG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES);
         if (e != hipSuccess) {
             return e;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(legendre_kernel<RTW>, dim3(nitems, nchunks), dim3(NTHR), L::BYTES, stream, p);
+    p.nitems        = nitems;
+    p.nchunks       = nchunks;
+    const int slots = (nitems + 7) / 8;
+    hipLaunchKernelGGL((legendre_kernel<RTW, NRG>), dim3(slots * nchunks * 8), dim3(L::NTHR), L::BYTES, stream, p);
     return hipGetLastError();
 }
 
-// r tiles per wave for a given number of fields: two wave groups cover 2*RTW tiles (32*RTW columns) per chunk
-int legendre_rtw(int nf) {
+// tiling for a given number of fields: rt = 16-column tiles; a workgroup covers NRG*RTW of them, the rest goes to
+// further column chunks (each chunk its own workgroup, re-reading the item's P block through L2).
+void legendre_tiling(int nf, int& rtw, int& nrg, int& nchunks) {
     const int rt = (2 * nf + 15) / 16;
-    int rtw      = (rt + 1) / 2;
-    if (rtw > 9) {
-        // several chunks: balance the chunk width
-        const int nchunk = (rt + 17) / 18;
-        rtw              = ((rt + nchunk - 1) / nchunk + 1) / 2;
+    // measured at TL1279/O1280/137 levels (18 tiles): 6 tiles per 8-wave workgroup (3 per wave) is the fastest of
+    // {9x2, 9x1, 6x1, 5x2, 3x3, 3x2, 2x3, 2x2}: 3-4 workgroups share a CU and cover each other's staging bubbles
+    nrg          = rt >= 2 ? 2 : 1;
+    nchunks      = (rt + 5) / 6;
+    rtw          = ((rt + nchunks - 1) / nchunks + nrg - 1) / nrg;
+    if (const char* e = std::getenv("ATLAS_AMD_LEG_CFG")) {  // A/B: "rtw,nrg"
+        int a = 0, b = 0;
+        if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && a <= 9 && b >= 1 && b <= 3 && (b < 3 || a <= 4)) {
+            rtw     = a;
+            nrg     = b;
+            nchunks = (rt + a * b - 1) / (a * b);
+        }
     }
-    return rtw < 1 ? 1 : rtw;
 }
 
 hipError_t launch_legendre(const LegendreParams& p, int nitems, hipStream_t stream) {
-    const int rt      = (2 * p.nf + 15) / 16;
-    const int rtw     = legendre_rtw(p.nf);
-    const int nchunks = (rt + 2 * rtw - 1) / (2 * rtw);
+    int rtw, nrg, nchunks;
+    legendre_tiling(p.nf, rtw, nrg, nchunks);
+#define LEG_CASE(R)                                                                      \
+    case R:                                                                              \
+        if (nrg == 1) return launch_cfg<R, 1>(p, nitems, nchunks, stream);               \
+        if (nrg == 2) return launch_cfg<R, 2>(p, nitems, nchunks, stream);               \
+        return launch_cfg<(R <= 4 ? R : 4), 3>(p, nitems, nchunks, stream);
     switch (rtw) {
-        case 1: return launch_rtw<1>(p, nitems, nchunks, stream);
-        case 2: return launch_rtw<2>(p, nitems, nchunks, stream);
-        case 3: return launch_rtw<3>(p, nitems, nchunks, stream);
-        case 4: return launch_rtw<4>(p, nitems, nchunks, stream);
-        case 5: return launch_rtw<5>(p, nitems, nchunks, stream);
-        case 6: return launch_rtw<6>(p, nitems, nchunks, stream);
-        case 7: return launch_rtw<7>(p, nitems, nchunks, stream);
-        case 8: return launch_rtw<8>(p, nitems, nchunks, stream);
-        case 9: return launch_rtw<9>(p, nitems, nchunks, stream);
+        LEG_CASE(1) LEG_CASE(2) LEG_CASE(3) LEG_CASE(4) LEG_CASE(5) LEG_CASE(6) LEG_CASE(7) LEG_CASE(8) LEG_CASE(9)
     }
+#undef LEG_CASE
     return hipErrorInvalidValue;
 }
 
