@@ -24,6 +24,16 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X spec, dense fp64 matrix (v_mfma_f64_16x1
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def measured_traffic():
+    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); collected by tools/prof_pmc.sh, not at bench time."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return json.load(f).get("traffic_bytes_per_launch", {})
+
+
 def cpu_baseline(sample_fields=8):
     """the oracle (CPU restatement of TransLocal: per-m GEMM pair + per-row c2r FFT) timed on the host cores on a
     bounded sample: `sample_fields` of the 137 levels, full TL1279 -> O1280 geometry."""
@@ -49,7 +59,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-fields", type=int, default=8)
+    ap.add_argument("--cpu-sample-fields", type=int, default=24)
     ap.add_argument("--force-dist", action="store_true", help="exercise the distributed driver even with one rank")
     args = ap.parse_args()
 
@@ -128,18 +138,24 @@ def main():
         # Fourier bytes = kept part of the intermediate read once + grid-point output written once
         leg_flops = tr.legendre_flops(nf) / world
         leg_tf = leg_flops / (leg_ms * 1e-3) / 1e12 if leg_ms > 0 else 0.0
-        fft_bytes = (tr.legendre_flops(nf) / (2.0 * nf * 2) / 1.0) * 0.0  # placeholder replaced below
         kept_modes = float(sum(int(tr.nlat0()[m] < g.ny() // 2) * 2 * (g.ny() // 2 - int(tr.nlat0()[m]))
                                for m in range(TRUNC + 1)))          # (lat, m) pairs with data
         fft_bytes = (kept_modes * nf * 16 + nf * g.size() * 8) / world
         fft_gbs = fft_bytes / (fft_ms * 1e-3) / 1e9 if fft_ms > 0 else 0.0
+        traffic = measured_traffic()
         kernels = [
-            {"kernel": "legendre_kernel<9>", "bound": "mfma", "achieved": leg_tf, "peak": FP64_MFMA_PEAK_TFLOPS,
-             "unit": "TFLOP/s", "frac": leg_tf / FP64_MFMA_PEAK_TFLOPS, "avg_ms": leg_ms, "traffic": None},
-            {"kernel": "fft_rows_kernel", "bound": "hbm", "achieved": fft_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": fft_gbs / HBM_PEAK_GBS, "avg_ms": fft_ms, "traffic": None},
+            # one launch per transform: the single largest kernel of the path (rocprofv3 --stats agrees, profiles/)
+            {"kernel": "legendre_kernel", "launches_per_transform": 1, "bound": "mfma", "achieved": leg_tf,
+             "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": leg_tf / FP64_MFMA_PEAK_TFLOPS,
+             "avg_ms": leg_ms, "traffic": traffic.get("legendre_kernel")},
+            # the Fourier stage is one launch per row-length class (fft_rows_ct_kernel<CtShape<F,K>> /
+            # fft_rows_kernel); bytes and time are those of the whole stage of one transform
+            {"kernel": "fft_rows_ct_kernel<*> (Fourier stage, all row classes)",
+             "launches_per_transform": int(tm.get("fourier_launches", 0)) or None, "bound": "hbm",
+             "achieved": fft_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fft_gbs / HBM_PEAK_GBS,
+             "avg_ms": fft_ms, "traffic": traffic.get("fourier_stage")},
         ]
-        dominant = max(kernels, key=lambda k: k["avg_ms"])
+        dominant = kernels[0] if leg_ms >= 0.45 * fft_ms else kernels[1]   # largest single kernel (FFT = ~20 launches)
         out = {
             "metric": "inverse SH transforms/sec (TL1279, O1280, 137 lev)",
             "value": transforms / dt, "unit": "transforms/s", "n_gpus": world, "steps": args.steps,

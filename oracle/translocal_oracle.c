@@ -455,16 +455,30 @@ void orc_c2r_direct(int n, const double* in, double* out) {
     free(cs);
 }
 
-/* ---- plain double-precision complex FFT (recursive mixed radix, generic odd radix, Bluestein) ---- */
+/* ---- double-precision c2r FFT: half-length complex transform (c2r pre-processing), recursive mixed radix with
+ *      table twiddles for 7-smooth lengths, Bluestein (power-of-two convolution) otherwise; per-length plans are
+ *      cached (tables are computed once, in extended precision). ---- */
 typedef struct { double re, im; } orc_cplx;
 
-static void orc_twiddle(int n, int j, double* c, double* s) {
-    /* exp(+2 pi i j / n) with octant reduction for accuracy */
+typedef struct orc_fftplan {
+    int n, h;        /* real length, complex half length */
+    orc_cplx* wn;    /* [h] exp(+2 pi i k / n) */
+    orc_cplx* wh;    /* [h] exp(+2 pi i k / h) (direct) */
+    int bluestein, M;
+    orc_cplx* wM;    /* [M] exp(+2 pi i k / M) */
+    orc_cplx* chirp; /* [h] exp(+i pi k^2 / h) */
+    orc_cplx* fb;    /* [M] FFT_M(conj chirp, wrapped) / M */
+    struct orc_fftplan* next;
+} orc_fftplan;
+
+static orc_fftplan* orc_plans = NULL;
+
+static orc_cplx orc_root(int64_t j, int64_t n) {
     j %= n;
     if (j < 0) j += n;
     long double ang = 2.0L * ORC_PIL * (long double)j / (long double)n;
-    *c = (double)cosl(ang);
-    *s = (double)sinl(ang);
+    orc_cplx w      = {(double)cosl(ang), (double)sinl(ang)};
+    return w;
 }
 
 static int orc_smallest_factor(int n) {
@@ -475,98 +489,39 @@ static int orc_smallest_factor(int n) {
     return n;
 }
 
-/* out[k] = sum_j in[j*stride] exp(sign 2 pi i jk/n); recursive decimation in time */
-static void orc_fft_rec(int n, int sign, const orc_cplx* in, int stride, orc_cplx* out, orc_cplx* scratch);
-
 static int orc_is_smooth(int n) {
-    while (n % 2 == 0) n /= 2;
-    while (n % 3 == 0) n /= 3;
-    while (n % 5 == 0) n /= 5;
-    while (n % 7 == 0) n /= 7;
+    for (int p = 2; p <= 7; p += (p == 2 ? 1 : 2))
+        while (n % p == 0) n /= p;
     return n == 1;
 }
 
-static void orc_fft_bluestein(int n, int sign, const orc_cplx* in, int stride, orc_cplx* out) {
-    int M = 1;
-    while (M < 2 * n - 1) M *= 2;
-    orc_cplx* a  = (orc_cplx*)calloc(M, sizeof(orc_cplx));
-    orc_cplx* b  = (orc_cplx*)calloc(M, sizeof(orc_cplx));
-    orc_cplx* fa = (orc_cplx*)malloc(sizeof(orc_cplx) * M);
-    orc_cplx* fb = (orc_cplx*)malloc(sizeof(orc_cplx) * M);
-    orc_cplx* sc = (orc_cplx*)malloc(sizeof(orc_cplx) * M);
-    orc_cplx* w  = (orc_cplx*)malloc(sizeof(orc_cplx) * n);
-    for (int j = 0; j < n; ++j) { /* w_j = exp(sign i pi j^2 / n), j^2 reduced mod 2n */
-        int64_t q = ((int64_t)j * j) % (2 * (int64_t)n);
-        double c, s;
-        orc_twiddle(2 * n, (int)q, &c, &s);
-        w[j].re = c;
-        w[j].im = sign * s;
-    }
-    for (int j = 0; j < n; ++j) {
-        orc_cplx x = in[(size_t)j * stride];
-        a[j].re    = x.re * w[j].re - x.im * w[j].im;
-        a[j].im    = x.re * w[j].im + x.im * w[j].re;
-        b[j].re    = w[j].re;
-        b[j].im    = -w[j].im;
-        if (j) {
-            b[M - j] = b[j];
-        }
-    }
-    orc_fft_rec(M, +1, a, 1, fa, sc);
-    orc_fft_rec(M, +1, b, 1, fb, sc);
-    for (int j = 0; j < M; ++j) {
-        double re = fa[j].re * fb[j].re - fa[j].im * fb[j].im;
-        double im = fa[j].re * fb[j].im + fa[j].im * fb[j].re;
-        a[j].re   = re;
-        a[j].im   = im;
-    }
-    orc_fft_rec(M, -1, a, 1, fa, sc);
-    for (int k = 0; k < n; ++k) {
-        double re = fa[k].re / M, im = fa[k].im / M;
-        out[k].re = re * w[k].re - im * w[k].im;
-        out[k].im = re * w[k].im + im * w[k].re;
-    }
-    free(a);
-    free(b);
-    free(fa);
-    free(fb);
-    free(sc);
-    free(w);
-}
-
-static void orc_fft_rec(int n, int sign, const orc_cplx* in, int stride, orc_cplx* out, orc_cplx* scratch) {
+/* out[k] = sum_j in[j*stride] exp(sign 2 pi i jk/n); recursive decimation in time.  w: table of N roots, N % n == 0 */
+static void orc_fft_rec(int n, int sign, const orc_cplx* in, int stride, orc_cplx* out, orc_cplx* scratch,
+                        const orc_cplx* w, int N) {
     if (n == 1) {
         out[0] = in[0];
         return;
     }
     int r = orc_smallest_factor(n);
-    if (r > 7 && !orc_is_smooth(n)) {
-        /* n has only large prime factors left */
-        orc_fft_bluestein(n, sign, in, stride, out);
-        return;
-    }
     int m = n / r;
-    /* r sub-transforms of length m on the decimated inputs */
-    for (int q = 0; q < r; ++q) orc_fft_rec(m, sign, in + (size_t)q * stride, stride * r, scratch + (size_t)q * m, out);
-    /* butterflies: out[k + p*m] = sum_q W_n^{q(k+pm)} S_q[k] */
-    orc_cplx t[8];
+    for (int q = 0; q < r; ++q) orc_fft_rec(m, sign, in + (size_t)q * stride, stride * r, scratch + (size_t)q * m, out, w, N);
+    const int tn = N / n, tr = N / r;
+    orc_cplx t[16];
     for (int k = 0; k < m; ++k) {
         for (int q = 0; q < r; ++q) {
-            double c, s;
-            orc_twiddle(n, (int)(((int64_t)q * k) % n), &c, &s);
-            s *= sign;
-            orc_cplx v = scratch[(size_t)q * m + k];
-            t[q].re    = v.re * c - v.im * s;
-            t[q].im    = v.re * s + v.im * c;
+            orc_cplx tw = w[(size_t)(((int64_t)q * k) % n) * tn];
+            double s    = sign * tw.im;
+            orc_cplx v  = scratch[(size_t)q * m + k];
+            t[q].re     = v.re * tw.re - v.im * s;
+            t[q].im     = v.re * s + v.im * tw.re;
         }
         for (int pp = 0; pp < r; ++pp) {
             double re = 0, im = 0;
             for (int q = 0; q < r; ++q) {
-                double c, s;
-                orc_twiddle(r, (pp * q) % r, &c, &s);
-                s *= sign;
-                re += t[q].re * c - t[q].im * s;
-                im += t[q].re * s + t[q].im * c;
+                orc_cplx tw = w[(size_t)((pp * q) % r) * tr];
+                double s    = sign * tw.im;
+                re += t[q].re * tw.re - t[q].im * s;
+                im += t[q].re * s + t[q].im * tw.re;
             }
             out[k + (size_t)pp * m].re = re;
             out[k + (size_t)pp * m].im = im;
@@ -574,31 +529,118 @@ static void orc_fft_rec(int n, int sign, const orc_cplx* in, int stride, orc_cpl
     }
 }
 
-void orc_c2r_fft(int n, const double* in, double* out) {
-    /* expand the Hermitian half spectrum and run a complex inverse (sign +) transform */
-    orc_cplx* x  = (orc_cplx*)malloc(sizeof(orc_cplx) * n);
-    orc_cplx* y  = (orc_cplx*)malloc(sizeof(orc_cplx) * n);
-    orc_cplx* sc = (orc_cplx*)malloc(sizeof(orc_cplx) * n);
-    x[0].re      = in[0];
-    x[0].im      = 0.;
-    for (int m = 1; m <= n / 2; ++m) {
-        double re = in[2 * m], im = in[2 * m + 1];
-        if (2 * m == n) {
-            x[m].re = re;
-            x[m].im = 0.;
-        }
-        else {
-            x[m].re     = re;
-            x[m].im     = im;
-            x[n - m].re = re;
-            x[n - m].im = -im;
+static orc_fftplan* orc_plan_for(int n) {
+    orc_fftplan* p;
+#pragma omp critical(orc_plan_cache)
+    {
+        for (p = orc_plans; p; p = p->next)
+            if (p->n == n) break;
+        if (!p) {
+            p       = (orc_fftplan*)calloc(1, sizeof(orc_fftplan));
+            p->n    = n;
+            int h   = n / 2;
+            p->h    = h;
+            p->wn   = (orc_cplx*)malloc(sizeof(orc_cplx) * (h > 0 ? h : 1));
+            for (int k = 0; k < h; ++k) p->wn[k] = orc_root(k, n);
+            if (h > 0 && orc_is_smooth(h)) {
+                p->wh = (orc_cplx*)malloc(sizeof(orc_cplx) * h);
+                for (int k = 0; k < h; ++k) p->wh[k] = orc_root(k, h);
+            }
+            else if (h > 0) {
+                p->bluestein = 1;
+                int M        = 1;
+                while (M < 2 * h - 1) M *= 2;
+                p->M     = M;
+                p->wM    = (orc_cplx*)malloc(sizeof(orc_cplx) * M);
+                p->chirp = (orc_cplx*)malloc(sizeof(orc_cplx) * h);
+                p->fb    = (orc_cplx*)malloc(sizeof(orc_cplx) * M);
+                for (int k = 0; k < M; ++k) p->wM[k] = orc_root(k, M);
+                orc_cplx* bb = (orc_cplx*)calloc(M, sizeof(orc_cplx));
+                orc_cplx* sc = (orc_cplx*)malloc(sizeof(orc_cplx) * M);
+                for (int k = 0; k < h; ++k) {
+                    p->chirp[k] = orc_root(((int64_t)k * k) % (2 * (int64_t)h), 2 * (int64_t)h);
+                    bb[k].re    = p->chirp[k].re;
+                    bb[k].im    = -p->chirp[k].im;
+                    if (k) bb[M - k] = bb[k];
+                }
+                orc_fft_rec(M, -1, bb, 1, p->fb, sc, p->wM, M);
+                for (int k = 0; k < M; ++k) {
+                    p->fb[k].re /= M;
+                    p->fb[k].im /= M;
+                }
+                free(bb);
+                free(sc);
+            }
+            p->next   = orc_plans;
+            orc_plans = p;
         }
     }
-    orc_fft_rec(n, +1, x, 1, y, sc);
-    for (int k = 0; k < n; ++k) out[k] = y[k].re;
-    free(x);
-    free(y);
-    free(sc);
+    return p;
+}
+
+/* work: at least 3*max(M,h) complex */
+static void orc_c2r_fft_work(int n, const double* in, double* out, orc_cplx* work) {
+    if (n % 2) { /* odd length: direct sum (never used by Gaussian grids) */
+        orc_c2r_direct(n, in, out);
+        return;
+    }
+    orc_fftplan* p = orc_plan_for(n);
+    const int h    = p->h;
+    const int L    = p->bluestein ? p->M : h;
+    orc_cplx *a = work, *b = work + L, *sc = work + 2 * (size_t)L;
+    /* c2r pre-processing: Z[k] = (X[k] + conj X[h-k]) + i w_n^k (X[k] - conj X[h-k]);  Im X[0] = Im X[h] = 0 */
+    for (int k = 0; k < h; ++k) {
+        double ar = in[2 * k], ai = (k == 0) ? 0. : in[2 * k + 1];
+        int kk    = h - k;
+        double br = in[2 * kk], bi = (kk == h) ? 0. : -in[2 * kk + 1];
+        double sr = ar + br, si = ai + bi, dr = ar - br, di = ai - bi;
+        double er = dr * p->wn[k].re - di * p->wn[k].im, ei = dr * p->wn[k].im + di * p->wn[k].re;
+        a[k].re   = sr - ei;
+        a[k].im   = si + er;
+    }
+    if (!p->bluestein) {
+        orc_fft_rec(h, +1, a, 1, b, sc, p->wh, h);
+    }
+    else {
+        const int M = p->M;
+        for (int k = 0; k < h; ++k) {
+            double re = a[k].re * p->chirp[k].re - a[k].im * p->chirp[k].im;
+            double im = a[k].re * p->chirp[k].im + a[k].im * p->chirp[k].re;
+            a[k].re   = re;
+            a[k].im   = im;
+        }
+        for (int k = h; k < M; ++k) a[k].re = a[k].im = 0.;
+        orc_fft_rec(M, -1, a, 1, b, sc, p->wM, M);
+        for (int k = 0; k < M; ++k) {
+            double re = b[k].re * p->fb[k].re - b[k].im * p->fb[k].im;
+            double im = b[k].re * p->fb[k].im + b[k].im * p->fb[k].re;
+            a[k].re   = re;
+            a[k].im   = im;
+        }
+        orc_fft_rec(M, +1, a, 1, b, sc, p->wM, M);
+        for (int k = 0; k < h; ++k) {
+            double re = b[k].re * p->chirp[k].re - b[k].im * p->chirp[k].im;
+            double im = b[k].re * p->chirp[k].im + b[k].im * p->chirp[k].re;
+            b[k].re   = re;
+            b[k].im   = im;
+        }
+    }
+    for (int j = 0; j < h; ++j) {
+        out[2 * j]     = b[j].re;
+        out[2 * j + 1] = b[j].im;
+    }
+}
+
+static size_t orc_fft_work_size(int nmax) {
+    size_t M = 1;
+    while (M < (size_t)nmax) M *= 2; /* >= 2h-1 for h = nmax/2 */
+    return 3 * (M > (size_t)nmax ? M : (size_t)nmax) + 16;
+}
+
+void orc_c2r_fft(int n, const double* in, double* out) {
+    orc_cplx* work = (orc_cplx*)malloc(sizeof(orc_cplx) * orc_fft_work_size(n));
+    orc_c2r_fft_work(n, in, out, work);
+    free(work);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -614,6 +656,7 @@ void orc_invtrans_fourier(const orc_plan* p, int nf, const double* scl_fourier, 
     {
         double* in  = (double*)malloc(sizeof(double) * 2 * (p->nxmax / 2 + 1));
         double* out = (double*)malloc(sizeof(double) * p->nxmax);
+        orc_cplx* fw = (orc_cplx*)malloc(sizeof(orc_cplx) * orc_fft_work_size(p->nxmax));
 #pragma omp for collapse(2) schedule(dynamic, 8)
         for (int f = 0; f < nf; ++f) {
             for (int jlat = 0; jlat < p->nlats; ++jlat) {
@@ -626,7 +669,7 @@ void orc_invtrans_fourier(const orc_plan* p, int nf, const double* scl_fourier, 
                         in[2 * m + imag] = (m <= T) ? scl_fourier[orc_pos_fourier(p, f, imag, jlat, m)] : 0.;
                     }
                 }
-                if (use_fft) orc_c2r_fft(n, in, out);
+                if (use_fft) orc_c2r_fft_work(n, in, out, fw);
                 else orc_c2r_direct(n, in, out);
                 double* dst = gp + (size_t)f * p->npts + rowoff[jlat];
                 for (int i = 0; i < p->nx[jlat]; ++i) dst[i] = out[i];
@@ -634,6 +677,7 @@ void orc_invtrans_fourier(const orc_plan* p, int nf, const double* scl_fourier, 
         }
         free(in);
         free(out);
+        free(fw);
     }
     free(rowoff);
 }

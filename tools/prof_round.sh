@@ -1,0 +1,22 @@
+#!/bin/bash
+# Dev tool (GPU box): the round's evidence in one call.
+#   1. default bench (with cpu_baseline)                      -> gpurun_out/round/bench_default.json
+#   2. rocprofv3 --kernel-trace --stats of the bench command  -> gpurun_out/round/stats/
+#   3. PMC passes (counters only): FETCH_SIZE, WRITE_SIZE, MFMA/LDS counters -> gpurun_out/round/pmc_*/
+#   4. summary: per-kernel average duration, HBM traffic per launch -> gpurun_out/round/{kernel_stats.txt,pmc_traffic.json}
+export TMPDIR=/tmp
+R=$PWD
+O=$R/gpurun_out/round
+rm -rf $O; mkdir -p $O
+( time python bench.py ) > $O/bench_default.json 2> $O/bench_default.err
+cd /tmp
+BENCH="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- $BENCH > $O/stats.log 2>&1
+for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" \
+            "sq SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU"; do
+  set -- $pass; name=$1; shift
+  rocprofv3 --kernel-trace --pmc "$@" -d $O/pmc_$name --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_$name.log 2>&1
+done
+cd $R
+python3 tools/prof_round_summary.py $O > $O/summary.txt 2>&1
+tail -40 $O/summary.txt
