@@ -359,7 +359,7 @@ int atlas_amd__fft_host_row(int n, const double* modes, int mmax, double* out) {
 }
 int atlas_amd__fft_host_row_generic(int n, const double* modes, int mmax, double* out) {
     AA_TRY
-    fft::FftPlanSet ps = fft::make_fft_plans({n});
+    fft::FftPlanSet ps = fft::make_fft_plans({n}, false);
     fft::host_execute_row(ps, 0, reinterpret_cast<const fft::cplx*>(modes), mmax, out, 256, false);
     AA_CATCH_INT
 }

@@ -34,6 +34,8 @@ struct LegendreParams {
     int m_cnt;   // number of owned wavenumbers == m-extent of F:  F[(lat*m_cnt + m/m_div)*RP + r]
     int nitems;  // filled in by the launcher
     int nchunks; // column chunks per item (filled in by the launcher)
+    int chunk0;  // first column chunk of this launch
+    int nchunks_run;  // column chunks computed by this launch (pipelined transform: a subset)
 };
 
 struct FourierParams {
@@ -52,9 +54,11 @@ struct FourierParams {
     int T;
     int RP;
     int nf;
+    int f_begin, f_end;               // fields transformed by this launch (pipelined transform: a subset)
     long long npts;
     int scale_uv_fields;              // first 2*nb_vordiv fields are multiplied by 1/cos(lat) (TransLocal.cc:1443-1469)
     const double* coslatinv;          // [nlats]
+    int abl;                          // dev builds (-DAA_FFT_ABLATE) only: access-ablation bits, see fft_core.h
     unsigned long long* prof;         // optional [64] per-phase cycle accumulators (dev profiling), else null
 };
 

@@ -207,15 +207,64 @@ AA_HD void bfly9(cplx* x, int dir) {
         for (int q1 = 0; q1 < 3; ++q1) x[3 * q1 + q0] = u[q1];
     }
 }
+// exp(dir * 2 pi i k / 120), k in [0,120): the index is a compile-time constant after unrolling, so the entries
+// become literal operands
+AA_HD cplx cmul_root120(cplx a, int k, int dir) {
+    constexpr double tab[120][2] = {
+#include "fft_roots120.inc"
+    };
+    if (k == 0) return a;
+    if (k == 30) return cmuli(a, dir);
+    if (k == 60) return cplx{-a.re, -a.im};
+    if (k == 90) return cmuli(a, -dir);
+    return cmulw(a, tab[k][0], tab[k][1], dir);
+}
+
+template <int R>
+AA_HD void bfly(cplx* x, int dir);
+
+// composite radix R = R1 * R2 (R1 odd, R2 a power of two), Cooley-Tukey inside registers:
+// p = R2 p1 + p0, q = R1 q1 + q0:  w_R^{pq} = w_R1^{p1 q0} w_R^{p0 q0} w_R2^{p0 q1}
+template <int R1, int R2>
+AA_HD void bfly_comp(cplx* x, int dir) {
+    constexpr int R = R1 * R2;
+    static_assert(120 % R == 0, "root table covers divisors of 120");
+    cplx t[R2][R1];
+#pragma unroll
+    for (int p0 = 0; p0 < R2; ++p0) {
+        cplx u[R1];
+#pragma unroll
+        for (int p1 = 0; p1 < R1; ++p1) u[p1] = x[R2 * p1 + p0];
+        bfly<R1>(u, dir);
+#pragma unroll
+        for (int q0 = 0; q0 < R1; ++q0) t[p0][q0] = cmul_root120(u[q0], ((p0 * q0) % R) * (120 / R), dir);
+    }
+#pragma unroll
+    for (int q0 = 0; q0 < R1; ++q0) {
+        cplx u[R2];
+#pragma unroll
+        for (int p0 = 0; p0 < R2; ++p0) u[p0] = t[p0][q0];
+        bfly<R2>(u, dir);
+#pragma unroll
+        for (int q1 = 0; q1 < R2; ++q1) x[R1 * q1 + q0] = u[q1];
+    }
+}
+
 template <int R>
 AA_HD void bfly(cplx* x, int dir) {
-    if (R == 2) bfly2(x);
-    else if (R == 9) bfly9(x, dir);
-    else if (R == 3) bfly3(x, dir);
-    else if (R == 4) bfly4(x, dir);
-    else if (R == 5) bfly5(x, dir);
-    else if (R == 8) bfly8(x, dir);
-    else if (R == 16) bfly16(x, dir);
+    if constexpr (R == 2) bfly2(x);
+    else if constexpr (R == 3) bfly3(x, dir);
+    else if constexpr (R == 4) bfly4(x, dir);
+    else if constexpr (R == 5) bfly5(x, dir);
+    else if constexpr (R == 8) bfly8(x, dir);
+    else if constexpr (R == 9) bfly9(x, dir);
+    else if constexpr (R == 16) bfly16(x, dir);
+    else if constexpr (R == 6) bfly_comp<3, 2>(x, dir);
+    else if constexpr (R == 10) bfly_comp<5, 2>(x, dir);
+    else if constexpr (R == 12) bfly_comp<3, 4>(x, dir);
+    else if constexpr (R == 20) bfly_comp<5, 4>(x, dir);
+    else if constexpr (R == 24) bfly_comp<3, 8>(x, dir);
+    else static_assert(R == 2, "unsupported radix");
 }
 
 // powers w^1 .. w^(R-1) by halving products (depth <= log2 R roundings)
@@ -319,6 +368,18 @@ AA_HD void bluestein_mid(cplx* d, int M, const cplx* __restrict__ bhat, int t, i
     }
 }
 
+// composite first radices of the specialised shapes: host only (planner, emulation); the generic device kernel is
+// never given a shape that contains them
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AA_RADIX_SWITCH_COMPOSITE(CALL)
+#else
+#define AA_RADIX_SWITCH_COMPOSITE(CALL)                  \
+        case 6: { constexpr int RR = 6; CALL; } break;   \
+        case 10: { constexpr int RR = 10; CALL; } break; \
+        case 12: { constexpr int RR = 12; CALL; } break; \
+        case 20: { constexpr int RR = 20; CALL; } break; \
+        case 24: { constexpr int RR = 24; CALL; } break;
+#endif
 #define AA_RADIX_SWITCH(R, CALL)                         \
     switch (R) {                                         \
         case 2: { constexpr int RR = 2; CALL; } break;   \
@@ -328,6 +389,7 @@ AA_HD void bluestein_mid(cplx* d, int M, const cplx* __restrict__ bhat, int t, i
         case 8: { constexpr int RR = 8; CALL; } break;   \
         case 9: { constexpr int RR = 9; CALL; } break;   \
         case 16: { constexpr int RR = 16; CALL; } break; \
+        AA_RADIX_SWITCH_COMPOSITE(CALL)                  \
     }
 
 AA_HD void dif_stage_any(int R, cplx* d, int M, int L, int lsh, const cplx* __restrict__ tw, int dir, int t, int nt) {
@@ -418,6 +480,28 @@ AA_HD cplx row_mode(const Reader& rd, int mmax, int m, int h) {
     return v;
 }
 
+// the two halves of row_mode() for callers that batch their loads: clamped mode index, then the masks
+AA_HD int row_mode_index(int mmax, int m) {
+    return m > mmax ? (mmax < 0 ? 0 : mmax) : m;
+}
+AA_HD cplx row_mode_mask(cplx v, int mmax, int m, int h) {
+    if (m > mmax || mmax < 0) {
+        v.re = 0.;
+        v.im = 0.;
+    }
+    if (m == 0 || m == h) {
+        v.im = 0.;
+    }
+    return v;
+}
+
+// scheduling fence (device): instructions are not moved across it
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AA_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define AA_SCHED_FENCE() ((void)0)
+#endif
+
 AA_HD int stage_L(const FftShape& s, int i) {
     int L = s.M;
     for (int q = 0; q < i; ++q) L /= s.radix[q];
@@ -492,21 +576,42 @@ AA_HD void row_phase(int ph, int t, int nt, const RowTables& r, const Reader& rd
 // fused into the last DIT stage (whose outputs k >= h are not needed): 2*NS-1 phases, 2*NS-2 barriers, 4 LDS round
 // trips for a 3-stage length instead of 6.  The filter spectrum is read through a [q][butterfly] transposed copy so
 // that the lanes of one load instruction are contiguous.
+// stage list of the specialised M = F * 2^K transform (DIF order); 0 past the end.
+//   M = R0 * 256 with R0 = F * 2^(K-8) <= 24 :  [R0, 16, 16]   (R0 = 1: [16, 16])
+//       one composite first stage (fused with the load; a 3/5-point DFT times a 2/4/8-point DFT in registers),
+//       then R0 independent 256-point blocks: their forward stages, the filter multiply and their inverse stages
+//       only move data between the 16 lanes that own the block (wave-local, no workgroup barrier)
+//   320 = [20, 16], 384 = [24, 16], 640 = [10, 8, 8], 8192 = [16, 16, 16, 2]
+AA_HD constexpr int ct_radix(int F, int K, int i) {
+    if (F == 5 && K == 7) {
+        return i == 0 ? 10 : (i < 3 ? 8 : 0);
+    }
+    if (K >= 8 && (F << (K - 8)) <= 24) {
+        const int r0 = F << (K - 8);
+        if (r0 == 1) return i < 2 ? 16 : 0;
+        return i == 0 ? r0 : (i < 3 ? 16 : 0);
+    }
+    const int n16 = K / 4, rem = 1 << (K % 4);
+    if (F > 1) {
+        if (i == 0) return F * rem;
+        return i - 1 < n16 ? 16 : 0;
+    }
+    if (i < n16) return 16;
+    return (i == n16 && rem > 1) ? rem : 0;
+}
+AA_HD constexpr int ct_nstages(int F, int K) {
+    int n = 0;
+    while (ct_radix(F, K, n) != 0) ++n;
+    return n;
+}
+
 template <int F_, int K_>
 struct CtShape {
-    static constexpr int F   = F_;
-    static constexpr int K   = K_;
-    static constexpr int M   = F_ << K_;
-    static constexpr int N16 = K_ / 4;
-    static constexpr int REM = 1 << (K_ % 4);
-    static constexpr int NS  = (F_ > 1 ? 1 : 0) + N16 + (REM > 1 ? 1 : 0);
-    static constexpr int radix(int i) {
-        if (F_ > 1) {
-            if (i == 0) return F_;
-            i -= 1;
-        }
-        return i < N16 ? 16 : REM;
-    }
+    static constexpr int F  = F_;
+    static constexpr int K  = K_;
+    static constexpr int M  = F_ << K_;
+    static constexpr int NS = ct_nstages(F_, K_);
+    static constexpr int radix(int i) { return ct_radix(F_, K_, i); }
     static constexpr int L(int i) {
         int l = M;
         for (int q = 0; q < i; ++q) l /= radix(q);
@@ -517,9 +622,28 @@ struct CtShape {
         while ((1 << s) < ls) ++s;
         return (1 << s) == ls ? s : -1;
     }
+    // stages 1.. all have the same radix R and a block (length L(1)) is owned by L(1)/R <= 64 consecutive workers:
+    // with a worker count that is a multiple of 64 the owners of a block are lanes of one wavefront in every one
+    // of these stages, so the phases between the first and the last only need wavefront-level ordering
+    static constexpr bool wave_local_middle() {
+        if (NS < 3) return false;
+        for (int i = 2; i < NS; ++i)
+            if (radix(i) != radix(1)) return false;
+        const int owners = L(1) / radix(1);
+        return owners <= 64 && 64 % owners == 0;
+    }
 };
 
+// Dev builds (-DAA_FFT_ABLATE): index multipliers that collapse one class of global accesses onto a single cache line
+// (same instructions, no memory traffic), to attribute kernel time; 1 everywhere in normal builds.
+#if defined(AA_FFT_ABLATE)
+#define AA_ABL(r, bit) (((r).abl >> (bit)) & 1 ? 0 : 1)
+#else
+#define AA_ABL(r, bit) 1
+#endif
+
 struct RowTablesCt {
+    int abl = 0;
     int n, h;
     const cplx* tw;       // [M]
     const cplx* pre;      // [h]
@@ -555,23 +679,46 @@ AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCt& r, const Reade
     const int h       = r.h;
     if (ph == 0) {
         // ---- fused: load + c2r pre-processing + chirp + DIF stage 0 (L = M, one block)
+        // M >= 2h-1 and M even: h <= M/2, so the inputs q >= NZ = ceil(R0/2) are zero padding for every b.
+        // The global loads are issued in batches of NB elements (4 loads each: X[k], X[h-k], pre, chirp; clamped
+        // addresses, masks applied afterwards) ahead of a scheduling fence: left alone, the compiler serialises
+        // them one round trip at a time to save registers.
+        constexpr int NZ = (R0 + 1) / 2;
+        constexpr int NB = NZ <= 5 ? NZ : (NZ % 5 == 0 ? 5 : (NZ % 4 == 0 ? 4 : (NZ % 3 == 0 ? 3 : 2)));
         for (int b = t; b < Ls0; b += nt) {
             cplx x[R0];
+            cplx w1 = r.tw[b];
 #pragma unroll
-            for (int q = 0; q < R0; ++q) {
-                const int k = b + q * Ls0;
-                if (k < h) {
-                    cplx A = row_mode(rd, io.mmax, k, h);
-                    cplx B = cconj(row_mode(rd, io.mmax, h - k, h));
-                    x[q]   = cmul(c2r_pre(A, B, r.pre[k]), r.chirp[k]);
+            for (int q0 = 0; q0 < NZ; q0 += NB) {
+                cplx A[NB], B[NB], P[NB], C[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    if (q0 + i < NZ) {
+                        const int k  = b + (q0 + i) * Ls0;
+                        const int kc = k < h ? k : h - 1;
+                        A[i]         = rd(row_mode_index(io.mmax, kc));
+                        B[i]         = rd(row_mode_index(io.mmax, h - kc));
+                        P[i]         = r.pre[kc * AA_ABL(r, 1)];
+                        C[i]         = r.chirp[kc * AA_ABL(r, 1)];
+                    }
                 }
-                else {
-                    x[q] = cplx{0., 0.};
+                AA_SCHED_FENCE();
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    if (q0 + i < NZ) {
+                        const int k  = b + (q0 + i) * Ls0;
+                        const int kc = k < h ? k : h - 1;
+                        const cplx a = row_mode_mask(A[i], io.mmax, kc, h);
+                        const cplx c = cconj(row_mode_mask(B[i], io.mmax, h - kc, h));
+                        const cplx z = cmul(c2r_pre(a, c, P[i]), C[i]);
+                        x[q0 + i]    = k < h ? z : cplx{0., 0.};
+                    }
                 }
             }
+#pragma unroll
+            for (int q = NZ; q < R0; ++q) x[q] = cplx{0., 0.};
             bfly<R0>(x, -1);
-            cplx w1 = r.tw[b];
-            w1.im   = -w1.im;
+            w1.im = -w1.im;
             cplx w[R0];
             twiddle_powers<R0>(w1, w);
             work[PAD(b)] = x[0];
@@ -592,12 +739,16 @@ AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCt& r, const Reade
     if (ph == NS - 1) {  // ---- fused middle: last DIF stage * filter * first DIT stage (L = RL, no twiddles)
         constexpr int nb = M / RL;
         for (int b = t; b < nb; b += nt) {
+            cplx f[RL];  // filter spectrum: all loads in flight before the LDS reads (see phase 0)
+#pragma unroll
+            for (int q = 0; q < RL; ++q) f[q] = r.bhat_t[(q * nb + b) * AA_ABL(r, 2)];
+            AA_SCHED_FENCE();
             cplx x[RL];
 #pragma unroll
             for (int q = 0; q < RL; ++q) x[q] = work[PAD(b * RL + q)];
             bfly<RL>(x, -1);
 #pragma unroll
-            for (int q = 0; q < RL; ++q) x[q] = cmul(x[q], r.bhat_t[q * nb + b]);
+            for (int q = 0; q < RL; ++q) x[q] = cmul(x[q], f[q]);
             bfly<RL>(x, +1);
 #pragma unroll
             for (int q = 0; q < RL; ++q) work[PAD(b * RL + q)] = x[q];
@@ -614,9 +765,17 @@ AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCt& r, const Reade
         });
         return;
     }
-    // ---- fused: DIT stage 0 + chirp + store (outputs k >= h are padding)
+    // ---- fused: DIT stage 0 + chirp + store (outputs q >= NZ are padding: their butterfly arithmetic is dead)
+    constexpr int NZ = (R0 + 1) / 2;
     for (int b = t; b < Ls0; b += nt) {
         cplx w1 = r.tw[b];
+        cplx c[NZ];
+#pragma unroll
+        for (int q = 0; q < NZ; ++q) {
+            const int k = b + q * Ls0;
+            c[q]        = r.chirp[(k < h ? k : h - 1) * AA_ABL(r, 3)];
+        }
+        AA_SCHED_FENCE();
         cplx w[R0];
         twiddle_powers<R0>(w1, w);
         cplx x[R0];
@@ -625,12 +784,12 @@ AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCt& r, const Reade
         for (int q = 1; q < R0; ++q) x[q] = cmul(work[PAD(b + q * Ls0)], w[q]);
         bfly<R0>(x, +1);
 #pragma unroll
-        for (int q = 0; q < R0; ++q) {
+        for (int q = 0; q < NZ; ++q) {
             const int k = b + q * Ls0;
             if (k < h) {
-                const cplx z = cmul(x[q], r.chirp[k]);
+                const cplx z = cmul(x[q], c[q]);
                 if (io.aligned16) {
-                    *reinterpret_cast<cplx*>(io.y + 2 * (int64_t)k) = z;
+                    *reinterpret_cast<cplx*>(io.y + 2 * (int64_t)k * AA_ABL(r, 4)) = z;
                 }
                 else {
                     io.y[2 * (int64_t)k]     = z.re * io.scale;
@@ -643,8 +802,7 @@ AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCt& r, const Reade
 
 // the (F, K) instances that exist (kernel and host emulation use the same list)
 AA_HD constexpr bool ct_supported(int f, int k) {
-    return (f == 1 && k >= 8 && k <= 13) || (f == 3 && k >= 7 && k <= 11) || (f == 5 && k >= 6 && k <= 10) ||
-           (f == 9 && k >= 5 && k <= 9);
+    return (f == 1 && k >= 8 && k <= 13) || (f == 3 && k >= 7 && k <= 11) || (f == 5 && k >= 6 && k <= 10);
 }
 #define AA_CT_CASE(FF, KK, CALL)                         \
     if (ctf == FF && ctk == KK) {                        \
@@ -655,9 +813,7 @@ AA_HD constexpr bool ct_supported(int f, int k) {
     AA_CT_CASE(1, 8, CALL) AA_CT_CASE(1, 9, CALL) AA_CT_CASE(1, 10, CALL) AA_CT_CASE(1, 11, CALL)               \
     AA_CT_CASE(1, 12, CALL) AA_CT_CASE(1, 13, CALL) AA_CT_CASE(3, 7, CALL) AA_CT_CASE(3, 8, CALL)               \
     AA_CT_CASE(3, 9, CALL) AA_CT_CASE(3, 10, CALL) AA_CT_CASE(3, 11, CALL) AA_CT_CASE(5, 6, CALL)               \
-    AA_CT_CASE(5, 7, CALL) AA_CT_CASE(5, 8, CALL) AA_CT_CASE(5, 9, CALL) AA_CT_CASE(5, 10, CALL)               \
-    AA_CT_CASE(9, 5, CALL) AA_CT_CASE(9, 6, CALL) AA_CT_CASE(9, 7, CALL) AA_CT_CASE(9, 8, CALL)                 \
-    AA_CT_CASE(9, 9, CALL)
+    AA_CT_CASE(5, 7, CALL) AA_CT_CASE(5, 8, CALL) AA_CT_CASE(5, 9, CALL) AA_CT_CASE(5, 10, CALL)
 
 }  // namespace fft
 }  // namespace atlas_amd

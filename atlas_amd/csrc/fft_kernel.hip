@@ -25,14 +25,14 @@ __device__ __forceinline__ bool fft_block_to_job(const FourierParams& p, int b, 
     const int q   = b >> 3;
     const int j   = q & 7;
     const int u   = (q >> 3) * 8 + x;
-    const int ngr = (p.nf + FGROUP - 1) / FGROUP;
+    const int ngr = (p.f_end - p.f_begin + FGROUP - 1) / FGROUP;
     const int ri  = u / ngr;
     const int fg  = u - ri * ngr;
     if (ri >= p.nrows) {
         return false;
     }
-    f = fg * FGROUP + j;
-    if (f >= p.nf) {
+    f = p.f_begin + fg * FGROUP + j;
+    if (f >= p.f_end) {
         return false;
     }
     row = p.rows[ri];
@@ -62,6 +62,9 @@ struct ModeReader {
                 }
             }
         }
+#if defined(AA_FFT_ABLATE)
+        if (p.abl & 1) ml = 0;
+#endif
         return *reinterpret_cast<const cplx*>(base + (lat_local * cnt + ml) * p.RP + f2);
     }
 };
@@ -154,7 +157,7 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR) fft_rows_kernel(FourierParams p)
 
 // ---- compile-time specialised Bluestein rows (fft_core.h: row_phase_ct) -------------------------------------------
 template <class S>
-__global__ void __launch_bounds__(FFT_MAX_NTHR) fft_rows_ct_kernel(FourierParams p) {
+__global__ void __launch_bounds__(FFT_MAX_NTHR, 3) fft_rows_ct_kernel(FourierParams p) {
     extern __shared__ double lds_raw[];
     cplx* work = reinterpret_cast<cplx*>(lds_raw);
     int row, f;
@@ -169,6 +172,9 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR) fft_rows_ct_kernel(FourierParams
     const int mmax            = p.row_mmax[row];
     const ModeReader rd{p, (long long)(row - p.lat0), 2 * f};
     fft::RowTablesCt r;
+#if defined(AA_FFT_ABLATE)
+    r.abl    = p.abl;
+#endif
     r.n      = pl->n;
     r.h      = pl->h;
     r.tw     = p.table + pl->off_tw;
@@ -190,7 +196,16 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR) fft_rows_ct_kernel(FourierParams
     for (int ph = 0; ph < NPH; ++ph) {
         fft::row_phase_ct<S>(ph, tid, nt, r, rd, io, work);
         if (ph < NPH - 1) {
-            __syncthreads();
+            if (S::wave_local_middle() && ph >= 1 && ph <= NPH - 3) {
+                // producer and consumer lanes of the next phase are in this wavefront: LDS executes a wavefront's
+                // instructions in order, only the compiler must not move accesses across this point
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            else {
+                __syncthreads();
+            }
         }
         if (prof) {
             const unsigned long long tn = clock64();
@@ -211,13 +226,22 @@ static hipError_t launch_ct(const FourierParams& p, int lds_bytes, int nthreads,
         }
         max_set = lds_bytes;
     }
+    static const bool debug = std::getenv("ATLAS_AMD_FFT_DEBUG") != nullptr;
+    if (debug) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fft_rows_ct_kernel<S>, nthreads, lds_bytes);
+        hipFuncAttributes fa{};
+        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&fft_rows_ct_kernel<S>));
+        std::fprintf(stderr, "[atlas_amd] fft ct M=%d threads=%d lds=%d blocks=%u regs=%d scratch=%zu -> %d workgroups/CU\n",
+                     S::M, nthreads, lds_bytes, nblk, fa.numRegs, (size_t)fa.localSizeBytes, nb);
+    }
     hipLaunchKernelGGL(fft_rows_ct_kernel<S>, dim3(nblk), dim3(nthreads), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
 hipError_t launch_fourier_ct(const FourierParams& p, int ctf, int ctk, int lds_bytes, int nthreads,
                              hipStream_t stream) {
-    const int ngr         = (p.nf + FGROUP - 1) / FGROUP;
+    const int ngr         = (p.f_end - p.f_begin + FGROUP - 1) / FGROUP;
     const long long units = (long long)p.nrows * ngr;
     const unsigned nblk   = (unsigned)((units + 7) / 8 * 64);
     AA_CT_DISPATCH(ctf, ctk, return launch_ct<S>(p, lds_bytes, nthreads, nblk, stream))
@@ -234,7 +258,7 @@ hipError_t launch_fourier(const FourierParams& p, int lds_bytes, int nthreads, h
         }
         max_set = lds_bytes;
     }
-    const int ngr         = (p.nf + FGROUP - 1) / FGROUP;
+    const int ngr         = (p.f_end - p.f_begin + FGROUP - 1) / FGROUP;
     const long long units = (long long)p.nrows * ngr;
     const long long nblk  = (units + 7) / 8 * 64;
     hipLaunchKernelGGL(fft_rows_kernel, dim3((unsigned)nblk), dim3(nthreads), lds_bytes, stream, p);

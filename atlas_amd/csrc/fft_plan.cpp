@@ -132,7 +132,24 @@ int FftPlanSet::plan_index(int n) const {
     return -1;
 }
 
-FftPlanSet make_fft_plans(const std::vector<int>& row_lengths) {
+// stage list of a specialised length (fft_core.h: ct_radix), as a run-time shape for the planner / emulation
+static FftShape make_ct_shape(int f, int k) {
+    FftShape s{};
+    s.M       = f << k;
+    s.nstages = ct_nstages(f, k);
+    int L     = s.M;
+    for (int i = 0; i < s.nstages; ++i) {
+        s.radix[i] = ct_radix(f, k, i);
+        s.lsh[i]   = ilog2_exact(L / s.radix[i]);
+        L /= s.radix[i];
+    }
+    if (L != 1) {
+        throw std::logic_error("make_ct_shape: stage list does not multiply to M");
+    }
+    return s;
+}
+
+FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, bool specialised_shapes) {
     FftPlanSet ps;
     std::vector<int> ns(row_lengths);
     std::sort(ns.begin(), ns.end());
@@ -172,8 +189,21 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths) {
             p.shape  = make_shape(h);
         }
         else {
-            p.method = FFT_BLUESTEIN;
-            p.shape  = make_shape(next_bluestein_length(2 * h - 1));
+            p.method     = FFT_BLUESTEIN;
+            const int Mb = next_bluestein_length(2 * h - 1);
+            // M = F * 2^K with a specialised instance?
+            if (specialised_shapes) {
+                for (int f : {1, 3, 5}) {
+                    if (Mb % f == 0) {
+                        const int k = ilog2_exact(Mb / f);
+                        if (k >= 0 && ct_supported(f, k)) {
+                            p.ct_f = f;
+                            p.ct_k = k;
+                        }
+                    }
+                }
+            }
+            p.shape = p.ct_k >= 0 ? make_ct_shape(p.ct_f, p.ct_k) : make_shape(Mb);
         }
         const int M   = p.shape.M;
         p.lds_complex = padded_size(M);
@@ -215,21 +245,8 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths) {
                     ps.table.push_back(ps.table[p.off_bhat + (int64_t)bb * RL + q]);
                 }
             }
-            // M = F * 2^K with a specialised instance?
-            p.ct_k = -1;
-            for (int f : {1, 3, 5, 9}) {
-                if (M % f == 0) {
-                    const int k = ilog2_exact(M / f);
-                    if (k >= 0 && ct_supported(f, k)) {
-                        p.ct_f = f;
-                        p.ct_k = k;
-                    }
-                }
-            }
         }
-        else {
-            p.ct_k = -1;
-        }
+
         ps.plans.push_back(p);
     }
     return ps;

@@ -42,7 +42,7 @@ bool is_smooth235(int n);
 int next_smooth235(int n);
 int next_bluestein_length(int n);  // smallest {1,3,5}*2^k >= n
 FftShape make_shape(int M);  // M must be {2,3,5}-smooth
-FftPlanSet make_fft_plans(const std::vector<int>& row_lengths);
+FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, bool specialised_shapes = true);
 
 // Host execution of one row with exactly the kernel's algorithm (used by CPU tests; NOT a product fallback:
 // nothing in the invtrans path calls it).  X: h+1 (or n/2+1) complex modes (zero beyond mmax); y: n reals.

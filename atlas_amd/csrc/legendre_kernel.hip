@@ -59,10 +59,10 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
     // block -> (item, column chunk).  Hardware places block b on XCD b % 8; the chunks of one item are given to
     // blocks b, b+8, b+16, ... (same XCD, dispatched back to back) so that a later chunk finds the item's P block
     // in that XCD's L2, and items keep the XCD their list position implies (trans_plan.cpp).  Speed heuristic only.
-    const int nchunks   = p.nchunks;
+    const int nchunks   = p.nchunks_run;
     const int bx        = blockIdx.x & 7;
     const int bq        = blockIdx.x >> 3;
-    const int chunk     = bq % nchunks;
+    const int chunk     = p.chunk0 + bq % nchunks;
     const int item_slot = (bq / nchunks) * 8 + bx;
     if (item_slot >= p.nitems) {
         return;
@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
 }
 
 template <int RTW, int NRG>
-static hipError_t launch_cfg(LegendreParams p, int nitems, int nchunks, hipStream_t stream) {
+static hipError_t launch_cfg(LegendreParams p, int nitems, int nchunks, int chunk0, int nrun, hipStream_t stream) {
     using L = LegLds<RTW, NRG>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -235,8 +235,10 @@ static hipError_t launch_cfg(LegendreParams p, int nitems, int nchunks, hipStrea
     }
     p.nitems        = nitems;
     p.nchunks       = nchunks;
+    p.chunk0        = chunk0;
+    p.nchunks_run   = nrun;
     const int slots = (nitems + 7) / 8;
-    hipLaunchKernelGGL((legendre_kernel<RTW, NRG>), dim3(slots * nchunks * 8), dim3(L::NTHR), L::BYTES, stream, p);
+    hipLaunchKernelGGL((legendre_kernel<RTW, NRG>), dim3(slots * nrun * 8), dim3(L::NTHR), L::BYTES, stream, p);
     return hipGetLastError();
 }
 
@@ -259,14 +261,19 @@ void legendre_tiling(int nf, int& rtw, int& nrg, int& nchunks) {
     }
 }
 
-hipError_t launch_legendre(const LegendreParams& p, int nitems, hipStream_t stream) {
+// chunk0 / nrun: the column chunks [chunk0, chunk0 + nrun) of legendre_tiling(); nrun <= 0: all
+hipError_t launch_legendre(const LegendreParams& p, int nitems, int chunk0, int nrun, hipStream_t stream) {
     int rtw, nrg, nchunks;
     legendre_tiling(p.nf, rtw, nrg, nchunks);
+    if (nrun <= 0) {
+        chunk0 = 0;
+        nrun   = nchunks;
+    }
 #define LEG_CASE(R)                                                                      \
     case R:                                                                              \
-        if (nrg == 1) return launch_cfg<R, 1>(p, nitems, nchunks, stream);               \
-        if (nrg == 2) return launch_cfg<R, 2>(p, nitems, nchunks, stream);               \
-        return launch_cfg<(R <= 4 ? R : 4), 3>(p, nitems, nchunks, stream);
+        if (nrg == 1) return launch_cfg<R, 1>(p, nitems, nchunks, chunk0, nrun, stream);               \
+        if (nrg == 2) return launch_cfg<R, 2>(p, nitems, nchunks, chunk0, nrun, stream);               \
+        return launch_cfg<(R <= 4 ? R : 4), 3>(p, nitems, nchunks, chunk0, nrun, stream);
     switch (rtw) {
         LEG_CASE(1) LEG_CASE(2) LEG_CASE(3) LEG_CASE(4) LEG_CASE(5) LEG_CASE(6) LEG_CASE(7) LEG_CASE(8) LEG_CASE(9)
     }

@@ -103,7 +103,10 @@ public:
 private:
     void upload();
     void collect_timings();
-    void timed_begin(int kind);
+    void timed_begin(int kind, hipStream_t s = nullptr);
+    void legendre_chunks(int trc_in, int nb_fields, const double* sp_dev, double* fourier_dev, int chunk0, int nrun);
+    void fourier_fields(int nb_fields, int nb_vordiv, const double* const* part_base, const int* part_cnt,
+                        double* gp_dev, int f_begin, int f_end, hipStream_t stream);
     void timed_end();
 
     TransGeometry geo_;
@@ -115,6 +118,10 @@ private:
     bool profile_       = false;
     bool use_ct_        = true;  // ATLAS_AMD_FFT_GENERIC=1 forces the generic FFT kernel (A/B comparisons)
     hipStream_t stream_ = nullptr;
+    hipStream_t stream2_ = nullptr;            // Fourier stage of the pipelined transform
+    hipStream_t ev_stream_ = nullptr;
+    std::vector<hipEvent_t> pipe_events_;
+    int pipeline_ = 1;                          // pieces of the Legendre/Fourier software pipeline (1: off)
     bool own_stream_    = false;
 
     // device state

@@ -15,7 +15,8 @@
 namespace atlas_amd {
 namespace trans {
 
-hipError_t launch_legendre(const LegendreParams& p, int nitems, hipStream_t stream);
+hipError_t launch_legendre(const LegendreParams& p, int nitems, int chunk0, int nrun, hipStream_t stream);
+void legendre_tiling(int nf, int& rtw, int& nrg, int& nchunks);
 hipError_t launch_fourier(const FourierParams& p, int lds_bytes, int nthreads, hipStream_t stream);
 hipError_t launch_fourier_ct(const FourierParams& p, int ctf, int ctk, int lds_bytes, int nthreads,
                              hipStream_t stream);
@@ -56,6 +57,9 @@ Trans::Trans(const grid::StructuredGrid& grid, int truncation, const TransConfig
         throw std::runtime_error(
             "atlas_amd::Trans needs a HIP device (MI355X / gfx950); there is no CPU fallback for the transform");
     }
+    if (const char* e = std::getenv("ATLAS_AMD_PIPELINE")) {
+        pipeline_ = std::max(1, atoi(e));
+    }
     if (const char* e = std::getenv("ATLAS_AMD_FFT_GENERIC")) {
         use_ct_ = !(e[0] == '1');
     }
@@ -72,7 +76,7 @@ Trans::Trans(const grid::StructuredGrid& grid, int truncation, const TransConfig
     else {
         lengths = geo_.nx;
     }
-    fftplans_ = fft::make_fft_plans(lengths);
+    fftplans_ = fft::make_fft_plans(lengths, use_ct_);
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     own_stream_ = true;
     upload();
@@ -105,6 +109,12 @@ Trans::~Trans() {
     fr(d_vd_);
     for (auto& e : events_) {
         (void)hipEventDestroy(e);
+    }
+    for (auto& e : pipe_events_) {
+        (void)hipEventDestroy(e);
+    }
+    if (stream2_) {
+        (void)hipStreamDestroy(stream2_);
     }
     if (own_stream_ && stream_) {
         (void)hipStreamDestroy(stream_);
@@ -247,28 +257,34 @@ double* Trans::fourier_buffer(int nb_fields) {
     return d_fourier_;
 }
 
-void Trans::timed_begin(int kind) {
+void Trans::timed_begin(int kind, hipStream_t s) {
     if (!profile_) {
         return;
     }
+    ev_stream_ = s ? s : stream_;
     while (events_.size() < ev_used_ + 2) {
         hipEvent_t e;
         HIP_CHECK(hipEventCreate(&e));
         events_.push_back(e);
     }
     ev_kind_.push_back(kind);
-    HIP_CHECK(hipEventRecord(events_[ev_used_], stream_));
+    HIP_CHECK(hipEventRecord(events_[ev_used_], ev_stream_));
 }
 
 void Trans::timed_end() {
     if (!profile_) {
         return;
     }
-    HIP_CHECK(hipEventRecord(events_[ev_used_ + 1], stream_));
+    HIP_CHECK(hipEventRecord(events_[ev_used_ + 1], ev_stream_));
     ev_used_ += 2;
 }
 
 void Trans::legendre_device(int trc_in, int nb_fields, const double* sp_dev, double* fourier_dev) {
+    legendre_chunks(trc_in, nb_fields, sp_dev, fourier_dev, 0, 0);
+}
+
+void Trans::legendre_chunks(int trc_in, int nb_fields, const double* sp_dev, double* fourier_dev, int chunk0,
+                            int nrun) {
     if (nb_fields <= 0) {
         return;
     }
@@ -290,14 +306,19 @@ void Trans::legendre_device(int trc_in, int nb_fields, const double* sp_dev, dou
     p.m_cnt  = m_cnt_;
     timed_begin(0);
     if (!work_.items.empty()) {
-        HIP_CHECK(launch_legendre(p, (int)work_.items.size(), stream_));
+        HIP_CHECK(launch_legendre(p, (int)work_.items.size(), chunk0, nrun, stream_));
     }
     timed_end();
 }
 
 void Trans::fourier_device(int nb_fields, int nb_vordiv, const double* const* part_base, const int* part_cnt,
                            double* gp_dev) {
-    if (nb_fields <= 0) {
+    fourier_fields(nb_fields, nb_vordiv, part_base, part_cnt, gp_dev, 0, nb_fields, stream_);
+}
+
+void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* part_base, const int* part_cnt,
+                           double* gp_dev, int f_begin, int f_end, hipStream_t stream) {
+    if (nb_fields <= 0 || f_end <= f_begin) {
         return;
     }
     FourierParams p;
@@ -316,19 +337,27 @@ void Trans::fourier_device(int nb_fields, int nb_vordiv, const double* const* pa
     p.T               = geo_.T;
     p.RP              = fourier_row_pitch(nb_fields);
     p.nf              = nb_fields;
+    p.f_begin         = f_begin;
+    p.f_end           = f_end;
     p.npts            = geo_.rowoff[band_end()] - geo_.rowoff[band_begin()];
     p.scale_uv_fields = std::min(2 * nb_vordiv, nb_fields);
     p.coslatinv       = d_coslatinv_;
     p.prof            = d_prof_;
-    timed_begin(1);
+    p.abl             = std::getenv("ATLAS_AMD_FFT_ABLATE") ? atoi(std::getenv("ATLAS_AMD_FFT_ABLATE")) : 0;
+    p.abl             = std::getenv("ATLAS_AMD_FFT_ABLATE") ? atoi(std::getenv("ATLAS_AMD_FFT_ABLATE")) : 0;
+    timed_begin(1, stream);
+    static const int only_m = std::getenv("ATLAS_AMD_FFT_ONLY_M") ? atoi(std::getenv("ATLAS_AMD_FFT_ONLY_M")) : 0;
     for (const SizeClass& c : classes_) {
         p.rows  = c.d_rows;
         p.nrows = c.nrows;
+        if (only_m && c.lds_bytes != fft::padded_size(only_m) * 16) {  // dev tool (tools/fft_phase_prof.py): one class
+            continue;
+        }
         if (c.ct_k >= 0 && use_ct_) {
-            HIP_CHECK(launch_fourier_ct(p, c.ct_f, c.ct_k, c.lds_bytes, c.nthreads, stream_));
+            HIP_CHECK(launch_fourier_ct(p, c.ct_f, c.ct_k, c.lds_bytes, c.nthreads, stream));
         }
         else {
-            HIP_CHECK(launch_fourier(p, c.lds_bytes, c.nthreads, stream_));
+            HIP_CHECK(launch_fourier(p, c.lds_bytes, c.nthreads, stream));
         }
     }
     timed_end();
@@ -351,8 +380,41 @@ void Trans::invtrans_uv_device(int trc_in, int nb_fields, int nb_vordiv, const d
         throw std::logic_error("invtrans_uv_device on a sharded Trans: use legendre_device / exchange / fourier_device");
     }
     double* F = fourier_buffer(nb_fields);
-    legendre_device(trc_in, nb_fields, sp_dev, F);
-    fourier_device(nb_fields, nb_vordiv, F, gp_dev);
+    int rtw, nrg, nchunks;
+    legendre_tiling(nb_fields, rtw, nrg, nchunks);
+    const int cols_per_chunk = 16 * rtw * nrg;  // interleaved (re, im) columns of one chunk
+    if (pipeline_ <= 1 || nchunks < 2 || cols_per_chunk % 16 != 0) {
+        legendre_device(trc_in, nb_fields, sp_dev, F);
+        fourier_device(nb_fields, nb_vordiv, F, gp_dev);
+        return;
+    }
+    // Software pipeline over column chunks: the Fourier stage of chunk c runs on a second stream while the Legendre
+    // stage of chunk c+1 occupies the matrix pipes (the two stages stress different units: MFMA + LDS staging vs
+    // VALU + LDS exchange + L2 gathers).  Chunks are whole groups of 8 fields, so both stages see aligned tiles.
+    if (!stream2_) {
+        HIP_CHECK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+    }
+    while (pipe_events_.size() < (size_t)nchunks + 1) {
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        pipe_events_.push_back(e);
+    }
+    const double* base[1] = {F};
+    const int cnt[1]      = {m_cnt_};
+    const int pieces      = std::min(pipeline_, nchunks);
+    int c0                = 0;
+    for (int i = 0; i < pieces; ++i) {
+        const int c1 = (int)((long long)nchunks * (i + 1) / pieces);
+        legendre_chunks(trc_in, nb_fields, sp_dev, F, c0, c1 - c0);
+        HIP_CHECK(hipEventRecord(pipe_events_[i], stream_));
+        HIP_CHECK(hipStreamWaitEvent(stream2_, pipe_events_[i], 0));
+        const int f0 = c0 * cols_per_chunk / 2;
+        const int f1 = std::min(nb_fields, c1 * cols_per_chunk / 2);
+        fourier_fields(nb_fields, nb_vordiv, base, cnt, gp_dev, f0, f1, stream2_);
+        c0 = c1;
+    }
+    HIP_CHECK(hipEventRecord(pipe_events_[pieces], stream2_));
+    HIP_CHECK(hipStreamWaitEvent(stream_, pipe_events_[pieces], 0));  // the call completes on stream()
 }
 
 void Trans::collect_timings() {

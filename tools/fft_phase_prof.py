@@ -19,8 +19,9 @@ _lib.check(_lib.Trans_fft_phase_profile(tr._h, 0, out))
 tm = tr.timings()
 v = np.array(out[:], dtype=np.float64)
 print("fourier ms", tm["fourier_ms"], "legendre ms", tm["legendre_ms"])
+print("ATLAS_AMD_FFT_ONLY_M =", os.environ.get("ATLAS_AMD_FFT_ONLY_M"))
 for name, sl in (("bluestein", slice(0, 32)), ("direct", slice(32, 64))):
     tot = v[sl].sum()
-    print(name, "total Gcycles(thread0 sum)", tot / 1e9)
+    print(name, "total Gcycles(thread0 sum; clock64 = 100 MHz ticks)", tot / 1e9)
     for i, x in enumerate(v[sl]):
         if x: print("   phase %2d: %6.2f %%" % (i, 100 * x / tot))
