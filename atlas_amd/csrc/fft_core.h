@@ -278,6 +278,33 @@ AA_HD void twiddle_powers(cplx w1, cplx* w) {
     }
 }
 
+// x[q] *= w1^q, q = 1..R-1, with few live twiddles: q = STEP*j + i walks w1^i * (w1^STEP)^j (chains of at most
+// R/STEP products); radix-16/20/24 stages would otherwise hold R twiddles (4 VGPRs each) next to R data elements
+template <int R>
+AA_HD void twiddle_apply(cplx* x, cplx w1) {
+    if constexpr (R <= 5) {
+        cplx w[R];
+        twiddle_powers<R>(w1, w);
+#pragma unroll
+        for (int q = 1; q < R; ++q) x[q] = cmul(x[q], w[q]);
+    }
+    else {
+        constexpr int STEP = 4;
+        cplx wi[STEP];
+        twiddle_powers<STEP>(w1, wi);
+        const cplx ws = cmul(wi[2], wi[2]);
+#pragma unroll
+        for (int i = 0; i < STEP; ++i) {
+            cplx t = wi[i];
+#pragma unroll
+            for (int q = i; q < R; q += STEP) {
+                if (q > 0) x[q] = cmul(x[q], t);
+                if (q + STEP < R) t = cmul(t, ws);
+            }
+        }
+    }
+}
+
 // butterfly index b -> (block, j) for sub-block length Ls (= 1 << lsh when lsh >= 0)
 AA_HD void split_index(int b, int Ls, int lsh, int& blk, int& j) {
     if (lsh >= 0) {
@@ -312,10 +339,9 @@ AA_HD void dif_stage(cplx* d, int M, int L, int lsh, const cplx* __restrict__ tw
         else {
             cplx w1 = tw[j * tws];
             if (dir < 0) w1.im = -w1.im;
-            cplx w[R];
-            twiddle_powers<R>(w1, w);
+            twiddle_apply<R>(x, w1);
 #pragma unroll
-            for (int q = 1; q < R; ++q) d[PAD(base + q * Ls)] = cmul(x[q], w[q]);
+            for (int q = 1; q < R; ++q) d[PAD(base + q * Ls)] = x[q];
         }
     }
 }
@@ -338,10 +364,9 @@ AA_HD void dit_stage(cplx* d, int M, int L, int lsh, const cplx* __restrict__ tw
         else {
             cplx w1 = tw[j * tws];
             if (dir < 0) w1.im = -w1.im;
-            cplx w[R];
-            twiddle_powers<R>(w1, w);
 #pragma unroll
-            for (int q = 1; q < R; ++q) x[q] = cmul(d[PAD(base + q * Ls)], w[q]);
+            for (int q = 1; q < R; ++q) x[q] = d[PAD(base + q * Ls)];
+            twiddle_apply<R>(x, w1);
         }
         bfly<R>(x, dir);
 #pragma unroll
@@ -719,11 +744,9 @@ AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCt& r, const Reade
             for (int q = NZ; q < R0; ++q) x[q] = cplx{0., 0.};
             bfly<R0>(x, -1);
             w1.im = -w1.im;
-            cplx w[R0];
-            twiddle_powers<R0>(w1, w);
-            work[PAD(b)] = x[0];
+            twiddle_apply<R0>(x, w1);
 #pragma unroll
-            for (int q = 1; q < R0; ++q) work[PAD(b + q * Ls0)] = cmul(x[q], w[q]);
+            for (int q = 0; q < R0; ++q) work[PAD(b + q * Ls0)] = x[q];
         }
         return;
     }
@@ -776,24 +799,33 @@ AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCt& r, const Reade
             c[q]        = r.chirp[(k < h ? k : h - 1) * AA_ABL(r, 3)];
         }
         AA_SCHED_FENCE();
-        cplx w[R0];
-        twiddle_powers<R0>(w1, w);
         cplx x[R0];
-        x[0] = work[PAD(b)];
 #pragma unroll
-        for (int q = 1; q < R0; ++q) x[q] = cmul(work[PAD(b + q * Ls0)], w[q]);
+        for (int q = 0; q < R0; ++q) x[q] = work[PAD(b + q * Ls0)];
+        twiddle_apply<R0>(x, w1);
         bfly<R0>(x, +1);
 #pragma unroll
         for (int q = 0; q < NZ; ++q) {
-            const int k = b + q * Ls0;
-            if (k < h) {
-                const cplx z = cmul(x[q], c[q]);
-                if (io.aligned16) {
-                    *reinterpret_cast<cplx*>(io.y + 2 * (int64_t)k * AA_ABL(r, 4)) = z;
+            x[q]    = cmul(x[q], c[q]);
+            x[q].re = x[q].re * io.scale;  // 1/cos(lat) for the wind fields, exactly 1 otherwise
+            x[q].im = x[q].im * io.scale;
+        }
+        if (io.aligned16) {  // uniform: the row starts on a 16-byte boundary
+#pragma unroll
+            for (int q = 0; q < NZ; ++q) {
+                const int k = b + q * Ls0;
+                if (k < h) {
+                    *reinterpret_cast<cplx*>(io.y + 2 * (int64_t)k * AA_ABL(r, 4)) = x[q];
                 }
-                else {
-                    io.y[2 * (int64_t)k]     = z.re * io.scale;
-                    io.y[2 * (int64_t)k + 1] = z.im * io.scale;
+            }
+        }
+        else {
+#pragma unroll
+            for (int q = 0; q < NZ; ++q) {
+                const int k = b + q * Ls0;
+                if (k < h) {
+                    io.y[2 * (int64_t)k]     = x[q].re;
+                    io.y[2 * (int64_t)k + 1] = x[q].im;
                 }
             }
         }

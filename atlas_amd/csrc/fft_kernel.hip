@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR, 3) fft_rows_ct_kernel(FourierPar
     fft::RowOut io;
     io.mmax      = mmax < r.h ? mmax : r.h;
     io.y         = p.gp + goff;
-    io.aligned16 = ((goff & 1) == 0) && scale == 1.0;
+    io.aligned16 = ((goff & 1) == 0);
     io.scale     = scale;
     constexpr int NPH = fft::row_num_phases_ct<S>();
     unsigned long long tprev = 0;

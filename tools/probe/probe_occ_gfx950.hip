@@ -17,9 +17,9 @@ __global__ void spin(long long clocks, double* out) {
 int main() {
     double* out;
     CK(hipMalloc(&out, 64));
-    const int sizes[] = {65536, 80896, 81408, 81920, 82432, 54016, 54784};
+    const int sizes[] = {16384, 20480, 27136, 32768, 36864, 40960, 41984, 49152, 53248, 54016};
     for (int lds : sizes) {
-        for (int nthr : {256, 320}) {
+        for (int nthr : {256, 512}) {
             CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&spin), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             int occ = -1;
             CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, spin, nthr, lds));
