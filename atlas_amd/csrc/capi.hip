@@ -157,6 +157,12 @@ atlas_amd_Trans* atlas_amd__Trans__new_config(const atlas_amd_Grid* grid, int tr
         else if (kv.first == "part") {
             cfg.part = std::stoi(kv.second);
         }
+        else if (kv.first == "shard") {
+            if (kv.second != "m" && kv.second != "band") {
+                throw std::invalid_argument("shard must be 'm' (wavenumbers, exchange follows) or 'band' (latitude bands)");
+            }
+            cfg.by_band = kv.second == "band";
+        }
         else if (kv.first == "type") {
             // atlas option::type: this library IS the "local" implementation (TransLocal.cc:57)
             if (kv.second != "local" && kv.second != "mi355x") {

@@ -32,6 +32,8 @@ struct LegendreParams {
     int nlats;
     int m_div;   // m-sharding: this device owns wavenumbers m with m % m_div == part; local index m / m_div
     int m_cnt;   // number of owned wavenumbers == m-extent of F:  F[(lat*m_cnt + m/m_div)*RP + r]
+    int row_begin, row_end;  // latitudes this device stores (band decomposition: its band; else all), F rows are
+                             // relative to row_begin
     int nitems;  // filled in by the launcher
     int nchunks; // column chunks per item (filled in by the launcher)
     int chunk0;  // first column chunk of this launch

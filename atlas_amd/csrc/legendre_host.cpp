@@ -172,6 +172,9 @@ inline void tiled_store(const TransGeometry& geo, const LegendreWork& work, doub
     for (int l = 0; l < nl; ++l) {
         const int c          = c0 + l;
         const LegendreItem& it = work.items_by_m[work.first_item_of_m[m] + c / LEG_BN];
+        if (it.p_off < 0) {
+            continue;  // tile of another latitude band
+        }
         const int col        = c % LEG_BN;
         double* blk          = table + it.p_off + col;
         const double* lp     = legpols[l] + LegendreEvaluator::idxmn(trc, m, m);  // lp[n-m]
@@ -201,6 +204,16 @@ void compute_legendre_table_tiled(const TransGeometry& geo, const LegendreWork& 
         for (int b = 0; b < nblk; ++b) {
             const int j0 = b * LB;
             const int nl = std::min(LB, nlats - j0);
+            bool wanted  = false;  // does any launched tile contain one of these rows?
+            for (int m = 0; m <= geo.T && !wanted; ++m) {
+                for (int l = std::max(j0, geo.nlat0[m]); l < j0 + nl && !wanted; ++l) {
+                    const int i = work.first_item_of_m[m] + (l - geo.nlat0[m]) / LEG_BN;
+                    wanted      = i < work.first_item_of_m[m + 1] && work.items_by_m[i].p_off >= 0;
+                }
+            }
+            if (!wanted) {
+                continue;
+            }
             for (int l = 0; l < nl; ++l) {
                 ev.evaluate(geo.lats_leg[j0 + l], legpol[l].data(), scratch.data());
             }
@@ -235,6 +248,9 @@ void retile_legendre_tables(const TransGeometry& geo, const LegendreWork& work, 
         for (int jlat = geo.nlat0[m]; jlat < geo.nlatsLegR; ++jlat) {
             const int c            = jlat - geo.nlat0[m];
             const LegendreItem& it = work.items_by_m[work.first_item_of_m[m] + c / LEG_BN];
+            if (it.p_off < 0) {
+                continue;
+            }
             double* blk            = table + it.p_off + (c % LEG_BN);
             const double* s        = leg_sym + geo.begin_sym[m] + ks * size_t(jlat);
             const double* a        = leg_asym + geo.begin_asym[m] + ka * size_t(jlat);

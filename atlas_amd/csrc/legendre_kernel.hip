@@ -200,8 +200,10 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
         if (c < it.nrows) {
             const int jn = jleg0 + c;
             const int js = nlats - 1 - jn;
-            double* fn   = p.F + ((long long)jn * p.m_cnt + ml) * RP;
-            double* fs   = p.F + ((long long)js * p.m_cnt + ml) * RP;
+            const bool st_n = jn != js && jn >= p.row_begin && jn < p.row_end;
+            const bool st_s = js >= p.row_begin && js < p.row_end;
+            double* fn   = p.F + ((long long)(jn - p.row_begin) * p.m_cnt + ml) * RP;
+            double* fs   = p.F + ((long long)(js - p.row_begin) * p.m_cnt + ml) * RP;
 #pragma unroll
             for (int j = 0; j < RTW; ++j) {
                 const int r = r0 + (rg * RTW + j) * 16 + (lane & 15);
@@ -211,10 +213,12 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
                         sy = 0.;
                         as = 0.;
                     }
-                    if (jn != js) {
+                    if (st_n) {
                         fn[r] = sy + as;
                     }
-                    fs[r] = sy - as;  // for an equator row the southern value wins (TransLocal.cc:1056-1068 runs last)
+                    if (st_s) {
+                        fs[r] = sy - as;  // for an equator row the southern value wins (TransLocal.cc:1056-1068 runs last)
+                    }
                 }
             }
         }

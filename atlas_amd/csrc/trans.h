@@ -33,6 +33,8 @@ struct TransConfig {
     size_t legendre_cache_size = 0;
     int nparts                 = 1;  // m-sharding / latitude-band decomposition
     int part                   = 0;
+    bool by_band               = false;  // nparts > 1: false = wavenumber sharding (all-to-all transposition follows),
+                                         // true = latitude-band sharding of both stages (no exchange, 2x Legendre work)
 };
 
 struct StageTimings {
@@ -58,6 +60,8 @@ public:
     int part() const { return cfg_.part; }
     int band_begin() const { return bands_[cfg_.part]; }
     int band_end() const { return bands_[cfg_.part + 1]; }
+    // producers the Fourier stage gathers from: the wavenumber owners, or just this device (latitude-band decomposition)
+    int fourier_parts() const { return cfg_.by_band ? 1 : cfg_.nparts; }
     const std::vector<int>& bands() const { return bands_; }
     int owned_wavenumbers() const { return m_cnt_; }
     hipStream_t stream() const { return stream_; }

@@ -63,10 +63,10 @@ Trans::Trans(const grid::StructuredGrid& grid, int truncation, const TransConfig
     if (const char* e = std::getenv("ATLAS_AMD_FFT_GENERIC")) {
         use_ct_ = !(e[0] == '1');
     }
-    work_ = make_legendre_work(geo_, cfg.nparts, cfg.part);
+    work_ = make_legendre_work(geo_, cfg.nparts, cfg.part, cfg.by_band);
     bands_ = latitude_bands(geo_, cfg.nparts);
     m_cnt_ = 0;
-    for (int m = cfg.part; m <= geo_.T; m += cfg.nparts) {
+    for (int m = cfg.by_band ? 0 : cfg.part; m <= geo_.T; m += cfg.by_band ? 1 : cfg.nparts) {
         m_cnt_++;
     }
     std::vector<int> lengths;
@@ -240,7 +240,8 @@ int Trans::fourier_row_pitch(int nb_fields) const {
 }
 
 size_t Trans::fourier_doubles(int nb_fields) const {
-    return size_t(geo_.nlats) * size_t(m_cnt_) * size_t(fourier_row_pitch(nb_fields));
+    const int rows = cfg_.by_band ? band_end() - band_begin() : geo_.nlats;
+    return size_t(rows) * size_t(m_cnt_) * size_t(fourier_row_pitch(nb_fields));
 }
 
 double* Trans::fourier_buffer(int nb_fields) {
@@ -302,8 +303,10 @@ void Trans::legendre_chunks(int trc_in, int nb_fields, const double* sp_dev, dou
     p.nf     = nb_fields;
     p.RP     = fourier_row_pitch(nb_fields);
     p.nlats  = geo_.nlats;
-    p.m_div  = cfg_.nparts;
+    p.m_div  = cfg_.by_band ? 1 : cfg_.nparts;
     p.m_cnt  = m_cnt_;
+    p.row_begin = cfg_.by_band ? band_begin() : 0;
+    p.row_end   = cfg_.by_band ? band_end() : geo_.nlats;
     timed_begin(0);
     if (!work_.items.empty()) {
         HIP_CHECK(launch_legendre(p, (int)work_.items.size(), chunk0, nrun, stream_));
@@ -323,10 +326,10 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
     }
     FourierParams p;
     for (int i = 0; i < fft::MAX_PARTS; ++i) {
-        p.part_base[i] = i < cfg_.nparts ? part_base[i] : nullptr;
-        p.part_cnt[i]  = i < cfg_.nparts ? part_cnt[i] : 0;
+        p.part_base[i] = i < fourier_parts() ? part_base[i] : nullptr;
+        p.part_cnt[i]  = i < fourier_parts() ? part_cnt[i] : 0;
     }
-    p.nparts          = cfg_.nparts;
+    p.nparts          = fourier_parts();
     p.lat0            = band_begin();
     p.gp              = gp_dev;
     p.plans           = (const fft::FftRowPlan*)d_fftplans_;
@@ -364,8 +367,8 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
 }
 
 void Trans::fourier_device(int nb_fields, int nb_vordiv, const double* fourier_dev, double* gp_dev) {
-    if (cfg_.nparts != 1) {
-        throw std::logic_error("single-buffer fourier_device needs nparts == 1");
+    if (fourier_parts() != 1) {
+        throw std::logic_error("single-buffer fourier_device needs nparts == 1 or the latitude-band decomposition");
     }
     const double* base[1] = {fourier_dev};
     int cnt[1]            = {m_cnt_};
@@ -376,8 +379,8 @@ void Trans::invtrans_uv_device(int trc_in, int nb_fields, int nb_vordiv, const d
     if (nb_fields <= 0) {
         return;
     }
-    if (cfg_.nparts != 1) {
-        throw std::logic_error("invtrans_uv_device on a sharded Trans: use legendre_device / exchange / fourier_device");
+    if (fourier_parts() != 1) {
+        throw std::logic_error("invtrans_uv_device on a wavenumber-sharded Trans: use legendre_device / exchange / fourier_device");
     }
     double* F = fourier_buffer(nb_fields);
     int rtw, nrg, nchunks;
@@ -498,8 +501,8 @@ void Trans::ensure(double*& ptr, size_t& cap, size_t n) {
 
 void Trans::invtrans_device(int nb_scalar, const double* sp_dev, int nb_vordiv, const double* vor_dev,
                             const double* div_dev, double* gp_dev) {
-    if (cfg_.nparts != 1) {
-        throw std::logic_error("invtrans_device on a sharded Trans: use the stage API");
+    if (fourier_parts() != 1) {
+        throw std::logic_error("invtrans_device on a wavenumber-sharded Trans: use the stage API");
     }
     if (nb_vordiv > 0) {
         const int T       = geo_.T;

@@ -159,15 +159,24 @@ double legendre_flops(const TransGeometry& geo, int nf) {
     return f;
 }
 
-LegendreWork make_legendre_work(const TransGeometry& geo, int nparts, int part) {
+LegendreWork make_legendre_work(const TransGeometry& geo, int nparts, int part, bool by_band) {
     LegendreWork w;
     const int T = geo.T;
     w.first_item_of_m.assign(T + 2, 0);
+    // by_band: this device computes every wavenumber, but only the Legendre rows whose northern or mirrored southern
+    // latitude lies in its own latitude band [b0, b1) (no hemisphere sharing between devices, no exchange)
+    int b0 = 0, b1 = geo.nlats;
+    if (by_band) {
+        const std::vector<int> bands = latitude_bands(geo, nparts);
+        b0                           = bands[part];
+        b1                           = bands[part + 1];
+    }
+    auto row_needed = [&](int jn) { return (jn >= b0 && jn < b1) || (geo.nlats - 1 - jn >= b0 && geo.nlats - 1 - jn < b1); };
     int64_t off = 0;
     for (int m = 0; m <= T; ++m) {
         w.first_item_of_m[m] = (int)w.items_by_m.size();
         const int L          = geo.L(m);
-        if (L <= 0 || (m % nparts) != part) {
+        if (L <= 0 || (!by_band && (m % nparts) != part)) {
             continue;
         }
         const int ks    = num_n(T + 1, m, true);
@@ -179,8 +188,17 @@ LegendreWork make_legendre_work(const TransGeometry& geo, int nparts, int part) 
             it.tile  = t;
             it.nrows = std::min(LEG_BN, L - t * LEG_BN);
             it.kpad  = kpad;
-            it.p_off = off;
-            off += int64_t(2) * kpad * LEG_BN;
+            bool needed = !by_band;
+            for (int c = 0; c < it.nrows && !needed; ++c) {
+                needed = row_needed(geo.nlat0[m] + t * LEG_BN + c);
+            }
+            if (needed) {
+                it.p_off = off;
+                off += int64_t(2) * kpad * LEG_BN;
+            }
+            else {
+                it.p_off = -1;  // tile of another band: kept in items_by_m (tile index = position), never launched
+            }
             w.items_by_m.push_back(it);
         }
     }
@@ -195,7 +213,10 @@ LegendreWork make_legendre_work(const TransGeometry& geo, int nparts, int part) 
     std::vector<int> ms;
     std::vector<double> cost(T + 1, 0.);
     for (int m = 0; m <= T; ++m) {
-        const int n = w.first_item_of_m[m + 1] - w.first_item_of_m[m];
+        int n = 0;
+        for (int i = w.first_item_of_m[m]; i < w.first_item_of_m[m + 1]; ++i) {
+            n += w.items_by_m[i].p_off >= 0;
+        }
         if (n > 0) {
             ms.push_back(m);
             cost[m] = double(n) * w.items_by_m[w.first_item_of_m[m]].kpad;
@@ -208,7 +229,9 @@ LegendreWork make_legendre_work(const TransGeometry& geo, int nparts, int part) 
         int x = int(std::min_element(load.begin(), load.end()) - load.begin());
         load[x] += cost[m];
         for (int i = w.first_item_of_m[m]; i < w.first_item_of_m[m + 1]; ++i) {
-            lists[x].push_back(w.items_by_m[i]);
+            if (w.items_by_m[i].p_off >= 0) {
+                lists[x].push_back(w.items_by_m[i]);
+            }
         }
     }
     size_t maxlen = 0;

@@ -42,13 +42,25 @@ def mode_address(plan, RP, lat_local, m, nparts, f2=0):
 
 
 class DistributedTrans:
-    def __init__(self, grid, truncation, group=None, profile=False):
+    def __init__(self, grid, truncation, group=None, profile=False, mode="auto"):
+        """mode: "alltoall" = Legendre stage sharded by wavenumber, RCCL all-to-all, Fourier stage on the local band
+                 "band"     = both stages on the local latitude band: no exchange, but the hemisphere symmetry cannot
+                              be shared between devices, so the Legendre stage costs 2/P instead of 1/P
+                 "auto"     = "band" below 8 ranks (the transposition moves 7.55 GB * (P-1)/P^2 per device and
+                              transform over P-1 point-to-point xGMI links: link-bound for P = 2, 4), else "alltoall"
+        """
         import torch
         import torch.distributed as dist
         self.group = group
         self.nparts = dist.get_world_size(group)
         self.part = dist.get_rank(group)
-        self.trans = Trans(grid, truncation, profile=profile, nparts=self.nparts, part=self.part)
+        if mode == "auto":
+            mode = "band" if self.nparts < 8 else "alltoall"
+        if mode not in ("alltoall", "band"):
+            raise ValueError("mode must be 'auto', 'alltoall' or 'band'")
+        self.mode = mode
+        self.trans = Trans(grid, truncation, profile=profile, nparts=self.nparts, part=self.part,
+                           shard="band" if mode == "band" else "m")
         self.trans.use_torch_stream()
         self.T = truncation
         self.bands = self.trans.bands()
@@ -80,6 +92,8 @@ class DistributedTrans:
 
     def invtrans(self, nf, sp, gp):
         """one distributed transform; sp: full spectra (replicated), gp: nf * local-band points"""
+        if self.mode == "band":
+            return self.trans.invtrans(nf, sp, gp)
         self._legendre_and_exchange(nf, sp, 0, async_op=False)
         self._fourier(nf, 0, gp)
         return gp
@@ -87,6 +101,10 @@ class DistributedTrans:
     def invtrans_many(self, nf, sps, gps):
         """software pipeline over several transforms: the all-to-all of transform i runs on RCCL's stream while
         the Legendre stage of transform i+1 and the Fourier stage of transform i-1 run on the compute stream"""
+        if self.mode == "band":
+            for sp, gp in zip(sps, gps):
+                self.trans.invtrans(nf, sp, gp)
+            return gps
         works = []
         for i, sp in enumerate(sps):
             works.append(self._legendre_and_exchange(nf, sp, i % 2, async_op=True))

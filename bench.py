@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-fields", type=int, default=24)
     ap.add_argument("--force-dist", action="store_true", help="exercise the distributed driver even with one rank")
+    ap.add_argument("--dist-mode", default="auto", choices=["auto", "alltoall", "band"],
+                    help="N > 1: wavenumber sharding + RCCL all-to-all, or exchange-free latitude-band sharding "
+                         "(auto: band below 8 ranks, all-to-all at 8; see atlas_amd/dist.py)")
     args = ap.parse_args()
 
     import numpy as np
@@ -94,7 +97,7 @@ def main():
         import torch.distributed as dist
         from atlas_amd.dist import DistributedTrans
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        dtr = DistributedTrans(g, TRUNC, profile=True)
+        dtr = DistributedTrans(g, TRUNC, profile=True, mode=args.dist_mode)
         tr = dtr.trans
         # every rank holds the spectra of the `world` transforms of a step (replicated input; each rank reads only
         # the wavenumbers it owns)
@@ -164,7 +167,11 @@ def main():
             "config": {"workload": f"TransLocal invtrans TL{TRUNC} -> {GRID}, {NLEV} levels (nb_scalar_fields={NLEV}) "
                                    f"per transform, {world} transform(s) per step",
                        "grid": GRID, "truncation": TRUNC, "levels": NLEV,
-                       "parallelism": "single GPU" if world == 1 else f"m-sharded Legendre + RCCL all-to-all + latitude-band FFT over {world} GPUs"},
+                       "parallelism": "single GPU" if not use_dist else (
+                           f"m-sharded Legendre + RCCL all-to-all + latitude-band FFT over {world} GPUs"
+                           if dtr.mode == "alltoall" else
+                           f"latitude-band sharding of both stages over {world} GPUs (no exchange; Legendre rows of a "
+                           f"band are computed without their mirror hemisphere: 2/P of the single-GPU Legendre work)")},
             "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")},
             "roofline_kernels": kernels,
         }

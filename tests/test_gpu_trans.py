@@ -257,3 +257,38 @@ def test_sharded_stages_reproduce_single_device_result(gridname, T, nf, nparts):
         lo, hi = off[bands[q]], off[bands[q + 1]]
         assert tr.nb_gridpoints() == hi - lo
         assert np.array_equal(gp.cpu().numpy().reshape(nf, -1), ref[:, lo:hi]), q
+
+
+@pytest.mark.parametrize("gridname,T,nf,nparts", [("O64", 63, 5, 2), ("O64", 63, 3, 3), ("F32", 31, 4, 4),
+                                                  ("O160", 159, 9, 8), ("O160", 159, 20, 5)])
+def test_latitude_band_sharding_reproduces_single_device_result(gridname, T, nf, nparts):
+    """shard="band": every device computes all wavenumbers for the rows of its own latitude band (Atlas bands rule)
+    and transforms them without any exchange.  The per-(m, latitude) and per-row arithmetic is that of the single
+    device, so the concatenated bands must equal its result bit for bit; also on the vor/div path."""
+    g, tr1 = get_trans(gridname, T)
+    sp = red_spectra(T, nf, seed=9)
+    ref = run_device(tr1, nf, sp).reshape(nf, -1)
+    sp_d = dev(sp)
+    off = np.concatenate([[0], np.cumsum(g.nx())])
+    nvd = 2
+    vor, div = red_spectra(T, nvd, seed=10), red_spectra(T, nvd, seed=11)
+    ref_uv = torch.zeros((nf + 2 * nvd) * g.size(), dtype=torch.float64, device="cuda")
+    tr1.invtrans(nf, sp_d, nvd, dev(vor), dev(div), ref_uv)
+    tr1.synchronize()
+    ref_uv = ref_uv.cpu().numpy().reshape(nf + 2 * nvd, -1)
+    total = 0
+    for p in range(nparts):
+        tr = atlas_amd.Trans(g, T, nparts=nparts, part=p, shard="band")
+        bands = tr.bands()
+        lo, hi = off[bands[p]], off[bands[p + 1]]
+        assert tr.nb_gridpoints() == hi - lo
+        total += tr.nb_gridpoints()
+        gp = torch.full((nf * tr.nb_gridpoints(),), np.nan, dtype=torch.float64, device="cuda")
+        tr.invtrans(nf, sp_d, gp)
+        tr.synchronize()
+        assert np.array_equal(gp.cpu().numpy().reshape(nf, -1), ref[:, lo:hi]), p
+        gp = torch.full(((nf + 2 * nvd) * tr.nb_gridpoints(),), np.nan, dtype=torch.float64, device="cuda")
+        tr.invtrans(nf, sp_d, nvd, dev(vor), dev(div), gp)
+        tr.synchronize()
+        assert np.array_equal(gp.cpu().numpy().reshape(nf + 2 * nvd, -1), ref_uv[:, lo:hi]), p
+    assert total == g.size()
