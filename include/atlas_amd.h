@@ -65,6 +65,10 @@ atlas_amd_Trans* atlas_amd__Trans__new(const atlas_amd_Grid* grid, int truncatio
 /* atlas__Trans__new_config(grid, truncation, config).  `config` is "key=value;key=value" with keys
  *   profile=0|1          record HIP events around the two stages (atlas_amd__Trans__timings)
  *   nparts=P;part=p      multi-GPU decomposition: this object owns wavenumbers m%P==p and latitude band p
+ *   shard=m|band         m (default): Legendre stage on the owned wavenumbers, Fourier stage on the owned band; the
+ *                        caller transposes in between (stage API below).  band: both stages on the owned latitude
+ *                        band, no exchange: the *_device invtrans entry points then return the band's grid points
+ *   type=local|mi355x    accepted for atlas option::type compatibility
  * legendre_cache / size: optional Legendre cache blob in TransLocal's file layout (TransLocal.cc:608-614), or NULL */
 atlas_amd_Trans* atlas_amd__Trans__new_config(const atlas_amd_Grid* grid, int truncation, const char* config,
                                               const void* legendre_cache, size_t legendre_cache_size);
