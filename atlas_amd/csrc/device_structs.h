@@ -25,6 +25,7 @@ struct LegendreParams {
     double* F;                     // Fourier intermediate F[(lat*(T+1)+m)*RP + r]
     const LegendreItemDev* items;  // launch-ordered work items
     const int* nlat0;              // [T+1]
+    const double* zero;            // a 0.0 in device memory (target of the spectra loads of padding columns)
     int T;
     int trc_in;  // truncation of the input layout (T, or T+1 on the vor/div path)
     int nf;

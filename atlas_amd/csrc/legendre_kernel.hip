@@ -23,6 +23,8 @@
 // Entries with m above the row's Fourier truncation are never written and never read (fft_kernel.hip).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <cstdio>
 #include <cstdlib>
 
@@ -114,32 +116,63 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
         plds[i]        = ppar * (KB * PSTR) + pk * PSTR + pc;
     }
 
-    auto load_stage = [&](int s) {
+    // Spectra operand: element i of this thread is row (parity, k) = q / SCOLS, column q % SCOLS of the stage tile.
+    // Its wavenumber n = n0 - 2*KB*s walks down a column of the reference layout, so the address is a running pointer;
+    // columns beyond the last field (and every column when m >= truncation) point at a zero in device memory with
+    // step 0, which removes the per-stage select.  Only the first/last stages of an item contain rows with n outside
+    // [m, nmax] (K padding): those run the bounds-checked path, all others three plain loads.  (The loop used to spend
+    // 4.7 VALU instructions per MFMA on rebuilding addresses and masks; MFMA and VALU issue contend.)
+    const double* sptr[RTW];
+    long long sstep[RTW];
+    int sn0[RTW];
+#pragma unroll
+    for (int i = 0; i < RTW; ++i) {
+        const int q     = tid + NTHR * i;
+        const int row   = q / L::SCOLS;  // 0..15 : parity*8 + k
+        const int col   = q - row * L::SCOLS;
+        const int r     = r0 + col;
+        const int f     = r >> 1, im = r & 1;
+        const bool fok  = m_ok && f < nf;
+        sn0[i]          = ((row >> 3) ? ntop1 : ntop0) - 2 * (row & 7);
+        sptr[i]         = fok ? sp + ((long long)(sn0[i] - m) * 2 * nf + im * nf + f) : p.zero;
+        sstep[i]        = fok ? (long long)2 * KB * 2 * nf : 0;
+    }
+    // stages whose 16 rows are all inside [m, nmax]
+    const int ntop_hi = ntop0 > ntop1 ? ntop0 : ntop1, ntop_lo = ntop0 < ntop1 ? ntop0 : ntop1;
+    const int s_ff    = ntop_hi > nmax ? (ntop_hi - nmax + 2 * KB - 1) / (2 * KB) : 0;
+    const int s_lf    = ntop_lo - 2 * (KB - 1) - m >= 0 ? (ntop_lo - 2 * (KB - 1) - m) / (2 * KB) : -1;
+
+    auto load_stage = [&](int s) {  // must be called for s = 0, 1, 2, ... in order
         if (p_loader) {
 #pragma unroll
             for (int i = 0; i < PPT; ++i) {
-                preg[i] = *reinterpret_cast<const double2*>(pg[i] + (long long)s * KB * BN);
+                preg[i] = *reinterpret_cast<const double2*>(pg[i]);
+                pg[i] += KB * BN;
             }
         }
+        if (s >= s_ff && s <= s_lf) {
 #pragma unroll
-        for (int i = 0; i < RTW; ++i) {
-            const int q    = tid + NTHR * i;
-            const int row  = q / L::SCOLS;  // 0..15 : parity*8 + k
-            const int col  = q - row * L::SCOLS;
-            const int par  = row >> 3;
-            const int k    = s * KB + (row & 7);
-            const int n    = (par ? ntop1 : ntop0) - 2 * k;
-            const int r    = r0 + col;
-            const int f    = r >> 1, im = r & 1;
-            double v       = 0.;
-            if (m_ok && n >= m && n <= nmax && f < nf) {
-                v = sp[(long long)(n - m) * 2 * nf + im * nf + f];
+            for (int i = 0; i < RTW; ++i) {
+                sreg[i] = *sptr[i];
+                sptr[i] -= sstep[i];
             }
-            sreg[i] = v;
+        }
+        else {
+#pragma unroll
+            for (int i = 0; i < RTW; ++i) {
+                const int n = sn0[i] - 2 * KB * s;
+                double v    = 0.;
+                if (n >= m && n <= nmax) {
+                    v = *sptr[i];
+                }
+                sreg[i] = v;
+                sptr[i] -= sstep[i];
+            }
         }
     };
-    auto store_stage = [&](int buf) {
-        double* base = lds + buf * L::STAGE;
+    auto store_stage = [&](auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        double* base      = lds + buf * L::STAGE;
         if (p_loader) {
 #pragma unroll
             for (int i = 0; i < PPT; ++i) {
@@ -157,14 +190,15 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
     };
 
     load_stage(0);
-    store_stage(0);
+    store_stage(std::integral_constant<int, 0>{});
     __syncthreads();
 
     const int a_off = (lane >> 4) * PSTR + lt * 16 + (lane & 15);
     const int b_off = (lane >> 4) * L::SSTR + rg * RTW * 16 + (lane & 15);
 
-    for (int s = 0; s < nstage; ++s) {
-        const int buf = s & 1;
+    // one stage from LDS buffer `buf` (compile-time: the fragment offsets become instruction immediates)
+    auto run_stage = [&](int s, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
         if (s + 1 < nstage) {
             load_stage(s + 1);
         }
@@ -184,9 +218,15 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
             }
         }
         if (s + 1 < nstage) {
-            store_stage(buf ^ 1);
+            store_stage(std::integral_constant<int, buf ^ 1>{});
         }
         __syncthreads();
+    };
+    for (int s = 0; s < nstage; s += 2) {
+        run_stage(s, std::integral_constant<int, 0>{});
+        if (s + 1 < nstage) {
+            run_stage(s + 1, std::integral_constant<int, 1>{});
+        }
     }
 
     // ---- epilogue: merge hemispheres and store ----

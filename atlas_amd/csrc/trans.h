@@ -132,6 +132,7 @@ private:
     double* d_P_         = nullptr;
     void* d_items_       = nullptr;
     int* d_nlat0_        = nullptr;
+    double* d_zero_      = nullptr;  // zeros: load target of padding columns in the Legendre kernel
     void* d_fftplans_    = nullptr;
     void* d_ffttable_    = nullptr;
     int* d_row_plan_     = nullptr;

@@ -92,6 +92,7 @@ Trans::~Trans() {
     fr(d_P_);
     fr(d_items_);
     fr(d_nlat0_);
+    fr(d_zero_);
     fr(d_fftplans_);
     fr(d_ffttable_);
     fr(d_row_plan_);
@@ -167,6 +168,10 @@ void Trans::upload() {
         d_items_ = dev_upload(items.data(), items.size());
     }
     d_nlat0_ = dev_upload(geo_.nlat0.data(), geo_.nlat0.size());
+    {
+        const double zeros[16] = {0.};
+        d_zero_                = dev_upload(zeros, 16);
+    }
     // ---- FFT plans / tables ----
     d_fftplans_ = dev_upload(fftplans_.plans.data(), fftplans_.plans.size());
     d_ffttable_ = dev_upload(fftplans_.table.data(), fftplans_.table.size());
@@ -298,6 +303,7 @@ void Trans::legendre_chunks(int trc_in, int nb_fields, const double* sp_dev, dou
     p.F      = fourier_dev;
     p.items  = (const LegendreItemDev*)d_items_;
     p.nlat0  = d_nlat0_;
+    p.zero   = d_zero_;
     p.T      = geo_.T;
     p.trc_in = trc_in;
     p.nf     = nb_fields;
