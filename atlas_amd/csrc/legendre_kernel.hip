@@ -195,6 +195,7 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
 
     const int a_off = (lane >> 4) * PSTR + lt * 16 + (lane & 15);
     const int b_off = (lane >> 4) * L::SSTR + rg * RTW * 16 + (lane & 15);
+    const bool lat_active = lt * 16 < it.nrows;
 
     // one stage from LDS buffer `buf` (compile-time: the fragment offsets become instruction immediates)
     auto run_stage = [&](int s, auto bufc) {
@@ -203,6 +204,7 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
             load_stage(s + 1);
         }
         const double* base = lds + buf * L::STAGE;
+        if (lat_active) {  // a wave whose 16 latitudes are all beyond the item's last row only helps with the staging
 #pragma unroll
         for (int par = 0; par < 2; ++par) {
             const double* pb = base + par * (KB * PSTR) + a_off;
@@ -216,6 +218,7 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
                     acc[par][j]    = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[par][j], 0, 0, 0);
                 }
             }
+        }
         }
         if (s + 1 < nstage) {
             store_stage(std::integral_constant<int, buf ^ 1>{});
