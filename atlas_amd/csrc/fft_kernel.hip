@@ -156,6 +156,14 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR) fft_rows_kernel(FourierParams p)
 }
 
 // ---- compile-time specialised Bluestein rows (fft_core.h: row_phase_ct) -------------------------------------------
+template <class S, int PH, class Fn>
+__device__ __forceinline__ void for_each_phase(Fn&& fn) {
+    if constexpr (PH < fft::row_num_phases_ct<S>()) {
+        fn(std::integral_constant<int, PH>{});
+        for_each_phase<S, PH + 1>(fn);
+    }
+}
+
 template <class S>
 __global__ void __launch_bounds__(FFT_MAX_NTHR, 3) fft_rows_ct_kernel(FourierParams p) {
     extern __shared__ double lds_raw[];
@@ -192,11 +200,13 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR, 3) fft_rows_ct_kernel(FourierPar
     if (prof) {
         tprev = clock64();
     }
-#pragma unroll
-    for (int ph = 0; ph < NPH; ++ph) {
+    // compile-time recursion over the phases: `#pragma unroll` gives up on the largest shapes ("unrolled size is too
+    // large") and would leave a run-time loop around a switch
+    for_each_phase<S, 0>([&](auto phc) {
+        constexpr int ph = decltype(phc)::value;
         fft::row_phase_ct<S>(ph, tid, nt, r, rd, io, work);
-        if (ph < NPH - 1) {
-            if (S::wave_local_middle() && ph >= 1 && ph <= NPH - 3) {
+        if constexpr (ph < NPH - 1) {
+            if constexpr (S::wave_local_middle() && ph >= 1 && ph <= NPH - 3) {
                 // producer and consumer lanes of the next phase are in this wavefront: LDS executes a wavefront's
                 // instructions in order, only the compiler must not move accesses across this point
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -212,7 +222,7 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR, 3) fft_rows_ct_kernel(FourierPar
             atomicAdd(&p.prof[ph], tn - tprev);
             tprev = tn;
         }
-    }
+    });
 }
 
 template <class S>
