@@ -539,15 +539,35 @@ AA_HD void row_phase(int ph, int t, int nt, const RowTables& r, const Reader& rd
     const int M  = r.shape->M;
     const int ns = r.shape->nstages;
     if (ph == 0) {  // ---- load + c2r pre-processing (+ chirp / zero padding)
-        for (int k = t; k < h; k += nt) {
-            cplx A = row_mode(rd, io.mmax, k, h);
-            cplx B = cconj(row_mode(rd, io.mmax, h - k, h));
-            cplx Z = c2r_pre(A, B, r.pre[k]);
-            if (r.method == 1) {
-                work[PAD(k)] = cmul(Z, r.chirp[k]);
+        // four elements per sweep, their loads (clamped addresses, masks applied afterwards) issued as one batch
+        // ahead of a scheduling fence (see row_phase_ct)
+        constexpr int NB = 4;
+        for (int k0 = t; k0 < h; k0 += NB * nt) {
+            cplx A[NB], B[NB], P[NB], C[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int k  = k0 + i * nt;
+                const int kc = k < h ? k : h - 1;
+                A[i]         = rd(row_mode_index(io.mmax, kc));
+                B[i]         = rd(row_mode_index(io.mmax, h - kc));
+                P[i]         = r.pre[kc];
+                C[i]         = r.method == 1 ? r.chirp[kc] : cplx{1., 0.};
             }
-            else {
-                work[PAD(pos_of_freq(*r.shape, k))] = Z;
+            AA_SCHED_FENCE();
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int k = k0 + i * nt;
+                if (k < h) {
+                    const cplx a = row_mode_mask(A[i], io.mmax, k, h);
+                    const cplx b = cconj(row_mode_mask(B[i], io.mmax, h - k, h));
+                    const cplx Z = c2r_pre(a, b, P[i]);
+                    if (r.method == 1) {
+                        work[PAD(k)] = cmul(Z, C[i]);
+                    }
+                    else {
+                        work[PAD(pos_of_freq(*r.shape, k))] = Z;
+                    }
+                }
             }
         }
         if (r.method == 1) {
