@@ -117,6 +117,11 @@ Trans::~Trans() {
     if (stream2_) {
         (void)hipStreamDestroy(stream2_);
     }
+    if (stream3_) {
+        (void)hipStreamDestroy(stream3_);
+        (void)hipEventDestroy(side_fork_);
+        (void)hipEventDestroy(side_join_);
+    }
     if (own_stream_ && stream_) {
         (void)hipStreamDestroy(stream_);
     }
@@ -353,21 +358,43 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
     p.coslatinv       = d_coslatinv_;
     p.prof            = d_prof_;
     p.abl             = std::getenv("ATLAS_AMD_FFT_ABLATE") ? atoi(std::getenv("ATLAS_AMD_FFT_ABLATE")) : 0;
-    p.abl             = std::getenv("ATLAS_AMD_FFT_ABLATE") ? atoi(std::getenv("ATLAS_AMD_FFT_ABLATE")) : 0;
     timed_begin(1, stream);
     static const int only_m = std::getenv("ATLAS_AMD_FFT_ONLY_M") ? atoi(std::getenv("ATLAS_AMD_FFT_ONLY_M")) : 0;
+    // Row-length classes with few workgroups (the four longest rows, the polar caps) cannot fill 256 CUs on their own:
+    // they go to a side stream and share the device with the big classes instead of each adding a launch tail.
+    static const bool side_env = std::getenv("ATLAS_AMD_FFT_SIDE") ? atoi(std::getenv("ATLAS_AMD_FFT_SIDE")) != 0 : true;
+    const long long groups     = (f_end - f_begin + 7) / 8;
+    bool side_used             = false;
     for (const SizeClass& c : classes_) {
         p.rows  = c.d_rows;
         p.nrows = c.nrows;
         if (only_m && c.lds_bytes != fft::padded_size(only_m) * 16) {  // dev tool (tools/fft_phase_prof.py): one class
             continue;
         }
+        hipStream_t st = stream;
+        if (side_env && (long long)c.nrows * groups * 8 <= 9000) {
+            if (!side_used) {
+                if (!stream3_) {
+                    HIP_CHECK(hipStreamCreateWithFlags(&stream3_, hipStreamNonBlocking));
+                    HIP_CHECK(hipEventCreateWithFlags(&side_fork_, hipEventDisableTiming));
+                    HIP_CHECK(hipEventCreateWithFlags(&side_join_, hipEventDisableTiming));
+                }
+                HIP_CHECK(hipEventRecord(side_fork_, stream));
+                HIP_CHECK(hipStreamWaitEvent(stream3_, side_fork_, 0));
+                side_used = true;
+            }
+            st = stream3_;
+        }
         if (c.ct_k >= 0 && use_ct_) {
-            HIP_CHECK(launch_fourier_ct(p, c.ct_f, c.ct_k, c.lds_bytes, c.nthreads, stream));
+            HIP_CHECK(launch_fourier_ct(p, c.ct_f, c.ct_k, c.lds_bytes, c.nthreads, st));
         }
         else {
-            HIP_CHECK(launch_fourier(p, c.lds_bytes, c.nthreads, stream));
+            HIP_CHECK(launch_fourier(p, c.lds_bytes, c.nthreads, st));
         }
+    }
+    if (side_used) {
+        HIP_CHECK(hipEventRecord(side_join_, stream3_));
+        HIP_CHECK(hipStreamWaitEvent(stream, side_join_, 0));
     }
     timed_end();
 }
