@@ -12,6 +12,13 @@ namespace functionspace {
 
 int StructuredColumns::partition_of(int64_t g) const {
     // part(g) = ((g / blocksize) * nparts) / nb_blocks   (BandsDistribution.h:32-34)
+    if (cfg_.blocksize == 0) {
+        // "row_bands": whole latitude rows, a row belongs to the equal_bands part of its FIRST point -- the output
+        // decomposition of the multi-GPU transform (trans_plan.cpp: latitude_bands).  For Atlas this is a user-supplied
+        // grid::Distribution (array of partitions), which StructuredColumns accepts like any other.
+        const int j = int(std::upper_bound(offsets_.begin(), offsets_.end(), g) - offsets_.begin()) - 1;
+        return int((offsets_[j] * cfg_.nparts) / npts_);
+    }
     const int64_t bs        = cfg_.blocksize;
     const int64_t nb_blocks = (npts_ + bs - 1) / bs;
     return int(((g / bs) * cfg_.nparts) / nb_blocks);
@@ -88,7 +95,7 @@ int64_t StructuredColumns::compute_g(int i, int j) const {  // :331-355
 }
 
 StructuredColumns::StructuredColumns(const grid::StructuredGrid& g, const StructuredColumnsConfig& cfg): cfg_(cfg) {
-    if (cfg.halo < 0 || cfg.nparts < 1 || cfg.part < 0 || cfg.part >= cfg.nparts || cfg.blocksize < 1) {
+    if (cfg.halo < 0 || cfg.nparts < 1 || cfg.part < 0 || cfg.part >= cfg.nparts || cfg.blocksize < 0) {
         throw std::invalid_argument("StructuredColumns: bad configuration");
     }
     nx_ = g.nx;

@@ -18,7 +18,7 @@ struct StructuredColumnsConfig {
     bool periodic_points = false;
     int nparts           = 1;
     int part             = 0;
-    int blocksize        = 1;  // bands distribution: 1 = "equal_bands", nx = "regular_bands"
+    int blocksize        = 1;  // bands distribution: 1 = "equal_bands", nx = "regular_bands", 0 = "row_bands" (whole rows)
 };
 
 class StructuredColumns {

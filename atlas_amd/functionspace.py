@@ -39,8 +39,12 @@ class StructuredColumns:
             if not grid.regular():
                 raise ValueError("regular_bands needs a regular grid")   # RegularBandsPartitioner
             bs = grid.nxmax()
+        elif distribution == "row_bands":
+            # whole rows, each with the equal_bands part of its first point: Trans.bands(), the output decomposition of
+            # the multi-GPU transform (for Atlas: a user-supplied grid::Distribution)
+            bs = 0
         else:
-            raise NotImplementedError(f"distribution '{distribution}' (supported: equal_bands, regular_bands)")
+            raise NotImplementedError(f"distribution '{distribution}' (supported: equal_bands, regular_bands, row_bands)")
         self.nparts, self.part = int(nparts), int(part)
         self._h = _lib.check_ptr(SC_new(grid._h, int(halo), int(bool(periodic_points)), self.nparts, self.part, bs))
         self._halo_exchange = None

@@ -220,7 +220,8 @@ int atlas_amd__HaloExchange__synchronize(atlas_amd_HaloExchange* h);
  * functionspace::StructuredColumns (global structured grids, band distributions): halo index construction
  * (src/atlas/functionspace/detail/StructuredColumns_setup.cc:88-663, _create_remote_index.cc:37-255) and the
  * halo-exchange dispatch of atlas__FunctionSpace__halo_exchange_field (FunctionSpaceInterface.h:40-43 ->
- * StructuredColumns.cc:811-911).  blocksize: 1 = "equal_bands", nx = "regular_bands"
+ * StructuredColumns.cc:811-911).  blocksize: 1 = "equal_bands", nx = "regular_bands", 0 = "row_bands" (whole rows, each
+ * with the equal_bands part of its first point: the decomposition atlas_amd__Trans__bands returns)
  * (src/atlas/grid/detail/distribution/BandsDistribution.h:32-34).  Indices are 0-based.
  * ------------------------------------------------------------------------------------------------------------- */
 atlas_amd_StructuredColumns* atlas_amd__StructuredColumns__new(const atlas_amd_Grid* grid, int halo,

@@ -30,6 +30,9 @@ class StructuredColumnsOracle:
         return 0.0 + float(i) * (360.0 / float(self.nx[j]))
 
     def partition(self, g):
+        if self.bs == 0:   # "row_bands": a whole row goes to the equal_bands part of its first point
+            j = int(np.searchsorted(self.offsets, int(g), side="right")) - 1
+            return bands_partition(int(self.offsets[j]), self.npts, self.nparts, 1)
         return bands_partition(int(g), self.npts, self.nparts, self.bs)
 
     def compute_j(self, j):   # :263-287 (not periodic in y)

@@ -62,3 +62,24 @@ def test_identical_to_oracle_lonlat_with_poles():
             orc = StructuredColumnsOracle(g.nx(), g.y(), halo=2, periodic_points=True, nparts=nparts, part=part,
                                           blocksize=bs)
             compare(fs, orc)
+
+
+def test_row_bands_distribution_matches_oracle_and_the_transform_bands():
+    """distribution="row_bands": whole rows, each with the equal_bands part of its first point -- the latitude bands of
+    the multi-GPU transform (atlas_amd/csrc/trans_plan.cpp: latitude_bands)."""
+    g = atlas_amd.Grid("O16")
+    off = np.concatenate([[0], np.cumsum(g.nx())])
+    for nparts in (2, 3, 5):
+        owned = []
+        for part in range(nparts):
+            fs = StructuredColumns(g, halo=2, periodic_points=True, nparts=nparts, part=part, distribution="row_bands")
+            orc = StructuredColumnsOracle(g.nx(), g.y(), halo=2, periodic_points=True, nparts=nparts, part=part,
+                                          blocksize=0)
+            compare(fs, orc)
+            gi = fs.global_index()[:fs.sizeOwned()] - 1
+            rows = np.searchsorted(off, gi, side="right") - 1
+            # whole rows, contiguous, in global order
+            assert np.array_equal(gi, np.arange(off[rows.min()], off[rows.max() + 1]))
+            assert all(((off[j] * nparts) // off[-1]) == part for j in np.unique(rows))
+            owned.append(gi)
+        assert np.array_equal(np.concatenate(owned), np.arange(off[-1]))
