@@ -178,11 +178,17 @@ def main():
         out["roofline"]["kernel"] = dominant["kernel"]
         if world == 1 and not use_dist and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_fields)
-        print(json.dumps(out))
     if use_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL prints its version banner through C stdio, which would
+        # otherwise be flushed after Python's line at exit
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":
