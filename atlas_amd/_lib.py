@@ -71,6 +71,35 @@ Trans_dirtrans_wind2vordiv = _sig("atlas_amd__Trans__dirtrans_wind2vordiv", C.c_
                                   c_void_p, c_void_p)
 Trans_invtrans_adj_scalar = _sig("atlas_amd__Trans__invtrans_adj_scalar", C.c_int, c_void_p, C.c_int, c_void_p,
                                  c_void_p)
+Trans_invtrans_adj = _sig("atlas_amd__Trans__invtrans_adj", C.c_int, c_void_p, C.c_int, c_void_p, C.c_int, c_void_p,
+                          c_void_p, c_void_p)
+Trans_invtrans_vordiv2wind_adj = _sig("atlas_amd__Trans__invtrans_vordiv2wind_adj", C.c_int, c_void_p, C.c_int,
+                                      c_void_p, c_void_p, c_void_p)
+Trans_has_backend = _sig("atlas_amd__Trans__has_backend", C.c_int, C.c_char_p)
+Trans_set_backend = _sig("atlas_amd__Trans__set_backend", C.c_int, C.c_char_p)
+Trans_backend = _sig("atlas_amd__Trans__backend", C.c_int, C.POINTER(c_void_p), C.POINTER(C.c_size_t))
+Trans_grid = _sig("atlas_amd__Trans__grid", c_void_p, c_void_p)
+
+
+class Field(C.Structure):
+    """atlas_amd_Field: host data pointer + C-order shape (what array::make_view sees)"""
+    _fields_ = [("data", c_void_p), ("rank", C.c_int), ("shape", C.c_long * 2)]
+
+
+_FP = C.POINTER(Field)
+Trans_invtrans_field = _sig("atlas_amd__Trans__invtrans_field", C.c_int, c_void_p, _FP, _FP)
+Trans_invtrans_fieldset = _sig("atlas_amd__Trans__invtrans_fieldset", C.c_int, c_void_p, _FP, C.c_int, _FP, C.c_int)
+Trans_invtrans_vordiv2wind_field = _sig("atlas_amd__Trans__invtrans_vordiv2wind_field", C.c_int, c_void_p, _FP, _FP, _FP)
+Trans_invtrans_grad_field = _sig("atlas_amd__Trans__invtrans_grad_field", C.c_int, c_void_p, _FP, _FP)
+Trans_invtrans_adj_field = _sig("atlas_amd__Trans__invtrans_adj_field", C.c_int, c_void_p, _FP, _FP)
+Trans_invtrans_adj_fieldset = _sig("atlas_amd__Trans__invtrans_adj_fieldset", C.c_int, c_void_p, _FP, C.c_int, _FP,
+                                   C.c_int)
+Trans_invtrans_grad_adj_field = _sig("atlas_amd__Trans__invtrans_grad_adj_field", C.c_int, c_void_p, _FP, _FP)
+Trans_invtrans_vordiv2wind_adj_field = _sig("atlas_amd__Trans__invtrans_vordiv2wind_adj_field", C.c_int, c_void_p, _FP,
+                                            _FP, _FP)
+Trans_dirtrans_field = _sig("atlas_amd__Trans__dirtrans_field", C.c_int, c_void_p, _FP, _FP)
+Trans_dirtrans_fieldset = _sig("atlas_amd__Trans__dirtrans_fieldset", C.c_int, c_void_p, _FP, C.c_int, _FP, C.c_int)
+Trans_dirtrans_wind2vordiv_field = _sig("atlas_amd__Trans__dirtrans_wind2vordiv_field", C.c_int, c_void_p, _FP, _FP, _FP)
 Trans_stream = _sig("atlas_amd__Trans__stream", c_void_p, c_void_p)
 Trans_set_stream = _sig("atlas_amd__Trans__set_stream", C.c_int, c_void_p, c_void_p)
 Trans_synchronize = _sig("atlas_amd__Trans__synchronize", C.c_int, c_void_p)

@@ -175,7 +175,7 @@ atlas_amd_Trans* atlas_amd__Trans__new_config(const atlas_amd_Grid* grid, int tr
     }
     cfg.legendre_cache      = legendre_cache;
     cfg.legendre_cache_size = legendre_cache_size;
-    return new atlas_amd_Trans{new trans::Trans(grid->g, truncation, cfg)};
+    return new atlas_amd_Trans{new trans::Trans(grid->g, truncation, cfg), grid};
     AA_CATCH_PTR
 }
 atlas_amd_Trans* atlas_amd__Trans__new(const atlas_amd_Grid* grid, int truncation) {
@@ -242,6 +242,134 @@ int atlas_amd__Trans__dirtrans_wind2vordiv(atlas_amd_Trans*, int, const double[]
 }
 int atlas_amd__Trans__invtrans_adj_scalar(atlas_amd_Trans*, int, const double[], double[]) {
     return not_implemented("invtrans_adj");
+}
+int atlas_amd__Trans__invtrans_adj(atlas_amd_Trans*, int, const double[], int, double[], double[], double[]) {
+    return not_implemented("invtrans_adj");
+}
+int atlas_amd__Trans__invtrans_vordiv2wind_adj(atlas_amd_Trans*, int, const double[], double[], double[]) {
+    return not_implemented("invtrans_vordiv2wind_adj");
+}
+
+// ---- backend registry (Trans.cc:37-48, TransFactory): one implementation under two names
+static std::string& current_backend() {
+    static std::string b = "local";
+    return b;
+}
+int atlas_amd__Trans__has_backend(const char* backend) {
+    return backend && (std::string(backend) == "local" || std::string(backend) == "mi355x");
+}
+int atlas_amd__Trans__set_backend(const char* backend) {
+    AA_TRY
+    if (!atlas_amd__Trans__has_backend(backend)) {   // ATLAS_ASSERT(hasBackend(backend)), Trans.cc:42
+        throw std::invalid_argument(std::string("no trans backend '") + (backend ? backend : "(null)") + "'");
+    }
+    current_backend() = backend;
+    AA_CATCH_INT
+}
+int atlas_amd__Trans__backend(char** backend, size_t* size) {
+    AA_TRY
+    const std::string& s = current_backend();
+    *size                = s.size();
+    *backend             = (char*)std::malloc(s.size() + 1);
+    std::memcpy(*backend, s.c_str(), s.size() + 1);
+    AA_CATCH_INT
+}
+const atlas_amd_Grid* atlas_amd__Trans__grid(const atlas_amd_Trans* t) {
+    return t ? t->grid : nullptr;
+}
+
+// ---- Field / FieldSet overloads (TransLocal.cc:818-897)
+static void require_rank1(const atlas_amd_Field* f, const char* what) {
+    if (!f || !f->data) {
+        throw std::invalid_argument(std::string(what) + ": field is NULL");
+    }
+    if (f->rank != 1) {  // ATLAS_ASSERT(field.rank() == 1, ...), TransLocal.cc:821-822,875-876
+        throw std::invalid_argument(std::string(what) + ": Only rank-1 fields supported at the moment");
+    }
+}
+int atlas_amd__Trans__invtrans_field(atlas_amd_Trans* t, const atlas_amd_Field* spfield, atlas_amd_Field* gpfield) {
+    AA_TRY
+    require_rank1(spfield, "spfield");
+    require_rank1(gpfield, "gpfield");
+    // TransLocal.cc:826-831 only prints debug output when the grid-point field is shorter than the grid; the call
+    // site's spectral size is not checked there either, but reading past the caller's buffer is not an option here
+    if ((size_t)spfield->shape[0] < t->impl->nb_spectral_coefficients() ||
+        gpfield->shape[0] < (long)t->impl->nb_gridpoints_global()) {
+        throw std::invalid_argument("invtrans(Field, Field): field shorter than the spectral / grid size");
+    }
+    t->impl->invtrans(1, spfield->data, gpfield->data);
+    AA_CATCH_INT
+}
+int atlas_amd__Trans__invtrans_fieldset(atlas_amd_Trans* t, const atlas_amd_Field* spfields, int nb_spfields,
+                                        atlas_amd_Field* gpfields, int nb_gpfields) {
+    if (nb_spfields != nb_gpfields) {  // ATLAS_ASSERT(spfields.size() == gpfields.size()), :840
+        atlas_amd::set_last_error("invtrans(FieldSet, FieldSet): spfields.size() != gpfields.size()");
+        return 1;
+    }
+    for (int f = 0; f < nb_spfields; ++f) {
+        const int rc = atlas_amd__Trans__invtrans_field(t, spfields + f, gpfields + f);
+        if (rc) {
+            return rc;
+        }
+    }
+    return 0;
+}
+int atlas_amd__Trans__invtrans_vordiv2wind_field(atlas_amd_Trans* t, const atlas_amd_Field* spvor,
+                                                 const atlas_amd_Field* spdiv, atlas_amd_Field* gpwind) {
+    AA_TRY
+    require_rank1(spvor, "spvor");
+    require_rank1(spdiv, "spdiv");
+    if (!gpwind || !gpwind->data || gpwind->rank != 2) {
+        throw std::invalid_argument("gpwind: rank-2 field expected");
+    }
+    const size_t nspec = t->impl->nb_spectral_coefficients();  // 2 * legendre_size(truncation) * 1, :881
+    if ((size_t)spvor->shape[0] != nspec || (size_t)spdiv->shape[0] != nspec) {
+        throw std::invalid_argument("invtrans_vordiv2wind: spectral field size != 2 * legendre_size(truncation)");
+    }
+    const long npts = (long)t->impl->nb_gridpoints_global();
+    if (gpwind->shape[0] == 2 && gpwind->shape[1] == npts) {
+        t->impl->invtrans(0, nullptr, 1, spvor->data, spdiv->data, gpwind->data);
+    }
+    else if (gpwind->shape[0] == npts && gpwind->shape[1] == 2) {
+        std::vector<double> tmp(size_t(2) * npts);
+        t->impl->invtrans(0, nullptr, 1, spvor->data, spdiv->data, tmp.data());
+        // gp_transpose(grid().size(), 2, gp_tmp, gp_fields), TransLocal.cc:861-867, taken literally
+        for (long jgp = 0; jgp < npts; ++jgp) {
+            for (int jfld = 0; jfld < 2; ++jfld) {
+                gpwind->data[jfld * npts + jgp] = tmp[jgp * 2 + jfld];
+            }
+        }
+    }
+    else {
+        return not_implemented("invtrans_vordiv2wind for this wind field shape");
+    }
+    AA_CATCH_INT
+}
+int atlas_amd__Trans__invtrans_grad_field(atlas_amd_Trans*, const atlas_amd_Field*, atlas_amd_Field*) {
+    return not_implemented("invtrans_grad");
+}
+int atlas_amd__Trans__invtrans_adj_field(atlas_amd_Trans*, const atlas_amd_Field*, atlas_amd_Field*) {
+    return not_implemented("invtrans_adj");
+}
+int atlas_amd__Trans__invtrans_adj_fieldset(atlas_amd_Trans*, const atlas_amd_Field*, int, atlas_amd_Field*, int) {
+    return not_implemented("invtrans_adj");
+}
+int atlas_amd__Trans__invtrans_grad_adj_field(atlas_amd_Trans*, const atlas_amd_Field*, atlas_amd_Field*) {
+    return not_implemented("invtrans_grad_adj");
+}
+int atlas_amd__Trans__invtrans_vordiv2wind_adj_field(atlas_amd_Trans*, const atlas_amd_Field*, atlas_amd_Field*,
+                                                     atlas_amd_Field*) {
+    return not_implemented("invtrans_vordiv2wind_adj");
+}
+int atlas_amd__Trans__dirtrans_field(atlas_amd_Trans*, const atlas_amd_Field*, atlas_amd_Field*) {
+    return not_implemented("dirtrans");
+}
+int atlas_amd__Trans__dirtrans_fieldset(atlas_amd_Trans*, const atlas_amd_Field*, int, atlas_amd_Field*, int) {
+    return not_implemented("dirtrans");
+}
+int atlas_amd__Trans__dirtrans_wind2vordiv_field(atlas_amd_Trans*, const atlas_amd_Field*, atlas_amd_Field*,
+                                                 atlas_amd_Field*) {
+    return not_implemented("dirtrans_wind2vordiv");
 }
 
 void* atlas_amd__Trans__stream(atlas_amd_Trans* t) {

@@ -14,6 +14,7 @@ struct atlas_amd_Grid {
 };
 struct atlas_amd_Trans {
     atlas_amd::trans::Trans* impl;
+    const atlas_amd_Grid* grid = nullptr;  // borrowed: what atlas__Trans__grid returns
 };
 struct atlas_amd_HaloExchange {
     atlas_amd::parallel::HaloExchange impl;

@@ -105,6 +105,67 @@ class Trans:
             return gp
         raise TypeError("invtrans(nb_scalar, sp, gp) or invtrans(nb_scalar, sp, nb_vordiv, vor, div, gp)")
 
+    # ---- Field / FieldSet overloads (TransLocal.cc:818-897): host numpy arrays stand in for atlas::Field ----
+    @staticmethod
+    def _field(a, name, writable=False):
+        if not isinstance(a, np.ndarray) or a.dtype != np.float64 or not a.flags.c_contiguous:
+            raise TypeError(f"{name}: C-contiguous float64 numpy array expected")
+        if writable and not a.flags.writeable:
+            raise TypeError(f"{name}: array is read-only")
+        f = _lib.Field()
+        f.data, f.rank = a.ctypes.data, a.ndim
+        for i in range(min(a.ndim, 2)):
+            f.shape[i] = a.shape[i]
+        return f
+
+    def invtrans_field(self, spfield, gpfield):
+        """invtrans(const Field& spfield, Field& gpfield)                        TransLocal.cc:818-834 (rank-1 only)"""
+        _lib.check(_lib.Trans_invtrans_field(self._h, self._field(spfield, "spfield"),
+                                             self._field(gpfield, "gpfield", True)))
+        return gpfield
+
+    def invtrans_fieldset(self, spfields, gpfields):
+        """invtrans(const FieldSet&, FieldSet&)                                  TransLocal.cc:838-844"""
+        sp = (_lib.Field * max(len(spfields), 1))(*[self._field(a, "spfields[]") for a in spfields])
+        gp = (_lib.Field * max(len(gpfields), 1))(*[self._field(a, "gpfields[]", True) for a in gpfields])
+        _lib.check(_lib.Trans_invtrans_fieldset(self._h, sp, len(spfields), gp, len(gpfields)))
+        return gpfields
+
+    def invtrans_vordiv2wind_field(self, spvor, spdiv, gpwind):
+        """invtrans_vordiv2wind(const Field& spvor, const Field& spdiv, Field& gpwind)   TransLocal.cc:871-897;
+        gpwind of shape (2, npts) or (npts, 2)"""
+        _lib.check(_lib.Trans_invtrans_vordiv2wind_field(self._h, self._field(spvor, "spvor"),
+                                                         self._field(spdiv, "spdiv"),
+                                                         self._field(gpwind, "gpwind", True)))
+        return gpwind
+
+    def invtrans_grad_field(self, spfield, gradfield):
+        _lib.check(_lib.Trans_invtrans_grad_field(self._h, None, None))
+
+    def invtrans_adj_field(self, gpfield, spfield):
+        _lib.check(_lib.Trans_invtrans_adj_field(self._h, None, None))
+
+    def dirtrans_field(self, gpfield, spfield):
+        _lib.check(_lib.Trans_dirtrans_field(self._h, None, None))
+
+    # ---- backend registry (Trans.cc:37-48) ----
+    @staticmethod
+    def hasBackend(name):
+        return bool(_lib.Trans_has_backend(name.encode()))
+
+    @staticmethod
+    def backend(name=None):
+        """Trans.backend() -> current backend name; Trans.backend(name) selects it (asserts hasBackend)"""
+        import ctypes as C
+        if name is not None:
+            _lib.check(_lib.Trans_set_backend(name.encode()))
+            return name
+        p, n = C.c_void_p(), C.c_size_t()
+        _lib.check(_lib.Trans_backend(C.byref(p), C.byref(n)))
+        s = C.string_at(p.value, n.value).decode()
+        C.CDLL(None).free(p)
+        return s
+
     def invtrans_vordiv2wind(self, nb_fields, vorticity_spectra, divergence_spectra, wind_fields):
         """TransLocal.cc:1486-1490 (pointer API)"""
         return self.invtrans(0, None, nb_fields, vorticity_spectra, divergence_spectra, wind_fields)

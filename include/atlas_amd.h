@@ -103,6 +103,50 @@ int atlas_amd__Trans__dirtrans_wind2vordiv(atlas_amd_Trans* t, int nb_fields, co
                                            double vorticity_spectra[], double divergence_spectra[]);
 int atlas_amd__Trans__invtrans_adj_scalar(atlas_amd_Trans* t, int nb_fields, const double gp_fields[],
                                           double scalar_spectra[]);
+/* atlas__Trans__invtrans_adj / __invtrans_vordiv2wind_adj                    TransInterface.h:61-68 (not implemented) */
+int atlas_amd__Trans__invtrans_adj(atlas_amd_Trans* t, int nb_scalar_fields, const double gp_fields[],
+                                   int nb_vordiv_fields, double vorticity_spectra[], double divergence_spectra[],
+                                   double scalar_spectra[]);
+int atlas_amd__Trans__invtrans_vordiv2wind_adj(atlas_amd_Trans* t, int nb_fields, const double wind_fields[],
+                                               double vorticity_spectra[], double divergence_spectra[]);
+
+/* Backend registry of atlas::trans::Trans (TransInterface.h:46-48, Trans.cc:37-48): this library provides the "local"
+ * implementation, also reachable under the name "mi355x".  __backend returns a malloc'ed copy (free with free()). */
+int atlas_amd__Trans__has_backend(const char* backend);
+int atlas_amd__Trans__set_backend(const char* backend);
+int atlas_amd__Trans__backend(char** backend, size_t* size);
+/* atlas__Trans__grid (TransInterface.h:103): the grid the object was built with (borrowed) */
+const atlas_amd_Grid* atlas_amd__Trans__grid(const atlas_amd_Trans* t);
+
+/* Field / FieldSet overloads (TransInterface.h:73-97, TransLocal.cc:818-897).  A field is described by its host data
+ * pointer and C-order shape (what array::make_view sees); only rank-1 fields are supported, as in TransLocal, plus the
+ * rank-2 wind field of invtrans_vordiv2wind_field in either (2, npts) or (npts, 2) shape.  NB the (npts, 2) branch
+ * reproduces TransLocal's gp_transpose call literally (TransLocal.cc:861-867,888-893): out[f*npts + g] = tmp[g*2 + f]
+ * with tmp the (2, npts) result. */
+typedef struct atlas_amd_Field {
+    double* data;
+    int rank;
+    long shape[2];
+} atlas_amd_Field;
+int atlas_amd__Trans__invtrans_field(atlas_amd_Trans* t, const atlas_amd_Field* spfield, atlas_amd_Field* gpfield);
+int atlas_amd__Trans__invtrans_fieldset(atlas_amd_Trans* t, const atlas_amd_Field* spfields, int nb_spfields,
+                                        atlas_amd_Field* gpfields, int nb_gpfields);
+int atlas_amd__Trans__invtrans_vordiv2wind_field(atlas_amd_Trans* t, const atlas_amd_Field* spvor,
+                                                 const atlas_amd_Field* spdiv, atlas_amd_Field* gpwind);
+/* not implemented by TransLocal: error "Not implemented" */
+int atlas_amd__Trans__invtrans_grad_field(atlas_amd_Trans* t, const atlas_amd_Field* spfield, atlas_amd_Field* gradfield);
+int atlas_amd__Trans__invtrans_adj_field(atlas_amd_Trans* t, const atlas_amd_Field* gpfield, atlas_amd_Field* spfield);
+int atlas_amd__Trans__invtrans_adj_fieldset(atlas_amd_Trans* t, const atlas_amd_Field* gpfields, int nb_gpfields,
+                                            atlas_amd_Field* spfields, int nb_spfields);
+int atlas_amd__Trans__invtrans_grad_adj_field(atlas_amd_Trans* t, const atlas_amd_Field* gpfield,
+                                              atlas_amd_Field* spfield);
+int atlas_amd__Trans__invtrans_vordiv2wind_adj_field(atlas_amd_Trans* t, const atlas_amd_Field* gpwind,
+                                                     atlas_amd_Field* spvor, atlas_amd_Field* spdiv);
+int atlas_amd__Trans__dirtrans_field(atlas_amd_Trans* t, const atlas_amd_Field* gpfield, atlas_amd_Field* spfield);
+int atlas_amd__Trans__dirtrans_fieldset(atlas_amd_Trans* t, const atlas_amd_Field* gpfields, int nb_gpfields,
+                                        atlas_amd_Field* spfields, int nb_spfields);
+int atlas_amd__Trans__dirtrans_wind2vordiv_field(atlas_amd_Trans* t, const atlas_amd_Field* gpwind,
+                                                 atlas_amd_Field* spvor, atlas_amd_Field* spdiv);
 
 /* stream control */
 void* atlas_amd__Trans__stream(atlas_amd_Trans* t);              /* hipStream_t */

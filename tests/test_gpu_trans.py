@@ -292,3 +292,44 @@ def test_latitude_band_sharding_reproduces_single_device_result(gridname, T, nf,
         tr.synchronize()
         assert np.array_equal(gp.cpu().numpy().reshape(nf + 2 * nvd, -1), ref_uv[:, lo:hi]), p
     assert total == g.size()
+
+
+def test_field_and_fieldset_overloads_like_translocal():
+    """TransLocal.cc:818-897: rank-1 Field / FieldSet wrappers over the pointer API, and the wind field of
+    invtrans_vordiv2wind in both accepted shapes -- the (npts, 2) branch goes through gp_transpose exactly as written in
+    the reference (out[f*npts + g] = tmp[g*2 + f], tmp = the (2, npts) result)."""
+    from atlas_amd._lib import AtlasAmdError
+    g, tr = get_trans("O32", 31)
+    npts, nspec = g.size(), tr.nb_spectral_coefficients()
+    sp = red_spectra(31, 1, seed=3)
+    want = np.zeros(npts)
+    tr.invtrans(1, sp, want)
+    got = tr.invtrans_field(sp.copy(), np.zeros(npts))
+    assert np.array_equal(got, want)
+    longer = tr.invtrans_field(sp.copy(), np.full(npts + 7, -1.0))     # "hopefully the halo is appended"
+    assert np.array_equal(longer[:npts], want) and np.all(longer[npts:] == -1.0)
+    sps = [red_spectra(31, 1, seed=s) for s in (4, 5, 6)]
+    gps = tr.invtrans_fieldset(sps, [np.zeros(npts) for _ in sps])
+    for s, gp in zip(sps, gps):
+        ref = np.zeros(npts)
+        tr.invtrans(1, s, ref)
+        assert np.array_equal(gp, ref)
+    with pytest.raises(AtlasAmdError):
+        tr.invtrans_fieldset(sps, [np.zeros(npts)])                    # sizes differ
+    with pytest.raises(AtlasAmdError):
+        tr.invtrans_field(np.zeros((nspec, 1)), np.zeros(npts))        # rank-1 only
+    vor, div = red_spectra(31, 1, seed=7), red_spectra(31, 1, seed=8)
+    uv = np.zeros(2 * npts)
+    tr.invtrans_vordiv2wind(1, vor, div, uv)
+    w2n = tr.invtrans_vordiv2wind_field(vor, div, np.zeros((2, npts)))
+    assert np.array_equal(w2n.ravel(), uv)
+    wn2 = tr.invtrans_vordiv2wind_field(vor, div, np.zeros((npts, 2)))
+    lit = np.empty(2 * npts)
+    for f in range(2):                                                  # gp_transpose, TransLocal.cc:861-867
+        lit[f * npts:(f + 1) * npts] = uv[np.arange(npts) * 2 + f]
+    assert np.array_equal(wn2.ravel(), lit)
+    with pytest.raises(NotImplementedError):
+        tr.invtrans_vordiv2wind_field(vor, div, np.zeros((3, npts)))
+    for fn in (tr.invtrans_grad_field, tr.invtrans_adj_field, tr.dirtrans_field):
+        with pytest.raises(NotImplementedError):
+            fn(None, None)

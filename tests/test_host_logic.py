@@ -132,3 +132,18 @@ def test_not_implemented_entry_points_behave_like_translocal():
 def test_no_cpu_fallback():
     with pytest.raises(_lib.AtlasAmdError, match="HIP device"):
         atlas_amd.Trans("O32", 31)
+
+
+def test_backend_registry_like_atlas_trans():
+    """Trans::hasBackend / backend (Trans.cc:37-48, TransInterface.h:46-48): one implementation, names 'local' and 'mi355x'"""
+    from atlas_amd.trans import Trans
+    from atlas_amd._lib import AtlasAmdError
+    assert Trans.hasBackend("local") and Trans.hasBackend("mi355x")
+    assert not Trans.hasBackend("ifs") and not Trans.hasBackend("")
+    assert Trans.backend() == "local"
+    Trans.backend("mi355x")
+    assert Trans.backend() == "mi355x"
+    Trans.backend("local")
+    with pytest.raises(AtlasAmdError):
+        Trans.backend("ifs")          # ATLAS_ASSERT(hasBackend(backend))
+    assert Trans.backend() == "local"
