@@ -177,3 +177,56 @@ class StructuredColumns:
             else:
                 raise TypeError("vector fix-up is implemented for device tensors")
         return field
+
+
+class NodeColumns:
+    """Halo exchange of functionspace::NodeColumns (src/atlas/functionspace/NodeColumns.cc:101-113,357-459).
+
+    Atlas builds it from a Mesh; here the three node arrays the reference hands to HaloExchange::setup are given
+    directly: `partition` = mesh.nodes().partition(), `remote_index` = mesh.nodes().remote_index() (base
+    REMOTE_IDX_BASE), and `nb_nodes` = metadata "nb_nodes_including_halo[halo]" (default: all nodes).  There is no
+    halo_begin: every node is tested for ghost-ness (NodeColumns.cc:110-111)."""
+
+    REMOTE_IDX_BASE = 0   # C++ value; the Fortran interface uses 1
+
+    def __init__(self, partition, remote_index, nb_nodes=None, remote_idx_base=None, comm=None, emulate=None):
+        from .parallel import HaloExchange
+        self.partition = np.ascontiguousarray(partition, dtype=np.int32)
+        self.remote_index = np.ascontiguousarray(remote_index, dtype=np.int32)
+        self.nb_nodes = int(len(self.partition) if nb_nodes is None else nb_nodes)
+        self.base = self.REMOTE_IDX_BASE if remote_idx_base is None else int(remote_idx_base)
+        self._hx = HaloExchange()
+        if emulate is not None:       # (nproc, myproc): single-process multi-rank setups (tests)
+            self._hx.setup_emulated(emulate[0], emulate[1], self.partition, self.remote_index, self.base, self.nb_nodes)
+        else:
+            self._hx.setup(self.partition, self.remote_index, self.base, self.nb_nodes, comm=comm)
+
+    def halo_exchange(self):
+        return self._hx
+
+    @staticmethod
+    def _fieldset(fields):
+        return list(fields) if isinstance(fields, (list, tuple)) else [fields]
+
+    @staticmethod
+    def _check(field):
+        from .parallel import _describe
+        try:
+            _describe(field)
+        except TypeError:
+            raise TypeError("datatype not supported")            # NodeColumns.cc:374,394
+        if not 1 <= len(field.shape) <= 4:
+            raise ValueError("Rank not supported")               # NodeColumns.cc:417,439
+
+    def haloExchange(self, fields, on_device=None):
+        """haloExchange(Field | FieldSet): rank 1..4, int / long / float / double (NodeColumns.cc:357-421,446-450)"""
+        for field in self._fieldset(fields):
+            self._check(field)
+            self._hx.execute(field)
+        return fields
+
+    def adjointHaloExchange(self, fields, on_device=None):
+        for field in self._fieldset(fields):
+            self._check(field)
+            self._hx.execute_adjoint(field)
+        return fields

@@ -169,3 +169,46 @@ def test_adjoint_dot_product_identity_on_device():
     lhs = sum(float((a.cpu().numpy() * b).sum()) for a, b in zip(hx, y))
     rhs = sum(float((a * b.cpu().numpy()).sum()) for a, b in zip(x, hty))
     assert abs(lhs - rhs) < 1e-11 * max(1.0, abs(lhs))
+
+
+def test_nodecolumns_halo_exchange_mirror():
+    """functionspace::NodeColumns::haloExchange (NodeColumns.cc:101-113,357-459): setup from (partition, remote_index,
+    REMOTE_IDX_BASE, nb_nodes) without halo_begin, Field or FieldSet, rank 1..4, the four datatypes; the reference's
+    3-rank fixture must come out as in test_haloexchange.cc."""
+    from atlas_amd.functionspace import NodeColumns
+    n = FIX["nranks"]
+    ncs = [NodeColumns(FIX["part"][r], FIX["ridx"][r], nb_nodes=FIX["nb_nodes"][r], emulate=(n, r)) for r in range(n)]
+    HaloExchange.finish_emulated([nc.halo_exchange() for nc in ncs])
+    case = sorted(FIX["cases"].keys())[0]
+    full, views, pdim = make_fields(case, np.float64)
+    if pdim == 0 and all(v.flags.c_contiguous for v in views):
+        dev = [torch.from_numpy(np.ascontiguousarray(v)).cuda() for v in views]
+        exchange_emulated([nc.halo_exchange() for nc in ncs], dev, 0)
+        for r in range(n):
+            assert dev[r].cpu().numpy().ravel().tolist() == FIX["cases"][case]["expected"][r]
+    # single rank: a periodic ring, node i of the second half is a ghost of node i - m
+    m = 50
+    part = np.zeros(2 * m, dtype=np.int32)
+    ridx = np.concatenate([np.arange(m), np.arange(m)]).astype(np.int32)
+    nc = NodeColumns(part, ridx)
+    for dtype in (torch.int32, torch.int64, torch.float32, torch.float64):
+        for tail in ((), (3,), (2, 3), (2, 3, 4)):
+            f = torch.zeros((2 * m,) + tail, dtype=dtype, device="cuda")
+            f[:m] = (torch.arange(m, device="cuda").reshape((m,) + (1,) * len(tail)) + 1).to(dtype)
+            nc.haloExchange(f)
+            nc.halo_exchange().synchronize()
+            assert torch.equal(f[m:], f[:m])
+    fs = [torch.zeros(2 * m, dtype=torch.float64, device="cuda") for _ in range(2)]
+    for i, f in enumerate(fs):
+        f[:m] = i + 1.0
+    nc.haloExchange(fs)                                            # FieldSet
+    nc.halo_exchange().synchronize()
+    assert all(torch.equal(f[m:], f[:m]) for f in fs)
+    with pytest.raises(TypeError, match="datatype not supported"):
+        nc.haloExchange(torch.zeros(2 * m, dtype=torch.float16, device="cuda"))
+    with pytest.raises(ValueError, match="Rank not supported"):
+        nc.haloExchange(torch.zeros((2 * m, 1, 1, 1, 1), dtype=torch.float64, device="cuda"))
+    a = torch.ones(2 * m, dtype=torch.float64, device="cuda")
+    nc.adjointHaloExchange(a)                                      # owned += ghost contribution, ghosts zeroed
+    nc.halo_exchange().synchronize()
+    assert torch.equal(a[:m], torch.full((m,), 2.0, device="cuda", dtype=torch.float64)) and float(a[m:].abs().sum()) == 0.0
