@@ -100,6 +100,10 @@ Trans_invtrans_vordiv2wind_adj_field = _sig("atlas_amd__Trans__invtrans_vordiv2w
 Trans_dirtrans_field = _sig("atlas_amd__Trans__dirtrans_field", C.c_int, c_void_p, _FP, _FP)
 Trans_dirtrans_fieldset = _sig("atlas_amd__Trans__dirtrans_fieldset", C.c_int, c_void_p, _FP, C.c_int, _FP, C.c_int)
 Trans_dirtrans_wind2vordiv_field = _sig("atlas_amd__Trans__dirtrans_wind2vordiv_field", C.c_int, c_void_p, _FP, _FP, _FP)
+VorDivToUV_execute = _sig("atlas_amd__VorDivToUV__execute", C.c_int, C.c_int, C.c_int, C.c_int, c_void_p, c_void_p,
+                          c_void_p, c_void_p)
+VorDivToUV_execute_device = _sig("atlas_amd__VorDivToUV__execute_device", C.c_int, C.c_int, C.c_int, C.c_int, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p)
 Trans_stream = _sig("atlas_amd__Trans__stream", c_void_p, c_void_p)
 Trans_set_stream = _sig("atlas_amd__Trans__set_stream", C.c_int, c_void_p, c_void_p)
 Trans_synchronize = _sig("atlas_amd__Trans__synchronize", C.c_int, c_void_p)

@@ -68,6 +68,13 @@ static std::map<std::string, std::string> parse_config(const char* cfg) {
     return kv;
 }
 
+namespace atlas_amd {
+namespace trans {
+hipError_t launch_vd2uv(const double* vor, const double* div, double* U, double* V, int T, int nf, hipStream_t stream);
+}  // namespace trans
+}  // namespace atlas_amd
+
+
 extern "C" {
 
 const char* atlas_amd__last_error(void) {
@@ -370,6 +377,57 @@ int atlas_amd__Trans__dirtrans_fieldset(atlas_amd_Trans*, const atlas_amd_Field*
 int atlas_amd__Trans__dirtrans_wind2vordiv_field(atlas_amd_Trans*, const atlas_amd_Field*, atlas_amd_Field*,
                                                  atlas_amd_Field*) {
     return not_implemented("dirtrans_wind2vordiv");
+}
+
+// ---- VorDivToUV::execute (VorDivToUVLocal.cc:187-189)
+static void vd2uv_check(int truncation, int nb_coeff, int nb_fields) {
+    if (truncation < 0 || nb_fields < 0) {
+        throw std::invalid_argument("VorDivToUV: negative truncation / field count");
+    }
+    if (nb_coeff != (truncation + 1) * (truncation + 2)) {
+        throw std::invalid_argument("VorDivToUV: nb_coeff != (truncation+1)*(truncation+2)");
+    }
+}
+int atlas_amd__VorDivToUV__execute_device(int truncation, int nb_coeff, int nb_fields, const double* vor,
+                                          const double* div, double* U, double* V, void* stream) {
+    AA_TRY
+    vd2uv_check(truncation, nb_coeff, nb_fields);
+    if (nb_fields > 0) {
+        hipError_t e = trans::launch_vd2uv(vor, div, U, V, truncation, nb_fields, (hipStream_t)stream);
+        if (e != hipSuccess) {
+            throw std::runtime_error(std::string("vd2uv launch: ") + hipGetErrorString(e));
+        }
+    }
+    AA_CATCH_INT
+}
+int atlas_amd__VorDivToUV__execute(int truncation, int nb_coeff, int nb_fields, const double vor[], const double div[],
+                                   double U[], double V[]) {
+    AA_TRY
+    vd2uv_check(truncation, nb_coeff, nb_fields);
+    const size_t n = size_t(nb_coeff) * size_t(nb_fields);
+    if (n == 0) {
+        return 0;
+    }
+    double* d = nullptr;
+    auto ck   = [](hipError_t e) {
+        if (e != hipSuccess) {
+            throw std::runtime_error(std::string("VorDivToUV: ") + hipGetErrorString(e));
+        }
+    };
+    ck(hipMalloc((void**)&d, 4 * n * sizeof(double)));
+    try {
+        ck(hipMemcpy(d, vor, n * sizeof(double), hipMemcpyHostToDevice));
+        ck(hipMemcpy(d + n, div, n * sizeof(double), hipMemcpyHostToDevice));
+        ck(trans::launch_vd2uv(d, d + n, d + 2 * n, d + 3 * n, truncation, nb_fields, nullptr));
+        ck(hipMemcpy(U, d + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost));
+        ck(hipMemcpy(V, d + 3 * n, n * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    catch (...) {
+        (void)hipFree(d);
+        throw;
+    }
+    (void)hipFree(d);
+    AA_CATCH_INT
 }
 
 void* atlas_amd__Trans__stream(atlas_amd_Trans* t) {

@@ -13,6 +13,8 @@
 // (m = 0: real parts only, no chi terms; imaginary parts are 0), vor/div taken as 0 outside m <= n <= T.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "device_structs.h"
 
 namespace atlas_amd {
@@ -93,6 +95,62 @@ __global__ void __launch_bounds__(256) spectra_prepare_kernel(PrepareParams p) {
         }
         p.out[obase + e] = v;
     }
+}
+
+// ---- stand-alone VorDivToUV::execute (VorDivToUV.h:36-133, VorDivToUVLocal.cc:62-189): U, V in the layout and with the
+// truncation of the inputs; wavenumbers above the truncation count as zero (the reference pads its work arrays)
+struct Vd2uvParams {
+    const double* vor;
+    const double* div;
+    double* U;
+    double* V;
+    int T;
+    int nf;
+};
+
+__global__ void __launch_bounds__(256) vd2uv_kernel(Vd2uvParams p) {
+    const int m   = blockIdx.y;
+    const int T   = p.T;
+    const int len = (T - m + 1) * 2 * p.nf;
+    const long long base = (long long)(2 * T + 3 - m) * m / 2 * 2;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < len; e += gridDim.x * blockDim.x) {
+        const int f    = e % p.nf;
+        const int rest = e / p.nf;
+        const int imag = rest & 1;
+        const int n    = m + (rest >> 1);
+        auto get = [&](const double* a, int nn, int im) -> double {
+            if (nn < m || nn > T) {
+                return 0.;
+            }
+            return a[(base + 2 * (nn - m) + im) * p.nf + f];
+        };
+        const double chi  = m * dev_lap(n);
+        const double psiM = (n - 1) * dev_eps(m, n) * dev_lap(n - 1);
+        const double psiP = (n + 2) * dev_eps(m, n + 1) * dev_lap(n + 1);
+        double u, v;
+        if (m == 0) {
+            u = imag ? 0. : (psiM * get(p.vor, n - 1, 0) - psiP * get(p.vor, n + 1, 0));
+            v = imag ? 0. : -(psiM * get(p.div, n - 1, 0) - psiP * get(p.div, n + 1, 0));
+        }
+        else if (imag == 0) {
+            u = -chi * get(p.div, n, 1) + (psiM * get(p.vor, n - 1, 0) - psiP * get(p.vor, n + 1, 0));
+            v = -chi * get(p.vor, n, 1) - (psiM * get(p.div, n - 1, 0) - psiP * get(p.div, n + 1, 0));
+        }
+        else {
+            u = +chi * get(p.div, n, 0) + (psiM * get(p.vor, n - 1, 1) - psiP * get(p.vor, n + 1, 1));
+            v = +chi * get(p.vor, n, 0) - (psiM * get(p.div, n - 1, 1) - psiP * get(p.div, n + 1, 1));
+        }
+        const long long o = (base + 2 * (n - m) + imag) * p.nf + f;
+        p.U[o]            = u * (1. / kEarthRadius);
+        p.V[o]            = v * (1. / kEarthRadius);
+    }
+}
+
+hipError_t launch_vd2uv(const double* vor, const double* div, double* U, double* V, int T, int nf, hipStream_t stream) {
+    Vd2uvParams p{vor, div, U, V, T, nf};
+    dim3 grid(std::min(64, ((T + 1) * 2 * nf + 255) / 256), T + 1);
+    hipLaunchKernelGGL(vd2uv_kernel, grid, dim3(256), 0, stream, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_spectra_prepare(const double* vor, const double* div, const double* sp, double* out, int T, int nvd,

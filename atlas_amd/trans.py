@@ -245,3 +245,30 @@ class Trans:
         bases = (C.c_void_p * n)(*[_ptr(p) for p in parts])
         cnts = (C.c_int * n)(*[int(c) for c in part_cnt])
         _lib.check(_lib.Trans_fourier_device(self._h, nf, nb_vordiv, bases, cnts, _ptr(gp)))
+
+
+class VorDivToUV:
+    """atlas::trans::VorDivToUV (src/atlas/trans/VorDivToUV.h:36-133, "local": VorDivToUVLocal.cc:62-189)"""
+
+    def __init__(self, truncation, type="local"):
+        if type not in ("local", "mi355x"):
+            raise ValueError(f"no VorDivToUV backend '{type}'")
+        self._truncation = int(truncation)
+
+    def truncation(self):
+        return self._truncation
+
+    def execute(self, nb_coeff, nb_fields, vorticity, divergence, U, V):
+        """U, V = u cos(lat), v cos(lat) spectra; arrays of nb_coeff * nb_fields doubles in the invtrans layout"""
+        n = int(nb_coeff) * int(nb_fields)
+        dev = _is_device(U)
+        ptrs = [_ptr(a, n, name, writable=w) for a, name, w in ((vorticity, "vorticity", False),
+                                                                (divergence, "divergence", False),
+                                                                (U, "U", True), (V, "V", True))]
+        if dev:
+            import torch
+            stream = torch.cuda.current_stream().cuda_stream
+            _lib.check(_lib.VorDivToUV_execute_device(self._truncation, int(nb_coeff), int(nb_fields), *ptrs, stream))
+        else:
+            _lib.check(_lib.VorDivToUV_execute(self._truncation, int(nb_coeff), int(nb_fields), *ptrs))
+        return U, V

@@ -148,6 +148,16 @@ int atlas_amd__Trans__dirtrans_fieldset(atlas_amd_Trans* t, const atlas_amd_Fiel
 int atlas_amd__Trans__dirtrans_wind2vordiv_field(atlas_amd_Trans* t, const atlas_amd_Field* gpwind,
                                                  atlas_amd_Field* spvor, atlas_amd_Field* spdiv);
 
+/* VorDivToUV (the sibling factory TransLocal uses, src/atlas/trans/VorDivToUV.h:36-133; "local" implementation
+ * VorDivToUVLocal.cc:62-189): spectral vorticity / divergence -> spectral U = u cos(lat), V = v cos(lat), all four arrays in
+ * the spectral layout of invtrans with `nb_fields` fields and truncation `truncation`; nb_coeff must be
+ * (truncation+1)*(truncation+2).  Host pointers; the _device variant takes device pointers and is asynchronous on
+ * `hip_stream` (NULL: the default stream). */
+int atlas_amd__VorDivToUV__execute(int truncation, int nb_coeff, int nb_fields, const double vorticity[],
+                                   const double divergence[], double U[], double V[]);
+int atlas_amd__VorDivToUV__execute_device(int truncation, int nb_coeff, int nb_fields, const double* vorticity,
+                                          const double* divergence, double* U, double* V, void* hip_stream);
+
 /* stream control */
 void* atlas_amd__Trans__stream(atlas_amd_Trans* t);              /* hipStream_t */
 int atlas_amd__Trans__set_stream(atlas_amd_Trans* t, void* hip_stream);

@@ -185,3 +185,13 @@ class OraclePlan:
             res.append(out[off:off + nf * n].reshape(nf, n))
             off += nf * n
         return res
+
+
+def vd2uv(trc, nf, vor, div):
+    """VorDivToUVLocal.cc:62-184: (U, V) spectra, layout and truncation of the inputs"""
+    vor = np.ascontiguousarray(vor, dtype=np.float64)
+    div = np.ascontiguousarray(div, dtype=np.float64)
+    U = np.zeros_like(vor)
+    V = np.zeros_like(vor)
+    lib().orc_vd2uv(int(trc), int(nf), vor.ctypes.data, div.ctypes.data, U.ctypes.data, V.ctypes.data)
+    return U, V

@@ -333,3 +333,23 @@ def test_field_and_fieldset_overloads_like_translocal():
     for fn in (tr.invtrans_grad_field, tr.invtrans_adj_field, tr.dirtrans_field):
         with pytest.raises(NotImplementedError):
             fn(None, None)
+
+
+@pytest.mark.parametrize("T,nf", [(31, 3), (63, 1), (159, 5)])
+def test_vordivtouv_execute_against_oracle(T, nf):
+    """VorDivToUV::execute (VorDivToUVLocal.cc:62-189), host and device pointers; tolerance 1e-14 relative to max |U|
+    (the oracle tabulates eps/lap as the reference does, the kernel evaluates them per element)."""
+    vor, div = red_spectra(T, nf, seed=31), red_spectra(T, nf, seed=32)
+    Uo, Vo = oracle.vd2uv(T, nf, vor, div)
+    vd = atlas_amd.VorDivToUV(T)
+    ncoef = (T + 1) * (T + 2)
+    U, V = vd.execute(ncoef, nf, vor, div, np.zeros_like(vor), np.zeros_like(vor))
+    for got, want in ((U, Uo), (V, Vo)):
+        assert np.abs(got - want).max() <= 1e-14 * np.abs(want).max()
+    Ud, Vd = vd.execute(ncoef, nf, dev(vor), dev(div), torch.zeros(vor.size, dtype=torch.float64, device="cuda"),
+                        torch.zeros(vor.size, dtype=torch.float64, device="cuda"))
+    torch.cuda.synchronize()
+    assert np.array_equal(Ud.cpu().numpy(), U) and np.array_equal(Vd.cpu().numpy(), V)
+    from atlas_amd._lib import AtlasAmdError
+    with pytest.raises(AtlasAmdError):
+        vd.execute(ncoef - 2, nf, vor, div, U, V)
