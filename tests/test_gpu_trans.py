@@ -167,6 +167,13 @@ def test_legendre_cache_round_trip():
     assert np.array_equal(run_device(tr, nf, sp), run_device(tr2, nf, sp))
     with pytest.raises(_lib.AtlasAmdError):
         atlas_amd.Trans(g, T, legendre_cache=blob[:-8])
+    # LegendreCacheCreator::create() / create(path) (LegendreCacheCreatorLocal.cc:150-160)
+    creator = atlas_amd.LegendreCacheCreator(g, T)
+    assert creator.supported() and creator.create().tobytes() == blob.tobytes()
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as d:
+        path = creator.create(os.path.join(d, creator.uid() + ".leg"))
+        assert np.fromfile(path, dtype=np.uint8).tobytes() == blob.tobytes()
 
 
 def test_regular_lonlat_grid_with_poles_and_equator():

@@ -147,3 +147,26 @@ def test_backend_registry_like_atlas_trans():
     with pytest.raises(AtlasAmdError):
         Trans.backend("ifs")          # ATLAS_ASSERT(hasBackend(backend))
     assert Trans.backend() == "local"
+
+
+def test_legendre_cache_creator_uid_pinned_by_reference_goldens():
+    """LegendreCacheCreatorLocal::uid (LegendreCacheCreatorLocal.cc:66-136).  Its two hash helpers are the ones of the
+    "ifs" creator (ifs/LegendreCacheCreatorIFS.cc:39-74), whose expected uids the reference test lists
+    (src/tests/trans/test_trans.cc:600-696): "-OPT4189816c2e" for flt=false, and "grid-800ac12540 / 0915e0f040 /
+    7c400822f0" for F320 / F640 / F1280 cropped to latitudes [-20, 20], "grid-7824deccdf / 7d1771559e" for L90 / L900.
+    Reproducing them also pins the Gaussian latitudes of those rows to 1e-8 degrees."""
+    from atlas_amd.trans import LegendreCacheCreator, legendre_cache_grid_hash, _md5_10
+    assert _md5_10(b"flt" + b"\x00") == "4189816c2e"
+    for N, want in ((320, "800ac12540"), (640, "0915e0f040"), (1280, "7c400822f0")):
+        y = np.array(atlas_amd.gaussian_latitudes(N))
+        assert legendre_cache_grid_hash(y[(y >= -20) & (y <= 20)]) == want, N
+    for n, want in ((90, "7824deccdf"), (900, "7d1771559e")):          # L<n>: ny = 2n+1 rows from 90 to -90
+        y = 90.0 - np.arange(2 * n + 1) * (90.0 / n)
+        assert legendre_cache_grid_hash(y[(y >= -20 - 1e-9) & (y <= 20 + 1e-9)]) == want, n
+    assert LegendreCacheCreator("O1280", 1279).uid() == "local-T1279-GaussianN1280-OPT4189816c2e"
+    assert LegendreCacheCreator("F64", 63).uid() == "local-T63-GaussianN64-OPT4189816c2e"
+    g = atlas_amd.StructuredGrid(nx=[72] * 37, y=90.0 - 5.0 * np.arange(37))
+    assert LegendreCacheCreator(g, 20).uid() == "local-T20-L-ny37-OPT4189816c2e"
+    g = atlas_amd.StructuredGrid(nx=[72] * 36, y=87.5 - 5.0 * np.arange(36))
+    assert LegendreCacheCreator(g, 20).uid() == "local-T20-S-ny36-OPT4189816c2e"
+    assert LegendreCacheCreator("O32", 31).estimate() == 31 ** 3 // 2 * 8
