@@ -852,6 +852,134 @@ AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCt& r, const Reade
     }
 }
 
+// ======================================================================================================
+// Compile-time specialised DIRECT rows: h = n/2 = M = F * 2^K itself is a length of the specialised family (regular
+// Gaussian / lon-lat grids: every row; reduced grids: their smooth rows).  One inverse DIT, NS phases:
+//   phase 0      : load + c2r pre-processing fused with the first DIT stage (the last radix of the DIF list, L = RL, no
+//                  twiddles).  Worker b' loads the modes k = b' + q * (M / RL), q < RL (coalesced over b'); they are the
+//                  frequencies held by positions b * RL + q of butterfly b, b = digit reversal of b'.
+//   phases 1..   : DIT stages NS-2 .. 1 in LDS
+//   last phase   : DIT stage 0 fused with the store of y[2k], y[2k+1], k = b + q * Ls0 (coalesced over b)
+template <class S>
+AA_HD constexpr int row_num_phases_dct() {
+    return S::NS;
+}
+
+// the stage list of S reversed: for the direct rows the load is fused with the LAST radix of the list and the store
+// with the first, and it is the load phase that is short of registers (3 loads per element in flight), so the small
+// composite radix goes there: [16, 16, R0]
+template <class S>
+struct CtShapeRev {
+    static constexpr int F  = S::F;
+    static constexpr int K  = S::K;
+    static constexpr int M  = S::M;
+    static constexpr int NS = S::NS;
+    static constexpr int radix(int i) { return S::radix(NS - 1 - i); }
+    static constexpr int L(int i) {
+        int l = M;
+        for (int q = 0; q < i; ++q) l /= radix(q);
+        return l;
+    }
+    static constexpr int lsh(int i) {
+        int ls = L(i) / radix(i), s = 0;
+        while ((1 << s) < ls) ++s;
+        return (1 << s) == ls ? s : -1;
+    }
+};
+
+// butterfly index of the first DIT stage whose positions b*RL + q hold the frequencies b' + q * M/RL
+template <class S0>
+AA_HD int dct_first_butterfly(int bp) {
+    using S = CtShapeRev<S0>;
+    int b = 0;
+#pragma unroll
+    for (int i = 0; i < S::NS - 1; ++i) {   // b' = sum_i d_i * (R_0 ... R_{i-1});  b = sum_i d_i * (R_{i+1} ... R_{NS-2})
+        const int d = bp % S::radix(i);
+        bp /= S::radix(i);
+        int w = 1;
+#pragma unroll
+        for (int j = i + 1; j < S::NS - 1; ++j) w *= S::radix(j);
+        b += d * w;
+    }
+    return b;
+}
+
+template <class S0, class Reader>
+AA_HD void row_phase_dct(int ph, int t, int nt, const RowTablesCt& r, const Reader& rd, const RowOut& io,
+                         cplx* work) {
+    using S           = CtShapeRev<S0>;
+    constexpr int M   = S::M;
+    constexpr int NS  = S::NS;
+    constexpr int R0  = S::radix(0);
+    constexpr int Ls0 = M / R0;
+    constexpr int RL  = S::radix(NS - 1);
+    constexpr int nbl = M / RL;
+    const int h       = r.h;  // == M
+    if (ph == 0) {
+        constexpr int NB = RL >= 16 ? 2 : (RL % 4 == 0 ? 4 : (RL % 5 == 0 ? 5 : (RL % 3 == 0 ? 3 : (RL % 2 == 0 ? 2 : 1))));
+        for (int bp = t; bp < nbl; bp += nt) {
+            cplx x[RL];
+#pragma unroll
+            for (int q0 = 0; q0 < RL; q0 += NB) {
+                cplx A[NB], B[NB], P[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int k = bp + (q0 + i) * nbl;
+                    A[i]        = rd(row_mode_index(io.mmax, k));
+                    B[i]        = rd(row_mode_index(io.mmax, h - k));
+                    P[i]        = r.pre[k];
+                }
+                AA_SCHED_FENCE();
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int k  = bp + (q0 + i) * nbl;
+                    const cplx a = row_mode_mask(A[i], io.mmax, k, h);
+                    const cplx c = cconj(row_mode_mask(B[i], io.mmax, h - k, h));
+                    x[q0 + i]    = c2r_pre(a, c, P[i]);
+                }
+            }
+            bfly<RL>(x, +1);
+            const int b = dct_first_butterfly<S0>(bp);
+#pragma unroll
+            for (int q = 0; q < RL; ++q) work[PAD(b * RL + q)] = x[q];
+        }
+        return;
+    }
+    if (ph < NS - 1) {  // DIT stages NS-2 .. 1
+        const int i = NS - 1 - ph;
+        ct_stage_dispatch<S, 1>(i, [&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            if constexpr (I >= 1 && I <= NS - 2) {
+                dit_stage<S::radix(I)>(work, M, S::L(I), S::lsh(I), r.tw, +1, t, nt);
+            }
+        });
+        return;
+    }
+    // ---- DIT stage 0 + store
+    for (int b = t; b < Ls0; b += nt) {
+        const cplx w1 = r.tw[b];
+        cplx x[R0];
+#pragma unroll
+        for (int q = 0; q < R0; ++q) x[q] = work[PAD(b + q * Ls0)];
+        twiddle_apply<R0>(x, w1);
+        bfly<R0>(x, +1);
+        if (io.aligned16) {
+#pragma unroll
+            for (int q = 0; q < R0; ++q) {
+                const cplx z = cplx{x[q].re * io.scale, x[q].im * io.scale};
+                *reinterpret_cast<cplx*>(io.y + 2 * (int64_t)(b + q * Ls0)) = z;
+            }
+        }
+        else {
+#pragma unroll
+            for (int q = 0; q < R0; ++q) {
+                io.y[2 * (int64_t)(b + q * Ls0)]     = x[q].re * io.scale;
+                io.y[2 * (int64_t)(b + q * Ls0) + 1] = x[q].im * io.scale;
+            }
+        }
+    }
+}
+
 // the (F, K) instances that exist (kernel and host emulation use the same list)
 AA_HD constexpr bool ct_supported(int f, int k) {
     return (f == 1 && k >= 8 && k <= 13) || (f == 3 && k >= 7 && k <= 11) || (f == 5 && k >= 6 && k <= 10);

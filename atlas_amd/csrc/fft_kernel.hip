@@ -156,6 +156,13 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR) fft_rows_kernel(FourierParams p)
 }
 
 // ---- compile-time specialised Bluestein rows (fft_core.h: row_phase_ct) -------------------------------------------
+template <int NPH, int PH, class Fn>
+__device__ __forceinline__ void for_each_phase_n(Fn&& fn) {
+    if constexpr (PH < NPH) {
+        fn(std::integral_constant<int, PH>{});
+        for_each_phase_n<NPH, PH + 1>(fn);
+    }
+}
 template <class S, int PH, class Fn>
 __device__ __forceinline__ void for_each_phase(Fn&& fn) {
     if constexpr (PH < fft::row_num_phases_ct<S>()) {
@@ -225,6 +232,68 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR, 3) fft_rows_ct_kernel(FourierPar
     });
 }
 
+// ---- compile-time specialised direct rows (fft_core.h: row_phase_dct): regular grids, smooth rows of reduced grids
+template <class S>
+__global__ void __launch_bounds__(FFT_MAX_NTHR, 3) fft_rows_dct_kernel(FourierParams p) {
+    extern __shared__ double lds_raw[];
+    cplx* work = reinterpret_cast<cplx*>(lds_raw);
+    int row, f;
+    if (!fft_block_to_job(p, blockIdx.x, row, f)) {
+        return;
+    }
+    const fft::FftRowPlan* pl = p.plans + p.row_plan[row];
+    const long long goff      = (long long)f * p.npts + (p.rowoff[row] - p.rowoff[p.lat0]);
+    const int tid             = threadIdx.x;
+    const int nt              = blockDim.x;
+    const double scale        = (f < p.scale_uv_fields) ? p.coslatinv[row] : 1.0;
+    const int mmax            = p.row_mmax[row];
+    const ModeReader rd{p, (long long)(row - p.lat0), 2 * f};
+    fft::RowTablesCt r;
+#if defined(AA_FFT_ABLATE)
+    r.abl    = p.abl;
+#endif
+    r.n      = pl->n;
+    r.h      = pl->h;
+    r.tw     = p.table + pl->off_tw;
+    r.pre    = p.table + pl->off_pre;
+    r.chirp  = nullptr;
+    r.bhat_t = nullptr;
+    fft::RowOut io;
+    io.mmax      = mmax < r.h ? mmax : r.h;
+    io.y         = p.gp + goff;
+    io.aligned16 = ((goff & 1) == 0);
+    io.scale     = scale;
+    constexpr int NPH = fft::row_num_phases_dct<S>();
+    unsigned long long tprev = 0;
+    const bool prof = p.prof != nullptr && tid == 0;
+    if (prof) {
+        tprev = clock64();
+    }
+    // compile-time recursion over the phases: `#pragma unroll` gives up on the largest shapes ("unrolled size is too
+    // large") and would leave a run-time loop around a switch
+    for_each_phase_n<NPH, 0>([&](auto phc) {
+        constexpr int ph = decltype(phc)::value;
+        fft::row_phase_dct<S>(ph, tid, nt, r, rd, io, work);
+        if constexpr (ph < NPH - 1) {
+            if constexpr (false) {
+                // producer and consumer lanes of the next phase are in this wavefront: LDS executes a wavefront's
+                // instructions in order, only the compiler must not move accesses across this point
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            else {
+                __syncthreads();
+            }
+        }
+        if (prof) {
+            const unsigned long long tn = clock64();
+            atomicAdd(&p.prof[32 + ph], tn - tprev);
+            tprev = tn;
+        }
+    });
+}
+
 template <class S>
 static hipError_t launch_ct(const FourierParams& p, int lds_bytes, int nthreads, unsigned nblk, hipStream_t stream) {
     static int max_set = 0;
@@ -255,6 +324,30 @@ hipError_t launch_fourier_ct(const FourierParams& p, int ctf, int ctk, int lds_b
     const long long units = (long long)p.nrows * ngr;
     const unsigned nblk   = (unsigned)((units + 7) / 8 * 64);
     AA_CT_DISPATCH(ctf, ctk, return launch_ct<S>(p, lds_bytes, nthreads, nblk, stream))
+    return hipErrorInvalidValue;
+}
+
+template <class S>
+static hipError_t launch_dct(const FourierParams& p, int lds_bytes, int nthreads, unsigned nblk, hipStream_t stream) {
+    static int max_set = 0;
+    if (lds_bytes > max_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_dct_kernel<S>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) {
+            return e;
+        }
+        max_set = lds_bytes;
+    }
+    hipLaunchKernelGGL(fft_rows_dct_kernel<S>, dim3(nblk), dim3(nthreads), lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_fourier_dct(const FourierParams& p, int ctf, int ctk, int lds_bytes, int nthreads,
+                              hipStream_t stream) {
+    const int ngr         = (p.f_end - p.f_begin + FGROUP - 1) / FGROUP;
+    const long long units = (long long)p.nrows * ngr;
+    const unsigned nblk   = (unsigned)((units + 7) / 8 * 64);
+    AA_CT_DISPATCH(ctf, ctk, return launch_dct<S>(p, lds_bytes, nthreads, nblk, stream))
     return hipErrorInvalidValue;
 }
 

@@ -186,7 +186,19 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, bool specialised_
         p.h         = h;
         if (is_smooth235(h)) {
             p.method = FFT_DIRECT;
-            p.shape  = make_shape(h);
+            // h itself a length of the specialised family?  (regular grids: every row)
+            if (specialised_shapes) {
+                for (int f : {1, 3, 5}) {
+                    if (h % f == 0) {
+                        const int k = ilog2_exact(h / f);
+                        if (k >= 0 && ct_supported(f, k)) {
+                            p.ct_f = f;
+                            p.ct_k = k;
+                        }
+                    }
+                }
+            }
+            p.shape = p.ct_k >= 0 ? make_ct_shape(p.ct_f, p.ct_k) : make_shape(h);
         }
         else {
             p.method     = FFT_BLUESTEIN;
@@ -284,6 +296,28 @@ void host_execute_row(const FftPlanSet& ps, int plan, const cplx* X, int mmax, d
     io.scale     = 1.0;
     auto rd      = [X](int m) { return X[m]; };
     std::vector<cplx> work(p.lds_complex);
+    if (use_specialised && p.method == FFT_DIRECT && p.ct_k >= 0) {
+        RowTablesCt rc;
+        rc.n      = p.n;
+        rc.h      = p.h;
+        rc.tw     = r.tw;
+        rc.pre    = r.pre;
+        rc.chirp  = nullptr;
+        rc.bhat_t = nullptr;
+        const int ctf = p.ct_f, ctk = p.ct_k;
+        bool done = false;
+        AA_CT_DISPATCH(ctf, ctk, {
+            for (int ph = 0; ph < row_num_phases_dct<S>(); ++ph) {
+                for (int t = 0; t < nthreads; ++t) {
+                    row_phase_dct<S>(ph, t, nthreads, rc, rd, io, work.data());
+                }
+            }
+            done = true;
+        })
+        if (done) {
+            return;
+        }
+    }
     if (use_specialised && p.method == FFT_BLUESTEIN && p.ct_k >= 0) {
         RowTablesCt rc;
         rc.n      = p.n;

@@ -145,6 +145,7 @@ private:
         int lds_bytes;
         int nthreads;
         int ct_f, ct_k;  // specialised kernel instance, or ct_k < 0
+        bool direct;     // specialised instance is the direct (no Bluestein) kernel
         int nrows;
         int* d_rows;
     };

@@ -20,6 +20,8 @@ void legendre_tiling(int nf, int& rtw, int& nrg, int& nchunks);
 hipError_t launch_fourier(const FourierParams& p, int lds_bytes, int nthreads, hipStream_t stream);
 hipError_t launch_fourier_ct(const FourierParams& p, int ctf, int ctk, int lds_bytes, int nthreads,
                              hipStream_t stream);
+hipError_t launch_fourier_dct(const FourierParams& p, int ctf, int ctk, int lds_bytes, int nthreads,
+                              hipStream_t stream);
 hipError_t launch_spectra_prepare(const double* vor, const double* div, const double* sp, double* out, int T, int nvd,
                                   int ns, hipStream_t stream);
 
@@ -206,6 +208,10 @@ void Trans::upload() {
             by_class[{1, pl.shape.M}].push_back(j);
             continue;
         }
+        if (pl.method == fft::FFT_DIRECT && pl.ct_k >= 0) {
+            by_class[{2, pl.shape.M}].push_back(j);  // specialised direct rows
+            continue;
+        }
         int cls = -1;
         for (int c : class_M) {
             if (pl.lds_complex <= fft::padded_size(c)) {
@@ -230,7 +236,8 @@ void Trans::upload() {
         c.nthreads  = std::min(512, std::max(64, (M / ntdiv + 63) / 64 * 64));
         c.nrows     = (int)it->second.size();
         c.ct_f = c.ct_k = -1;
-        if (it->first.first == 1) {
+        c.direct = it->first.first == 2;
+        if (it->first.first >= 1) {
             const fft::FftRowPlan& pl = fftplans_.plans[row_plan[it->second[0]]];
             c.ct_f                    = pl.ct_f;
             c.ct_k                    = pl.ct_k;
@@ -386,7 +393,12 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
             st = stream3_;
         }
         if (c.ct_k >= 0 && use_ct_) {
-            HIP_CHECK(launch_fourier_ct(p, c.ct_f, c.ct_k, c.lds_bytes, c.nthreads, st));
+            if (c.direct) {
+                HIP_CHECK(launch_fourier_dct(p, c.ct_f, c.ct_k, c.lds_bytes, c.nthreads, st));
+            }
+            else {
+                HIP_CHECK(launch_fourier_ct(p, c.ct_f, c.ct_k, c.lds_bytes, c.nthreads, st));
+            }
         }
         else {
             HIP_CHECK(launch_fourier(p, c.lds_bytes, c.nthreads, st));

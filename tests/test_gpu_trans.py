@@ -51,6 +51,8 @@ def get_trans(gridname, T):
     ("O48", 95, 5),      # linear truncation branch (T >= ndgl-1)
     ("O80", 100, 4),     # quadratic branch
     ("O160", 159, 60),   # BASELINE config C2
+    ("F320", 319, 3),    # regular Gaussian grid, h = 640 = 5*2^7: specialised direct (no Bluestein) kernel
+    ("F256", 255, 2),    # h = 512 = 2^9
 ])
 def test_invtrans_parity_with_oracle(gridname, T, nf):
     g, tr = get_trans(gridname, T)
@@ -208,7 +210,7 @@ def test_full_size_sampled_rows_against_oracle(trans_full):
     T, nf = 1279, 137
     sp = red_spectra(T, nf)
     gp = run_device(tr, nf, sp).reshape(nf, -1)
-    rows = [0, 1, 639, 1279, 1280, 2000, 2559]
+    rows = [0, 1, 639, 1275, 1279, 1280, 2000, 2559]   # 1275: n = 5120, h = 2560 -> specialised direct kernel
     op = oracle.OraclePlan(T, g.nx(), g.y(), with_tables=False)
     off = np.concatenate([[0], np.cumsum(g.nx())])
     for r, ref in zip(rows, op.invtrans_rows(nf, sp, rows, use_fft=True)):
@@ -360,3 +362,18 @@ def test_vordivtouv_execute_against_oracle(T, nf):
     from atlas_amd._lib import AtlasAmdError
     with pytest.raises(AtlasAmdError):
         vd.execute(ncoef - 2, nf, vor, div, U, V)
+
+
+def test_regular_gaussian_full_size_sampled_rows():
+    """BASELINE config C5's grid in fp64: TL1279 -> F1280 (every row n = 5120, h = 2560 = 5*2^9: specialised direct
+    kernel), sampled rows against the oracle."""
+    g = atlas_amd.Grid("F1280")
+    tr = atlas_amd.Trans(g, 1279)
+    T, nf = 1279, 6
+    sp = red_spectra(T, nf, seed=17)
+    gp = run_device(tr, nf, sp).reshape(nf, -1)
+    rows = [0, 7, 1279, 1280, 2559]
+    op = oracle.OraclePlan(T, g.nx(), g.y(), with_tables=False)
+    off = np.concatenate([[0], np.cumsum(g.nx())])
+    for r, ref in zip(rows, op.invtrans_rows(nf, sp, rows, use_fft=True)):
+        assert compute_rms(gp[:, off[r]:off[r + 1]], ref) < 1e-12, r

@@ -100,7 +100,9 @@ def test_legendre_cache_is_grid_independent():
 
 
 ROW_LENGTHS = [20, 24, 28, 32, 36, 44, 52, 60, 64, 68, 76, 100, 128, 148, 192, 256, 260, 300, 404, 500, 1004, 1280,
-               2048, 2560, 4 * 1283, 5120, 5136, 21, 35, 45]
+               2048, 2560, 4 * 1283, 5120, 5136, 21, 35, 45,
+               # h = n/2 in the specialised family F*2^K: the direct (no Bluestein) specialised phases
+               512, 640, 768, 1536, 3072, 6144, 8192, 10240]
 
 
 @pytest.mark.parametrize("n", ROW_LENGTHS)

@@ -1,0 +1,25 @@
+"""Dev tool (GPU box): stage times for an arbitrary (grid, truncation, levels): python tools/bench_grid.py F1280 1279 137"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch, atlas_amd
+from helpers import red_spectra
+grid, T, nf = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+g = atlas_amd.Grid(grid)
+t0 = time.time()
+tr = atlas_amd.Trans(g, T, profile=True)
+print(f"{grid} T{T} nf={nf}: setup {time.time() - t0:.1f} s, npts {g.size()}", flush=True)
+tr.use_torch_stream()
+sp = torch.from_numpy(red_spectra(T, nf)).cuda()
+gp = torch.zeros(nf * g.size(), dtype=torch.float64, device="cuda")
+for _ in range(2):
+    tr.invtrans(nf, sp, gp)
+torch.cuda.synchronize()
+tr.timings(reset=True)
+t0 = time.perf_counter()
+for _ in range(5):
+    tr.invtrans(nf, sp, gp)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 5 * 1e3
+tm = tr.timings()
+print(f"{dt:.2f} ms/transform  legendre {tm['legendre_ms']/tm['legendre_calls']:.2f} ms  fourier {tm['fourier_ms']/tm['fourier_calls']:.2f} ms")
