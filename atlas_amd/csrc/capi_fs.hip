@@ -84,6 +84,27 @@ atlas_amd_StructuredColumns* atlas_amd__StructuredColumns__new(const atlas_amd_G
         return nullptr;
     }
 }
+atlas_amd_StructuredColumns* atlas_amd__StructuredColumns__new_distribution(const atlas_amd_Grid* grid, int halo,
+                                                                            int periodic_points, int nparts, int part,
+                                                                            const int* partition, long long npts) {
+    try {
+        if (!grid || !partition) {
+            throw std::invalid_argument("grid / partition is NULL");
+        }
+        StructuredColumnsConfig c;
+        c.halo            = halo;
+        c.periodic_points = periodic_points != 0;
+        c.nparts          = nparts;
+        c.part            = part;
+        c.blocksize       = 1;
+        c.distribution.assign(partition, partition + npts);
+        return new atlas_amd_StructuredColumns(grid->g, c);
+    }
+    catch (const std::exception& e) {
+        atlas_amd::set_last_error(e.what());
+        return nullptr;
+    }
+}
 void atlas_amd__StructuredColumns__delete(atlas_amd_StructuredColumns* fs) {
     delete fs;
 }

@@ -11,6 +11,9 @@ namespace atlas_amd {
 namespace functionspace {
 
 int StructuredColumns::partition_of(int64_t g) const {
+    if (!cfg_.distribution.empty()) {
+        return cfg_.distribution[(size_t)g];  // distribution.partition(c), StructuredColumns_setup.cc:141
+    }
     // part(g) = ((g / blocksize) * nparts) / nb_blocks   (BandsDistribution.h:32-34)
     if (cfg_.blocksize == 0) {
         // "row_bands": whole latitude rows, a row belongs to the equal_bands part of its FIRST point -- the output
@@ -106,6 +109,16 @@ StructuredColumns::StructuredColumns(const grid::StructuredGrid& g, const Struct
         offsets_[j + 1] = offsets_[j] + nx_[j];
     }
     npts_ = offsets_[ny_];
+    if (!cfg.distribution.empty()) {
+        if ((int64_t)cfg.distribution.size() != npts_) {
+            throw std::invalid_argument("StructuredColumns: distribution must hold one partition per grid point");
+        }
+        for (int p : cfg.distribution) {
+            if (p < 0 || p >= cfg.nparts) {
+                throw std::invalid_argument("StructuredColumns: distribution entry outside [0, nparts)");
+            }
+        }
+    }
     if (npts_ > std::numeric_limits<int>::max()) {
         throw std::invalid_argument("StructuredColumns: grid too large for 32-bit local indices");
     }
@@ -248,6 +261,35 @@ StructuredColumns::StructuredColumns(const grid::StructuredGrid& g, const Struct
         ij_table_[row_start_[r] + (pi[n] - row_imin_[r])] = n;
     }
 
+    // ---- owner-side numbering for explicit distributions: every part stores its owned points row by row over its
+    // [i_begin, i_end) range (StructuredColumns_setup.cc:591-616), so the index of global point (i, j) on its owner p
+    // is row_start[p][j] + (i - i_begin[p][j]).  (The reference obtains it by asking the owner,
+    // StructuredColumns_create_remote_index.cc:37-255; every part holds the whole distribution, so it is computed here.)
+    std::vector<int> dist_ibeg, dist_rowstart;
+    if (!cfg.distribution.empty() && cfg.nparts > 1) {
+        const size_t np = (size_t)cfg.nparts;
+        std::vector<int> iend(np * ny_, std::numeric_limits<int>::min());
+        dist_ibeg.assign(np * ny_, BIG);
+        dist_rowstart.assign(np * ny_, 0);
+        int64_t c = 0;
+        for (int j = 0; j < ny_; ++j) {
+            for (int i = 0; i < nx_[j]; ++i, ++c) {
+                const size_t o = (size_t)cfg.distribution[(size_t)c] * ny_ + j;
+                dist_ibeg[o]   = std::min(dist_ibeg[o], i);
+                iend[o]        = std::max(iend[o], i + 1);
+            }
+        }
+        for (size_t p = 0; p < np; ++p) {
+            int acc = 0;
+            for (int j = 0; j < ny_; ++j) {
+                dist_rowstart[p * ny_ + j] = acc;
+                if (iend[p * ny_ + j] > dist_ibeg[p * ny_ + j]) {
+                    acc += iend[p * ny_ + j] - dist_ibeg[p * ny_ + j];
+                }
+            }
+        }
+    }
+
     // ---- fields (:583-662)
     partition_.assign(size_halo_, 0);
     ghost_.assign(size_halo_, 0);
@@ -277,7 +319,18 @@ StructuredColumns::StructuredColumns(const grid::StructuredGrid& g, const Struct
         // remote index (StructuredColumns_create_remote_index.cc): own index for owned points; for halo points the
         // index of the global point in its owner's owned ordering.  A band owns a contiguous global-index range whose
         // points are stored in global order, hence  remote = g - first_global_index(owner)  without communication.
-        remote_idx_[n] = n < owned ? n : int(glb_idx_[n] - 1 - first_of_part_[partition_[n]]);
+        if (n < owned) {
+            remote_idx_[n] = n;
+        }
+        else if (!dist_ibeg.empty()) {
+            const int64_t g0 = glb_idx_[n] - 1;
+            const int jj     = int(std::upper_bound(offsets_.begin(), offsets_.end(), g0) - offsets_.begin()) - 1;
+            const size_t o   = (size_t)partition_[n] * ny_ + jj;
+            remote_idx_[n]   = dist_rowstart[o] + (int(g0 - offsets_[jj]) - dist_ibeg[o]);
+        }
+        else {
+            remote_idx_[n] = int(glb_idx_[n] - 1 - first_of_part_[partition_[n]]);
+        }
     }
 }
 

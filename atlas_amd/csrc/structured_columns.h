@@ -19,6 +19,10 @@ struct StructuredColumnsConfig {
     int nparts           = 1;
     int part             = 0;
     int blocksize        = 1;  // bands distribution: 1 = "equal_bands", nx = "regular_bands", 0 = "row_bands" (whole rows)
+    // explicit grid::Distribution (partition of every grid point in global order), as Atlas hands one over for its
+    // other partitioners (equal_regions, checkerboard, ...); empty: the bands rule above.  As in the reference, the
+    // points a part owns in a row must form one contiguous i-range (StructuredColumns_setup.cc:125-226)
+    std::vector<int> distribution;
 };
 
 class StructuredColumns {

@@ -11,6 +11,8 @@ from .parallel import HaloExchange, _describe
 c_void_p, c_int = C.c_void_p, C.c_int
 _sig = _lib._sig
 SC_new = _sig("atlas_amd__StructuredColumns__new", c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int)
+SC_new_distribution = _sig("atlas_amd__StructuredColumns__new_distribution", c_void_p, c_void_p, c_int, c_int, c_int,
+                           c_int, c_void_p, C.c_longlong)
 SC_delete = _sig("atlas_amd__StructuredColumns__delete", None, c_void_p)
 SC_size_owned = _sig("atlas_amd__StructuredColumns__size_owned", c_int, c_void_p)
 SC_size_halo = _sig("atlas_amd__StructuredColumns__size_halo", c_int, c_void_p)
@@ -33,6 +35,15 @@ class StructuredColumns:
         if isinstance(grid, str):
             grid = StructuredGrid(name=grid)
         self.grid = grid
+        if not isinstance(distribution, str):
+            # explicit grid::Distribution: partition of every grid point in global order (equal_regions, checkerboard,
+            # ... computed by the caller, as Atlas does before it constructs the function space)
+            dist = np.ascontiguousarray(distribution, dtype=np.int32)
+            self.nparts, self.part = int(nparts), int(part)
+            self._h = _lib.check_ptr(SC_new_distribution(grid._h, int(halo), int(bool(periodic_points)), self.nparts,
+                                                         self.part, dist.ctypes.data, dist.size))
+            self._halo_exchange = None
+            return
         if distribution == "equal_bands":
             bs = 1
         elif distribution == "regular_bands":

@@ -281,6 +281,12 @@ int atlas_amd__HaloExchange__synchronize(atlas_amd_HaloExchange* h);
 atlas_amd_StructuredColumns* atlas_amd__StructuredColumns__new(const atlas_amd_Grid* grid, int halo,
                                                                int periodic_points, int nparts, int part,
                                                                int blocksize);
+/* the same for an explicit grid::Distribution: partition[g] of every grid point g in global order (what Atlas's
+ * equal_regions / checkerboard / ... partitioners produce; StructuredColumns_setup.cc:141 distribution.partition(c)).
+ * As in the reference the points a part owns in one row must be one contiguous i-range. */
+atlas_amd_StructuredColumns* atlas_amd__StructuredColumns__new_distribution(const atlas_amd_Grid* grid, int halo,
+                                                                            int periodic_points, int nparts, int part,
+                                                                            const int* partition, long long npts);
 void atlas_amd__StructuredColumns__delete(atlas_amd_StructuredColumns* fs);
 int atlas_amd__StructuredColumns__size_owned(const atlas_amd_StructuredColumns* fs);
 int atlas_amd__StructuredColumns__size_halo(const atlas_amd_StructuredColumns* fs);

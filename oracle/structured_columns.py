@@ -16,7 +16,8 @@ def bands_partition(g, npts, nparts, blocksize=1):
 
 
 class StructuredColumnsOracle:
-    def __init__(self, nx, y, halo=0, periodic_points=False, nparts=1, part=0, blocksize=1):
+    def __init__(self, nx, y, halo=0, periodic_points=False, nparts=1, part=0, blocksize=1, distribution=None):
+        self.distribution = None if distribution is None else np.asarray(distribution, dtype=np.int64)
         self.nx = [int(v) for v in nx]
         self.y = [float(v) for v in y]
         self.ny = len(self.nx)
@@ -30,6 +31,8 @@ class StructuredColumnsOracle:
         return 0.0 + float(i) * (360.0 / float(self.nx[j]))
 
     def partition(self, g):
+        if self.distribution is not None:   # distribution.partition(c), StructuredColumns_setup.cc:141
+            return int(self.distribution[int(g)])
         if self.bs == 0:   # "row_bands": a whole row goes to the equal_bands part of its first point
             j = int(np.searchsorted(self.offsets, int(g), side="right")) - 1
             return bands_partition(int(self.offsets[j]), self.npts, self.nparts, 1)
@@ -188,6 +191,22 @@ class StructuredColumnsOracle:
         for p in range(self.nparts):
             first[p] = next(g for g in range(self.npts) if self.partition(g) == p) if self.nparts > 1 else 0
         self.remote_idx = np.zeros(n, dtype=np.int32)
+        if self.distribution is not None and self.nparts > 1:
+            # general distribution: replay every owner's own numbering (owned points row by row over its
+            # [i_begin, i_end) range, setup.cc:591-616) -- what the reference learns by asking the owner
+            local = {}
+            for p in range(self.nparts):
+                cnt = 0
+                for j in range(self.ny):
+                    row = self.distribution[self.offsets[j]:self.offsets[j + 1]]
+                    idx = np.nonzero(row == p)[0]
+                    if idx.size:
+                        for i in range(int(idx.min()), int(idx.max()) + 1):
+                            local[(p, int(self.offsets[j]) + i)] = cnt
+                            cnt += 1
+            for r in range(n):
+                self.remote_idx[r] = r if r < owned else local[(int(self.partition_f[r]), int(self.glb_idx[r]) - 1)]
+            return
         for r in range(n):
             self.remote_idx[r] = r if r < owned else int(self.glb_idx[r]) - 1 - first[int(self.partition_f[r])]
 

@@ -75,3 +75,24 @@ def test_vector_fields_flip_sign_beyond_the_poles():
     want[pole, :, 0] *= -1
     want[pole, :, 1] *= -1            # XX and YY only; further components untouched
     assert np.array_equal(got, want)
+
+
+def test_equal_regions_like_distribution_emulated():
+    """explicit grid::Distribution (latitude bands cut into longitude sectors, as equal_regions produces): after the halo
+    exchange every node of every part holds its global index (device pack/unpack, device copies for the transport)."""
+    from test_host_structuredcolumns import sector_distribution
+    g = atlas_amd.Grid("O16")
+    ny = g.ny()
+    dist, nparts = sector_distribution(g, [(0, 5), (5, 14), (14, 21), (21, 27), (27, ny)], [1, 3, 4, 3, 1])
+    fss = [StructuredColumns(g, halo=2, periodic_points=True, nparts=nparts, part=p, distribution=dist)
+           for p in range(nparts)]
+    hxs = [f.begin_halo_exchange() for f in fss]
+    HaloExchange.finish_emulated(hxs)
+    fields = []
+    for f in fss:
+        a = np.where(f.ghost() == 0, f.global_index(), -1).astype(np.int64)
+        fields.append(torch.from_numpy(np.repeat(a[:, None], 3, axis=1).copy()).cuda())
+    exchange_emulated(hxs, fields)
+    for f, a in zip(fss, fields):
+        assert np.array_equal(a.cpu().numpy()[:, 0], f.global_index())
+        assert np.array_equal(a.cpu().numpy()[:, 2], f.global_index())

@@ -83,3 +83,40 @@ def test_row_bands_distribution_matches_oracle_and_the_transform_bands():
             assert all(((off[j] * nparts) // off[-1]) == part for j in np.unique(rows))
             owned.append(gi)
         assert np.array_equal(np.concatenate(owned), np.arange(off[-1]))
+
+
+def sector_distribution(g, bands, sectors):
+    """equal-regions-like distribution: latitude bands (row ranges), band b cut into sectors[b] longitude sectors"""
+    nx, part, p0 = g.nx(), [], 0
+    for (j0, j1), ns in zip(bands, sectors):
+        for j in range(j0, j1):
+            part.append(p0 + (np.arange(nx[j]) * ns) // nx[j])
+        p0 += ns
+    return np.concatenate(part).astype(np.int32), p0
+
+
+def test_explicit_distribution_matches_oracle():
+    """an explicit grid::Distribution, shaped like equal_regions output (polar caps + collars of several sectors):
+    every index array of every part equals the oracle's, and the parts tile the grid."""
+    g = atlas_amd.Grid("O16")
+    ny = g.ny()
+    dist, nparts = sector_distribution(g, [(0, 5), (5, 14), (14, 21), (21, 27), (27, ny)], [1, 3, 4, 3, 1])
+    seen = []
+    for part in range(nparts):
+        fs = StructuredColumns(g, halo=2, periodic_points=True, nparts=nparts, part=part, distribution=dist)
+        orc = StructuredColumnsOracle(g.nx(), g.y(), halo=2, periodic_points=True, nparts=nparts, part=part,
+                                      distribution=dist)
+        compare(fs, orc)
+        gi = fs.global_index()[:fs.sizeOwned()] - 1
+        assert np.all(dist[gi] == part)
+        seen.append(gi)
+    assert np.array_equal(np.sort(np.concatenate(seen)), np.arange(g.size()))
+    # remote index really is the owner's local index of the same global point (what the reference learns from the owner)
+    fss = [StructuredColumns(g, halo=2, periodic_points=True, nparts=nparts, part=p, distribution=dist)
+           for p in range(nparts)]
+    for fs in fss:
+        part, ridx, gi = fs.partition(), fs.remote_index(), fs.global_index()
+        for n in range(fs.sizeOwned(), fs.sizeHalo()):
+            assert fss[part[n]].global_index()[ridx[n]] == gi[n]
+    with pytest.raises(Exception):
+        StructuredColumns(g, halo=1, nparts=nparts, part=0, distribution=dist[:-1])
