@@ -164,6 +164,14 @@ atlas_amd_Trans* atlas_amd__Trans__new_config(const atlas_amd_Grid* grid, int tr
         else if (kv.first == "part") {
             cfg.part = std::stoi(kv.second);
         }
+        else if (kv.first == "rows") {  // "j0:j1": zonal-band crop
+            const size_t colon = kv.second.find(':');
+            if (colon == std::string::npos) {
+                throw std::invalid_argument("rows must be 'j0:j1'");
+            }
+            cfg.row_begin = std::stoi(kv.second.substr(0, colon));
+            cfg.row_end   = std::stoi(kv.second.substr(colon + 1));
+        }
         else if (kv.first == "shard") {
             if (kv.second != "m" && kv.second != "band") {
                 throw std::invalid_argument("shard must be 'm' (wavenumbers, exchange follows) or 'band' (latitude bands)");

@@ -33,6 +33,8 @@ struct TransConfig {
     size_t legendre_cache_size = 0;
     int nparts                 = 1;  // m-sharding / latitude-band decomposition
     int part                   = 0;
+    int row_begin = 0, row_end = 0;        // row_end > row_begin: transform only these latitude rows (a zonal-band
+                                           // crop of the global grid, TransLocal.cc:394-470 "nested" case)
     bool by_band               = false;  // nparts > 1: false = wavenumber sharding (all-to-all transposition follows),
                                          // true = latitude-band sharding of both stages (no exchange, 2x Legendre work)
 };

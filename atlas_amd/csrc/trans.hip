@@ -65,10 +65,20 @@ Trans::Trans(const grid::StructuredGrid& grid, int truncation, const TransConfig
     if (const char* e = std::getenv("ATLAS_AMD_FFT_GENERIC")) {
         use_ct_ = !(e[0] == '1');
     }
-    work_ = make_legendre_work(geo_, cfg.nparts, cfg.part, cfg.by_band);
-    bands_ = latitude_bands(geo_, cfg.nparts);
+    if (cfg.row_end > cfg.row_begin) {
+        // zonal-band crop: the machinery of the latitude-band decomposition with one explicit band
+        if (cfg.nparts != 1 || cfg.row_begin < 0 || cfg.row_end > geo_.nlats) {
+            throw std::invalid_argument("Trans: rows=j0:j1 needs nparts == 1 and 0 <= j0 < j1 <= ny");
+        }
+        cfg_.by_band = true;
+        bands_       = {cfg.row_begin, cfg.row_end};
+    }
+    else {
+        bands_ = latitude_bands(geo_, cfg.nparts);
+    }
+    work_ = make_legendre_work(geo_, cfg.nparts, cfg.part, cfg_.by_band, cfg.row_begin, cfg.row_end);
     m_cnt_ = 0;
-    for (int m = cfg.by_band ? 0 : cfg.part; m <= geo_.T; m += cfg.by_band ? 1 : cfg.nparts) {
+    for (int m = cfg_.by_band ? 0 : cfg.part; m <= geo_.T; m += cfg_.by_band ? 1 : cfg.nparts) {
         m_cnt_++;
     }
     std::vector<int> lengths;
@@ -500,7 +510,7 @@ void Trans::invtrans(int nb_scalar_fields, const double scalar_spectra[], double
         throw std::logic_error("host invtrans needs nparts == 1");
     }
     const size_t nsp = nb_spectral_coefficients() * (size_t)nb_scalar_fields;
-    const size_t ngp = (size_t)geo_.npts * (size_t)nb_scalar_fields;
+    const size_t ngp = (size_t)nb_gridpoints() * (size_t)nb_scalar_fields;  // all points, or the rows of a crop
     ensure(d_sp_, sp_cap_, nsp);
     ensure(d_gp_, gp_cap_, ngp);
     HIP_CHECK(hipMemcpyAsync(d_sp_, scalar_spectra, nsp * sizeof(double), hipMemcpyHostToDevice, stream_));
@@ -572,7 +582,7 @@ void Trans::invtrans(int nb_scalar, const double sp[], int nb_vordiv, const doub
     const size_t ncoef = nb_spectral_coefficients();
     const size_t nvd   = ncoef * (size_t)nb_vordiv;
     const size_t nsp   = ncoef * (size_t)nb_scalar;
-    const size_t ngp   = (size_t)geo_.npts * (size_t)(2 * nb_vordiv + nb_scalar);
+    const size_t ngp   = (size_t)nb_gridpoints() * (size_t)(2 * nb_vordiv + nb_scalar);
     ensure(d_vd_, vd_cap_, 2 * nvd);
     ensure(d_sp_, sp_cap_, std::max<size_t>(nsp, 1));
     ensure(d_gp_, gp_cap_, ngp);

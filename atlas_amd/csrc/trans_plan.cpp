@@ -159,7 +159,8 @@ double legendre_flops(const TransGeometry& geo, int nf) {
     return f;
 }
 
-LegendreWork make_legendre_work(const TransGeometry& geo, int nparts, int part, bool by_band) {
+LegendreWork make_legendre_work(const TransGeometry& geo, int nparts, int part, bool by_band, int row_begin,
+                                int row_end) {
     LegendreWork w;
     const int T = geo.T;
     w.first_item_of_m.assign(T + 2, 0);
@@ -167,9 +168,15 @@ LegendreWork make_legendre_work(const TransGeometry& geo, int nparts, int part, 
     // latitude lies in its own latitude band [b0, b1) (no hemisphere sharing between devices, no exchange)
     int b0 = 0, b1 = geo.nlats;
     if (by_band) {
-        const std::vector<int> bands = latitude_bands(geo, nparts);
-        b0                           = bands[part];
-        b1                           = bands[part + 1];
+        if (row_end > row_begin) {  // explicit row range (zonal-band crop of the grid)
+            b0 = row_begin;
+            b1 = row_end;
+        }
+        else {
+            const std::vector<int> bands = latitude_bands(geo, nparts);
+            b0                           = bands[part];
+            b1                           = bands[part + 1];
+        }
     }
     auto row_needed = [&](int jn) { return (jn >= b0 && jn < b1) || (geo.nlats - 1 - jn >= b0 && geo.nlats - 1 - jn < b1); };
     int64_t off = 0;

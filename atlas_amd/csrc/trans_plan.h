@@ -71,7 +71,8 @@ struct LegendreWork {
 };
 
 // nparts/part: m-sharding for the multi-GPU decomposition -- only wavenumbers m with m % nparts == part get items
-LegendreWork make_legendre_work(const TransGeometry& geo, int nparts = 1, int part = 0, bool by_band = false);
+LegendreWork make_legendre_work(const TransGeometry& geo, int nparts = 1, int part = 0, bool by_band = false,
+                                int row_begin = 0, int row_end = 0);
 // whole-row latitude bands balanced by grid points: row j goes to the band that Atlas's BandsDistribution rule
 // part(g) = ((g / blocksize) * nparts) / nb_blocks  (src/atlas/grid/detail/distribution/BandsDistribution.h:32-34,
 // blocksize 1 == equal_bands) assigns to the row's FIRST point.  Returns nparts+1 row boundaries.

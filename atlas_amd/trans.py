@@ -39,19 +39,22 @@ def _ptr(a, n=None, name="array", writable=False):
 class Trans:
     """trans::Trans(grid, truncation, config) with option::type("local") semantics, running on an MI355X."""
 
-    def __init__(self, grid, truncation, profile=False, nparts=1, part=0, legendre_cache=None, shard="m"):
+    def __init__(self, grid, truncation, profile=False, nparts=1, part=0, legendre_cache=None, shard="m", rows=None):
         if isinstance(grid, str):
             grid = StructuredGrid(name=grid)
         self.grid = grid
         # shard (nparts > 1): "m" = this device owns wavenumbers m % nparts == part (stage API + exchange),
         #                      "band" = it owns latitude band `part` of both stages (plain invtrans on device arrays)
         cfg = f"profile={int(bool(profile))};nparts={int(nparts)};part={int(part)};shard={shard}"
+        if rows is not None:   # (j0, j1): zonal-band crop of the grid (regional domain that keeps whole latitude rows)
+            cfg += f";rows={int(rows[0])}:{int(rows[1])}"
         cache_ptr, cache_size = None, 0
         if legendre_cache is not None:
             self._cache = np.ascontiguousarray(np.frombuffer(legendre_cache, dtype=np.uint8))
             cache_ptr, cache_size = self._cache.ctypes.data, self._cache.size
         self._h = _lib.check_ptr(_lib.Trans_new_config(grid._h, int(truncation), cfg.encode(), cache_ptr, cache_size))
         self.nparts, self.part, self.shard = int(nparts), int(part), shard
+        self.rows = rows
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -80,7 +83,7 @@ class Trans:
         """invtrans(nb_scalar, sp, gp)                                    TransLocal.cc:931-934
            invtrans(nb_scalar, sp, nb_vordiv, vor, div, gp)               TransLocal.cc:1523-1597"""
         ncoef = self.nb_spectral_coefficients()
-        npts = self.nb_gridpoints() if self.nparts > 1 else self.nb_gridpoints_global()
+        npts = self.nb_gridpoints() if (self.nparts > 1 or self.rows is not None) else self.nb_gridpoints_global()
         if len(args) == 1:
             (gp,) = args
             nf = int(nb_scalar_fields)

@@ -68,6 +68,9 @@ atlas_amd_Trans* atlas_amd__Trans__new(const atlas_amd_Grid* grid, int truncatio
  *   shard=m|band         m (default): Legendre stage on the owned wavenumbers, Fourier stage on the owned band; the
  *                        caller transposes in between (stage API below).  band: both stages on the owned latitude
  *                        band, no exchange: the *_device invtrans entry points then return the band's grid points
+ *   rows=j0:j1           zonal-band crop: transform only latitude rows j0..j1-1 of the (global) grid -- the nested
+ *                        regional case of TransLocal (TransLocal.cc:394-470) for domains that keep whole rows;
+ *                        nb_gridpoints and the output arrays then cover these rows only
  *   type=local|mi355x    accepted for atlas option::type compatibility
  * legendre_cache / size: optional Legendre cache blob in TransLocal's file layout (TransLocal.cc:608-614), or NULL */
 atlas_amd_Trans* atlas_amd__Trans__new_config(const atlas_amd_Grid* grid, int truncation, const char* config,

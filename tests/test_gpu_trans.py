@@ -377,3 +377,33 @@ def test_regular_gaussian_full_size_sampled_rows():
     off = np.concatenate([[0], np.cumsum(g.nx())])
     for r, ref in zip(rows, op.invtrans_rows(nf, sp, rows, use_fft=True)):
         assert compute_rms(gp[:, off[r]:off[r + 1]], ref) < 1e-12, r
+
+
+@pytest.mark.parametrize("gridname,T,nf,rows", [("O64", 63, 4, (10, 40)), ("F32", 31, 3, (0, 9)), ("O160", 159, 7, (200, 320)),
+                                                ("O64", 63, 2, (60, 70))])
+def test_zonal_band_crop_equals_rows_of_the_global_transform(gridname, T, nf, rows):
+    """rows=(j0, j1): the nested regional case of TransLocal for domains that keep whole latitude rows
+    (TransLocal.cc:394-470): the result is rows j0..j1-1 of the global transform, bit for bit, on the scalar and the
+    vor/div path and through the host-pointer API."""
+    g, tr1 = get_trans(gridname, T)
+    sp = red_spectra(T, nf, seed=41)
+    ref = run_device(tr1, nf, sp).reshape(nf, -1)
+    off = np.concatenate([[0], np.cumsum(g.nx())])
+    lo, hi = off[rows[0]], off[rows[1]]
+    tr = atlas_amd.Trans(g, T, rows=rows)
+    assert tr.nb_gridpoints() == hi - lo and list(tr.bands()) == list(rows)
+    gp = torch.full((nf * (hi - lo),), np.nan, dtype=torch.float64, device="cuda")
+    tr.invtrans(nf, dev(sp), gp)
+    tr.synchronize()
+    assert np.array_equal(gp.cpu().numpy().reshape(nf, -1), ref[:, lo:hi])
+    host = np.full(nf * (hi - lo), np.nan)
+    tr.invtrans(nf, sp, host)
+    assert np.array_equal(host.reshape(nf, -1), ref[:, lo:hi])
+    vor, div = red_spectra(T, 1, seed=42), red_spectra(T, 1, seed=43)
+    full = np.zeros((nf + 2) * g.size())
+    tr1.invtrans(nf, sp, 1, vor, div, full)
+    part = np.full((nf + 2) * (hi - lo), np.nan)
+    tr.invtrans(nf, sp, 1, vor, div, part)
+    assert np.array_equal(part.reshape(nf + 2, -1), full.reshape(nf + 2, -1)[:, lo:hi])
+    with pytest.raises(_lib.AtlasAmdError):
+        atlas_amd.Trans(g, T, rows=(5, g.ny() + 1))
