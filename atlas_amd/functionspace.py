@@ -35,6 +35,10 @@ class StructuredColumns:
         if isinstance(grid, str):
             grid = StructuredGrid(name=grid)
         self.grid = grid
+        if isinstance(distribution, str) and distribution == "equal_regions":
+            # Atlas's default partitioner for structured grids (EqualRegionsPartitioner.cc), mirrored in partitioner.py
+            from .partitioner import EqualRegionsPartitioner
+            distribution = EqualRegionsPartitioner(int(nparts)).partition(grid)
         if not isinstance(distribution, str):
             # explicit grid::Distribution: partition of every grid point in global order (equal_regions, checkerboard,
             # ... computed by the caller, as Atlas does before it constructs the function space)
@@ -55,7 +59,7 @@ class StructuredColumns:
             # the multi-GPU transform (for Atlas: a user-supplied grid::Distribution)
             bs = 0
         else:
-            raise NotImplementedError(f"distribution '{distribution}' (supported: equal_bands, regular_bands, row_bands)")
+            raise NotImplementedError(f"distribution '{distribution}' (supported: equal_regions, equal_bands, regular_bands, row_bands, or an explicit partition array)")
         self.nparts, self.part = int(nparts), int(part)
         self._h = _lib.check_ptr(SC_new(grid._h, int(halo), int(bool(periodic_points)), self.nparts, self.part, bs))
         self._halo_exchange = None

@@ -96,3 +96,22 @@ def test_equal_regions_like_distribution_emulated():
     for f, a in zip(fss, fields):
         assert np.array_equal(a.cpu().numpy()[:, 0], f.global_index())
         assert np.array_equal(a.cpu().numpy()[:, 2], f.global_index())
+
+
+@pytest.mark.parametrize("gridname,nparts,halo", [("O16", 12, 2), ("O32", 7, 1)])
+def test_equal_regions_halo_exchange_emulated(gridname, nparts, halo):
+    """distribution="equal_regions" (Atlas's default; mirror of EqualRegionsPartitioner): after the exchange every node
+    of every part holds its global index"""
+    g = atlas_amd.Grid(gridname)
+    fss = [StructuredColumns(g, halo=halo, periodic_points=True, nparts=nparts, part=p, distribution="equal_regions")
+           for p in range(nparts)]
+    assert sum(f.sizeOwned() for f in fss) == g.size()
+    hxs = [f.begin_halo_exchange() for f in fss]
+    HaloExchange.finish_emulated(hxs)
+    fields = []
+    for f in fss:
+        a = np.where(f.ghost() == 0, f.global_index(), -1).astype(np.int64)
+        fields.append(torch.from_numpy(np.repeat(a[:, None], 2, axis=1).copy()).cuda())
+    exchange_emulated(hxs, fields)
+    for f, a in zip(fss, fields):
+        assert np.array_equal(a.cpu().numpy()[:, 1], f.global_index())

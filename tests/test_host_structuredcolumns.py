@@ -120,3 +120,36 @@ def test_explicit_distribution_matches_oracle():
             assert fss[part[n]].global_index()[ridx[n]] == gi[n]
     with pytest.raises(Exception):
         StructuredColumns(g, halo=1, nparts=nparts, part=0, distribution=dist[:-1])
+
+
+def test_equal_regions_partitioner_goldens_and_structuredcolumns():
+    """eq_caps / EqualRegionsPartitioner against the reference's expected values (src/tests/mesh/test_rgg.cc:103-165), and
+    StructuredColumns built on its output against the oracle (explicit grid::Distribution)."""
+    from atlas_amd.partitioner import EqualRegionsPartitioner, eq_caps
+    assert eq_caps(6)[0] == [1, 4, 1] and eq_caps(10)[0] == [1, 4, 4, 1]
+    for N, want in ((12, [1, 5, 5, 1]), (24, [1, 6, 10, 6, 1]), (48, [1, 6, 11, 12, 11, 6, 1]),
+                    (96, [1, 6, 11, 14, 16, 16, 14, 11, 6, 1])):
+        p = EqualRegionsPartitioner(N)
+        assert p.nb_bands() == len(want) and [p.nb_regions(b) for b in range(p.nb_bands())] == want
+    g = atlas_amd.Grid("O16")
+    for N in (1, 2, 5, 12):
+        part = EqualRegionsPartitioner(N).partition(g)
+        cnt = np.bincount(part, minlength=N)
+        assert cnt.sum() == g.size() and cnt.max() - cnt.min() <= 1      # chunks of npts/N (+1)
+        off = np.concatenate([[0], np.cumsum(g.nx())])
+        for j in range(g.ny()):                                           # one contiguous i-range per part and row
+            row = part[off[j]:off[j + 1]]
+            for q in np.unique(row):
+                idx = np.nonzero(row == q)[0]
+                assert idx.max() - idx.min() + 1 == idx.size
+    part = EqualRegionsPartitioner(12).partition(g)
+    fss = []
+    for p in range(12):
+        fs = StructuredColumns(g, halo=1, periodic_points=True, nparts=12, part=p, distribution=part)
+        compare(fs, StructuredColumnsOracle(g.nx(), g.y(), halo=1, periodic_points=True, nparts=12, part=p,
+                                            distribution=part))
+        fss.append(fs)
+    for fs in fss:
+        pp, ridx, gi = fs.partition(), fs.remote_index(), fs.global_index()
+        for n in range(fs.sizeOwned(), fs.sizeHalo()):
+            assert fss[pp[n]].global_index()[ridx[n]] == gi[n]
