@@ -244,6 +244,10 @@ void Trans::upload() {
             ntdiv = std::max(1, atoi(e));
         }
         c.nthreads  = std::min(512, std::max(64, (M / ntdiv + 63) / 64 * 64));
+        if (it->first.first == 2 && M >= 256 && !std::getenv("ATLAS_AMD_FFT_NT_DIV")) {
+            // specialised direct rows [16, 16, R0]: the load phase has M / R0 = 256 butterflies, give it one sweep
+            c.nthreads = std::min(512, std::max(256, c.nthreads));
+        }
         c.nrows     = (int)it->second.size();
         c.ct_f = c.ct_k = -1;
         c.direct = it->first.first == 2;
