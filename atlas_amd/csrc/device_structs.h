@@ -19,13 +19,14 @@ struct LegendreItemDev {  // mirrors trans_plan.h: LegendreItem
     long long p_off;
 };
 
-struct LegendreParams {
-    const double* P;               // tile-blocked Legendre table
-    const double* sp;              // spectra, layout of TransLocal.cc:970-987 with truncation trc_in
-    double* F;                     // Fourier intermediate F[(lat*(T+1)+m)*RP + r]
+template <class Real>
+struct LegendreParamsT {
+    const Real* P;               // tile-blocked Legendre table
+    const Real* sp;              // spectra, layout of TransLocal.cc:970-987 with truncation trc_in
+    Real* F;                     // Fourier intermediate F[(lat*(T+1)+m)*RP + r]
     const LegendreItemDev* items;  // launch-ordered work items
     const int* nlat0;              // [T+1]
-    const double* zero;            // a 0.0 in device memory (target of the spectra loads of padding columns)
+    const Real* zero;            // a 0.0 in device memory (target of the spectra loads of padding columns)
     int T;
     int trc_in;  // truncation of the input layout (T, or T+1 on the vor/div path)
     int nf;
@@ -40,6 +41,8 @@ struct LegendreParams {
     int chunk0;  // first column chunk of this launch
     int nchunks_run;  // column chunks computed by this launch (pipelined transform: a subset)
 };
+using LegendreParams    = LegendreParamsT<double>;
+using LegendreParamsF32 = LegendreParamsT<float>;   // fp32 variant (BASELINE config C5)
 
 struct FourierParams {
     const double* part_base[fft::MAX_PARTS];  // Fourier intermediate pieces, one per m-owner (see fft_core.h: RowIO)
@@ -57,6 +60,7 @@ struct FourierParams {
     int T;
     int RP;
     int nf;
+    int f32;                          // fp32 variant: part_base and gp point to float arrays (same element indexing)
     int f_begin, f_end;               // fields transformed by this launch (pipelined transform: a subset)
     long long npts;
     int scale_uv_fields;              // first 2*nb_vordiv fields are multiplied by 1/cos(lat) (TransLocal.cc:1443-1469)

@@ -477,9 +477,70 @@ struct RowTables {
 struct RowOut {
     int mmax;                // highest non-zero mode, mmax <= h
     double* y;               // n reals
-    int aligned16;           // y is 16-byte aligned and scale == 1: store complex pairs directly
+    int aligned16;           // the row starts on a pair boundary (16 bytes; 8 bytes for f32): pairs are stored whole
+    int f32 = 0;             // y points to float (fp32 variant: fp32 in HBM, the FFT arithmetic stays fp64)
     double scale;            // 1/cos(lat) for the u,v fields of the vor/div path (TransLocal.cc:1443-1469), else 1
 };
+
+struct alignas(8) fpair {
+    float x, y;
+};
+// y[2k], y[2k+1] = z  for either output type
+AA_HD void store_pair(const RowOut& io, int64_t k, cplx z) {
+    if (io.f32) {
+        float* yf = reinterpret_cast<float*>(io.y);
+        if (io.aligned16) {
+            *reinterpret_cast<fpair*>(yf + 2 * k) = fpair{(float)z.re, (float)z.im};
+        }
+        else {
+            yf[2 * k]     = (float)z.re;
+            yf[2 * k + 1] = (float)z.im;
+        }
+    }
+    else if (io.aligned16) {
+        *reinterpret_cast<cplx*>(io.y + 2 * k) = z;
+    }
+    else {
+        io.y[2 * k]     = z.re;
+        io.y[2 * k + 1] = z.im;
+    }
+}
+
+// the same with the two (uniform) decisions taken by the caller, outside its element loop
+template <bool F32, bool ALIGNED>
+AA_HD void store_pair_t(const RowOut& io, int64_t k, cplx z) {
+    if (F32) {
+        float* yf = reinterpret_cast<float*>(io.y);
+        if (ALIGNED) {
+            *reinterpret_cast<fpair*>(yf + 2 * k) = fpair{(float)z.re, (float)z.im};
+        }
+        else {
+            yf[2 * k]     = (float)z.re;
+            yf[2 * k + 1] = (float)z.im;
+        }
+    }
+    else if (ALIGNED) {
+        *reinterpret_cast<cplx*>(io.y + 2 * k) = z;
+    }
+    else {
+        io.y[2 * k]     = z.re;
+        io.y[2 * k + 1] = z.im;
+    }
+}
+// calls fn(std::integral_constant<bool, f32>, std::integral_constant<bool, aligned>) for the row's flavour
+template <class Fn>
+AA_HD void with_store_flavour(const RowOut& io, Fn&& fn) {
+    using T = std::true_type;
+    using F = std::false_type;
+    if (io.f32) {
+        if (io.aligned16) fn(T{}, T{});
+        else fn(T{}, F{});
+    }
+    else {
+        if (io.aligned16) fn(F{}, T{});
+        else fn(F{}, F{});
+    }
+}
 
 AA_HD int row_num_phases(const RowTables& r) {
     // direct   : load | DIT stages (ns) | store
@@ -603,13 +664,7 @@ AA_HD void row_phase(int ph, int t, int nt, const RowTables& r, const Reader& rd
         if (r.method == 1) {
             z = cmul(z, r.chirp[j]);
         }
-        if (io.aligned16) {
-            *reinterpret_cast<cplx*>(io.y + 2 * (int64_t)j) = z;
-        }
-        else {
-            io.y[2 * (int64_t)j]     = z.re;
-            io.y[2 * (int64_t)j + 1] = z.im;
-        }
+        store_pair(io, j, z);
     }
 }
 
@@ -830,25 +885,15 @@ AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCt& r, const Reade
             x[q].re = x[q].re * io.scale;  // 1/cos(lat) for the wind fields, exactly 1 otherwise
             x[q].im = x[q].im * io.scale;
         }
-        if (io.aligned16) {  // uniform: the row starts on a 16-byte boundary
+        with_store_flavour(io, [&](auto f32c, auto alc) {
 #pragma unroll
             for (int q = 0; q < NZ; ++q) {
                 const int k = b + q * Ls0;
                 if (k < h) {
-                    *reinterpret_cast<cplx*>(io.y + 2 * (int64_t)k * AA_ABL(r, 4)) = x[q];
+                    store_pair_t<decltype(f32c)::value, decltype(alc)::value>(io, (int64_t)k * AA_ABL(r, 4), x[q]);
                 }
             }
-        }
-        else {
-#pragma unroll
-            for (int q = 0; q < NZ; ++q) {
-                const int k = b + q * Ls0;
-                if (k < h) {
-                    io.y[2 * (int64_t)k]     = x[q].re;
-                    io.y[2 * (int64_t)k + 1] = x[q].im;
-                }
-            }
-        }
+        });
     }
 }
 
@@ -963,20 +1008,13 @@ AA_HD void row_phase_dct(int ph, int t, int nt, const RowTablesCt& r, const Read
         for (int q = 0; q < R0; ++q) x[q] = work[PAD(b + q * Ls0)];
         twiddle_apply<R0>(x, w1);
         bfly<R0>(x, +1);
-        if (io.aligned16) {
+        with_store_flavour(io, [&](auto f32c, auto alc) {
 #pragma unroll
             for (int q = 0; q < R0; ++q) {
-                const cplx z = cplx{x[q].re * io.scale, x[q].im * io.scale};
-                *reinterpret_cast<cplx*>(io.y + 2 * (int64_t)(b + q * Ls0)) = z;
+                store_pair_t<decltype(f32c)::value, decltype(alc)::value>(
+                    io, b + q * Ls0, cplx{x[q].re * io.scale, x[q].im * io.scale});
             }
-        }
-        else {
-#pragma unroll
-            for (int q = 0; q < R0; ++q) {
-                io.y[2 * (int64_t)(b + q * Ls0)]     = x[q].re * io.scale;
-                io.y[2 * (int64_t)(b + q * Ls0) + 1] = x[q].im * io.scale;
-            }
-        }
+        });
     }
 }
 

@@ -43,7 +43,9 @@ __device__ __forceinline__ bool fft_block_to_job(const FourierParams& p, int b, 
 // producers (multi-GPU m-sharding: wavenumber m belongs to part m % nparts, local index m / nparts):
 //   X[m] = *(cplx*)(base[m % nparts] + (lat_local * cnt[m % nparts] + m / nparts) * RP + 2*field)
 // nparts == 1 is the single-device layout F[(lat*(T+1) + m)*RP + r].
-struct ModeReader {
+// STORAGE: 0 = double intermediate, 1 = float (fp32 variant), 2 = decided at run time by p.f32 (generic kernel)
+template <int STORAGE>
+struct ModeReaderT {
     const FourierParams& p;
     long long lat_local;
     int f2;
@@ -65,9 +67,15 @@ struct ModeReader {
 #if defined(AA_FFT_ABLATE)
         if (p.abl & 1) ml = 0;
 #endif
-        return *reinterpret_cast<const cplx*>(base + (lat_local * cnt + ml) * p.RP + f2);
+        const long long o = (lat_local * cnt + ml) * p.RP + f2;
+        if (STORAGE == 1 || (STORAGE == 2 && p.f32)) {  // fp32 intermediate: same element indexing, float storage
+            const fft::fpair v = *reinterpret_cast<const fft::fpair*>(reinterpret_cast<const float*>(base) + o);
+            return cplx{(double)v.x, (double)v.y};
+        }
+        return *reinterpret_cast<const cplx*>(base + o);
     }
 };
+using ModeReader = ModeReaderT<2>;
 
 __global__ void __launch_bounds__(FFT_MAX_NTHR) fft_rows_kernel(FourierParams p) {
     extern __shared__ double lds_raw[];
@@ -79,7 +87,8 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR) fft_rows_kernel(FourierParams p)
     const fft::FftRowPlan* pl = p.plans + p.row_plan[row];
     const long long goff      = (long long)f * p.npts + (p.rowoff[row] - p.rowoff[p.lat0]);
     const int nx              = (int)(p.rowoff[row + 1] - p.rowoff[row]);
-    double* y                 = p.gp + goff;
+    double* y                 = p.f32 ? reinterpret_cast<double*>(reinterpret_cast<float*>(p.gp) + goff) : p.gp + goff;
+    float* yf                 = reinterpret_cast<float*>(y);
     const int tid             = threadIdx.x;
     const int FFT_NTHR        = blockDim.x;
     const double scale        = (f < p.scale_uv_fields) ? p.coslatinv[row] : 1.0;
@@ -100,7 +109,12 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR) fft_rows_kernel(FourierParams p)
                 const cplx v = rd(m);
                 s += 2.0 * (v.re * t.re - v.im * t.im);
             }
-            y[k] = s * scale;
+            if (p.f32) {
+                yf[k] = (float)(s * scale);
+            }
+            else {
+                y[k] = s * scale;
+            }
         }
         return;
     }
@@ -119,6 +133,7 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR) fft_rows_kernel(FourierParams p)
     io.y         = y;
     io.aligned16 = ((goff & 1) == 0) && (nx == n) && scale == 1.0;
     io.scale     = scale;
+    io.f32       = p.f32;
 
     const int nph = fft::row_num_phases(r);
     unsigned long long tprev = 0;
@@ -146,8 +161,14 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR) fft_rows_kernel(FourierParams p)
             if (method == 1) {
                 z = fft::cmul(z, r.chirp[j]);
             }
-            if (2 * j < nx) y[2 * j] = z.re * scale;
-            if (2 * j + 1 < nx) y[2 * j + 1] = z.im * scale;
+            if (p.f32) {
+                if (2 * j < nx) yf[2 * j] = (float)(z.re * scale);
+                if (2 * j + 1 < nx) yf[2 * j + 1] = (float)(z.im * scale);
+            }
+            else {
+                if (2 * j < nx) y[2 * j] = z.re * scale;
+                if (2 * j + 1 < nx) y[2 * j + 1] = z.im * scale;
+            }
         }
     }
     if (prof) {
@@ -171,7 +192,7 @@ __device__ __forceinline__ void for_each_phase(Fn&& fn) {
     }
 }
 
-template <class S>
+template <class S, bool F32>
 __global__ void __launch_bounds__(FFT_MAX_NTHR, 3) fft_rows_ct_kernel(FourierParams p) {
     extern __shared__ double lds_raw[];
     cplx* work = reinterpret_cast<cplx*>(lds_raw);
@@ -185,7 +206,7 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR, 3) fft_rows_ct_kernel(FourierPar
     const int nt              = blockDim.x;
     const double scale        = (f < p.scale_uv_fields) ? p.coslatinv[row] : 1.0;
     const int mmax            = p.row_mmax[row];
-    const ModeReader rd{p, (long long)(row - p.lat0), 2 * f};
+    const ModeReaderT<(F32 ? 1 : 0)> rd{p, (long long)(row - p.lat0), 2 * f};
     fft::RowTablesCt r;
 #if defined(AA_FFT_ABLATE)
     r.abl    = p.abl;
@@ -198,8 +219,9 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR, 3) fft_rows_ct_kernel(FourierPar
     r.bhat_t = p.table + pl->off_bhat_t;
     fft::RowOut io;
     io.mmax      = mmax < r.h ? mmax : r.h;
-    io.y         = p.gp + goff;
+    io.y         = F32 ? reinterpret_cast<double*>(reinterpret_cast<float*>(p.gp) + goff) : p.gp + goff;
     io.aligned16 = ((goff & 1) == 0);
+    io.f32       = F32 ? 1 : 0;
     io.scale     = scale;
     constexpr int NPH = fft::row_num_phases_ct<S>();
     unsigned long long tprev = 0;
@@ -233,7 +255,7 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR, 3) fft_rows_ct_kernel(FourierPar
 }
 
 // ---- compile-time specialised direct rows (fft_core.h: row_phase_dct): regular grids, smooth rows of reduced grids
-template <class S>
+template <class S, bool F32>
 __global__ void __launch_bounds__(FFT_MAX_NTHR, 3) fft_rows_dct_kernel(FourierParams p) {
     extern __shared__ double lds_raw[];
     cplx* work = reinterpret_cast<cplx*>(lds_raw);
@@ -247,7 +269,7 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR, 3) fft_rows_dct_kernel(FourierPa
     const int nt              = blockDim.x;
     const double scale        = (f < p.scale_uv_fields) ? p.coslatinv[row] : 1.0;
     const int mmax            = p.row_mmax[row];
-    const ModeReader rd{p, (long long)(row - p.lat0), 2 * f};
+    const ModeReaderT<(F32 ? 1 : 0)> rd{p, (long long)(row - p.lat0), 2 * f};
     fft::RowTablesCt r;
 #if defined(AA_FFT_ABLATE)
     r.abl    = p.abl;
@@ -260,8 +282,9 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR, 3) fft_rows_dct_kernel(FourierPa
     r.bhat_t = nullptr;
     fft::RowOut io;
     io.mmax      = mmax < r.h ? mmax : r.h;
-    io.y         = p.gp + goff;
+    io.y         = F32 ? reinterpret_cast<double*>(reinterpret_cast<float*>(p.gp) + goff) : p.gp + goff;
     io.aligned16 = ((goff & 1) == 0);
+    io.f32       = F32 ? 1 : 0;
     io.scale     = scale;
     constexpr int NPH = fft::row_num_phases_dct<S>();
     unsigned long long tprev = 0;
@@ -294,11 +317,11 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR, 3) fft_rows_dct_kernel(FourierPa
     });
 }
 
-template <class S>
-static hipError_t launch_ct(const FourierParams& p, int lds_bytes, int nthreads, unsigned nblk, hipStream_t stream) {
+template <class S, bool F32>
+static hipError_t launch_ct_t(const FourierParams& p, int lds_bytes, int nthreads, unsigned nblk, hipStream_t stream) {
     static int max_set = 0;
     if (lds_bytes > max_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_ct_kernel<S>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_ct_kernel<S, F32>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) {
             return e;
@@ -308,14 +331,19 @@ static hipError_t launch_ct(const FourierParams& p, int lds_bytes, int nthreads,
     static const bool debug = std::getenv("ATLAS_AMD_FFT_DEBUG") != nullptr;
     if (debug) {
         int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fft_rows_ct_kernel<S>, nthreads, lds_bytes);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fft_rows_ct_kernel<S, F32>, nthreads, lds_bytes);
         hipFuncAttributes fa{};
-        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&fft_rows_ct_kernel<S>));
+        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&fft_rows_ct_kernel<S, F32>));
         std::fprintf(stderr, "[atlas_amd] fft ct M=%d threads=%d lds=%d blocks=%u regs=%d scratch=%zu -> %d workgroups/CU\n",
                      S::M, nthreads, lds_bytes, nblk, fa.numRegs, (size_t)fa.localSizeBytes, nb);
     }
-    hipLaunchKernelGGL(fft_rows_ct_kernel<S>, dim3(nblk), dim3(nthreads), lds_bytes, stream, p);
+    hipLaunchKernelGGL((fft_rows_ct_kernel<S, F32>), dim3(nblk), dim3(nthreads), lds_bytes, stream, p);
     return hipGetLastError();
+}
+template <class S>
+static hipError_t launch_ct(const FourierParams& p, int lds_bytes, int nthreads, unsigned nblk, hipStream_t stream) {
+    return p.f32 ? launch_ct_t<S, true>(p, lds_bytes, nthreads, nblk, stream)
+                 : launch_ct_t<S, false>(p, lds_bytes, nthreads, nblk, stream);
 }
 
 hipError_t launch_fourier_ct(const FourierParams& p, int ctf, int ctk, int lds_bytes, int nthreads,
@@ -327,19 +355,24 @@ hipError_t launch_fourier_ct(const FourierParams& p, int ctf, int ctk, int lds_b
     return hipErrorInvalidValue;
 }
 
-template <class S>
-static hipError_t launch_dct(const FourierParams& p, int lds_bytes, int nthreads, unsigned nblk, hipStream_t stream) {
+template <class S, bool F32>
+static hipError_t launch_dct_t(const FourierParams& p, int lds_bytes, int nthreads, unsigned nblk, hipStream_t stream) {
     static int max_set = 0;
     if (lds_bytes > max_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_dct_kernel<S>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_dct_kernel<S, F32>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) {
             return e;
         }
         max_set = lds_bytes;
     }
-    hipLaunchKernelGGL(fft_rows_dct_kernel<S>, dim3(nblk), dim3(nthreads), lds_bytes, stream, p);
+    hipLaunchKernelGGL((fft_rows_dct_kernel<S, F32>), dim3(nblk), dim3(nthreads), lds_bytes, stream, p);
     return hipGetLastError();
+}
+template <class S>
+static hipError_t launch_dct(const FourierParams& p, int lds_bytes, int nthreads, unsigned nblk, hipStream_t stream) {
+    return p.f32 ? launch_dct_t<S, true>(p, lds_bytes, nthreads, nblk, stream)
+                 : launch_dct_t<S, false>(p, lds_bytes, nthreads, nblk, stream);
 }
 
 hipError_t launch_fourier_dct(const FourierParams& p, int ctf, int ctk, int lds_bytes, int nthreads,

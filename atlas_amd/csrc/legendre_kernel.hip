@@ -34,6 +34,35 @@ namespace atlas_amd {
 namespace trans {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// scalar type of the transform: double (v_mfma_f64_16x16x4_f64) or float (v_mfma_f32_16x16x4_f32, BASELINE config C5).
+// Both MFMAs take A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15] from lane l; the result tile differs: the f64 variant
+// keeps rows (l>>4) + 4*reg in a lane, the f32 variant rows 4*(l>>4) + reg (tools/probe/probe_f32_gfx950.hip).
+template <class Real>
+struct RealTraits;
+template <>
+struct RealTraits<double> {
+    typedef d4 acc_t;
+    typedef double2 vec_t;                  // 16-byte staging load
+    static constexpr int EPL      = 2;      // elements per 16-byte load
+    static constexpr int BANK_MOD = 32;     // LDS row strides are == 16 modulo this many elements (conflict-free)
+    __device__ static __forceinline__ acc_t mma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ int row_of(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <>
+struct RealTraits<float> {
+    typedef f4 acc_t;
+    typedef float4 vec_t;
+    static constexpr int EPL      = 4;
+    static constexpr int BANK_MOD = 64;
+    __device__ static __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ int row_of(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+};
 
 constexpr int KB   = LEG_KB_DEV;  // 8 total wavenumbers per stage
 constexpr int BN   = LEG_BN_DEV;  // 64 latitudes per item
@@ -41,22 +70,28 @@ constexpr int PSTR = BN + 16;     // LDS row stride of the P stage (== 16 mod 32
 
 // RTW = 16-column tiles per wave, NRG = column groups (of RTW tiles) per workgroup; a workgroup has 4*NRG waves:
 // wave w handles latitude tile (w & 3) and column group (w >> 2).
-template <int RTW, int NRG>
+template <int RTW, int NRG, class Real = double>
 struct LegLds {
     static constexpr int NTHR   = 256 * NRG;
     static constexpr int SCOLS  = 16 * RTW * NRG;
-    static constexpr int SSTR   = SCOLS + ((16 - SCOLS % 32) + 32) % 32;  // smallest stride >= SCOLS that is == 16 mod 32
+    static constexpr int BM     = RealTraits<Real>::BANK_MOD;
+    static constexpr int SSTR   = SCOLS + ((16 - SCOLS % BM) + BM) % BM;  // smallest stride >= SCOLS that is == 16 mod BM
     static constexpr int P_ELEM = 2 * KB * PSTR;
     static constexpr int S_ELEM = 2 * KB * SSTR;
     static constexpr int STAGE  = P_ELEM + S_ELEM;
-    static constexpr int BYTES  = 2 * STAGE * 8;  // double buffered
+    static constexpr int BYTES  = 2 * STAGE * (int)sizeof(Real);  // double buffered
 };
 
-template <int RTW, int NRG>
-__global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel(LegendreParams p) {
-    using L = LegLds<RTW, NRG>;
+template <int RTW, int NRG, class Real>
+__global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel(LegendreParamsT<Real> p) {
+    using L  = LegLds<RTW, NRG, Real>;
+    using RT = RealTraits<Real>;
+    using acc_t = typename RT::acc_t;
+    using vec_t = typename RT::vec_t;
     constexpr int NTHR = L::NTHR;
-    extern __shared__ double lds[];
+    constexpr int EPL  = RT::EPL;
+    extern __shared__ double lds_raw[];
+    Real* lds = reinterpret_cast<Real*>(lds_raw);
 
     // block -> (item, column chunk).  Hardware places block b on XCD b % 8; the chunks of one item are given to
     // blocks b, b+8, b+16, ... (same XCD, dispatched back to back) so that a later chunk finds the item's P block
@@ -90,27 +125,28 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
     const int nmax  = trc < TL ? trc : TL;  // highest n present in the input spectra
     const bool m_ok = m < trc;              // TransLocal.cc:982  (jm < truncation)
     const long long ioff = (long long)(2 * trc + 3 - m) * m / 2 * nf * 2;
-    const double* __restrict__ sp = p.sp + ioff;
-    const double* __restrict__ Pb = p.P + it.p_off;
+    const Real* __restrict__ sp = p.sp + ioff;
+    const Real* __restrict__ Pb = p.P + it.p_off;
     const int nstage = it.kpad / KB;
 
-    d4 acc[2][RTW];
+    acc_t acc[2][RTW];
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int j = 0; j < RTW; ++j) acc[q][j] = d4{0., 0., 0., 0.};
+        for (int j = 0; j < RTW; ++j) acc[q][j] = acc_t{0, 0, 0, 0};
 
     // ---- staging: registers for one stage ----
-    constexpr int PPT   = NTHR >= 512 ? 1 : 512 / NTHR;  // double2 of P per thread (1024 doubles per stage)
-    const bool p_loader = NTHR <= 512 || tid < 512;      // with more than 512 threads only the first 512 stage P
-    double2 preg[PPT];
-    double sreg[RTW];   // S: RTW doubles per thread (16 rows x SCOLS columns per stage)
-    // P element ids 2*(tid + NTHR*i):  parity = e / 512, k = (e % 512) / 64, c = e % 64
-    const double* pg[PPT];
+    constexpr int PLOADS = 1024 / EPL;  // 16-byte loads per P stage (1024 elements: 2 parities x 8 k x 64 latitudes)
+    constexpr int PPT    = NTHR >= PLOADS ? 1 : PLOADS / NTHR;  // loads per thread
+    const bool p_loader  = NTHR <= PLOADS || tid < PLOADS;      // with more threads than loads only the first ones stage P
+    vec_t preg[PPT];
+    Real sreg[RTW];   // S: RTW elements per thread (16 rows x SCOLS columns per stage)
+    // P element ids EPL*(tid + NTHR*i):  parity = e / 512, k = (e % 512) / 64, c = e % 64
+    const Real* pg[PPT];
     int plds[PPT];
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-        const int pe   = (2 * (tid + NTHR * i)) & 1023;
+        const int pe   = (EPL * (tid + NTHR * i)) & 1023;
         const int ppar = pe >> 9, pk = (pe & 511) >> 6, pc = pe & 63;
         pg[i]          = Pb + (long long)ppar * it.kpad * BN + pk * BN + pc;
         plds[i]        = ppar * (KB * PSTR) + pk * PSTR + pc;
@@ -122,7 +158,7 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
     // step 0, which removes the per-stage select.  Only the first/last stages of an item contain rows with n outside
     // [m, nmax] (K padding): those run the bounds-checked path, all others three plain loads.  (The loop used to spend
     // 4.7 VALU instructions per MFMA on rebuilding addresses and masks; MFMA and VALU issue contend.)
-    const double* sptr[RTW];
+    const Real* sptr[RTW];
     long long sstep[RTW];
     int sn0[RTW];
 #pragma unroll
@@ -146,7 +182,7 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
         if (p_loader) {
 #pragma unroll
             for (int i = 0; i < PPT; ++i) {
-                preg[i] = *reinterpret_cast<const double2*>(pg[i]);
+                preg[i] = *reinterpret_cast<const vec_t*>(pg[i]);
                 pg[i] += KB * BN;
             }
         }
@@ -161,7 +197,7 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
 #pragma unroll
             for (int i = 0; i < RTW; ++i) {
                 const int n = sn0[i] - 2 * KB * s;
-                double v    = 0.;
+                Real v      = 0;
                 if (n >= m && n <= nmax) {
                     v = *sptr[i];
                 }
@@ -172,14 +208,14 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
     };
     auto store_stage = [&](auto bufc) {
         constexpr int buf = decltype(bufc)::value;
-        double* base      = lds + buf * L::STAGE;
+        Real* base        = lds + buf * L::STAGE;
         if (p_loader) {
 #pragma unroll
             for (int i = 0; i < PPT; ++i) {
-                *reinterpret_cast<double2*>(base + plds[i]) = preg[i];
+                *reinterpret_cast<vec_t*>(base + plds[i]) = preg[i];
             }
         }
-        double* sb = base + L::P_ELEM;
+        Real* sb = base + L::P_ELEM;
 #pragma unroll
         for (int i = 0; i < RTW; ++i) {
             const int q   = tid + NTHR * i;
@@ -203,19 +239,19 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
         if (s + 1 < nstage) {
             load_stage(s + 1);
         }
-        const double* base = lds + buf * L::STAGE;
+        const Real* base = lds + buf * L::STAGE;
         if (lat_active) {  // a wave whose 16 latitudes are all beyond the item's last row only helps with the staging
 #pragma unroll
         for (int par = 0; par < 2; ++par) {
-            const double* pb = base + par * (KB * PSTR) + a_off;
-            const double* sb = base + L::P_ELEM + par * (KB * L::SSTR) + b_off;
+            const Real* pb = base + par * (KB * PSTR) + a_off;
+            const Real* sb = base + L::P_ELEM + par * (KB * L::SSTR) + b_off;
 #pragma unroll
             for (int ks = 0; ks < KB / 4; ++ks) {
-                const double a = pb[ks * 4 * PSTR];
+                const Real a = pb[ks * 4 * PSTR];
 #pragma unroll
                 for (int j = 0; j < RTW; ++j) {
-                    const double b = sb[ks * 4 * L::SSTR + j * 16];
-                    acc[par][j]    = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[par][j], 0, 0, 0);
+                    const Real b = sb[ks * 4 * L::SSTR + j * 16];
+                    acc[par][j]  = RT::mma(a, b, acc[par][j]);
                 }
             }
         }
@@ -239,22 +275,22 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
     const int ml       = m / p.m_div;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const int c = lt * 16 + (lane >> 4) + 4 * g;
+        const int c = lt * 16 + RT::row_of(lane, g);
         if (c < it.nrows) {
             const int jn = jleg0 + c;
             const int js = nlats - 1 - jn;
             const bool st_n = jn != js && jn >= p.row_begin && jn < p.row_end;
             const bool st_s = js >= p.row_begin && js < p.row_end;
-            double* fn   = p.F + ((long long)(jn - p.row_begin) * p.m_cnt + ml) * RP;
-            double* fs   = p.F + ((long long)(js - p.row_begin) * p.m_cnt + ml) * RP;
+            Real* fn     = p.F + ((long long)(jn - p.row_begin) * p.m_cnt + ml) * RP;
+            Real* fs     = p.F + ((long long)(js - p.row_begin) * p.m_cnt + ml) * RP;
 #pragma unroll
             for (int j = 0; j < RTW; ++j) {
                 const int r = r0 + (rg * RTW + j) * 16 + (lane & 15);
                 if (r < RP) {
-                    double sy = acc[0][j][g], as = acc[1][j][g];
+                    Real sy = acc[0][j][g], as = acc[1][j][g];
                     if (m == 0 && (r & 1)) {  // n_imag = 1 for m = 0 (TransLocal.cc:953)
-                        sy = 0.;
-                        as = 0.;
+                        sy = 0;
+                        as = 0;
                     }
                     if (st_n) {
                         fn[r] = sy + as;
@@ -268,12 +304,12 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
     }
 }
 
-template <int RTW, int NRG>
-static hipError_t launch_cfg(LegendreParams p, int nitems, int nchunks, int chunk0, int nrun, hipStream_t stream) {
-    using L = LegLds<RTW, NRG>;
+template <int RTW, int NRG, class Real>
+static hipError_t launch_cfg(LegendreParamsT<Real> p, int nitems, int nchunks, int chunk0, int nrun, hipStream_t stream) {
+    using L = LegLds<RTW, NRG, Real>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&legendre_kernel<RTW, NRG>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&legendre_kernel<RTW, NRG, Real>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES);
         if (e != hipSuccess) {
             return e;
@@ -285,7 +321,7 @@ static hipError_t launch_cfg(LegendreParams p, int nitems, int nchunks, int chun
     p.chunk0        = chunk0;
     p.nchunks_run   = nrun;
     const int slots = (nitems + 7) / 8;
-    hipLaunchKernelGGL((legendre_kernel<RTW, NRG>), dim3(slots * nrun * 8), dim3(L::NTHR), L::BYTES, stream, p);
+    hipLaunchKernelGGL((legendre_kernel<RTW, NRG, Real>), dim3(slots * nrun * 8), dim3(L::NTHR), L::BYTES, stream, p);
     return hipGetLastError();
 }
 
@@ -309,23 +345,32 @@ void legendre_tiling(int nf, int& rtw, int& nrg, int& nchunks) {
 }
 
 // chunk0 / nrun: the column chunks [chunk0, chunk0 + nrun) of legendre_tiling(); nrun <= 0: all
-hipError_t launch_legendre(const LegendreParams& p, int nitems, int chunk0, int nrun, hipStream_t stream) {
+template <class Real>
+static hipError_t launch_legendre_t(const LegendreParamsT<Real>& p, int nitems, int chunk0, int nrun, hipStream_t stream) {
     int rtw, nrg, nchunks;
     legendre_tiling(p.nf, rtw, nrg, nchunks);
     if (nrun <= 0) {
         chunk0 = 0;
         nrun   = nchunks;
     }
-#define LEG_CASE(R)                                                                      \
-    case R:                                                                              \
-        if (nrg == 1) return launch_cfg<R, 1>(p, nitems, nchunks, chunk0, nrun, stream);               \
-        if (nrg == 2) return launch_cfg<R, 2>(p, nitems, nchunks, chunk0, nrun, stream);               \
-        return launch_cfg<(R <= 4 ? R : 4), 3>(p, nitems, nchunks, chunk0, nrun, stream);
+#define LEG_CASE(R)                                                                                    \
+    case R:                                                                                            \
+        if (nrg == 1) return launch_cfg<R, 1, Real>(p, nitems, nchunks, chunk0, nrun, stream);         \
+        if (nrg == 2) return launch_cfg<R, 2, Real>(p, nitems, nchunks, chunk0, nrun, stream);         \
+        return launch_cfg<(R <= 4 ? R : 4), 3, Real>(p, nitems, nchunks, chunk0, nrun, stream);
     switch (rtw) {
         LEG_CASE(1) LEG_CASE(2) LEG_CASE(3) LEG_CASE(4) LEG_CASE(5) LEG_CASE(6) LEG_CASE(7) LEG_CASE(8) LEG_CASE(9)
     }
 #undef LEG_CASE
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_legendre(const LegendreParams& p, int nitems, int chunk0, int nrun, hipStream_t stream) {
+    return launch_legendre_t<double>(p, nitems, chunk0, nrun, stream);
+}
+// fp32 variant: same work list, tiling and table layout (the table converted to float)
+hipError_t launch_legendre_f32(const LegendreParamsF32& p, int nitems, int chunk0, int nrun, hipStream_t stream) {
+    return launch_legendre_t<float>(p, nitems, chunk0, nrun, stream);
 }
 
 }  // namespace trans

@@ -71,6 +71,7 @@ public:
     void synchronize() const;
 
     // ---- device-pointer API (asynchronous on stream()) ----
+    void invtrans_scalar_device_f32(int nb_fields, const float* sp_dev, float* gp_dev);  // fp32 variant
     // TransLocal::invtrans_uv (TransLocal.cc:1409-1484); the first 2*nb_vordiv fields are scaled by 1/cos(lat)
     void invtrans_uv_device(int trc_in, int nb_fields, int nb_vordiv, const double* sp_dev, double* gp_dev);
     // the two stages separately (multi-GPU driver, stage-level parity tests)
@@ -112,7 +113,7 @@ private:
     void timed_begin(int kind, hipStream_t s = nullptr);
     void legendre_chunks(int trc_in, int nb_fields, const double* sp_dev, double* fourier_dev, int chunk0, int nrun);
     void fourier_fields(int nb_fields, int nb_vordiv, const double* const* part_base, const int* part_cnt,
-                        double* gp_dev, int f_begin, int f_end, hipStream_t stream);
+                        double* gp_dev, int f_begin, int f_end, hipStream_t stream, bool f32 = false);
     void timed_end();
 
     TransGeometry geo_;
@@ -137,6 +138,10 @@ private:
     void* d_items_       = nullptr;
     int* d_nlat0_        = nullptr;
     double* d_zero_      = nullptr;  // zeros: load target of padding columns in the Legendre kernel
+    float* d_P32_        = nullptr;  // fp32 variant: table, zero target and Fourier intermediate in float (lazily)
+    float* d_zero32_     = nullptr;
+    float* d_fourier32_  = nullptr;
+    size_t fourier32_cap_ = 0;
     void* d_fftplans_    = nullptr;
     void* d_ffttable_    = nullptr;
     int* d_row_plan_     = nullptr;

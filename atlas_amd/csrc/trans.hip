@@ -17,6 +17,8 @@ namespace trans {
 
 hipError_t launch_legendre(const LegendreParams& p, int nitems, int chunk0, int nrun, hipStream_t stream);
 void legendre_tiling(int nf, int& rtw, int& nrg, int& nchunks);
+hipError_t launch_legendre_f32(const LegendreParamsF32& p, int nitems, int chunk0, int nrun, hipStream_t stream);
+hipError_t launch_convert_f64_f32(const double* src, float* dst, size_t n, hipStream_t stream);
 hipError_t launch_fourier(const FourierParams& p, int lds_bytes, int nthreads, hipStream_t stream);
 hipError_t launch_fourier_ct(const FourierParams& p, int ctf, int ctk, int lds_bytes, int nthreads,
                              hipStream_t stream);
@@ -105,6 +107,9 @@ Trans::~Trans() {
     fr(d_items_);
     fr(d_nlat0_);
     fr(d_zero_);
+    fr(d_P32_);
+    fr(d_zero32_);
+    fr(d_fourier32_);
     fr(d_fftplans_);
     fr(d_ffttable_);
     fr(d_row_plan_);
@@ -352,7 +357,7 @@ void Trans::fourier_device(int nb_fields, int nb_vordiv, const double* const* pa
 }
 
 void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* part_base, const int* part_cnt,
-                           double* gp_dev, int f_begin, int f_end, hipStream_t stream) {
+                           double* gp_dev, int f_begin, int f_end, hipStream_t stream, bool f32) {
     if (nb_fields <= 0 || f_end <= f_begin) {
         return;
     }
@@ -372,6 +377,7 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
     p.T               = geo_.T;
     p.RP              = fourier_row_pitch(nb_fields);
     p.nf              = nb_fields;
+    p.f32             = f32 ? 1 : 0;
     p.f_begin         = f_begin;
     p.f_end           = f_end;
     p.npts            = geo_.rowoff[band_end()] - geo_.rowoff[band_begin()];
@@ -477,6 +483,58 @@ void Trans::invtrans_uv_device(int trc_in, int nb_fields, int nb_vordiv, const d
     }
     HIP_CHECK(hipEventRecord(pipe_events_[pieces], stream2_));
     HIP_CHECK(hipStreamWaitEvent(stream_, pipe_events_[pieces], 0));  // the call completes on stream()
+}
+
+// ---- fp32 variant (BASELINE config C5): fp32 spectra / table / intermediate / grid points, v_mfma_f32_16x16x4_f32 in the
+// Legendre stage; the Fourier stage converts on load and store and keeps its arithmetic in fp64.
+void Trans::invtrans_scalar_device_f32(int nb_fields, const float* sp_dev, float* gp_dev) {
+    if (nb_fields <= 0) {
+        return;
+    }
+    if (fourier_parts() != 1) {
+        throw std::logic_error("fp32 invtrans on a wavenumber-sharded Trans is not implemented");
+    }
+    if (!d_P32_) {  // the table, once, in float
+        const size_t n = (size_t)work_.table_doubles;
+        HIP_CHECK(hipMalloc((void**)&d_P32_, std::max<size_t>(n, 1) * sizeof(float)));
+        HIP_CHECK(launch_convert_f64_f32(d_P_, d_P32_, n, stream_));
+        HIP_CHECK(hipMalloc((void**)&d_zero32_, 64));
+        HIP_CHECK(hipMemsetAsync(d_zero32_, 0, 64, stream_));
+    }
+    const size_t need = fourier_doubles(nb_fields);  // same element count, float storage
+    if (need > fourier32_cap_) {
+        synchronize();
+        if (d_fourier32_) {
+            HIP_CHECK(hipFree(d_fourier32_));
+            d_fourier32_ = nullptr;
+        }
+        HIP_CHECK(hipMalloc((void**)&d_fourier32_, need * sizeof(float)));
+        fourier32_cap_ = need;
+    }
+    LegendreParamsF32 p;
+    p.P         = d_P32_;
+    p.sp        = sp_dev;
+    p.F         = d_fourier32_;
+    p.items     = (const LegendreItemDev*)d_items_;
+    p.nlat0     = d_nlat0_;
+    p.zero      = d_zero32_;
+    p.T         = geo_.T;
+    p.trc_in    = geo_.T;
+    p.nf        = nb_fields;
+    p.RP        = fourier_row_pitch(nb_fields);
+    p.nlats     = geo_.nlats;
+    p.m_div     = 1;
+    p.m_cnt     = m_cnt_;
+    p.row_begin = cfg_.by_band ? band_begin() : 0;
+    p.row_end   = cfg_.by_band ? band_end() : geo_.nlats;
+    timed_begin(0);
+    if (!work_.items.empty()) {
+        HIP_CHECK(launch_legendre_f32(p, (int)work_.items.size(), 0, 0, stream_));
+    }
+    timed_end();
+    const double* base[1] = {reinterpret_cast<const double*>(d_fourier32_)};
+    const int cnt[1]      = {m_cnt_};
+    fourier_fields(nb_fields, 0, base, cnt, reinterpret_cast<double*>(gp_dev), 0, nb_fields, stream_, true);
 }
 
 void Trans::collect_timings() {

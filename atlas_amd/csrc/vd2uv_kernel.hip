@@ -153,6 +153,20 @@ hipError_t launch_vd2uv(const double* vor, const double* div, double* U, double*
     return hipGetLastError();
 }
 
+__global__ void __launch_bounds__(256) convert_f64_f32_kernel(const double* __restrict__ src, float* __restrict__ dst,
+                                                             size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        dst[i] = (float)src[i];
+    }
+}
+hipError_t launch_convert_f64_f32(const double* src, float* dst, size_t n, hipStream_t stream) {
+    if (n == 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(convert_f64_f32_kernel, dim3(4096), dim3(256), 0, stream, src, dst, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_spectra_prepare(const double* vor, const double* div, const double* sp, double* out, int T, int nvd,
                                   int ns, hipStream_t stream) {
     PrepareParams p{vor, div, sp, out, T, nvd, ns};

@@ -88,6 +88,17 @@ class Trans:
             (gp,) = args
             nf = int(nb_scalar_fields)
             dev = _is_device(gp)
+            if dev and _is_device(scalar_spectra):
+                import torch
+                if gp.dtype == torch.float32 and scalar_spectra.dtype == torch.float32:
+                    # fp32 variant (an extension; BASELINE config C5): float device arrays in the same layouts
+                    if not (gp.is_contiguous() and scalar_spectra.is_contiguous()):
+                        raise TypeError("need contiguous float32 tensors")
+                    if scalar_spectra.numel() < ncoef * nf or gp.numel() < npts * nf:
+                        raise ValueError("float32 arrays too small")
+                    _lib.check(_lib.Trans_invtrans_scalar_device_f32(self._h, nf, scalar_spectra.data_ptr(),
+                                                                     gp.data_ptr()))
+                    return gp
             if dev != _is_device(scalar_spectra):
                 raise TypeError("spectra and grid-point arrays must both be host or both be device")
             sp_p = _ptr(scalar_spectra, ncoef * nf, "scalar_spectra")

@@ -98,6 +98,12 @@ int atlas_amd__Trans__invtrans_scalar_device(atlas_amd_Trans* t, int nb_fields, 
 int atlas_amd__Trans__invtrans_device(atlas_amd_Trans* t, int nb_scalar_fields, const double* scalar_spectra_dev,
                                       int nb_vordiv_fields, const double* vorticity_spectra_dev,
                                       const double* divergence_spectra_dev, double* gp_fields_dev);
+/* fp32 variant of invtrans_scalar on device arrays (an extension: TransLocal is double only; BASELINE config C5).
+ * float spectra and grid points in the layouts above; Legendre stage on v_mfma_f32_16x16x4_f32 with the table converted
+ * to float, Fourier stage with fp32 loads/stores around fp64 arithmetic.  Expect ~1e-6 relative accuracy. */
+int atlas_amd__Trans__invtrans_scalar_device_f32(atlas_amd_Trans* t, int nb_fields, const float* scalar_spectra,
+                                                 float* gp_fields);
+
 /* direct transforms and adjoints: not implemented by TransLocal either (TransLocal.cc:848-857,899-927,1599-1685);
  * these return an error whose message starts with "Not implemented" */
 int atlas_amd__Trans__dirtrans_scalar(atlas_amd_Trans* t, int nb_fields, const double scalar_fields[],

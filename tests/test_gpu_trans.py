@@ -407,3 +407,22 @@ def test_zonal_band_crop_equals_rows_of_the_global_transform(gridname, T, nf, ro
     assert np.array_equal(part.reshape(nf + 2, -1), full.reshape(nf + 2, -1)[:, lo:hi])
     with pytest.raises(_lib.AtlasAmdError):
         atlas_amd.Trans(g, T, rows=(5, g.ny() + 1))
+
+
+@pytest.mark.parametrize("gridname,T,nf", [("O64", 63, 5), ("F64", 63, 3), ("O160", 159, 20), ("F320", 319, 9)])
+def test_fp32_variant_against_fp64(gridname, T, nf):
+    """BASELINE config C5's precision: float spectra / table / grid points, fp32 MFMA in the Legendre stage.  Tolerance:
+    rel-RMS <= 2e-6 against the fp64 result of the same (float-rounded) spectra; fields stay independent."""
+    g, tr = get_trans(gridname, T)
+    sp32 = red_spectra(T, nf, seed=51).astype(np.float32)
+    ref = run_device(tr, nf, sp32.astype(np.float64))
+    gp = torch.full((nf * g.size(),), float("nan"), dtype=torch.float32, device="cuda")
+    tr.invtrans(nf, torch.from_numpy(sp32).cuda(), gp)
+    tr.synchronize()
+    got = gp.cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all()
+    assert compute_rms(got, ref) < 2e-6
+    one = torch.zeros(g.size(), dtype=torch.float32, device="cuda")
+    tr.invtrans(1, torch.from_numpy(np.ascontiguousarray(sp32.reshape(-1, nf)[:, 2])).cuda(), one)
+    tr.synchronize()
+    assert np.array_equal(one.cpu().numpy(), gp.cpu().numpy().reshape(nf, -1)[2])

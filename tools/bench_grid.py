@@ -1,10 +1,11 @@
-"""Dev tool (GPU box): stage times for an arbitrary (grid, truncation, levels): python tools/bench_grid.py F1280 1279 137"""
+"""Dev tool (GPU box): stage times for an arbitrary (grid, truncation, levels): python tools/bench_grid.py F1280 1279 137 [f32]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch, atlas_amd
 from helpers import red_spectra
 grid, T, nf = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+f32 = len(sys.argv) > 4 and sys.argv[4] == "f32"   # fp32 variant (BASELINE config C5)
 g = atlas_amd.Grid(grid)
 t0 = time.time()
 tr = atlas_amd.Trans(g, T, profile=True)
@@ -17,7 +18,9 @@ else:   # many fields: tile a 137-field block on the device (host generation of 
     reps = (nf + 136) // 137
     sp = blk.repeat(1, reps)[:, :nf].contiguous().reshape(-1)
     del blk
-gp = torch.zeros(nf * g.size(), dtype=torch.float64, device="cuda")
+gp = torch.zeros(nf * g.size(), dtype=torch.float32 if f32 else torch.float64, device="cuda")
+if f32:
+    sp = sp.to(torch.float32)
 for _ in range(2):
     tr.invtrans(nf, sp, gp)
 torch.cuda.synchronize()
