@@ -250,6 +250,12 @@ int atlas_amd__Trans__invtrans_scalar_device_f32(atlas_amd_Trans* t, int nb_fiel
     t->impl->invtrans_scalar_device_f32(nb_fields, scalar_spectra, gp_fields);
     AA_CATCH_INT
 }
+int atlas_amd__Trans__invtrans_scalar_f32(atlas_amd_Trans* t, int nb_fields, const float scalar_spectra[],
+                                          float gp_fields[]) {
+    AA_TRY
+    t->impl->invtrans_scalar_f32(nb_fields, scalar_spectra, gp_fields);
+    AA_CATCH_INT
+}
 static int not_implemented(const char* what) {
     atlas_amd::set_last_error(std::string("Not implemented: ") + what +
                               " (TransLocal does not implement it either, TransLocal.cc:848-857,899-927,1599-1685)");

@@ -537,6 +537,21 @@ void Trans::invtrans_scalar_device_f32(int nb_fields, const float* sp_dev, float
     fourier_fields(nb_fields, 0, base, cnt, reinterpret_cast<double*>(gp_dev), 0, nb_fields, stream_, true);
 }
 
+void Trans::invtrans_scalar_f32(int nb_fields, const float scalar_spectra[], float gp_fields[]) {
+    if (nb_fields <= 0) {
+        return;
+    }
+    const size_t nsp = nb_spectral_coefficients() * (size_t)nb_fields;
+    const size_t ngp = (size_t)nb_gridpoints() * (size_t)nb_fields;
+    // staging buffers shared with the fp64 host API (sized in doubles: twice what the floats need)
+    ensure(d_sp_, sp_cap_, (nsp + 1) / 2);
+    ensure(d_gp_, gp_cap_, (ngp + 1) / 2);
+    HIP_CHECK(hipMemcpyAsync(d_sp_, scalar_spectra, nsp * sizeof(float), hipMemcpyHostToDevice, stream_));
+    invtrans_scalar_device_f32(nb_fields, reinterpret_cast<const float*>(d_sp_), reinterpret_cast<float*>(d_gp_));
+    HIP_CHECK(hipMemcpyAsync(gp_fields, d_gp_, ngp * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    synchronize();
+}
+
 void Trans::collect_timings() {
     if (ev_used_ == 0) {
         return;

@@ -99,6 +99,14 @@ class Trans:
                     _lib.check(_lib.Trans_invtrans_scalar_device_f32(self._h, nf, scalar_spectra.data_ptr(),
                                                                      gp.data_ptr()))
                     return gp
+            if (not dev and isinstance(gp, np.ndarray) and isinstance(scalar_spectra, np.ndarray)
+                    and gp.dtype == np.float32 and scalar_spectra.dtype == np.float32):
+                if not (gp.flags.c_contiguous and scalar_spectra.flags.c_contiguous and gp.flags.writeable):
+                    raise TypeError("need C-contiguous float32 arrays")
+                if scalar_spectra.size < ncoef * nf or gp.size < npts * nf:
+                    raise ValueError("float32 arrays too small")
+                _lib.check(_lib.Trans_invtrans_scalar_f32(self._h, nf, scalar_spectra.ctypes.data, gp.ctypes.data))
+                return gp
             if dev != _is_device(scalar_spectra):
                 raise TypeError("spectra and grid-point arrays must both be host or both be device")
             sp_p = _ptr(scalar_spectra, ncoef * nf, "scalar_spectra")

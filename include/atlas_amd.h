@@ -103,6 +103,8 @@ int atlas_amd__Trans__invtrans_device(atlas_amd_Trans* t, int nb_scalar_fields, 
  * to float, Fourier stage with fp32 loads/stores around fp64 arithmetic.  Expect ~1e-6 relative accuracy. */
 int atlas_amd__Trans__invtrans_scalar_device_f32(atlas_amd_Trans* t, int nb_fields, const float* scalar_spectra,
                                                  float* gp_fields);
+int atlas_amd__Trans__invtrans_scalar_f32(atlas_amd_Trans* t, int nb_fields, const float scalar_spectra[],
+                                          float gp_fields[]); /* host pointers */
 
 /* direct transforms and adjoints: not implemented by TransLocal either (TransLocal.cc:848-857,899-927,1599-1685);
  * these return an error whose message starts with "Not implemented" */

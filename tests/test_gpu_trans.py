@@ -426,3 +426,6 @@ def test_fp32_variant_against_fp64(gridname, T, nf):
     tr.invtrans(1, torch.from_numpy(np.ascontiguousarray(sp32.reshape(-1, nf)[:, 2])).cuda(), one)
     tr.synchronize()
     assert np.array_equal(one.cpu().numpy(), gp.cpu().numpy().reshape(nf, -1)[2])
+    host = np.full(nf * g.size(), np.nan, dtype=np.float32)       # host-pointer entry point
+    tr.invtrans(nf, sp32, host)
+    assert np.array_equal(host, gp.cpu().numpy())
