@@ -41,6 +41,70 @@ def mode_address(plan, RP, lat_local, m, nparts, f2=0):
     return plan["out_offsets"][p] + (lat_local * plan["cnt"][p] + ml) * RP + f2
 
 
+# RCCL message-size guard.  Measured on one MI355X (RCCL 2.26.6, tools/dist_selfcheck.py, profiles/
+# r01_rccl_message_probe.txt): a float64 all_to_all_single delivers messages up to 1.00 GiB completely, but only the
+# first half of a message of 2.00 GiB or more (the 7.03 GiB slab of a lone rank lost its southern hemisphere) -- no
+# error is raised.  One all_to_all_single is therefore used only while the largest per-pair message of the whole
+# exchange is <= 512 MiB (8 GPUs at TL1279/O1280/137 levels: 235 MB to a polar band, 60 MB between equatorial
+# ones); otherwise the slabs go out as batched point-to-point messages of at most 512 MiB.  A lone rank copies on
+# device.  The choice depends on global quantities only, so every rank takes the same path.
+MAX_MESSAGE_ELEMS = 1 << 26      # doubles per message (512 MiB)
+FORCE_RCCL_SINGLE_RANK = False   # dev switch (tools/dist_selfcheck.py): send a lone rank's slab through RCCL as well
+
+
+def exchange_messages(plan, bands, RP, nparts, part, max_message_elems=MAX_MESSAGE_ELEMS):
+    """the bounded-size messages of the m -> latitude transpose for rank `part`:
+    list of (peer, send_begin, send_end, recv_begin, recv_end) in doubles, offsets into F (flat) and R.  A peer's
+    slab is cut by rows into K pieces; K depends only on global quantities, so both ends cut alike, and the pieces
+    of one pair are listed (and therefore sent and received) in the same order on both ends."""
+    cnt, rows = plan["cnt"], plan["rows"]
+    biggest = max(rows) * max(cnt) * RP
+    K = max(1, -(-biggest // max_message_elems))
+    K = max(1, min(K, min(r for r in rows if r > 0))) if any(rows) else 1
+    msgs = []
+    for k in range(K):
+        for peer in range(nparts):
+            s0, s1 = rows[peer] * k // K, rows[peer] * (k + 1) // K          # rows of the peer's band I send
+            r0, r1 = rows[part] * k // K, rows[part] * (k + 1) // K          # rows of my band I receive
+            sb = (int(bands[peer]) + s0) * cnt[part] * RP
+            se = (int(bands[peer]) + s1) * cnt[part] * RP
+            rb = plan["out_offsets"][peer] + r0 * cnt[peer] * RP
+            re = plan["out_offsets"][peer] + r1 * cnt[peer] * RP
+            msgs.append((peer, sb, se, rb, re))
+    return msgs
+
+
+def transpose_exchange(F, R, plan, bands, RP, nparts, part, group=None, async_op=False,
+                       max_message_elems=MAX_MESSAGE_ELEMS):
+    """m -> latitude transpose of the Fourier intermediate, F (this rank's wavenumbers, all rows) -> R (all
+    wavenumbers, this rank's rows).  Returns the list of outstanding work handles (empty when complete or when the
+    remaining work is ordered on the current stream)."""
+    import torch.distributed as dist
+    Ff = F.reshape(-1)
+    if nparts == 1 and not FORCE_RCCL_SINGLE_RANK:
+        R[:plan["out_splits"][0]].copy_(Ff[:plan["in_splits"][0]])        # nothing to exchange: one device copy
+        return []
+    if max(plan["rows"]) * max(plan["cnt"]) * RP <= max_message_elems:      # the largest message of ANY pair
+        w = dist.all_to_all_single(R, Ff, output_split_sizes=plan["out_splits"], input_split_sizes=plan["in_splits"],
+                                   group=group, async_op=async_op)
+        return [w] if async_op else []
+    ops = []
+    for peer, sb, se, rb, re in exchange_messages(plan, bands, RP, nparts, part, max_message_elems):
+        if peer == part:
+            R[rb:re].copy_(Ff[sb:se])
+        else:
+            if se > sb:
+                ops.append(dist.P2POp(dist.isend, Ff[sb:se], peer, group))
+            if re > rb:
+                ops.append(dist.P2POp(dist.irecv, R[rb:re], peer, group))
+    works = dist.batch_isend_irecv(ops) if ops else []
+    if async_op:
+        return list(works)
+    for w in works:
+        w.wait()
+    return []
+
+
 class DistributedTrans:
     def __init__(self, grid, truncation, group=None, profile=False, mode="auto"):
         """mode: "alltoall" = Legendre stage sharded by wavenumber, RCCL all-to-all, Fourier stage on the local band
@@ -81,9 +145,8 @@ class DistributedTrans:
     def _legendre_and_exchange(self, nf, sp, slot, async_op):
         F, R, plan, RP = self._buffers(nf, slot)
         self.trans.legendre_device(self.T, nf, sp, F)
-        work = self._dist.all_to_all_single(R, F, output_split_sizes=plan["out_splits"],
-                                            input_split_sizes=plan["in_splits"], group=self.group, async_op=async_op)
-        return work
+        return transpose_exchange(F, R, plan, self.bands, RP, self.nparts, self.part, group=self.group,
+                                  async_op=async_op)
 
     def _fourier(self, nf, slot, gp):
         F, R, plan, RP = self._buffers(nf, slot)
@@ -109,8 +172,10 @@ class DistributedTrans:
         for i, sp in enumerate(sps):
             works.append(self._legendre_and_exchange(nf, sp, i % 2, async_op=True))
             if i > 0:
-                works[i - 1].wait()
+                for w in works[i - 1]:
+                    w.wait()
                 self._fourier(nf, (i - 1) % 2, gps[i - 1])
-        works[-1].wait()
+        for w in works[-1]:
+            w.wait()
         self._fourier(nf, (len(sps) - 1) % 2, gps[-1])
         return gps

@@ -137,6 +137,33 @@ def main():
     transforms = args.steps * world
     ms_per_step = dt / args.steps * 1e3
 
+    # multi-GPU parity evidence (outside the timed region): the transposed decomposition must reproduce, bit for bit,
+    # what the exchange-free latitude-band decomposition computes for this rank's rows (tests/test_gpu_trans.py shows
+    # both equal the single-device result).  Only run when the all-to-all is the timed mode anyway, so that the
+    # exchange-free runs stay free of collectives in the data path; ATLAS_AMD_BENCH_CROSSCHECK=1 forces it.
+    crosscheck = None
+    if use_dist and ((world > 1 and dtr.mode == "alltoall") or os.environ.get("ATLAS_AMD_BENCH_CROSSCHECK") == "1"):
+        import torch.distributed as dist
+        other = "band" if dtr.mode == "alltoall" else "alltoall"
+        ok, err = 0, None
+        try:
+            dto = DistributedTrans(g, TRUNC, mode=other)
+            gp_a, gp_b = torch.empty_like(gp), torch.empty_like(gp)
+            dtr.invtrans(nf, sps[0], gp_a)
+            dto.invtrans(nf, sps[0], gp_b)
+            torch.cuda.synchronize()
+            ok = int(bool(torch.equal(gp_a, gp_b)) and bool(torch.isfinite(gp_a).all())
+                     and float(gp_a.abs().max()) > 0.0)
+            del dto, gp_a, gp_b
+        except Exception as e:  # the check must never cost the measurement
+            err = f"{type(e).__name__}: {e}"
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")   # every rank takes part, failed or not
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        crosscheck = {"compared": f"{dtr.mode} vs {other} decomposition, {nf} fields, every rank's latitude band",
+                      "bitwise_equal_on_all_ranks": bool(int(flag.item()))}
+        if err:
+            crosscheck["error_on_rank0"] = err
+
     if rank == 0:
         leg_ms = tm["legendre_ms"] / max(tm["legendre_calls"], 1)
         fft_ms = tm["fourier_ms"] / max(tm["fourier_calls"], 1)
@@ -179,6 +206,8 @@ def main():
             "roofline_kernels": kernels,
         }
         out["roofline"]["kernel"] = dominant["kernel"]
+        if crosscheck is not None:
+            out["multi_gpu_crosscheck"] = crosscheck
         if world == 1 and not use_dist and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_fields)
     if use_dist:

@@ -36,9 +36,9 @@ def _bands(nx, nparts):
     return b
 
 
-def _transpose_worker(rank, world, port, T, RP, nx, q):
+def _transpose_worker(rank, world, port, T, RP, nx, q, limits=None, async_op=False):
     sys.path.insert(0, ROOT)
-    from atlas_amd.dist import mode_address, owned_wavenumbers, transpose_plan
+    from atlas_amd.dist import mode_address, owned_wavenumbers, transpose_exchange, transpose_plan
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     nlats = len(nx)
     bands = _bands(nx, world)
@@ -50,9 +50,17 @@ def _transpose_worker(rank, world, port, T, RP, nx, q):
         m = rank + ml * world
         F[:, ml, :] = (torch.arange(nlats, dtype=torch.float64)[:, None] * 1e6 + m * 1e3
                        + torch.arange(RP, dtype=torch.float64)[None, :])
-    R = torch.zeros(sum(plan["out_splits"]), dtype=torch.float64)
-    dist.all_to_all_single(R, F.reshape(-1), output_split_sizes=plan["out_splits"],
-                           input_split_sizes=plan["in_splits"])
+    R = torch.full((sum(plan["out_splits"]),), -1.0, dtype=torch.float64)
+    if limits is None:
+        # the call the 8-GPU run makes: one all_to_all_single with per-peer split sizes
+        dist.all_to_all_single(R, F.reshape(-1), output_split_sizes=plan["out_splits"],
+                               input_split_sizes=plan["in_splits"])
+    else:
+        # the product's exchange entry point; small limits force the bounded-size point-to-point path
+        works = transpose_exchange(F, R, plan, bands, RP, world, rank, async_op=async_op,
+                                   max_message_elems=limits)
+        for w in works:
+            w.wait()
     ok = True
     for lat in range(bands[rank], bands[rank + 1]):
         for m in range(T + 1):
@@ -79,6 +87,53 @@ def test_m_to_latitude_transpose_over_gloo(world):
     assert all(ok for _, ok, _ in res)
     bands = res[0][2]
     assert bands[0] == 0 and bands[-1] == len(nx) and all(b >= a for a, b in zip(bands, bands[1:]))
+
+
+@pytest.mark.parametrize("world,limits,async_op", [(2, 1 << 26, False),   # default limit: one all_to_all_single
+                                                   (2, 100, True),        # 100-double messages: K > 1
+                                                   (3, 64, False),
+                                                   (3, 300, True)])
+def test_bounded_size_exchange_over_gloo(world, limits, async_op):
+    """atlas_amd.dist.transpose_exchange: the single all_to_all_single and the bounded-size point-to-point messages
+    must deliver the same transposed intermediate"""
+    nx = np.array([20 + 4 * j for j in range(8)] + [20 + 4 * j for j in range(8)][::-1])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_transpose_worker, args=(r, world, port, 11, 16, nx, q, limits, async_op))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok, _ in res)
+
+
+def test_exchange_messages_cover_both_buffers_exactly_once():
+    from atlas_amd.dist import exchange_messages, transpose_plan
+    nx = np.array([20 + 4 * j for j in range(40)] + [20 + 4 * j for j in range(40)][::-1])
+    T, RP = 47, 32
+    for world in (1, 2, 3, 8):
+        bands = _bands(nx, world)
+        plans = [transpose_plan(len(nx), T, RP, bands, world, r) for r in range(world)]
+        for limit in (1 << 27, 3000, 700):
+            msgs = [exchange_messages(plans[r], bands, RP, world, r, limit) for r in range(world)]
+            for r in range(world):
+                sent = np.zeros(len(nx) * plans[r]["cnt"][r] * RP, dtype=np.int32)
+                recv = np.zeros(sum(plans[r]["out_splits"]), dtype=np.int32)
+                for peer, sb, se, rb, re in msgs[r]:
+                    sent[sb:se] += 1
+                    recv[rb:re] += 1
+                    one_row = RP * max(plans[r]["cnt"])
+                    if limit >= one_row:       # a message is whole rows: bounded up to the rounding to one row
+                        assert se - sb <= limit + one_row
+                assert (sent == 1).all() and (recv == 1).all()
+                # what r sends to `peer` in piece k is what `peer` expects from r in piece k
+                for peer in range(world):
+                    mine = [(se - sb) for p, sb, se, rb, re in msgs[r] if p == peer]
+                    theirs = [(re - rb) for p, sb, se, rb, re in msgs[peer] if p == r]
+                    assert mine == theirs
 
 
 def _halo_worker(rank, world, port, parts, ridxs, sizes, q):
