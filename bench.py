@@ -15,6 +15,13 @@ import os
 import sys
 import time
 
+# torch.distributed.run exports OMP_NUM_THREADS=1 to every rank; the (untimed) set-up computes the Legendre tables on
+# the host with OpenMP -- about 80 s on one thread at T1279 -- so give every rank its share of the cores.  Must happen
+# before any OpenMP runtime is loaded (the library, torch).
+_lws = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+if _lws > 1 and os.environ.get("OMP_NUM_THREADS", "1") == "1":
+    os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 1) // _lws))
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
