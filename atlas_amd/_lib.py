@@ -123,6 +123,10 @@ Trans_fourier_device = _sig("atlas_amd__Trans__fourier_device", C.c_int, c_void_
 Trans_nlat0 = _sig("atlas_amd__Trans__nlat0", C.c_int, c_void_p, c_void_p)
 Trans_legendre_flops = _sig("atlas_amd__Trans__legendre_flops", C.c_double, c_void_p, C.c_int)
 Trans_legendre_table_bytes = _sig("atlas_amd__Trans__legendre_table_bytes", C.c_int64, c_void_p)
+Trans_legendre_table_download = _sig("atlas_amd__Trans__legendre_table_download", C.c_int, c_void_p, c_void_p,
+                                     C.c_size_t)
+legendre_gen_host_selfcheck = _sig("atlas_amd__legendre_gen_host_selfcheck", C.c_int, c_void_p, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong))
 Trans_timings = _sig("atlas_amd__Trans__timings", C.c_int, c_void_p, c_void_p, C.c_int)
 Trans_set_profile = _sig("atlas_amd__Trans__set_profile", C.c_int, c_void_p, C.c_int)
 Trans_fft_phase_profile = _sig("atlas_amd__Trans__fft_phase_profile", C.c_int, c_void_p, C.c_int, c_void_p)

@@ -6,6 +6,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "../../include/atlas_amd.h"
 #include "capi_types.h"
@@ -177,6 +178,12 @@ atlas_amd_Trans* atlas_amd__Trans__new_config(const atlas_amd_Grid* grid, int tr
                 throw std::invalid_argument("shard must be 'm' (wavenumbers, exchange follows) or 'band' (latitude bands)");
             }
             cfg.by_band = kv.second == "band";
+        }
+        else if (kv.first == "tables") {
+            if (kv.second != "host" && kv.second != "device") {
+                throw std::invalid_argument("tables must be 'host' or 'device'");
+            }
+            cfg.device_tables = kv.second == "device" ? 1 : 0;
         }
         else if (kv.first == "type") {
             // atlas option::type: this library IS the "local" implementation (TransLocal.cc:57)
@@ -474,6 +481,11 @@ int atlas_amd__Trans__legendre_cache_export(const atlas_amd_Trans* t, void* buff
     t->impl->export_legendre_cache(buffer);
     AA_CATCH_INT
 }
+int atlas_amd__Trans__legendre_table_download(const atlas_amd_Trans* t, double* out, size_t size) {
+    AA_TRY
+    t->impl->download_legendre_table(out, size);
+    AA_CATCH_INT
+}
 int atlas_amd__Trans__fourier_row_pitch(const atlas_amd_Trans* t, int nb_fields) {
     return t->impl->fourier_row_pitch(nb_fields);
 }
@@ -561,6 +573,26 @@ int atlas_amd__legendre_reference_tables(const atlas_amd_Grid* grid, int truncat
     std::memset(leg_sym, 0, size_sym * sizeof(double));
     std::memset(leg_asym, 0, size_asym * sizeof(double));
     trans::compute_legendre_tables_reference_layout(geo, leg_sym, leg_asym);
+    AA_CATCH_INT
+}
+int atlas_amd__legendre_gen_host_selfcheck(const atlas_amd_Grid* grid, int truncation, int nparts, int part,
+                                           int by_band, long long* table_doubles, long long* mismatches) {
+    AA_TRY
+    if (nparts < 1 || part < 0 || part >= nparts) {
+        throw std::invalid_argument("legendre_gen_host_selfcheck: bad nparts / part");
+    }
+    trans::TransGeometry geo = trans::make_geometry(grid->g, truncation);
+    trans::LegendreWork work = trans::make_legendre_work(geo, nparts, part, by_band != 0);
+    const size_t n           = (size_t)work.table_doubles;
+    std::vector<double> a(n, 0.), b(n, 0.);
+    trans::compute_legendre_table_tiled(geo, work, a.data());
+    trans::compute_legendre_table_tiled_emulated(geo, work, b.data());
+    long long bad = 0;
+    for (size_t i = 0; i < n; ++i) {
+        bad += std::memcmp(&a[i], &b[i], sizeof(double)) != 0;
+    }
+    *table_doubles = (long long)n;
+    *mismatches    = bad;
     AA_CATCH_INT
 }
 int atlas_amd__fft_host_row(int n, const double* modes, int mmax, double* out) {

@@ -2,6 +2,8 @@
 // in the order the reference writes it.
 #include "legendre_host.h"
 
+#include "legendre_gen_core.h"
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -58,19 +60,14 @@ LegendreEvaluator::LegendreEvaluator(int trc): trc_(trc), tri_(size_t(trc + 2) *
     }
 }
 
-void LegendreEvaluator::evaluate(double lat, double* legpol, double* scratch) const {
-    const int trc   = trc_;
-    const size_t ld = size_t(trc) + 1;
-    double* vsin    = scratch;
-    double* vcos    = scratch + ld;
-    // 1. first two columns (:58-115)
-    const double zdlx1       = (M_PI_2 - lat);
-    double zdlx              = std::cos(zdlx1);
-    volatile double zdlsita  = std::sqrt(1. - zdlx * zdlx);
-    legpol[idxmn(trc, 0, 0)] = 1.;
-    for (int j = 1; j <= trc; j++) {
-        vsin[j] = std::sin(j * zdlx1);
-        vcos[j] = std::cos(j * zdlx1);
+void LegendreEvaluator::colatitude_terms(double lat, double* vsin, double* vcos, size_t stride, double& zdlx_out,
+                                         double& sint_out, double& zdl1sita_out) const {
+    const double zdlx1      = (M_PI_2 - lat);
+    double zdlx             = std::cos(zdlx1);
+    volatile double zdlsita = std::sqrt(1. - zdlx * zdlx);
+    for (int j = 1; j <= trc_; j++) {
+        vsin[size_t(j) * stride] = std::sin(j * zdlx1);
+        vcos[size_t(j) * stride] = std::cos(j * zdlx1);
     }
     double zdl1sita = 0.;
     if (std::abs(zdlsita) <= std::sqrt(std::numeric_limits<double>::epsilon())) {
@@ -80,6 +77,34 @@ void LegendreEvaluator::evaluate(double lat, double* legpol, double* scratch) co
     else {
         zdl1sita = 1. / zdlsita;
     }
+    zdlx_out     = zdlx;
+    sint_out     = zdlsita;
+    zdl1sita_out = zdl1sita;
+}
+
+void LegendreEvaluator::diagonal(double p11, double sint, double zdl1sita, double* diag, size_t stride) const {
+    const double zdls = zdl1sita * std::numeric_limits<double>::min();
+    double prev       = p11;
+    for (int jn = 2; jn <= trc_; ++jn) {
+        double v = prev * sint * diag_[jn];
+        if (std::abs(v) < zdls) {
+            v = 0.0;
+        }
+        diag[size_t(jn) * stride] = v;
+        prev                      = v;
+    }
+}
+
+void LegendreEvaluator::evaluate(double lat, double* legpol, double* scratch) const {
+    const int trc   = trc_;
+    const size_t ld = size_t(trc) + 1;
+    double* vsin    = scratch;
+    double* vcos    = scratch + ld;
+    // 1. first two columns (:58-115)
+    double zdlx, zdlsita_, zdl1sita;
+    colatitude_terms(lat, vsin, vcos, 1, zdlx, zdlsita_, zdl1sita);
+    const double zdlsita     = zdlsita_;
+    legpol[idxmn(trc, 0, 0)] = 1.;
     for (int jn = 2; jn <= trc; jn += 2) {
         const double* z = &zfn_[jn * ld];
         double zdlk     = 0.5 * z[0];
@@ -232,6 +257,75 @@ void compute_legendre_table_tiled(const TransGeometry& geo, const LegendreWork& 
                 }
                 tiled_store(geo, work, table, m, lo, j0 + nl - lo, ptrs);
             }
+        }
+    }
+}
+
+LegendreGenInputs prepare_legendre_gen(const TransGeometry& geo, const LegendreWork& work) {
+    LegendreGenInputs in;
+    in.trc       = geo.T + 1;
+    in.T         = geo.T;
+    in.nlats     = geo.nlatsLegR;
+    in.lat_pitch = (std::max(in.nlats, 1) + LG_TILE - 1) / LG_TILE * LG_TILE;
+    const LegendreEvaluator ev(in.trc);
+    in.zfn = ev.zfn();
+    in.sq1 = ev.sq1();
+    in.ca  = ev.ca();
+    in.cb  = ev.cb();
+    in.cc  = ev.cc();
+    const size_t pitch = size_t(in.lat_pitch), ld = size_t(in.trc) + 1;
+    in.vcos.assign(ld * pitch, 0.);
+    in.vsin.assign(ld * pitch, 0.);
+    in.diag.assign(ld * pitch, 0.);
+    in.zdlx.assign(pitch, 0.);
+    in.mstop.assign(pitch, -1);
+#pragma omp parallel for schedule(static)
+    for (int jlat = 0; jlat < in.nlats; ++jlat) {
+        double zdlx, sint, zdl1sita;
+        ev.colatitude_terms(geo.lats_leg[jlat], in.vsin.data() + jlat, in.vcos.data() + jlat, pitch, zdlx, sint,
+                            zdl1sita);
+        in.zdlx[jlat] = zdlx;
+        // P(1,1): the n = 1 term of the series (the kernel computes the same value into its column)
+        double p01, p11;
+        legendre_series_point(in.zfn.data() + ld, 1, in.sq1[1], in.vcos.data() + jlat, in.vsin.data() + jlat, pitch, p01,
+                              p11);
+        in.diag[pitch + jlat] = p11;
+        ev.diagonal(p11, sint, zdl1sita, in.diag.data() + jlat, pitch);
+        in.mstop[jlat] = geo.mmax_leg[jlat] < geo.T ? geo.mmax_leg[jlat] : geo.T;
+    }
+    in.nlat0           = geo.nlat0;
+    in.first_item_of_m = work.first_item_of_m;
+    in.item_p_off.resize(work.items_by_m.size());
+    in.item_kpad.resize(work.items_by_m.size());
+    for (size_t i = 0; i < work.items_by_m.size(); ++i) {
+        in.item_p_off[i] = work.items_by_m[i].p_off;
+        in.item_kpad[i]  = work.items_by_m[i].kpad;
+    }
+    return in;
+}
+
+void compute_legendre_table_tiled_emulated(const TransGeometry& geo, const LegendreWork& work, double* table) {
+    const LegendreGenInputs in = prepare_legendre_gen(geo, work);
+    std::vector<double> col01(in.col01_doubles(), 0.), rows(in.rows_doubles(), 0.);
+    LegendreGenParams g;
+    g.trc = in.trc, g.T = in.T, g.nlats = in.nlats, g.lat_pitch = in.lat_pitch;
+    g.zfn = in.zfn.data(), g.sq1 = in.sq1.data(), g.ca = in.ca.data(), g.cb = in.cb.data(), g.cc = in.cc.data();
+    g.vcos = in.vcos.data(), g.vsin = in.vsin.data(), g.diag = in.diag.data(), g.zdlx = in.zdlx.data();
+    g.mstop = in.mstop.data();
+    g.col01 = col01.data(), g.rows = rows.data(), g.table = table;
+    g.nlat0 = in.nlat0.data(), g.first_item_of_m = in.first_item_of_m.data();
+    g.item_p_off = in.item_p_off.data(), g.item_kpad = in.item_kpad.data();
+    // the two kernels of legendre_gen_kernel.hip, one loop iteration per device thread
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int jn = 0; jn <= in.trc; ++jn) {
+        for (int lat = 0; lat < in.nlats; ++lat) {
+            legendre_series_store(g, lat, jn);
+        }
+    }
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+    for (int lat = 0; lat < in.nlats; ++lat) {
+        for (int parity = 0; parity < 2; ++parity) {
+            legendre_chain(g, lat, parity);
         }
     }
 }

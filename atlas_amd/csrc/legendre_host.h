@@ -21,6 +21,18 @@ public:
     static size_t idxmn(int trc, int m, int n) { return size_t(2 * trc + 3 - m) * size_t(m) / 2 + size_t(n - m); }
     // legpol: packed triangle of size triangle_size(); scratch: 2*(trc+1) doubles
     void evaluate(double lat_rad, double* legpol, double* scratch) const;
+    // the latitude-dependent scalars and cos/sin tables at the head of compute_legendre_polynomials_lat
+    // (LegendrePolynomials.cc:58-83): vsin[j*stride], vcos[j*stride] for j = 1..trc; zdlx = sin(lat) (1 at a pole),
+    // sint = cos(lat) (0 at a pole), zdl1sita = 1/sint (0 at a pole)
+    void colatitude_terms(double lat_rad, double* vsin, double* vcos, size_t stride, double& zdlx, double& sint,
+                          double& zdl1sita) const;
+    // P(m,m) for m = 2..trc from P(1,1) (:122-130), written to diag[m*stride]
+    void diagonal(double p11, double sint, double zdl1sita, double* diag, size_t stride) const;
+    const std::vector<double>& zfn() const { return zfn_; }
+    const std::vector<double>& sq1() const { return sq1_; }
+    const std::vector<double>& ca() const { return ca_; }
+    const std::vector<double>& cb() const { return cb_; }
+    const std::vector<double>& cc() const { return cc_; }
 
 private:
     int trc_;
@@ -37,6 +49,21 @@ void compute_legendre_tables_reference_layout(const TransGeometry& geo, double* 
 
 // Tile-blocked device layout (see trans_plan.h / DESIGN.md): item block = [parity][kpad][LEG_BN].
 void compute_legendre_table_tiled(const TransGeometry& geo, const LegendreWork& work, double* table);
+
+// Inputs of the device generation of the tiled table (legendre_gen_core.h): everything with sqrt / division / sin /
+// cos, prepared on the host (O(T^2)); params() points at these host arrays.
+struct LegendreGenParams;
+struct LegendreGenInputs {
+    int trc = 0, T = 0, nlats = 0, lat_pitch = 0;
+    std::vector<double> zfn, sq1, ca, cb, cc, vcos, vsin, diag, zdlx;
+    std::vector<int> mstop, nlat0, first_item_of_m, item_kpad;
+    std::vector<long long> item_p_off;
+    size_t col01_doubles() const { return size_t(2) * size_t(trc + 1) * size_t(lat_pitch); }
+    size_t rows_doubles() const { return size_t(4) * size_t(trc + 1) * size_t(lat_pitch); }
+};
+LegendreGenInputs prepare_legendre_gen(const TransGeometry& geo, const LegendreWork& work);
+// host run of the device code (legendre_gen_core.h): must reproduce compute_legendre_table_tiled bit for bit
+void compute_legendre_table_tiled_emulated(const TransGeometry& geo, const LegendreWork& work, double* table);
 
 // reference layout -> tiled layout (used when importing a Legendre cache blob)
 void retile_legendre_tables(const TransGeometry& geo, const LegendreWork& work, const double* leg_sym,

@@ -37,6 +37,8 @@ struct TransConfig {
                                            // crop of the global grid, TransLocal.cc:394-470 "nested" case)
     bool by_band               = false;  // nparts > 1: false = wavenumber sharding (all-to-all transposition follows),
                                          // true = latitude-band sharding of both stages (no exchange, 2x Legendre work)
+    int device_tables          = -1;  // Legendre table computed on the device (1) or on the host and uploaded (0);
+                                      // -1: environment variable ATLAS_AMD_TABLES=device|host, default host
 };
 
 struct StageTimings {
@@ -97,6 +99,8 @@ public:
     // Legendre cache, byte-compatible with TransLocal's write_legendre file (TransLocal.cc:638-647)
     size_t legendre_cache_bytes() const { return (geo_.size_sym() + geo_.size_asym()) * sizeof(double); }
     void export_legendre_cache(void* buffer) const;
+    void download_legendre_table(double* out, size_t size_doubles) const;  // test hook
+    bool tables_on_device() const { return tables_on_device_; }
 
     StageTimings timings();
     void reset_timings() {
@@ -125,6 +129,8 @@ private:
     int m_cnt_          = 0;
     bool profile_       = false;
     bool use_ct_        = true;  // ATLAS_AMD_FFT_GENERIC=1 forces the generic FFT kernel (A/B comparisons)
+    bool tables_on_device_ = false;  // the Legendre table was generated by legendre_gen_kernel.hip
+    void generate_table_on_device();
     hipStream_t stream_ = nullptr;
     hipStream_t stream2_ = nullptr;            // Fourier stage of the pipelined transform
     hipStream_t ev_stream_ = nullptr;

@@ -11,11 +11,14 @@
 #include <stdexcept>
 
 #include "device_structs.h"
+#include "legendre_gen_core.h"
+#include "legendre_host.h"
 
 namespace atlas_amd {
 namespace trans {
 
 hipError_t launch_legendre(const LegendreParams& p, int nitems, int chunk0, int nrun, hipStream_t stream);
+hipError_t launch_legendre_gen(const LegendreGenParams& g, hipStream_t stream);
 void legendre_tiling(int nf, int& rtw, int& nrg, int& nchunks);
 hipError_t launch_legendre_f32(const LegendreParamsF32& p, int nitems, int chunk0, int nrun, hipStream_t stream);
 hipError_t launch_convert_f64_f32(const double* src, float* dst, size_t n, hipStream_t stream);
@@ -157,9 +160,61 @@ void Trans::synchronize() const {
     HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
+// Legendre table computed on the device (legendre_gen_kernel.hip) from O(T^2) host-prepared inputs: no host
+// generation of the O(T^2 N) table, no multi-GB upload
+void Trans::generate_table_on_device() {
+    const LegendreGenInputs in = prepare_legendre_gen(geo_, work_);
+    const size_t n             = (size_t)work_.table_doubles;
+    HIP_CHECK(hipMalloc((void**)&d_P_, std::max<size_t>(n, 1) * sizeof(double)));
+    HIP_CHECK(hipMemsetAsync(d_P_, 0, std::max<size_t>(n, 1) * sizeof(double), stream_));  // K / latitude padding
+    std::vector<void*> tmp;
+    auto up = [&](const auto& v) {
+        auto* d = dev_upload(v.data(), v.size());
+        tmp.push_back((void*)d);
+        return d;
+    };
+    LegendreGenParams g;
+    g.trc = in.trc, g.T = in.T, g.nlats = in.nlats, g.lat_pitch = in.lat_pitch;
+    g.zfn = up(in.zfn), g.sq1 = up(in.sq1), g.ca = up(in.ca), g.cb = up(in.cb), g.cc = up(in.cc);
+    g.vcos = up(in.vcos), g.vsin = up(in.vsin), g.diag = up(in.diag), g.zdlx = up(in.zdlx);
+    g.mstop = up(in.mstop);
+    g.nlat0 = up(in.nlat0), g.first_item_of_m = up(in.first_item_of_m);
+    g.item_p_off = up(in.item_p_off), g.item_kpad = up(in.item_kpad);
+    double *col01 = nullptr, *rows = nullptr;
+    HIP_CHECK(hipMalloc((void**)&col01, in.col01_doubles() * sizeof(double)));
+    tmp.push_back(col01);
+    HIP_CHECK(hipMalloc((void**)&rows, in.rows_doubles() * sizeof(double)));
+    tmp.push_back(rows);
+    g.col01 = col01, g.rows = rows, g.table = d_P_;
+    HIP_CHECK(launch_legendre_gen(g, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    for (void* d : tmp) {
+        (void)hipFree(d);
+    }
+    tables_on_device_ = true;
+}
+
+void Trans::download_legendre_table(double* out, size_t size_doubles) const {
+    if (size_doubles != (size_t)work_.table_doubles) {
+        throw std::invalid_argument("legendre_table_download: wrong size");
+    }
+    synchronize();
+    if (size_doubles) {
+        HIP_CHECK(hipMemcpy(out, d_P_, size_doubles * sizeof(double), hipMemcpyDeviceToHost));
+    }
+}
+
 void Trans::upload() {
     // ---- Legendre table (tile-blocked), owned wavenumbers only ----
-    {
+    bool on_device = cfg_.device_tables == 1;
+    if (cfg_.device_tables < 0) {
+        const char* e = std::getenv("ATLAS_AMD_TABLES");
+        on_device     = e && std::string(e) == "device";
+    }
+    if (on_device && !cfg_.legendre_cache) {
+        generate_table_on_device();
+    }
+    else {
         const size_t n = (size_t)work_.table_doubles;
         double* host   = (double*)calloc(std::max<size_t>(n, 1), sizeof(double));
         if (!host) {

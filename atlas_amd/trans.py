@@ -39,13 +39,16 @@ def _ptr(a, n=None, name="array", writable=False):
 class Trans:
     """trans::Trans(grid, truncation, config) with option::type("local") semantics, running on an MI355X."""
 
-    def __init__(self, grid, truncation, profile=False, nparts=1, part=0, legendre_cache=None, shard="m", rows=None):
+    def __init__(self, grid, truncation, profile=False, nparts=1, part=0, legendre_cache=None, shard="m", rows=None,
+                 tables=None):
         if isinstance(grid, str):
             grid = StructuredGrid(name=grid)
         self.grid = grid
         # shard (nparts > 1): "m" = this device owns wavenumbers m % nparts == part (stage API + exchange),
         #                      "band" = it owns latitude band `part` of both stages (plain invtrans on device arrays)
         cfg = f"profile={int(bool(profile))};nparts={int(nparts)};part={int(part)};shard={shard}"
+        if tables is not None:  # "host" | "device": where the Legendre table is computed (default: ATLAS_AMD_TABLES)
+            cfg += f";tables={tables}"
         if rows is not None:   # (j0, j1): zonal-band crop of the grid (regional domain that keeps whole latitude rows)
             cfg += f";rows={int(rows[0])}:{int(rows[1])}"
         cache_ptr, cache_size = None, 0
@@ -258,6 +261,12 @@ class Trans:
 
     def legendre_table_bytes(self):
         return _lib.Trans_legendre_table_bytes(self._h)
+
+    def legendre_table(self):
+        """the tile-blocked Legendre table as it sits in device memory (test hook)"""
+        out = np.empty(self.legendre_table_bytes() // 8, dtype=np.float64)
+        _lib.check(_lib.Trans_legendre_table_download(self._h, out.ctypes.data, out.size))
+        return out
 
     def legendre_device(self, truncation_in, nf, spectra, fourier):
         _lib.check(_lib.Trans_legendre_device(self._h, truncation_in, nf, _ptr(spectra), _ptr(fourier)))

@@ -72,6 +72,9 @@ atlas_amd_Trans* atlas_amd__Trans__new(const atlas_amd_Grid* grid, int truncatio
  *                        regional case of TransLocal (TransLocal.cc:394-470) for domains that keep whole rows;
  *                        nb_gridpoints and the output arrays then cover these rows only
  *   type=local|mi355x    accepted for atlas option::type compatibility
+ *   tables=host|device   where the Legendre table is computed when no cache is given: on the host (OpenMP, then
+ *                        uploaded) or on the device from O(T^2) host-prepared inputs (bit-identical; default: the
+ *                        environment variable ATLAS_AMD_TABLES, else host)
  * legendre_cache / size: optional Legendre cache blob in TransLocal's file layout (TransLocal.cc:608-614), or NULL */
 atlas_amd_Trans* atlas_amd__Trans__new_config(const atlas_amd_Grid* grid, int truncation, const char* config,
                                               const void* legendre_cache, size_t legendre_cache_size);
@@ -179,6 +182,10 @@ int atlas_amd__Trans__synchronize(atlas_amd_Trans* t);
 size_t atlas_amd__Trans__legendre_cache_size(const atlas_amd_Trans* t);
 int atlas_amd__Trans__legendre_cache_export(const atlas_amd_Trans* t, void* buffer, size_t size);
 
+/* the tile-blocked Legendre table as it sits in device memory (legendre_table_bytes / 8 doubles): test hook for the
+ * device generation of the table (config key tables=device|host) */
+int atlas_amd__Trans__legendre_table_download(const atlas_amd_Trans* t, double* out, size_t size_doubles);
+
 /* the two stages separately: multi-GPU drivers and stage-level parity tests.
  * Fourier intermediate layout: F[(lat*m_cnt + m/nparts)*RP + 2*fld + imag], RP = fourier_row_pitch */
 int atlas_amd__Trans__fourier_row_pitch(const atlas_amd_Trans* t, int nb_fields);
@@ -209,6 +216,11 @@ int atlas_amd__legendre_reference_tables(const atlas_amd_Grid* grid, int truncat
                                          size_t size_sym, double* leg_asym, size_t size_asym);
 int atlas_amd__legendre_reference_sizes(const atlas_amd_Grid* grid, int truncation, size_t* size_sym,
                                         size_t* size_asym);
+/* host run of the device generator of the Legendre table (legendre_gen_core.h, the code of legendre_gen_kernel.hip)
+ * against the host generator, for the decomposition (nparts, part, by_band): number of table entries that differ in
+ * any bit.  Test hook only. */
+int atlas_amd__legendre_gen_host_selfcheck(const atlas_amd_Grid* grid, int truncation, int nparts, int part,
+                                           int by_band, long long* table_doubles, long long* mismatches);
 /* run ONE row of the c2r transform on the host with the kernel's own phase code (fft_core.h); modes: n/2+1
  * interleaved complex values; out: n reals.  Test hook only -- the product never computes on the CPU. */
 int atlas_amd__fft_host_row(int n, const double* modes, int mmax, double* out);

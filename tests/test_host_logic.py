@@ -99,6 +99,20 @@ def test_legendre_cache_is_grid_independent():
     assert blobs[0] == blobs[1]
 
 
+@pytest.mark.parametrize("gridname,T,nparts,part,by_band", [("O32", 31, 1, 0, 0), ("F32", 31, 1, 0, 0),
+                                                            ("O48", 95, 1, 0, 0), ("O64", 63, 3, 1, 0),
+                                                            ("O64", 63, 4, 2, 1), ("O160", 159, 8, 7, 1),
+                                                            ("F64", 20, 1, 0, 0)])
+def test_device_table_generator_code_matches_host_generator(gridname, T, nparts, part, by_band):
+    """legendre_gen_core.h (the code of the device kernels that build the Legendre table, tables=device) run on the host:
+    every entry of the tile-blocked table must equal the host generator's (LegendrePolynomials.cc restated in
+    legendre_host.cpp) in every bit, for the whole table and for the sharded decompositions"""
+    g = atlas_amd.Grid(gridname)
+    n, bad = C.c_longlong(), C.c_longlong()
+    _lib.check(_lib.legendre_gen_host_selfcheck(g._h, T, nparts, part, by_band, C.byref(n), C.byref(bad)))
+    assert n.value > 0 and bad.value == 0
+
+
 ROW_LENGTHS = [20, 24, 28, 32, 36, 44, 52, 60, 64, 68, 76, 100, 128, 148, 192, 256, 260, 300, 404, 500, 1004, 1280,
                2048, 2560, 4 * 1283, 5120, 5136, 21, 35, 45,
                # h = n/2 in the specialised family F*2^K: the direct (no Bluestein) specialised phases
