@@ -63,6 +63,26 @@ def cpu_baseline(sample_fields=8):
                       f"built beforehand); scaled by {NLEV}/{sample_fields}"}
 
 
+def cpu_baseline_blas(sample_fields=8):
+    """second CPU baseline (opt-in, --cpu-baseline-blas): the same algorithm with library kernels, BLAS dgemm (numpy) and
+    pocketfft (scipy.fft) -- the reference's eckit "lapack" + pocketfft configuration (oracle/translocal_blas.py)"""
+    import numpy as np
+    import atlas_amd
+    import oracle
+    from oracle.translocal_blas import invtrans_blas
+    from helpers import red_spectra
+    g = atlas_amd.Grid(GRID)
+    op = oracle.OraclePlan(TRUNC, g.nx(), g.y(), with_tables=True)
+    sp = red_spectra(TRUNC, sample_fields)
+    invtrans_blas(op, 1, np.ascontiguousarray(sp.reshape(-1, sample_fields)[:, :1]).reshape(-1))   # warm-up
+    t0 = time.perf_counter()
+    invtrans_blas(op, sample_fields, sp)
+    dt = time.perf_counter() - t0
+    return {"value": (sample_fields / NLEV) / dt, "unit": "transforms/s", "cores": os.cpu_count() or 1, "kind": "port",
+            "sample": f"{sample_fields} of {NLEV} levels in {dt:.2f} s, numpy/OpenBLAS dgemm + scipy pocketfft "
+                      f"(oracle/translocal_blas.py); scaled by {NLEV}/{sample_fields}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,6 +90,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-fields", type=int, default=24)
+    ap.add_argument("--cpu-baseline-blas", action="store_true",
+                    help="also time the BLAS dgemm + pocketfft variant of the CPU restatement (cpu_baseline_blas)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the distributed driver even with one rank")
     ap.add_argument("--dist-mode", default="auto", choices=["auto", "alltoall", "band"],
                     help="N > 1: wavenumber sharding + RCCL all-to-all, or exchange-free latitude-band sharding "
@@ -217,6 +239,8 @@ def main():
             out["multi_gpu_crosscheck"] = crosscheck
         if world == 1 and not use_dist and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_fields)
+            if args.cpu_baseline_blas:
+                out["cpu_baseline_blas"] = cpu_baseline_blas(args.cpu_sample_fields)
     if use_dist:
         import torch.distributed as dist
         dist.barrier()

@@ -75,6 +75,17 @@ def test_oracle_fft_equals_direct_on_transform():
     assert compute_rms(op.invtrans(3, sp, use_fft=True), op.invtrans(3, sp, use_fft=False)) < 1e-15
 
 
+@pytest.mark.parametrize("gridname,T,nf", [("O32", 31, 3), ("F32", 31, 2), ("O48", 95, 2), ("O160", 159, 4)])
+def test_blas_pocketfft_variant_equals_plain_oracle(gridname, T, nf):
+    """oracle/translocal_blas.py (BLAS dgemm + pocketfft, the tuned CPU baseline of bench.py) against the plain
+    restatement: same algorithm and tables, only the summation order of the two library kernels differs"""
+    from oracle.translocal_blas import invtrans_blas
+    g, nx, lat = grid_arrays(gridname)
+    op = oracle.OraclePlan(T, nx, lat)
+    sp = red_spectra(T, nf, seed=4)
+    assert compute_rms(invtrans_blas(op, nf, sp), op.invtrans(nf, sp, use_fft=True)) < 1e-15
+
+
 def test_oracle_rows_equals_table_path():
     g, nx, lat = grid_arrays("O32")
     T, nf = 31, 4
