@@ -59,6 +59,29 @@ def _describe(field):
         [s // field.itemsize for s in field.strides], False, field.itemsize
 
 
+def exchange_packed(outbuf, inbuf, out_cnt, out_dsp, in_cnt, in_dsp, var_size, group=None):
+    """the communication step of HaloExchange::execute (HaloExchange.h:191-215: iReceive / iSend per peer with
+    counts and displacements scaled by var_size, :318-331) on packed buffers: one batched send/recv per peer over
+    torch.distributed (RCCL on device tensors; any backend in tests), the rank's own part (periodic / pole duplicates)
+    as a local copy"""
+    import torch.distributed as dist
+    me, ops = dist.get_rank(group), []
+    for peer in range(len(out_cnt)):
+        o = outbuf[int(out_dsp[peer]) * var_size:int(out_dsp[peer] + out_cnt[peer]) * var_size]
+        i = inbuf[int(in_dsp[peer]) * var_size:int(in_dsp[peer] + in_cnt[peer]) * var_size]
+        if peer == me:
+            i.copy_(o)
+            continue
+        g = dist.get_global_rank(group, peer) if group is not None else peer
+        if i.numel():
+            ops.append(dist.P2POp(dist.irecv, i, g, group=group))
+        if o.numel():
+            ops.append(dist.P2POp(dist.isend, o, g, group=group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
 class HaloExchange:
     def __init__(self, name=""):
         self.name = name
@@ -221,21 +244,7 @@ class HaloExchange:
         outbuf = torch.empty(int(out_cnt.sum()) * vs, dtype=field.dtype, device=field.device)
         inbuf = torch.empty(int(in_cnt.sum()) * vs, dtype=field.dtype, device=field.device)
         (self.pack_adjoint if adjoint else self.pack)(field, outbuf, parallel_dim)
-        me, ops = dist.get_rank(self._group), []
-        for peer in range(self.nproc()):
-            o = outbuf[int(out_dsp[peer]) * vs:int(out_dsp[peer] + out_cnt[peer]) * vs]
-            i = inbuf[int(in_dsp[peer]) * vs:int(in_dsp[peer] + in_cnt[peer]) * vs]
-            if peer == me:
-                i.copy_(o)
-                continue
-            g = dist.get_global_rank(self._group, peer) if self._group is not None else peer
-            if i.numel():
-                ops.append(dist.P2POp(dist.irecv, i, g, group=self._group))
-            if o.numel():
-                ops.append(dist.P2POp(dist.isend, o, g, group=self._group))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        exchange_packed(outbuf, inbuf, out_cnt, out_dsp, in_cnt, in_dsp, vs, self._group)
         if adjoint:
             self.unpack_adjoint(inbuf, field, parallel_dim)
             self.zero_halos(field, parallel_dim)

@@ -171,6 +171,56 @@ def test_halo_setup_over_gloo_matches_oracle():
             assert res[r][k] == getattr(ranks[r], k).tolist(), (r, k)
 
 
+def _halo_exchange_worker(rank, world, port, gridname, halo, nlev, q):
+    sys.path.insert(0, ROOT)
+    import atlas_amd
+    from atlas_amd.functionspace import StructuredColumns
+    from atlas_amd.parallel import HaloExchange, exchange_packed
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    g = atlas_amd.Grid(gridname)
+    fs = StructuredColumns(g, halo=halo, nparts=world, part=rank)
+    hx = HaloExchange()
+    # StructuredColumns.cc:145-148: setup(partition, remote_index, base 0, sizeHalo, halo_begin = sizeOwned)
+    hx.setup(fs.partition(), fs.remote_index(), 0, fs.sizeHalo(), halo_begin=fs.sizeOwned(), comm=True)
+    p = hx.plan()
+    glb = fs.global_index().astype(np.float64)
+    field = np.full((fs.sizeHalo(), nlev), -1.0)
+    field[:fs.sizeOwned()] = glb[:fs.sizeOwned(), None] * 10.0 + np.arange(nlev)[None, :]
+    # pack / unpack of the packed-buffer layout (HaloExchange.h:318-331) in numpy -- the device kernels are tested on
+    # the GPU; this test is about the communication step between real processes
+    sendbuf = torch.from_numpy(np.ascontiguousarray(field[p["sendmap"]]).reshape(-1))
+    recvbuf = torch.full((int(p["recvcounts"].sum()) * nlev,), -2.0, dtype=torch.float64)
+    exchange_packed(sendbuf, recvbuf, p["sendcounts"], p["senddispls"], p["recvcounts"], p["recvdispls"], nlev)
+    field[p["recvmap"]] = recvbuf.numpy().reshape(-1, nlev)
+    ok = bool(np.array_equal(field, glb[:, None] * 10.0 + np.arange(nlev)[None, :]))
+    # adjoint direction: counts swapped (HaloExchange.h:258-279) -- every owner receives one contribution per ghost copy
+    back = torch.full((int(p["sendcounts"].sum()) * nlev,), -3.0, dtype=torch.float64)
+    exchange_packed(recvbuf, back, p["recvcounts"], p["recvdispls"], p["sendcounts"], p["senddispls"], nlev)
+    ok = ok and bool(np.array_equal(back.numpy().reshape(-1, nlev), field[p["sendmap"]]))
+    q.put((rank, ok, int(p["recvcounts"].sum()), int((np.asarray(p["sendcounts"]) > 0).sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,gridname,halo", [(2, "O16", 1), (3, "O16", 2), (4, "F16", 1)])
+def test_halo_exchange_communication_step_over_gloo(world, gridname, halo):
+    """StructuredColumns partitions (Atlas equal_bands) in `world` real processes: distributed HaloExchange.setup, then
+    the send/recv step of execute (atlas_amd.parallel.exchange_packed) on packed buffers; afterwards every halo point
+    must hold the value of the point it mirrors (test_structuredcolumns_haloexchange.cc:38-60 in spirit)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_halo_exchange_worker, args=(r, world, port, gridname, halo, 3, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok, _, _ in res), res
+    assert all(nrecv > 0 for _, _, nrecv, _ in res)
+
+
 def test_latitude_bands_follow_bands_distribution_rule():
     # product bands (C++: trans_plan.cpp latitude_bands) are exposed through a Trans object -> GPU only; here the
     # pure rule: band of a row = BandsDistribution partition of the row's first point
