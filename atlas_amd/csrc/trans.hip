@@ -167,7 +167,15 @@ void Trans::generate_table_on_device() {
     const size_t n             = (size_t)work_.table_doubles;
     HIP_CHECK(hipMalloc((void**)&d_P_, std::max<size_t>(n, 1) * sizeof(double)));
     HIP_CHECK(hipMemsetAsync(d_P_, 0, std::max<size_t>(n, 1) * sizeof(double), stream_));  // K / latitude padding
-    std::vector<void*> tmp;
+    struct Scratch {  // device buffers that only live for the generation, released on every exit path
+        std::vector<void*> ptrs;
+        void push_back(void* p) { ptrs.push_back(p); }
+        ~Scratch() {
+            for (void* p : ptrs) {
+                (void)hipFree(p);
+            }
+        }
+    } tmp;
     auto up = [&](const auto& v) {
         auto* d = dev_upload(v.data(), v.size());
         tmp.push_back((void*)d);
@@ -188,9 +196,6 @@ void Trans::generate_table_on_device() {
     g.col01 = col01, g.rows = rows, g.table = d_P_;
     HIP_CHECK(launch_legendre_gen(g, stream_));
     HIP_CHECK(hipStreamSynchronize(stream_));
-    for (void* d : tmp) {
-        (void)hipFree(d);
-    }
     tables_on_device_ = true;
 }
 
