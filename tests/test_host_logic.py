@@ -137,6 +137,31 @@ def test_fft_phase_code_against_pocketfft(n):
         assert compute_rms(out, ref) < 2e-15, (n, mmax)
 
 
+@pytest.mark.parametrize("N", [1280, 640])
+def test_fft_phase_code_on_every_row_length_of_the_octahedral_grid(N):
+    """every distinct row length of O<N> (n = 20 + 4j: 4 % direct, 96 % Bluestein at N = 1280) through the host run of
+    the kernel's phase code, with the row's own Fourier truncation as mmax, against pocketfft"""
+    g = atlas_amd.Grid(f"O{N}")
+    T = N - 1
+    rng = np.random.default_rng(N)
+    nx, y = g.nx(), g.y()
+    worst = 0.0
+    for j in range(N):
+        n = int(nx[j])
+        nc = n // 2 + 1
+        mmax = _lib.fourier_truncation(T, n, g.nxmax(), 2 * N, math.radians(y[j]), 0)
+        assert 0 <= mmax <= min(T, nc - 1)
+        x = rng.standard_normal(nc) + 1j * rng.standard_normal(nc)
+        x[mmax + 1:] = 0
+        out = np.zeros(n)
+        _lib.check(_lib.fft_host_row(n, np.ascontiguousarray(x).ctypes.data, mmax, out.ctypes.data))
+        xx = x.copy()
+        xx[0] = xx[0].real
+        xx[-1] = xx[-1].real
+        worst = max(worst, compute_rms(out, np.fft.irfft(xx, n) * n))
+    assert worst < 2e-15, worst
+
+
 def test_not_implemented_entry_points_behave_like_translocal():
     # TransLocal: dirtrans / adjoints are ATLAS_NOTIMPLEMENTED (TransLocal.cc:848-857,899-927,1599-1685)
     assert _lib.Trans_dirtrans_scalar(None, 1, None, None) != 0
