@@ -5,9 +5,13 @@ one such transform per GPU with spectra and grid-point arrays resident in HBM.
     python bench.py --gpus N --steps K --warmup W
 N = 1: single MI355X (the whole transform on one device).
 N > 1: launched by torch.distributed.run, one rank per GPU; every step processes N transforms (weak scaling), each
-       transform distributed over all N GPUs: Legendre stage sharded by zonal wavenumber, RCCL all-to-all of the
-       Fourier intermediate (m -> latitude-band transpose), Fourier stage on the local latitude band
-       (atlas_amd/dist.py).
+       transform distributed over all N GPUs and returned in Atlas's latitude bands (atlas_amd/dist.py):
+       N = 8 : Legendre stage sharded by zonal wavenumber, RCCL all-to-all of the Fourier intermediate (m ->
+               latitude-band transpose) pipelined against the neighbouring transforms, Fourier stage on the local band;
+               after the timed region one transform is re-run with the other decomposition and compared bit for bit
+               ("multi_gpu_crosscheck");
+       N < 8 : both stages on the local latitude band, no exchange (the transposition would be bound by the one or
+               three xGMI links between 2 or 4 GPUs); --dist-mode overrides.
 Prints ONE JSON line (rank 0)."""
 import argparse
 import json
