@@ -163,6 +163,21 @@ StructuredColumns::StructuredColumns(const grid::StructuredGrid& g, const Struct
         if (owned == 0) {
             throw std::invalid_argument("StructuredColumns: partition owns no points");
         }
+        // The construction below (like the reference's, StructuredColumns_setup.cc:125-226) describes the owned region
+        // by one row range and one i-range per row: every row of [j_begin, j_end) must hold owned points and they must
+        // be contiguous.  Reject anything else instead of building halos around empty rows.
+        int64_t in_ranges = 0;
+        for (int j = j_begin_; j < j_end_; ++j) {
+            if (i_end_[j] <= i_begin_[j]) {
+                throw std::invalid_argument("StructuredColumns: the rows a partition owns must be contiguous (row " +
+                                            std::to_string(j) + " inside its row range holds none of its points)");
+            }
+            in_ranges += i_end_[j] - i_begin_[j];
+        }
+        if (in_ranges != owned) {
+            throw std::invalid_argument(
+                "StructuredColumns: the points a partition owns in one row must form one contiguous i-range");
+        }
     }
     size_owned_   = owned;
     j_begin_halo_ = j_begin_ - halo;

@@ -118,6 +118,11 @@ class StructuredColumnsOracle:
                         self.i_end[j] = max(self.i_end[j], i + 1)
                         owned += 1
                     c += 1
+            # the reference describes the owned region by one row range and one i-range per row (:125-226); anything
+            # else makes it build halos around empty rows -- rejected here as in the product
+            if owned == 0 or any(self.i_end[j] <= self.i_begin[j] for j in range(self.j_begin, self.j_end)) or \
+                    sum(self.i_end[j] - self.i_begin[j] for j in range(self.j_begin, self.j_end)) != owned:
+                raise ValueError("the points of a partition must form one row range with one i-range per row")
         self.size_owned = owned
         self.j_begin_halo, self.j_end_halo = self.j_begin - halo, self.j_end + halo
         ibh, ieh = {}, {}

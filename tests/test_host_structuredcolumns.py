@@ -122,6 +122,25 @@ def test_explicit_distribution_matches_oracle():
         StructuredColumns(g, halo=1, nparts=nparts, part=0, distribution=dist[:-1])
 
 
+def test_distributions_the_construction_cannot_describe_are_rejected():
+    """the owned region is one row range with one i-range per row (StructuredColumns_setup.cc:125-226): a part with two
+    separate row ranges, or with a hole inside a row, is refused (product and oracle) instead of building halos around
+    empty rows"""
+    g = atlas_amd.Grid("O16")
+    off = np.concatenate([[0], np.cumsum(g.nx())])
+    two_ranges = np.zeros(g.size(), dtype=np.int32)
+    two_ranges[off[4]:off[28]] = 1                       # part 0: rows 0-3 and 28-31
+    hole = np.zeros(g.size(), dtype=np.int32)
+    hole[off[10] + 5:off[10] + 9] = 1                    # part 0: a hole in row 10
+    for dist in (two_ranges, hole):
+        with pytest.raises(Exception, match="contiguous"):
+            StructuredColumns(g, halo=1, nparts=2, part=0, distribution=dist)
+        with pytest.raises(ValueError):
+            StructuredColumnsOracle(g.nx(), g.y(), halo=1, nparts=2, part=0, distribution=dist)
+        fs = StructuredColumns(g, halo=1, nparts=2, part=1, distribution=dist)     # the other part is fine
+        assert fs.sizeOwned() == int((dist == 1).sum())
+
+
 def test_equal_regions_partitioner_goldens_and_structuredcolumns():
     """eq_caps / EqualRegionsPartitioner against the reference's expected values (src/tests/mesh/test_rgg.cc:103-165), and
     StructuredColumns built on its output against the oracle (explicit grid::Distribution)."""
