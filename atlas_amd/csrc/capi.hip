@@ -107,6 +107,15 @@ atlas_amd_Grid* atlas_amd__Grid__new_structured(int ny, const int nx[], const do
     if (ny <= 0 || !nx || !lat_deg) {
         throw std::invalid_argument("Grid__new_structured: bad arguments");
     }
+    for (int j = 0; j < ny; ++j) {
+        if (nx[j] < 1) {
+            throw std::invalid_argument("Grid__new_structured: every latitude needs at least one point");
+        }
+        if (!(lat_deg[j] <= 90. && lat_deg[j] >= -90.) || (j > 0 && !(lat_deg[j] < lat_deg[j - 1]))) {
+            throw std::invalid_argument(
+                "Grid__new_structured: latitudes must lie in [-90, 90] and decrease strictly (north to south)");
+        }
+    }
     grid::StructuredGrid g;
     g.nx.assign(nx, nx + ny);
     g.y.assign(lat_deg, lat_deg + ny);
@@ -143,6 +152,9 @@ int atlas_amd__Grid__y(const atlas_amd_Grid* g, double y_out[]) {
 }
 int atlas_amd__gaussian_latitudes_npole_spole(int N, double lats_out[]) {
     AA_TRY
+    if (N < 1 || N > grid::kMaxGaussianN || !lats_out) {
+        throw std::invalid_argument("gaussian_latitudes_npole_spole: N out of range or NULL output");
+    }
     grid::gaussian_latitudes_npole_spole(N, lats_out);
     AA_CATCH_INT
 }
@@ -597,12 +609,18 @@ int atlas_amd__legendre_gen_host_selfcheck(const atlas_amd_Grid* grid, int trunc
 }
 int atlas_amd__fft_host_row(int n, const double* modes, int mmax, double* out) {
     AA_TRY
+    if (n < 1 || !modes || !out) {
+        throw std::invalid_argument("fft_host_row: n >= 1 and non-null arrays are required");
+    }
     fft::FftPlanSet ps = fft::make_fft_plans({n});
     fft::host_execute_row(ps, 0, reinterpret_cast<const fft::cplx*>(modes), mmax, out);
     AA_CATCH_INT
 }
 int atlas_amd__fft_host_row_generic(int n, const double* modes, int mmax, double* out) {
     AA_TRY
+    if (n < 1 || !modes || !out) {
+        throw std::invalid_argument("fft_host_row_generic: n >= 1 and non-null arrays are required");
+    }
     fft::FftPlanSet ps = fft::make_fft_plans({n}, false);
     fft::host_execute_row(ps, 0, reinterpret_cast<const fft::cplx*>(modes), mmax, out, 256, false);
     AA_CATCH_INT

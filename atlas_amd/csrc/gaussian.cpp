@@ -205,6 +205,9 @@ StructuredGrid make_gaussian_grid(const std::string& name) {
     catch (...) {
         N = 0;
     }
+    if (N > kMaxGaussianN) {
+        throw std::invalid_argument("Gaussian number too large (max " + std::to_string(kMaxGaussianN) + "): " + name);
+    }
     if (N <= 0) {
         throw std::invalid_argument("cannot parse grid name: " + name);
     }

@@ -30,6 +30,10 @@ struct StructuredGrid {
     double x(int i, int j) const { return 0. + (double)i * (360. / (double)nx[j]); }
 };
 
+// largest Gaussian number accepted by name (the reference tabulates up to N8000; 16000 leaves room for TCo15999 and
+// keeps the Newton iteration and the 32-bit row lengths bounded)
+constexpr int kMaxGaussianN = 16000;
+
 bool gaussian_latitudes_tabulated(int N);
 void gaussian_latitudes_npole_equator(int N, double lats[]);
 void gaussian_latitudes_npole_spole(int N, double lats[]);

@@ -63,6 +63,22 @@ def test_grid_builders():
         atlas_amd.Grid("X12")
 
 
+def test_malformed_grids_and_arguments_are_errors_not_crashes():
+    for nx, y in (([8, 0, 8, 8], [60, 20, -20, -60]), ([8, -4, 8, 8], [60, 20, -20, -60]),
+                  ([8, 8, 8, 8], [20, 60, -20, -60]), ([8, 8, 8, 8], [120, 20, -20, -60]),
+                  ([8, 8, 8, 8], [60, 20, 20, -60])):
+        with pytest.raises(_lib.AtlasAmdError):
+            atlas_amd.StructuredGrid(nx=nx, y=y)
+    for name in ("O0", "O-4", "O12abc", "F99999999", "", "O"):
+        with pytest.raises(_lib.AtlasAmdError):
+            atlas_amd.Grid(name)
+    assert _lib.fft_host_row(0, None, 0, None) != 0
+    g = atlas_amd.Grid("O8")
+    ss, sa = C.c_size_t(), C.c_size_t()
+    assert _lib.legendre_reference_sizes(g._h, -1, C.byref(ss), C.byref(sa)) != 0
+    assert atlas_amd.StructuredGrid(nx=[4, 4, 4], y=[90, 0, -90]).size() == 12      # poles and equator are fine
+
+
 @pytest.mark.parametrize("gridname,T", [("F64", 63), ("O64", 63), ("O32", 31), ("O160", 159), ("F32", 31), ("O48", 95)])
 def test_geometry_and_tables_bit_identical_to_oracle(gridname, T):
     g = atlas_amd.Grid(gridname)
