@@ -123,6 +123,9 @@ Trans_fourier_device = _sig("atlas_amd__Trans__fourier_device", C.c_int, c_void_
 Trans_nlat0 = _sig("atlas_amd__Trans__nlat0", C.c_int, c_void_p, c_void_p)
 Trans_legendre_flops = _sig("atlas_amd__Trans__legendre_flops", C.c_double, c_void_p, C.c_int)
 Trans_legendre_table_bytes = _sig("atlas_amd__Trans__legendre_table_bytes", C.c_int64, c_void_p)
+Trans_mirror_rows = _sig("atlas_amd__Trans__mirror_rows", C.c_int, c_void_p, c_void_p)
+mirror_bands = _sig("atlas_amd__mirror_bands", C.c_int, c_void_p, C.c_int, c_void_p)
+trans_geometry_probe = _sig("atlas_amd__trans_geometry_probe", C.c_int, c_void_p, C.c_int, C.c_int, c_void_p, c_void_p)
 Trans_legendre_table_download = _sig("atlas_amd__Trans__legendre_table_download", C.c_int, c_void_p, c_void_p,
                                      C.c_size_t)
 legendre_gen_host_selfcheck = _sig("atlas_amd__legendre_gen_host_selfcheck", C.c_int, c_void_p, C.c_int, C.c_int,

@@ -167,6 +167,7 @@ atlas_amd_Trans* atlas_amd__Trans__new_config(const atlas_amd_Grid* grid, int tr
         throw std::invalid_argument("grid is NULL");
     }
     trans::TransConfig cfg;
+    bool mirror = false;
     for (auto& kv : parse_config(config)) {
         if (kv.first == "profile") {
             cfg.profile = std::stoi(kv.second) != 0;
@@ -186,10 +187,13 @@ atlas_amd_Trans* atlas_amd__Trans__new_config(const atlas_amd_Grid* grid, int tr
             cfg.row_end   = std::stoi(kv.second.substr(colon + 1));
         }
         else if (kv.first == "shard") {
-            if (kv.second != "m" && kv.second != "band") {
-                throw std::invalid_argument("shard must be 'm' (wavenumbers, exchange follows) or 'band' (latitude bands)");
+            if (kv.second != "m" && kv.second != "band" && kv.second != "mirror") {
+                throw std::invalid_argument(
+                    "shard must be 'm' (wavenumbers, exchange follows), 'band' (latitude bands) or 'mirror' (a northern "
+                    "band and its mirror image)");
             }
             cfg.by_band = kv.second == "band";
+            mirror      = kv.second == "mirror";
         }
         else if (kv.first == "tables") {
             if (kv.second != "host" && kv.second != "device") {
@@ -209,6 +213,30 @@ atlas_amd_Trans* atlas_amd__Trans__new_config(const atlas_amd_Grid* grid, int tr
     }
     cfg.legendre_cache      = legendre_cache;
     cfg.legendre_cache_size = legendre_cache_size;
+    if (mirror) {
+        // Mirror-band decomposition: this object transforms the Legendre rows [b0, b1) of the grid in both hemispheres.
+        // Every latitude is transformed independently of the others, so this is the zonal-band crop rows = [b0, 2 b1 - b0)
+        // of the grid's two polar caps [0, b1) + [ny - b1, ny) taken as a grid of 2 b1 latitudes -- with the Fourier
+        // truncation still computed for the full grid (ndgl, nxmax).  Same kernels, same arithmetic per row.
+        if (cfg.row_end > cfg.row_begin || legendre_cache) {
+            throw std::invalid_argument("shard=mirror cannot be combined with rows= or a Legendre cache");
+        }
+        const std::vector<int> b = trans::mirror_bands(grid->g, cfg.nparts);
+        if (cfg.part < 0 || cfg.part >= cfg.nparts) {
+            throw std::invalid_argument("Trans: invalid (nparts, part)");
+        }
+        const int b0 = b[cfg.part], b1 = b[cfg.part + 1];
+        if (b1 <= b0) {
+            throw std::invalid_argument("shard=mirror: more parts than the grid has row pairs to give them");
+        }
+        trans::TransConfig c2 = cfg;
+        c2.nparts = 1, c2.part = 0, c2.by_band = false;
+        c2.row_begin = b0, c2.row_end = 2 * b1 - b0;
+        c2.ndgl = grid->g.ny(), c2.nxmax = grid->g.nxmax();
+        auto* t      = new atlas_amd_Trans{new trans::Trans(trans::polar_caps_grid(grid->g, b1), truncation, c2), grid};
+        t->mirror_b0 = b0, t->mirror_b1 = b1;
+        return t;
+    }
     return new atlas_amd_Trans{new trans::Trans(grid->g, truncation, cfg), grid};
     AA_CATCH_PTR
 }
@@ -491,6 +519,37 @@ int atlas_amd__Trans__legendre_cache_export(const atlas_amd_Trans* t, void* buff
         throw std::invalid_argument("legendre_cache_export: wrong buffer size");
     }
     t->impl->export_legendre_cache(buffer);
+    AA_CATCH_INT
+}
+int atlas_amd__Trans__mirror_rows(const atlas_amd_Trans* t, int out[2]) {
+    AA_TRY
+    if (t->mirror_b0 < 0) {
+        throw std::invalid_argument("Trans__mirror_rows: the object was not built with shard=mirror");
+    }
+    out[0] = t->mirror_b0;
+    out[1] = t->mirror_b1;
+    AA_CATCH_INT
+}
+int atlas_amd__mirror_bands(const atlas_amd_Grid* grid, int nparts, int bands_out[]) {
+    AA_TRY
+    const std::vector<int> b = trans::mirror_bands(grid->g, nparts);
+    std::memcpy(bands_out, b.data(), sizeof(int) * b.size());
+    AA_CATCH_INT
+}
+int atlas_amd__trans_geometry_probe(const atlas_amd_Grid* grid, int truncation, int caps_rows, int nlat0_out[],
+                                    int row_mmax_out[]) {
+    AA_TRY
+    // geometry of the grid itself (caps_rows == 0) or of its two polar caps of caps_rows latitudes each, seen as part
+    // of the full grid (what shard=mirror builds)
+    const trans::TransGeometry geo =
+        caps_rows > 0 ? trans::make_geometry(trans::polar_caps_grid(grid->g, caps_rows), truncation, grid->g.ny(),
+                                             grid->g.nxmax())
+                      : trans::make_geometry(grid->g, truncation);
+    std::memcpy(nlat0_out, geo.nlat0.data(), sizeof(int) * geo.nlat0.size());
+    for (int j = 0; j < geo.nlats; ++j) {
+        const int jleg  = j < geo.nlatsLeg ? j : geo.nlats - 1 - j;
+        row_mmax_out[j] = geo.mmax_leg[jleg];
+    }
     AA_CATCH_INT
 }
 int atlas_amd__Trans__legendre_table_download(const atlas_amd_Trans* t, double* out, size_t size) {

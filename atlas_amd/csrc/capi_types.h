@@ -15,6 +15,7 @@ struct atlas_amd_Grid {
 struct atlas_amd_Trans {
     atlas_amd::trans::Trans* impl;
     const atlas_amd_Grid* grid = nullptr;  // borrowed: what atlas__Trans__grid returns
+    int mirror_b0 = -1, mirror_b1 = -1;    // shard=mirror: the Legendre rows [b0, b1) this object transforms in both hemispheres
 };
 struct atlas_amd_HaloExchange {
     atlas_amd::parallel::HaloExchange impl;

@@ -55,7 +55,7 @@ T* dev_upload(const T* host, size_t n) {
 }  // namespace
 
 Trans::Trans(const grid::StructuredGrid& grid, int truncation, const TransConfig& cfg):
-    geo_(make_geometry(grid, truncation)), cfg_(cfg), profile_(cfg.profile) {
+    geo_(make_geometry(grid, truncation, cfg.ndgl, cfg.nxmax)), cfg_(cfg), profile_(cfg.profile) {
     if (cfg.nparts < 1 || cfg.nparts > fft::MAX_PARTS || cfg.part < 0 || cfg.part >= cfg.nparts) {
         throw std::invalid_argument("Trans: invalid (nparts, part)");
     }

@@ -52,7 +52,15 @@ struct TransGeometry {
     int L(int m) const { return nlatsLegR - nlat0[m]; }
 };
 
-TransGeometry make_geometry(const grid::StructuredGrid& g, int truncation);
+// ndgl / nxmax: number of latitudes and longest row that fourier_truncation sees (0: those of `g`).  They differ from
+// g's when `g` is a row subset of a larger global grid (mirror-band decomposition, below).
+TransGeometry make_geometry(const grid::StructuredGrid& g, int truncation, int ndgl = 0, int nxmax = 0);
+// Mirror-band decomposition: part q owns the Legendre rows [b[q], b[q+1]) in BOTH hemispheres (a northern band and its
+// mirror image), balanced by grid points with the BandsDistribution rule applied to the northern half.  nparts+1
+// boundaries over the rows 0 .. ny/2 of a grid that is symmetric about the equator (even ny).
+std::vector<int> mirror_bands(const grid::StructuredGrid& g, int nparts);
+// the rows [0, b1) and [ny-b1, ny) of g as a grid of 2*b1 latitudes
+grid::StructuredGrid polar_caps_grid(const grid::StructuredGrid& g, int b1);
 
 struct LegendreItem {
     int m;

@@ -110,6 +110,9 @@ class DistributedTrans:
         """mode: "alltoall" = Legendre stage sharded by wavenumber, RCCL all-to-all, Fourier stage on the local band
                  "band"     = both stages on the local latitude band: no exchange, but the hemisphere symmetry cannot
                               be shared between devices, so the Legendre stage costs 2/P instead of 1/P
+                 "mirror"   = both stages on a northern band of rows and its mirror image in the south: no exchange
+                              AND the hemisphere symmetry is kept (work 1/P); the rank's output is two row ranges
+                              (Trans.owned_rows()), not one Atlas band
                  "auto"     = "band" below 8 ranks (the transposition moves 7.55 GB * (P-1)/P^2 per device and
                               transform over P-1 point-to-point xGMI links: link-bound for P = 2, 4), else "alltoall"
         """
@@ -120,14 +123,14 @@ class DistributedTrans:
         self.part = dist.get_rank(group)
         if mode == "auto":
             mode = "band" if self.nparts < 8 else "alltoall"
-        if mode not in ("alltoall", "band"):
-            raise ValueError("mode must be 'auto', 'alltoall' or 'band'")
+        if mode not in ("alltoall", "band", "mirror"):
+            raise ValueError("mode must be 'auto', 'alltoall', 'band' or 'mirror'")
         self.mode = mode
         self.trans = Trans(grid, truncation, profile=profile, nparts=self.nparts, part=self.part,
-                           shard="band" if mode == "band" else "m")
+                           shard={"band": "band", "mirror": "mirror", "alltoall": "m"}[mode])
         self.trans.use_torch_stream()
         self.T = truncation
-        self.bands = self.trans.bands()
+        self.bands = self.trans.bands() if mode != "mirror" else None
         self._buf = {}
         self._torch, self._dist = torch, dist
 
@@ -155,7 +158,7 @@ class DistributedTrans:
 
     def invtrans(self, nf, sp, gp):
         """one distributed transform; sp: full spectra (replicated), gp: nf * local-band points"""
-        if self.mode == "band":
+        if self.mode in ("band", "mirror"):
             return self.trans.invtrans(nf, sp, gp)
         self._legendre_and_exchange(nf, sp, 0, async_op=False)
         self._fourier(nf, 0, gp)
@@ -164,7 +167,7 @@ class DistributedTrans:
     def invtrans_many(self, nf, sps, gps):
         """software pipeline over several transforms: the all-to-all of transform i runs on RCCL's stream while
         the Legendre stage of transform i+1 and the Fourier stage of transform i-1 run on the compute stream"""
-        if self.mode == "band":
+        if self.mode in ("band", "mirror"):
             for sp, gp in zip(sps, gps):
                 self.trans.invtrans(nf, sp, gp)
             return gps

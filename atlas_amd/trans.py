@@ -45,7 +45,9 @@ class Trans:
             grid = StructuredGrid(name=grid)
         self.grid = grid
         # shard (nparts > 1): "m" = this device owns wavenumbers m % nparts == part (stage API + exchange),
-        #                      "band" = it owns latitude band `part` of both stages (plain invtrans on device arrays)
+        #                      "band" = it owns latitude band `part` of both stages (plain invtrans on device arrays),
+        #                      "mirror" = it owns a northern band of rows and its mirror image (plain invtrans; output =
+        #                      the northern rows, then the southern rows; see owned_rows())
         cfg = f"profile={int(bool(profile))};nparts={int(nparts)};part={int(part)};shard={shard}"
         if tables is not None:  # "host" | "device": where the Legendre table is computed (default: ATLAS_AMD_TABLES)
             cfg += f";tables={tables}"
@@ -250,6 +252,25 @@ class Trans:
         out = np.zeros(self.nparts + 1, dtype=np.int32)
         _lib.Trans_bands(self._h, out.ctypes.data)
         return out
+
+    def mirror_rows(self):
+        """shard="mirror": (b0, b1) -- this object transforms rows [b0, b1) and their mirror images [ny-b1, ny-b0)"""
+        out = np.zeros(2, dtype=np.int32)
+        _lib.check(_lib.Trans_mirror_rows(self._h, out.ctypes.data))
+        return int(out[0]), int(out[1])
+
+    def owned_rows(self):
+        """latitude rows of the grid whose points the invtrans output holds, in output order"""
+        ny = len(self.grid.nx())
+        if self.shard == "mirror":
+            b0, b1 = self.mirror_rows()
+            return np.concatenate([np.arange(b0, b1), np.arange(ny - b1, ny - b0)])
+        if self.rows is not None:
+            return np.arange(int(self.rows[0]), int(self.rows[1]))
+        if self.nparts > 1:
+            b = self.bands()
+            return np.arange(int(b[self.part]), int(b[self.part + 1]))
+        return np.arange(ny)
 
     def nlat0(self):
         out = np.zeros(self.truncation() + 1, dtype=np.int32)

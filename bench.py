@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--cpu-baseline-blas", action="store_true",
                     help="also time the BLAS dgemm + pocketfft variant of the CPU restatement (cpu_baseline_blas)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the distributed driver even with one rank")
-    ap.add_argument("--dist-mode", default="auto", choices=["auto", "alltoall", "band"],
+    ap.add_argument("--dist-mode", default="auto", choices=["auto", "alltoall", "band", "mirror"],
                     help="N > 1: wavenumber sharding + RCCL all-to-all, or exchange-free latitude-band sharding "
                          "(auto: band below 8 ranks, all-to-all at 8; see atlas_amd/dist.py)")
     args = ap.parse_args()
@@ -175,7 +175,8 @@ def main():
     # both equal the single-device result).  Only run when the all-to-all is the timed mode anyway, so that the
     # exchange-free runs stay free of collectives in the data path; ATLAS_AMD_BENCH_CROSSCHECK=1 forces it.
     crosscheck = None
-    if use_dist and ((world > 1 and dtr.mode == "alltoall") or os.environ.get("ATLAS_AMD_BENCH_CROSSCHECK") == "1"):
+    if use_dist and dtr.mode != "mirror" and ((world > 1 and dtr.mode == "alltoall")
+                                             or os.environ.get("ATLAS_AMD_BENCH_CROSSCHECK") == "1"):
         import torch.distributed as dist
         other = "band" if dtr.mode == "alltoall" else "alltoall"
         ok, err = 0, None
@@ -202,11 +203,18 @@ def main():
         fft_ms = tm["fourier_ms"] / max(tm["fourier_calls"], 1)
         # algorithmic work per launch (DESIGN.md "Kernels"): Legendre flops of SURVEY 8(d) / world (m-sharding);
         # Fourier bytes = kept part of the intermediate read once + grid-point output written once
-        leg_flops = tr.legendre_flops(nf) / world
+        if use_dist and dtr.mode == "mirror":
+            # rank 0 owns rows [0, b1) and their mirror images: the geometry of its object is exactly its share
+            b1 = tr.mirror_rows()[1]
+            leg_flops = tr.legendre_flops(nf)
+            kept_modes = float(sum(2 * max(0, b1 - int(v)) for v in tr.nlat0()))
+            fft_bytes = kept_modes * nf * 16 + nf * tr.nb_gridpoints() * 8
+        else:
+            leg_flops = tr.legendre_flops(nf) / world
+            kept_modes = float(sum(int(tr.nlat0()[m] < g.ny() // 2) * 2 * (g.ny() // 2 - int(tr.nlat0()[m]))
+                                   for m in range(TRUNC + 1)))          # (lat, m) pairs with data
+            fft_bytes = (kept_modes * nf * 16 + nf * g.size() * 8) / world
         leg_tf = leg_flops / (leg_ms * 1e-3) / 1e12 if leg_ms > 0 else 0.0
-        kept_modes = float(sum(int(tr.nlat0()[m] < g.ny() // 2) * 2 * (g.ny() // 2 - int(tr.nlat0()[m]))
-                               for m in range(TRUNC + 1)))          # (lat, m) pairs with data
-        fft_bytes = (kept_modes * nf * 16 + nf * g.size() * 8) / world
         fft_gbs = fft_bytes / (fft_ms * 1e-3) / 1e9 if fft_ms > 0 else 0.0
         traffic = measured_traffic()
         kernels = [
@@ -233,6 +241,8 @@ def main():
                        "parallelism": "single GPU" if not use_dist else (
                            f"m-sharded Legendre + RCCL all-to-all + latitude-band FFT over {world} GPUs"
                            if dtr.mode == "alltoall" else
+                           f"mirror-band sharding of both stages over {world} GPUs (a northern band of rows and its mirror "
+                           f"image per GPU: no exchange, hemisphere symmetry kept)" if dtr.mode == "mirror" else
                            f"latitude-band sharding of both stages over {world} GPUs (no exchange; Legendre rows of a "
                            f"band are computed without their mirror hemisphere: 2/P of the single-GPU Legendre work)")},
             "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")},

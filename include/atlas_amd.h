@@ -65,9 +65,12 @@ atlas_amd_Trans* atlas_amd__Trans__new(const atlas_amd_Grid* grid, int truncatio
 /* atlas__Trans__new_config(grid, truncation, config).  `config` is "key=value;key=value" with keys
  *   profile=0|1          record HIP events around the two stages (atlas_amd__Trans__timings)
  *   nparts=P;part=p      multi-GPU decomposition: this object owns wavenumbers m%P==p and latitude band p
- *   shard=m|band         m (default): Legendre stage on the owned wavenumbers, Fourier stage on the owned band; the
+ *   shard=m|band|mirror  m (default): Legendre stage on the owned wavenumbers, Fourier stage on the owned band; the
  *                        caller transposes in between (stage API below).  band: both stages on the owned latitude
- *                        band, no exchange: the *_device invtrans entry points then return the band's grid points
+ *                        band, no exchange: the *_device invtrans entry points then return the band's grid points.
+ *                        mirror: both stages on a northern band of rows AND its mirror image in the south
+ *                        (atlas_amd__Trans__mirror_rows): no exchange and the hemisphere symmetry of the Legendre stage
+ *                        is kept; the output holds the northern rows, then the southern rows (both north to south)
  *   rows=j0:j1           zonal-band crop: transform only latitude rows j0..j1-1 of the (global) grid -- the nested
  *                        regional case of TransLocal (TransLocal.cc:394-470) for domains that keep whole rows;
  *                        nb_gridpoints and the output arrays then cover these rows only
@@ -182,6 +185,14 @@ int atlas_amd__Trans__synchronize(atlas_amd_Trans* t);
 size_t atlas_amd__Trans__legendre_cache_size(const atlas_amd_Trans* t);
 int atlas_amd__Trans__legendre_cache_export(const atlas_amd_Trans* t, void* buffer, size_t size);
 
+/* shard=mirror: out = {b0, b1}: the object transforms rows [b0, b1) and [ny-b1, ny-b0) of the grid */
+int atlas_amd__Trans__mirror_rows(const atlas_amd_Trans* t, int out[2]);
+/* the row boundaries shard=mirror uses for nparts parts (nparts+1 values over rows 0 .. ny/2; host only) */
+int atlas_amd__mirror_bands(const atlas_amd_Grid* grid, int nparts, int bands_out[]);
+/* host-only test hook: nlat0[T+1] and the Fourier truncation of every row, for the grid (caps_rows = 0) or for its two
+ * polar caps of caps_rows latitudes each taken as a grid inside the full one (2*caps_rows rows) */
+int atlas_amd__trans_geometry_probe(const atlas_amd_Grid* grid, int truncation, int caps_rows, int nlat0_out[],
+                                    int row_mmax_out[]);
 /* the tile-blocked Legendre table as it sits in device memory (legendre_table_bytes / 8 doubles): test hook for the
  * device generation of the table (config key tables=device|host) */
 int atlas_amd__Trans__legendre_table_download(const atlas_amd_Trans* t, double* out, size_t size_doubles);

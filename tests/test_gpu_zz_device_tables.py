@@ -35,3 +35,22 @@ def test_transform_on_device_generated_table():
         tr.invtrans(nf, sp, gp)
         out.append(gp)
     assert np.abs(out[0]).max() > 0 and np.array_equal(out[0], out[1])
+
+
+# ---------------------------------------------------------------- mirror-band decomposition (shard="mirror")
+# Built after the round's GPU budget was spent: the kernels and the crop path it uses are the tested ones, the geometry
+# equivalence is tested on the CPU (tests/test_host_logic.py), but the mode itself has not run on hardware yet --
+# hence non-strict xfail, and a child process so that nothing it does can take the test session down.
+@pytest.mark.xfail(strict=False, reason="shard=mirror has not been run on hardware yet")
+@pytest.mark.parametrize("gridname,T,nf,nparts", [("O64", 63, 3, 2), ("O64", 63, 5, 3), ("F32", 31, 4, 4),
+                                                  ("O160", 159, 9, 8)])
+def test_mirror_band_sharding_reproduces_single_device_result(gridname, T, nf, nparts):
+    """every part transforms a northern band of rows and its mirror image; the rows must equal those of the
+    single-device transform bit for bit (same arithmetic per (m, latitude) and per row), scalar and vor/div paths"""
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mirror_check.py")
+    r = subprocess.run([sys.executable, script, gridname, str(T), str(nf), str(nparts)], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and "MIRROR OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -63,6 +63,35 @@ def test_grid_builders():
         atlas_amd.Grid("X12")
 
 
+@pytest.mark.parametrize("gridname,T", [("O64", 63), ("F32", 31), ("O48", 95), ("O160", 159), ("O1280", 1279)])
+def test_mirror_band_geometry_equals_the_full_grid_rows(gridname, T):
+    """shard=mirror builds its object on the two polar caps [0, b1) + [ny-b1, ny) of the grid taken as a grid of 2 b1
+    latitudes inside the full one (ndgl, nxmax of the full grid).  Its per-row Fourier truncations and nlat0 must be
+    those of the same rows of the full grid -- then every row is transformed exactly as in the full transform."""
+    g = atlas_amd.Grid(gridname)
+    ny, nx = g.ny(), g.nx()
+
+    def probe(caps):
+        nlat0 = np.zeros(T + 1, dtype=np.int32)
+        mmax = np.zeros(ny if caps == 0 else 2 * caps, dtype=np.int32)
+        _lib.check(_lib.trans_geometry_probe(g._h, T, caps, nlat0.ctypes.data, mmax.ctypes.data))
+        return nlat0, mmax
+
+    n0, mm = probe(0)
+    for P in (1, 2, 3, 8):
+        b = np.zeros(P + 1, dtype=np.int32)
+        _lib.check(_lib.mirror_bands(g._h, P, b.ctypes.data))
+        assert b[0] == 0 and b[P] == ny // 2 and np.all(np.diff(b) > 0)
+        pts = [int(nx[b[q]:b[q + 1]].sum()) for q in range(P)]
+        assert max(pts) <= 1.5 * min(pts)                        # balanced by points (Atlas bands rule on whole rows)
+        for q in range(P):
+            b1 = int(b[q + 1])
+            n0v, mmv = probe(b1)
+            rows = np.concatenate([np.arange(b1), np.arange(ny - b1, ny)])
+            assert np.array_equal(mmv, mm[rows])
+            assert np.array_equal(n0v, np.where(n0 < b1, n0, b1))
+
+
 def test_malformed_grids_and_arguments_are_errors_not_crashes():
     for nx, y in (([8, 0, 8, 8], [60, 20, -20, -60]), ([8, -4, 8, 8], [60, 20, -20, -60]),
                   ([8, 8, 8, 8], [20, 60, -20, -60]), ([8, 8, 8, 8], [120, 20, -20, -60]),
