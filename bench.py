@@ -10,8 +10,11 @@ N > 1: launched by torch.distributed.run, one rank per GPU; every step processes
                latitude-band transpose) pipelined against the neighbouring transforms, Fourier stage on the local band;
                after the timed region one transform is re-run with the other decomposition and compared bit for bit
                ("multi_gpu_crosscheck");
-       N < 8 : both stages on the local latitude band, no exchange (the transposition would be bound by the one or
-               three xGMI links between 2 or 4 GPUs); --dist-mode overrides.
+       N < 8 : exchange-free (the transposition would be bound by the one or three xGMI links between 2 or 4 GPUs):
+               every GPU transforms a northern band of rows and its mirror image ("mirror", work 1/N) if that
+               decomposition first reproduces, bit for bit on every rank, the same rows computed through the tested
+               zonal-band crop path ("mirror_selfcheck"); otherwise its own latitude band ("band", Legendre work 2/N).
+       --dist-mode overrides.
 Prints ONE JSON line (rank 0)."""
 import argparse
 import json
@@ -133,11 +136,50 @@ def main():
         import torch.distributed as dist
         from atlas_amd.dist import DistributedTrans
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        dtr = DistributedTrans(g, TRUNC, profile=True, mode=args.dist_mode)
-        tr = dtr.trans
         # every rank holds the spectra of the `world` transforms of a step (replicated input; each rank reads only
         # the wavenumbers it owns)
         sps = [torch.from_numpy(red_spectra(TRUNC, nf, seed=20251114 + i)).cuda() for i in range(min(world, 2))]
+        mode, mirror_selfcheck, dtr = args.dist_mode, None, None
+        if mode == "auto" and 1 < world < 8:
+            # Below 8 GPUs the exchange-free decompositions win (the transposition is bound by 1 or 3 xGMI links).  The
+            # mirror-band one keeps the hemisphere sharing (work 1/P instead of 2/P) but was built after round 1's GPU
+            # budget was spent: adopt it only if, on every rank, it reproduces bit for bit the rows computed through the
+            # tested zonal-band crop path; otherwise fall back to the latitude-band decomposition.
+            ok = 0
+            try:
+                dtr = DistributedTrans(g, TRUNC, profile=True, mode="mirror")
+                b0, b1 = dtr.trans.mirror_rows()
+                gp_m = torch.empty(nf * dtr.trans.nb_gridpoints(), dtype=torch.float64, device="cuda")
+                dtr.invtrans(nf, sps[0], gp_m)
+                ok, first = 1, 0
+                for j0, j1 in ((b0, b1), (g.ny() - b1, g.ny() - b0)):
+                    tc = atlas_amd.Trans(g, TRUNC, rows=(j0, j1))
+                    tc.use_torch_stream()
+                    n = tc.nb_gridpoints()
+                    gp_c = torch.empty(nf * n, dtype=torch.float64, device="cuda")
+                    tc.invtrans(nf, sps[0], gp_c)
+                    torch.cuda.synchronize()
+                    same = torch.equal(gp_m.view(nf, -1)[:, first:first + n], gp_c.view(nf, -1))
+                    ok = ok if (same and bool(torch.isfinite(gp_c).all()) and float(gp_c.abs().max()) > 0.0) else 0
+                    first += n
+                    del tc, gp_c
+                ok = ok if first * nf == gp_m.numel() else 0
+                del gp_m
+            except Exception as e:   # any failure means: do not use it
+                sys.stderr.write(f"[bench] rank {rank}: mirror-band self-check failed: {type(e).__name__}: {e}\n")
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            mirror_selfcheck = {"compared": "mirror-band rows vs the same rows through the zonal-band crop path, "
+                                            f"{nf} fields, every rank", "bitwise_equal_on_all_ranks": bool(int(flag.item()))}
+            if int(flag.item()) == 1:
+                mode = "mirror"
+            else:
+                mode, dtr = "band", None
+            torch.cuda.empty_cache()
+        if mode != "mirror" or dtr is None:
+            dtr = DistributedTrans(g, TRUNC, profile=True, mode=mode)
+        tr = dtr.trans
         gp = torch.zeros(nf * tr.nb_gridpoints(), dtype=torch.float64, device="cuda")
 
         gps = [gp] * world
@@ -251,6 +293,8 @@ def main():
         out["roofline"]["kernel"] = dominant["kernel"]
         if crosscheck is not None:
             out["multi_gpu_crosscheck"] = crosscheck
+        if use_dist and mirror_selfcheck is not None:
+            out["mirror_selfcheck"] = mirror_selfcheck
         if world == 1 and not use_dist and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_fields)
             if args.cpu_baseline_blas:
