@@ -1,6 +1,6 @@
-"""Dev tool (GPU box): per-rank cost of the two multi-GPU decompositions at TL1279 -> O1280, 137 levels, emulated on one
-device (one rank's share at a time): latitude-band sharding (both stages local) and wavenumber sharding (Legendre
-stage only; its Fourier stage equals the band one)."""
+"""Dev tool (GPU box): per-rank cost of the multi-GPU decompositions at TL1279 -> O1280, 137 levels, emulated on one
+device (one rank's share at a time): latitude-band and mirror-band sharding (both stages local) and wavenumber sharding
+(Legendre stage only; its Fourier stage equals the band one)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -11,10 +11,10 @@ g = atlas_amd.Grid("O1280")
 sp = torch.from_numpy(red_spectra(T, nf)).cuda()
 for P, parts in ((2, (0,)), (4, (0, 1)), (8, (0, 3))):
     for part in parts:
-        for shard in ("band", "m"):
+        for shard in ("band", "mirror", "m"):
             tr = atlas_amd.Trans(g, T, profile=True, nparts=P, part=part, shard=shard)
             tr.use_torch_stream()
-            if shard == "band":
+            if shard in ("band", "mirror"):
                 gp = torch.zeros(nf * tr.nb_gridpoints(), dtype=torch.float64, device="cuda")
                 run = lambda: tr.invtrans(nf, sp, gp)
             else:
