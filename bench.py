@@ -258,7 +258,7 @@ def main():
             fft_bytes = (kept_modes * nf * 16 + nf * g.size() * 8) / world
         leg_tf = leg_flops / (leg_ms * 1e-3) / 1e12 if leg_ms > 0 else 0.0
         fft_gbs = fft_bytes / (fft_ms * 1e-3) / 1e9 if fft_ms > 0 else 0.0
-        traffic = measured_traffic()
+        traffic = measured_traffic() if world == 1 else {}     # the PMC passes were taken on the single-GPU workload
         kernels = [
             # one launch per transform: the single largest kernel of the path (rocprofv3 --stats agrees, profiles/)
             {"kernel": "legendre_kernel", "launches_per_transform": 1, "bound": "mfma", "achieved": leg_tf,
