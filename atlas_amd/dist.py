@@ -49,6 +49,7 @@ def mode_address(plan, RP, lat_local, m, nparts, f2=0):
 # ones); otherwise the slabs go out as batched point-to-point messages of at most 512 MiB.  A lone rank copies on
 # device.  The choice depends on global quantities only, so every rank takes the same path.
 MAX_MESSAGE_ELEMS = 1 << 26      # doubles per message (512 MiB)
+DEVICE = "cuda"                  # where the exchange buffers live (tests run the control flow on "cpu" over gloo)
 FORCE_RCCL_SINGLE_RANK = False   # dev switch (tools/dist_selfcheck.py): send a lone rank's slab through RCCL as well
 
 
@@ -140,8 +141,8 @@ class DistributedTrans:
             torch = self._torch
             RP = self.trans.fourier_row_pitch(nf)
             plan = transpose_plan(len(self.trans.grid.nx()), self.T, RP, self.bands, self.nparts, self.part)
-            F = torch.empty(self.trans.fourier_size(nf), dtype=torch.float64, device="cuda")
-            R = torch.empty(max(sum(plan["out_splits"]), 1), dtype=torch.float64, device="cuda")
+            F = torch.empty(self.trans.fourier_size(nf), dtype=torch.float64, device=DEVICE)
+            R = torch.empty(max(sum(plan["out_splits"]), 1), dtype=torch.float64, device=DEVICE)
             self._buf[key] = (F, R, plan, RP)
         return self._buf[key]
 

@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 GRID, TRUNC, NLEV = "O1280", 1279, 137
+DEVICE = "cuda"                # tests/test_bench_logic.py runs this file's control flow on "cpu" with a stand-in transform
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X spec, dense fp64 matrix (v_mfma_f64_16x16x4_f64: 77.2 TF/s measured, tools/probe)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -116,7 +117,13 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
+    on_gpu = DEVICE == "cuda"
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
     nf = NLEV
     g = atlas_amd.Grid(GRID)
 
@@ -124,21 +131,24 @@ def main():
     if not use_dist:
         tr = atlas_amd.Trans(g, TRUNC, profile=True)
         tr.use_torch_stream()
-        sp = torch.from_numpy(red_spectra(TRUNC, nf)).cuda()
-        gp = torch.zeros(nf * g.size(), dtype=torch.float64, device="cuda")
+        sp = torch.from_numpy(red_spectra(TRUNC, nf)).to(DEVICE)
+        gp = torch.zeros(nf * g.size(), dtype=torch.float64, device=DEVICE)
 
         def step():
             tr.invtrans(nf, sp, gp)
 
         def barrier():
-            torch.cuda.synchronize()
+            sync()
     else:
         import torch.distributed as dist
         from atlas_amd.dist import DistributedTrans
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if on_gpu:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
         # every rank holds the spectra of the `world` transforms of a step (replicated input; each rank reads only
         # the wavenumbers it owns)
-        sps = [torch.from_numpy(red_spectra(TRUNC, nf, seed=20251114 + i)).cuda() for i in range(min(world, 2))]
+        sps = [torch.from_numpy(red_spectra(TRUNC, nf, seed=20251114 + i)).to(DEVICE) for i in range(min(world, 2))]
         mode, mirror_selfcheck, dtr = args.dist_mode, None, None
         if mode == "auto" and 1 < world < 8:
             # Below 8 GPUs the exchange-free decompositions win (the transposition is bound by 1 or 3 xGMI links).  The
@@ -149,16 +159,16 @@ def main():
             try:
                 dtr = DistributedTrans(g, TRUNC, profile=True, mode="mirror")
                 b0, b1 = dtr.trans.mirror_rows()
-                gp_m = torch.empty(nf * dtr.trans.nb_gridpoints(), dtype=torch.float64, device="cuda")
+                gp_m = torch.empty(nf * dtr.trans.nb_gridpoints(), dtype=torch.float64, device=DEVICE)
                 dtr.invtrans(nf, sps[0], gp_m)
                 ok, first = 1, 0
                 for j0, j1 in ((b0, b1), (g.ny() - b1, g.ny() - b0)):
                     tc = atlas_amd.Trans(g, TRUNC, rows=(j0, j1))
                     tc.use_torch_stream()
                     n = tc.nb_gridpoints()
-                    gp_c = torch.empty(nf * n, dtype=torch.float64, device="cuda")
+                    gp_c = torch.empty(nf * n, dtype=torch.float64, device=DEVICE)
                     tc.invtrans(nf, sps[0], gp_c)
-                    torch.cuda.synchronize()
+                    sync()
                     same = torch.equal(gp_m.view(nf, -1)[:, first:first + n], gp_c.view(nf, -1))
                     ok = ok if (same and bool(torch.isfinite(gp_c).all()) and float(gp_c.abs().max()) > 0.0) else 0
                     first += n
@@ -168,7 +178,7 @@ def main():
             except Exception as e:   # any failure means: do not use it
                 sys.stderr.write(f"[bench] rank {rank}: mirror-band self-check failed: {type(e).__name__}: {e}\n")
                 ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            flag = torch.tensor([ok], dtype=torch.int32, device=DEVICE)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             mirror_selfcheck = {"compared": "mirror-band rows vs the same rows through the zonal-band crop path, "
                                             f"{nf} fields, every rank", "bitwise_equal_on_all_ranks": bool(int(flag.item()))}
@@ -176,11 +186,12 @@ def main():
                 mode = "mirror"
             else:
                 mode, dtr = "band", None
-            torch.cuda.empty_cache()
+            if on_gpu:
+                torch.cuda.empty_cache()
         if mode != "mirror" or dtr is None:
             dtr = DistributedTrans(g, TRUNC, profile=True, mode=mode)
         tr = dtr.trans
-        gp = torch.zeros(nf * tr.nb_gridpoints(), dtype=torch.float64, device="cuda")
+        gp = torch.zeros(nf * tr.nb_gridpoints(), dtype=torch.float64, device=DEVICE)
 
         gps = [gp] * world
 
@@ -190,9 +201,9 @@ def main():
             dtr.invtrans_many(nf, [sps[i % len(sps)] for i in range(world)], gps)
 
         def barrier():
-            torch.cuda.synchronize()
+            sync()
             dist.barrier()
-            torch.cuda.synchronize()
+            sync()
 
     for _ in range(args.warmup):
         step()
@@ -205,7 +216,7 @@ def main():
     dt = time.perf_counter() - t0
     if use_dist:
         import torch.distributed as dist
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=DEVICE)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     tm = tr.timings()
@@ -227,13 +238,13 @@ def main():
             gp_a, gp_b = torch.empty_like(gp), torch.empty_like(gp)
             dtr.invtrans(nf, sps[0], gp_a)
             dto.invtrans(nf, sps[0], gp_b)
-            torch.cuda.synchronize()
+            sync()
             ok = int(bool(torch.equal(gp_a, gp_b)) and bool(torch.isfinite(gp_a).all())
                      and float(gp_a.abs().max()) > 0.0)
             del dto, gp_a, gp_b
         except Exception as e:  # the check must never cost the measurement
             err = f"{type(e).__name__}: {e}"
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")   # every rank takes part, failed or not
+        flag = torch.tensor([ok], dtype=torch.int32, device=DEVICE)   # every rank takes part, failed or not
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         crosscheck = {"compared": f"{dtr.mode} vs {other} decomposition, {nf} fields, every rank's latitude band",
                       "bitwise_equal_on_all_ranks": bool(int(flag.item()))}

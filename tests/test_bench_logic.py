@@ -1,0 +1,115 @@
+"""CPU tests of the DRIVER logic of bench.py and atlas_amd/dist.py -- argument handling, the one-JSON-line contract,
+the choice of the multi-GPU decomposition with its run-time self-check and fallback, the all-to-all pipeline with its
+cross-check, barriers and max-over-ranks timing -- in real processes over gloo, with tests/fake_trans.py standing in for
+the device transform (the transform itself is tested on the GPU; nothing here measures anything)."""
+import json
+import os
+import socket
+import sys
+
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _bench_worker(rank, world, port, argv, grid, corrupt_mirror, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank),
+                       "LOCAL_WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    os.environ.pop("ATLAS_AMD_BENCH_CROSSCHECK", None)
+    import atlas_amd
+    import atlas_amd.dist as aadist
+    import bench
+    from fake_trans import FakeTrans
+    FakeTrans.corrupt_mirror = corrupt_mirror
+    atlas_amd.Trans = FakeTrans
+    aadist.Trans = FakeTrans
+    aadist.DEVICE = "cpu"
+    bench.DEVICE = "cpu"
+    bench.GRID, bench.TRUNC, bench.NLEV = grid, 15, 3
+    sys.argv = ["bench.py"] + argv
+    sys.stdout = open(os.path.join(outdir, f"stdout_{rank}.txt"), "w")
+    try:
+        bench.main()
+    finally:
+        sys.stdout.flush()
+
+
+def run_bench(tmp_path, world, argv, grid="O16", corrupt_mirror=False):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, argv, grid, corrupt_mirror, str(tmp_path)))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0, f"bench rank exited with {p.exitcode}"
+    lines = [ln for ln in open(tmp_path / "stdout_0.txt").read().splitlines() if ln.strip()]
+    out = json.loads(lines[-1])                       # the JSON line is the LAST line of rank 0's stdout
+    for r in range(1, world):
+        assert open(tmp_path / f"stdout_{r}.txt").read().strip() == ""     # only rank 0 prints
+    for k in REQUIRED:
+        assert k in out, k
+    assert out["n_gpus"] == world and out["scaling"] == "weak" and out["vs_baseline"] is None
+    assert out["higher_is_better"] is True and out["dtype"] == "f64" and out["data"] == "synthetic"
+    assert out["value"] > 0 and out["ms_per_step"] > 0 and "workload" in out["config"]
+    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    return out
+
+
+def test_single_gpu_line_has_roofline_and_cpu_baseline(tmp_path):
+    out = run_bench(tmp_path, 1, ["--gpus", "1", "--steps", "2", "--warmup", "1", "--cpu-sample-fields", "2"])
+    assert out["steps"] == 2 and out["warmup"] == 1
+    assert out["config"]["parallelism"] == "single GPU"
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "transforms/s"
+    assert "multi_gpu_crosscheck" not in out and "mirror_selfcheck" not in out
+
+
+def test_two_ranks_adopt_the_mirror_band_decomposition_after_its_self_check(tmp_path):
+    out = run_bench(tmp_path, 2, ["--gpus", "2", "--steps", "2", "--warmup", "1"])
+    assert out["mirror_selfcheck"]["bitwise_equal_on_all_ranks"] is True
+    assert out["config"]["parallelism"].startswith("mirror-band")
+    assert "cpu_baseline" not in out                                      # rank 0 at N = 1 only
+
+
+def test_two_ranks_fall_back_to_latitude_bands_when_the_self_check_fails(tmp_path):
+    out = run_bench(tmp_path, 2, ["--gpus", "2", "--steps", "1", "--warmup", "0"], corrupt_mirror=True)
+    assert out["mirror_selfcheck"]["bitwise_equal_on_all_ranks"] is False
+    assert out["config"]["parallelism"].startswith("latitude-band")
+
+
+def test_all_to_all_decomposition_with_cross_check(tmp_path):
+    """what the 8-GPU run does (mode alltoall: Legendre stage by wavenumber, all_to_all_single, pipelined transforms,
+    then the bitwise cross-check against the band decomposition), here with 3 ranks"""
+    out = run_bench(tmp_path, 3, ["--gpus", "3", "--steps", "2", "--warmup", "1", "--dist-mode", "alltoall"])
+    assert out["config"]["parallelism"].startswith("m-sharded")
+    assert out["multi_gpu_crosscheck"]["bitwise_equal_on_all_ranks"] is True
+    assert "mirror_selfcheck" not in out
+
+
+def test_explicit_modes(tmp_path):
+    out = run_bench(tmp_path, 2, ["--gpus", "2", "--steps", "1", "--warmup", "0", "--dist-mode", "band"])
+    assert out["config"]["parallelism"].startswith("latitude-band") and "mirror_selfcheck" not in out
+    out = run_bench(tmp_path, 2, ["--gpus", "2", "--steps", "1", "--warmup", "0", "--dist-mode", "mirror"])
+    assert out["config"]["parallelism"].startswith("mirror-band") and "mirror_selfcheck" not in out
+
+
+def test_eight_ranks_auto_is_the_all_to_all_decomposition(tmp_path):
+    out = run_bench(tmp_path, 8, ["--gpus", "8", "--steps", "1", "--warmup", "1"], grid="O32")
+    assert out["n_gpus"] == 8 and out["config"]["parallelism"].startswith("m-sharded")
+    assert out["multi_gpu_crosscheck"]["bitwise_equal_on_all_ranks"] is True
+    assert "8 transform(s) per step" in out["config"]["workload"]
