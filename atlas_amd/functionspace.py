@@ -194,6 +194,104 @@ class StructuredColumns:
         return field
 
 
+def mirror_band_distribution(grid, nparts):
+    """grid::Distribution of the mirror-band decomposition of the transform (Trans(shard="mirror")): part q owns the
+    rows [b[q], b[q+1]) and their mirror images [ny-b[q+1], ny-b[q]).  Returns (partition of every grid point, b)."""
+    b = np.zeros(int(nparts) + 1, dtype=np.int32)
+    _lib.check(_lib.mirror_bands(grid._h, int(nparts), b.ctypes.data))
+    nx = np.asarray(grid.nx())
+    ny = len(nx)
+    row_part = np.zeros(ny, dtype=np.int32)
+    for q in range(int(nparts)):
+        row_part[b[q]:b[q + 1]] = q
+        row_part[ny - b[q + 1]:ny - b[q]] = q
+    return np.repeat(row_part, nx).astype(np.int32), b
+
+
+class MirrorBandColumns:
+    """Function space of the mirror-band decomposition: every part owns TWO row ranges (a northern band and its mirror
+    image).  StructuredColumns -- the reference's and ours -- describes a part by one row range, so this is a
+    composition of two StructuredColumns blocks built on the 2*nparts single-range parts
+        virtual part 2q = northern band of q,   2q+1 = its mirror image
+    with the owners and remote indices mapped back to the real parts.  Local numbering:
+        [owned north][owned south][halo of the north block][halo of the south block]
+    i.e. the owned part is exactly the output order of Trans(shard="mirror").invtrans.  partition() / remote_index() are
+    what HaloExchange::setup needs (StructuredColumns.cc:145-148); halo_begin = sizeOwned()."""
+
+    def __init__(self, grid, halo=1, periodic_points=False, nparts=1, part=0):
+        if isinstance(grid, str):
+            grid = StructuredGrid(name=grid)
+        self.grid, self.nparts, self.part = grid, int(nparts), int(part)
+        dist, self.bands = mirror_band_distribution(grid, nparts)
+        nx = np.asarray(grid.nx())
+        ny = len(nx)
+        off = np.concatenate([[0], np.cumsum(nx)])
+        # the same distribution with the two ranges of a part told apart: virtual part = 2*part + (row in the south)
+        south = np.repeat((np.arange(ny) >= ny // 2).astype(np.int32), nx)
+        vdist = (2 * dist + south).astype(np.int32)
+        self.blocks = [StructuredColumns(grid, halo=halo, periodic_points=periodic_points, nparts=2 * self.nparts,
+                                         part=2 * self.part + s, distribution=vdist) for s in (0, 1)]
+        # owned size of the northern block of every part: the offset of its southern block in the owner's numbering
+        north_owned = np.array([int(off[self.bands[q + 1]] - off[self.bands[q]]) for q in range(self.nparts)])
+        nA, nB = self.blocks[0].sizeOwned(), self.blocks[1].sizeOwned()
+        hA = self.blocks[0].sizeHalo() - nA
+        hB = self.blocks[1].sizeHalo() - nB
+        self._owned, self._size = nA + nB, nA + nB + hA + hB
+        # local index of block-local point i
+        self._local = [np.concatenate([np.arange(nA), nA + nB + np.arange(hA)]),
+                       np.concatenate([nA + np.arange(nB), nA + nB + hA + np.arange(hB)])]
+
+        def gather(name, dtype):
+            out = np.zeros(self._size, dtype=dtype)
+            for blk, loc in zip(self.blocks, self._local):
+                out[loc] = getattr(blk, name)()
+            return out
+
+        vpart = gather("partition", np.int32)
+        vridx = gather("remote_index", np.int32)
+        self._partition = (vpart // 2).astype(np.int32)
+        self._remote = (vridx + np.where(vpart % 2 == 1, north_owned[vpart // 2], 0)).astype(np.int32)
+        self._glb = gather("global_index", np.int64)
+        self._index_i, self._index_j = gather("index_i", np.int32), gather("index_j", np.int32)
+        self._ghost = gather("ghost", np.int32)
+        self._halo_exchange = None
+
+    def sizeOwned(self):
+        return self._owned
+
+    def sizeHalo(self):
+        return self._size
+
+    def partition(self):
+        return self._partition
+
+    def remote_index(self):
+        return self._remote
+
+    def global_index(self):
+        return self._glb
+
+    def index_i(self):
+        return self._index_i
+
+    def index_j(self):
+        return self._index_j
+
+    def ghost(self):
+        return self._ghost
+
+    def begin_halo_exchange(self, comm=None):
+        """HaloExchange::setup(partition, remote_index, 0, sizeHalo, sizeOwned): comm = a torch.distributed group (or
+        True) for one part per process; None (with nparts == 1) for a single part"""
+        hx = HaloExchange()
+        if comm is None and self.nparts != 1:
+            hx.setup_emulated(self.nparts, self.part, self._partition, self._remote, 0, self._size, self._owned)
+        else:
+            hx.setup(self._partition, self._remote, 0, self._size, halo_begin=self._owned, comm=comm)
+        self._halo_exchange = hx
+        return hx
+
+
 class NodeColumns:
     """Halo exchange of functionspace::NodeColumns (src/atlas/functionspace/NodeColumns.cc:101-113,357-459).
 

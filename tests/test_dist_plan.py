@@ -171,14 +171,14 @@ def test_halo_setup_over_gloo_matches_oracle():
             assert res[r][k] == getattr(ranks[r], k).tolist(), (r, k)
 
 
-def _halo_exchange_worker(rank, world, port, gridname, halo, nlev, q):
+def _halo_exchange_worker(rank, world, port, gridname, halo, nlev, q, mirror=False):
     sys.path.insert(0, ROOT)
     import atlas_amd
-    from atlas_amd.functionspace import StructuredColumns
+    from atlas_amd.functionspace import MirrorBandColumns, StructuredColumns
     from atlas_amd.parallel import HaloExchange, exchange_packed
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     g = atlas_amd.Grid(gridname)
-    fs = StructuredColumns(g, halo=halo, nparts=world, part=rank)
+    fs = (MirrorBandColumns if mirror else StructuredColumns)(g, halo=halo, nparts=world, part=rank)
     hx = HaloExchange()
     # StructuredColumns.cc:145-148: setup(partition, remote_index, base 0, sizeHalo, halo_begin = sizeOwned)
     hx.setup(fs.partition(), fs.remote_index(), 0, fs.sizeHalo(), halo_begin=fs.sizeOwned(), comm=True)
@@ -202,15 +202,17 @@ def _halo_exchange_worker(rank, world, port, gridname, halo, nlev, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,gridname,halo", [(2, "O16", 1), (3, "O16", 2), (4, "F16", 1)])
-def test_halo_exchange_communication_step_over_gloo(world, gridname, halo):
-    """StructuredColumns partitions (Atlas equal_bands) in `world` real processes: distributed HaloExchange.setup, then
+@pytest.mark.parametrize("world,gridname,halo,mirror", [(2, "O16", 1, False), (3, "O16", 2, False), (4, "F16", 1, False),
+                                                        (2, "O16", 2, True), (3, "O16", 1, True)])
+def test_halo_exchange_communication_step_over_gloo(world, gridname, halo, mirror):
+    """StructuredColumns partitions (Atlas equal_bands), or the two-range parts of the mirror-band decomposition
+    (MirrorBandColumns), in `world` real processes: distributed HaloExchange.setup, then
     the send/recv step of execute (atlas_amd.parallel.exchange_packed) on packed buffers; afterwards every halo point
     must hold the value of the point it mirrors (test_structuredcolumns_haloexchange.cc:38-60 in spirit)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_halo_exchange_worker, args=(r, world, port, gridname, halo, 3, q))
+    procs = [ctx.Process(target=_halo_exchange_worker, args=(r, world, port, gridname, halo, 3, q, mirror))
              for r in range(world)]
     for p in procs:
         p.start()

@@ -122,6 +122,29 @@ def test_explicit_distribution_matches_oracle():
         StructuredColumns(g, halo=1, nparts=nparts, part=0, distribution=dist[:-1])
 
 
+@pytest.mark.parametrize("gridname,halo,nparts", [("O16", 2, 1), ("O16", 1, 2), ("O16", 2, 3), ("F16", 1, 4)])
+def test_mirror_band_columns_indices_are_consistent(gridname, halo, nparts):
+    """MirrorBandColumns (function space of Trans(shard="mirror"): two row ranges per part, composed of two
+    StructuredColumns blocks): the owned points are the part's points in transform-output order, and every local point's
+    (partition, remote_index) names the same global point in its owner's numbering -- what HaloExchange::setup needs"""
+    from atlas_amd.functionspace import MirrorBandColumns, mirror_band_distribution
+    g = atlas_amd.Grid(gridname)
+    dist, b = mirror_band_distribution(g, nparts)
+    fss = [MirrorBandColumns(g, halo=halo, nparts=nparts, part=p) for p in range(nparts)]
+    assert sum(fs.sizeOwned() for fs in fss) == g.size()
+    off = np.concatenate([[0], np.cumsum(g.nx())])
+    for p, fs in enumerate(fss):
+        gi, part, ridx = fs.global_index(), fs.partition(), fs.remote_index()
+        own = gi[:fs.sizeOwned()] - 1
+        rows = np.concatenate([np.arange(b[p], b[p + 1]), np.arange(g.ny() - b[p + 1], g.ny() - b[p])])
+        assert np.array_equal(own, np.concatenate([np.arange(off[j], off[j + 1]) for j in rows]))   # invtrans order
+        assert np.all(dist[own] == p)
+        assert np.all(part[:fs.sizeOwned()] == p) and np.array_equal(ridx[:fs.sizeOwned()], np.arange(fs.sizeOwned()))
+        assert fs.sizeHalo() > fs.sizeOwned() and np.all(fs.ghost()[fs.sizeOwned():] == 1)
+        for n in range(fs.sizeOwned(), fs.sizeHalo()):
+            assert ridx[n] < fss[part[n]].sizeOwned() and fss[part[n]].global_index()[ridx[n]] == gi[n]
+
+
 def test_distributions_the_construction_cannot_describe_are_rejected():
     """the owned region is one row range with one i-range per row (StructuredColumns_setup.cc:125-226): a part with two
     separate row ranges, or with a hole inside a row, is refused (product and oracle) instead of building halos around
