@@ -54,3 +54,26 @@ def test_mirror_band_sharding_reproduces_single_device_result(gridname, T, nf, n
     r = subprocess.run([sys.executable, script, gridname, str(T), str(nf), str(nparts)], capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0 and "MIRROR OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.xfail(strict=False, reason="MirrorBandColumns was built after the round's GPU budget was spent")
+@pytest.mark.parametrize("gridname,nparts,halo", [("O16", 2, 2), ("O16", 3, 1)])
+def test_mirror_band_columns_halo_exchange_emulated(gridname, nparts, halo):
+    """function space of the mirror-band decomposition (two row ranges per part): after the halo exchange (device pack /
+    unpack, device copies for the transport) every node of every part holds its global index"""
+    import torch
+    from atlas_amd.functionspace import MirrorBandColumns
+    from atlas_amd.parallel import HaloExchange
+    from test_gpu_halo import exchange_emulated
+    g = atlas_amd.Grid(gridname)
+    fss = [MirrorBandColumns(g, halo=halo, nparts=nparts, part=p) for p in range(nparts)]
+    hxs = [f.begin_halo_exchange() for f in fss]
+    HaloExchange.finish_emulated(hxs)
+    fields = []
+    for f in fss:
+        a = np.where(f.ghost() == 0, f.global_index(), -1).astype(np.int64)
+        fields.append(torch.from_numpy(np.repeat(a[:, None], 3, axis=1).copy()).cuda())
+    exchange_emulated(hxs, fields)
+    for f, a in zip(fss, fields):
+        assert np.array_equal(a.cpu().numpy()[:, 0], f.global_index())
+        assert np.array_equal(a.cpu().numpy()[:, 2], f.global_index())
