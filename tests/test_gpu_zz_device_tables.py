@@ -1,7 +1,11 @@
-"""Device generation of the Legendre table (csrc/legendre_gen_kernel.hip; config key tables=device): the table in
+"""Last GPU test module of the session (the name sorts it after the others).
+
+1. Device generation of the Legendre table (csrc/legendre_gen_kernel.hip; config key tables=device): the table in
 device memory must equal the host-generated one bit for bit -- the kernels perform the reference's multiplications and
 additions in the reference's order (LegendrePolynomials.cc:85-149) without contraction -- for the whole table and for
-the wavenumber-sharded and latitude-band decompositions; the transform built on it then gives identical results."""
+the wavenumber-sharded and latitude-band decompositions; the transform built on it then gives identical results.
+2. The mirror-band decomposition (Trans(shard="mirror"), functionspace.MirrorBandColumns), built after round 1's GPU
+budget was spent: non-strict xfail until it has run on hardware once."""
 import numpy as np
 import pytest
 
