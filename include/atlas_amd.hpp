@@ -275,6 +275,14 @@ public:
                                                      vorticity_spectra, divergence_spectra, scalar_spectra));
     }
 
+    // Config("shard", "mirror"): this object transforms rows [first, second) of the grid and their mirror images
+    // [ny - second, ny - first); the output holds the northern rows, then the southern ones
+    std::pair<int, int> mirror_rows() const {
+        int b[2];
+        detail::check(atlas_amd__Trans__mirror_rows(h_, b));
+        return {b[0], b[1]};
+    }
+
     // Legendre cache blob in TransLocal's file layout (what LegendreCacheCreatorLocal::create() writes)
     std::vector<char> legendre_cache() const {
         std::vector<char> blob(atlas_amd__Trans__legendre_cache_size(h_));
