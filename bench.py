@@ -25,6 +25,9 @@ import time
 # torch.distributed.run exports OMP_NUM_THREADS=1 to every rank; the (untimed) set-up computes the Legendre tables on
 # the host with OpenMP -- about 80 s on one thread at T1279 -- so give every rank its share of the cores.  Must happen
 # before any OpenMP runtime is loaded (the library, torch).
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL / tensor sharing fail with the legacy mode); the GPU
+# box exports this already -- keep it if some launcher dropped it.  Must be set before the HIP runtime starts.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 _lws = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
 if _lws > 1 and os.environ.get("OMP_NUM_THREADS", "1") == "1":
     os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 1) // _lws))
