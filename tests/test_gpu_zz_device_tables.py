@@ -81,3 +81,30 @@ def test_mirror_band_columns_halo_exchange_emulated(gridname, nparts, halo):
     for f, a in zip(fss, fields):
         assert np.array_equal(a.cpu().numpy()[:, 0], f.global_index())
         assert np.array_equal(a.cpu().numpy()[:, 2], f.global_index())
+
+
+@pytest.mark.xfail(strict=False, reason="the adjoint goldens were added after the round's GPU budget was spent")
+@pytest.mark.parametrize("dtype", [np.float64, np.float32, np.int32, np.int64])
+@pytest.mark.parametrize("case", ["rank0_arrview", "rank1", "rank1_strided_v1", "rank1_strided_v2", "rank2", "rank2_l1",
+                                  "rank2_l2_v2", "rank2_v2", "rank0_wrap", "rank1_paralleldim1", "rank2_paralleldim2"])
+def test_reference_adjoint_fixture_on_device(case, dtype):
+    """execute_adjoint on the device (pack_adjoint / unpack_adjoint / zero_halos kernels on strided views) against every
+    expected array of src/tests/parallel/test_haloexchange_adjoint.cc (tests/golden/halo_adjoint_fixture.json)"""
+    import torch
+    from test_gpu_halo import exchange_emulated, fixture_objs
+    from test_oracle_halo import FIX, adjoint_expected, make_adjoint_fields
+    objs = fixture_objs()
+    full, views, pdim = make_adjoint_fields(case, dtype)
+    dev_full = [torch.from_numpy(a).cuda() for a in full]
+    dev_views = []
+    for a, v, d in zip(full, views, dev_full):
+        off = (v.__array_interface__["data"][0] - a.__array_interface__["data"][0]) // a.itemsize
+        dev_views.append(torch.as_strided(d, v.shape, [s // a.itemsize for s in v.strides], off))
+    exchange_emulated(objs, dev_views, pdim, adjoint=True)
+    checked = 0
+    for r in range(FIX["nranks"]):
+        want = adjoint_expected(case, r, full[r].size)
+        if want is not None:
+            assert dev_full[r].cpu().numpy().ravel().tolist() == want, (case, r)
+            checked += 1
+    assert checked >= 2

@@ -1,5 +1,6 @@
 """Pins the HaloExchange ORACLE (oracle/halo.py) against the reference's 3-rank fixture and every expected array of
-src/tests/parallel/test_haloexchange.cc:109-706 (tests/golden/halo_fixture.json), bit-exact."""
+src/tests/parallel/test_haloexchange.cc:109-706 (tests/golden/halo_fixture.json) and of
+src/tests/parallel/test_haloexchange_adjoint.cc (tests/golden/halo_adjoint_fixture.json), bit-exact."""
 import json
 import os
 
@@ -68,6 +69,63 @@ def test_oracle_reproduces_reference_expected_arrays(case):
     HaloExchangeOracle.execute(ranks, views, pdim)
     for r in range(FIX["nranks"]):
         assert full[r].ravel().tolist() == [float(x) for x in FIX["cases"][case]["expected"][r]], (case, r)
+
+
+ADJ = json.load(open(os.path.join(ROOT, "tests", "golden", "halo_adjoint_fixture.json")))
+
+
+def make_adjoint_fields(case, dtype=np.float64):
+    """the initial arrays of each case of test_haloexchange_adjoint.cc: values on every node (owned and halo);
+    returns (full arrays, views that take part in the exchange, parallel_dim)"""
+    full, views, pdim = [], [], 0
+    for r in range(FIX["nranks"]):
+        b = np.array(ADJ["cases"][case]["input"][r], dtype=dtype)
+        N = b.size
+        if case in ("rank0_arrview", "rank0_wrap"):
+            a = b.copy(); v = a
+        elif case in ("rank1", "rank1_cinterface", "rank1_strided_v1", "rank1_strided_v2"):
+            a = np.stack([b * 10, b * 100], axis=1)
+            v = {"rank1_strided_v1": a[:, 0:1], "rank1_strided_v2": a[:, 1:2]}.get(case, a)
+        elif case in ("rank2", "rank2_l1", "rank2_l2_v2", "rank2_v2"):
+            a = np.zeros((N, 3, 2), dtype=dtype)
+            for i in range(3):
+                a[:, i, 0] = -b * 10 ** i
+                a[:, i, 1] = b * 10 ** i
+            v = {"rank2": a, "rank2_l1": a[:, 0:1, :], "rank2_l2_v2": a[:, 1:2, 1:2], "rank2_v2": a[:, :, 1:2]}[case]
+        elif case == "rank1_paralleldim1":
+            a = np.stack([b * 10, b * 100], axis=0); v = a; pdim = 1
+        elif case == "rank2_paralleldim2":
+            a = np.zeros((3, N, 2), dtype=dtype)
+            for i in range(3):
+                a[i, :, 0] = -b * 10 ** i
+                a[i, :, 1] = b * 10 ** i
+            v = a; pdim = 1
+        else:
+            raise KeyError(case)
+        full.append(a); views.append(v)
+    return full, views, pdim
+
+
+def adjoint_expected(case, r, size):
+    """expected array of rank r, or None where the reference's own array is unusable (test_rank2_l2_v2, rank 1: a
+    missing comma makes it one entry short)"""
+    e = ADJ["cases"][case]["expected"][r]
+    return None if len(e) != size else [float(x) for x in e]
+
+
+@pytest.mark.parametrize("case", sorted(ADJ["cases"].keys()))
+def test_oracle_reproduces_reference_adjoint_expected_arrays(case):
+    """every expected array of src/tests/parallel/test_haloexchange_adjoint.cc (tests/golden/halo_adjoint_fixture.json)"""
+    ranks = fixture_ranks()
+    full, views, pdim = make_adjoint_fields(case)
+    HaloExchangeOracle.execute_adjoint(ranks, views, pdim)
+    checked = 0
+    for r in range(FIX["nranks"]):
+        want = adjoint_expected(case, r, full[r].size)
+        if want is not None:
+            assert full[r].ravel().tolist() == want, (case, r)
+            checked += 1
+    assert checked >= 2
 
 
 def test_adjoint_dot_product_identity():
