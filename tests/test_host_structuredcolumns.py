@@ -145,6 +145,31 @@ def test_mirror_band_columns_indices_are_consistent(gridname, halo, nparts):
             assert ridx[n] < fss[part[n]].sizeOwned() and fss[part[n]].global_index()[ridx[n]] == gi[n]
 
 
+@pytest.mark.parametrize("gridname", ["L40x21", "L40x20", "Slat100x50"])
+@pytest.mark.parametrize("nparts", [1, 2, 3, 4, 5])
+def test_regular_bands_properties_of_the_reference_test(gridname, nparts):
+    """src/tests/grid/test_distribution_regular_bands.cc:60-140 (CASE test_regular_bands): with the regular_bands
+    distribution every latitude lies in one partition, the partitions count all points once, and a StructuredColumns
+    with halo 1 and periodic points has i_begin_halo = -1, i_end_halo = nx + 2 on every row of its halo range"""
+    kind, dims = gridname[:-len(gridname.lstrip("LSlat"))], gridname.lstrip("LSlat")
+    nx, ny = (int(v) for v in dims.split("x"))
+    if kind == "L":
+        y = np.array([90.0 - j * 180.0 / (ny - 1) for j in range(ny)])          # poles included
+    else:
+        y = np.array([90.0 - (j + 0.5) * 180.0 / ny for j in range(ny)])        # shifted latitudes
+    g = atlas_amd.StructuredGrid(nx=np.full(ny, nx), y=y)
+    counted = 0
+    for part in range(nparts):
+        fs = StructuredColumns(g, halo=1, periodic_points=True, nparts=nparts, part=part, distribution="regular_bands")
+        owned_rows = fs.index_j()[:fs.sizeOwned()]
+        assert fs.sizeOwned() == nx * len(np.unique(owned_rows))               # whole latitudes only
+        assert np.all(fs.partition()[:fs.sizeOwned()] == part)
+        counted += fs.sizeOwned()
+        for j in range(fs.j_begin_halo(), fs.j_end_halo()):
+            assert (fs.i_begin_halo(j), fs.i_end_halo(j)) == (-1, nx + 2), (part, j)
+    assert counted == nx * ny
+
+
 def test_distributions_the_construction_cannot_describe_are_rejected():
     """the owned region is one row range with one i-range per row (StructuredColumns_setup.cc:125-226): a part with two
     separate row ranges, or with a hole inside a row, is refused (product and oracle) instead of building halos around
