@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <stdexcept>
 
@@ -77,7 +78,7 @@ int next_bluestein_length(int n) {
     return best;
 }
 
-FftShape make_shape(int M) {
+FftShape make_shape(int M, int max_pow2_radix) {
     if (!is_smooth235(M)) {
         throw std::invalid_argument("make_shape: M is not {2,3,5}-smooth");
     }
@@ -104,9 +105,13 @@ FftShape make_shape(int M) {
         push(3);
         r /= 3;
     }
-    while (r % 16 == 0) {
+    while (max_pow2_radix >= 16 && r % 16 == 0) {
         push(16);
         r /= 16;
+    }
+    while (r % 8 == 0 && r > 8) {
+        push(8);
+        r /= 8;
     }
     if (r == 8 || r == 4 || r == 2) {
         push(r);
@@ -149,7 +154,26 @@ static FftShape make_ct_shape(int f, int k) {
     return s;
 }
 
+int hybrid_dense_radix(int h) {
+    for (int p : {2, 3, 5}) {
+        while (h % p == 0) {
+            h /= p;
+        }
+    }
+    return h;
+}
+
 FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, bool specialised_shapes) {
+    PlanOptions opt;
+    opt.specialised_shapes = specialised_shapes;
+    if (const char* e = std::getenv("ATLAS_AMD_FFT_HYBRID")) {
+        opt.hybrid = atoi(e) != 0;
+    }
+    return make_fft_plans(row_lengths, opt);
+}
+
+FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, const PlanOptions& opt) {
+    const bool specialised_shapes = opt.specialised_shapes;
     FftPlanSet ps;
     std::vector<int> ns(row_lengths);
     std::sort(ns.begin(), ns.end());
@@ -200,6 +224,23 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, bool specialised_
             }
             p.shape = p.ct_k >= 0 ? make_ct_shape(p.ct_f, p.ct_k) : make_shape(h);
         }
+        else if (opt.hybrid && h >= opt.hybrid_min_h && hybrid_dense_radix(h) <= std::min(opt.hybrid_max_a, HYB_MAX_A)) {
+            p.method = FFT_HYBRID;
+            p.hyb_A  = hybrid_dense_radix(h);
+            p.hyb_B  = h / p.hyb_A;
+            p.shape  = make_shape(p.hyb_B, 8);   // radix-16 butterflies would cost the kernel a wavefront per SIMD
+            if (p.shape.nstages >= MAX_STAGES) {
+                throw std::runtime_error("make_fft_plans: too many stages");
+            }
+            p.shape.M                       = h;
+            p.shape.radix[p.shape.nstages]  = p.hyb_A;
+            p.shape.nstages += 1;
+            int L = h;
+            for (int i = 0; i < p.shape.nstages; ++i) {
+                p.shape.lsh[i] = ilog2_exact(L / p.shape.radix[i]);
+                L /= p.shape.radix[i];
+            }
+        }
         else {
             p.method     = FFT_BLUESTEIN;
             const int Mb = next_bluestein_length(2 * h - 1);
@@ -223,6 +264,29 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, bool specialised_
         p.off_pre     = (int64_t)ps.table.size();
         for (int k = 0; k < h; ++k) {
             ps.table.push_back(unit_root(k, n));
+        }
+        if (p.method == FFT_HYBRID) {
+            const int A = p.hyb_A, Kp = (A + 1) / 2;
+            p.hyb_Mt    = (Kp + 15) / 16;
+            p.hyb_Ks    = (Kp + 3) / 4;
+            p.hyb_raw   = std::min(h, opt.max_mode) + 1;
+            p.lds_complex += p.hyb_raw;
+            p.off_cs    = (int64_t)ps.table.size();
+            for (int mt = 0; mt < p.hyb_Mt; ++mt) {
+                for (int ks = 0; ks < p.hyb_Ks; ++ks) {
+                    for (int l = 0; l < 64; ++l) {
+                        const int j = 16 * mt + (l & 15), q = 4 * ks + (l >> 4);
+                        cplx v{0., 0.};
+                        if (j < Kp && q < Kp) {
+                            v = unit_root((int64_t)j * q, A);
+                            if (j == 0 || q == 0) {
+                                v.im = 0.;
+                            }
+                        }
+                        ps.table.push_back(v);
+                    }
+                }
+            }
         }
         if (p.method == FFT_BLUESTEIN) {
             // chirp c[k] = exp(+i pi k^2 / h) = exp(2 pi i (k^2 mod 2h) / 2h)
@@ -277,6 +341,35 @@ void host_execute_row(const FftPlanSet& ps, int plan, const cplx* X, int mmax, d
                 s += 2.0 * (X[m].re * t.re - X[m].im * t.im);
             }
             y[k] = s;
+        }
+        return;
+    }
+    if (p.method == FFT_HYBRID) {
+        RowTablesHyb r;
+        r.n = p.n, r.h = p.h, r.A = p.hyb_A, r.B = p.hyb_B, r.Kp = (p.hyb_A + 1) / 2;
+        r.Mt = p.hyb_Mt, r.Ks = p.hyb_Ks;
+        r.shape = &p.shape;
+        r.tw    = ps.table.data() + p.off_tw;
+        r.pre   = ps.table.data() + p.off_pre;
+        r.cs    = ps.table.data() + p.off_cs;
+        RowOut io;
+        io.mmax      = std::min(mmax, p.h);
+        io.y         = y;
+        io.aligned16 = 0;
+        io.scale     = 1.0;
+        auto rd      = [X](int m) { return X[m]; };
+        std::vector<cplx> work(padded_size(p.h)), raw(p.h + 1);
+        for (int t = 0; t < nthreads; ++t) {
+            hyb_gather(r, rd, io, raw.data(), t, nthreads);
+        }
+        for (int t = 0; t < nthreads; ++t) {
+            hyb_fold_split(r, io, raw.data(), work.data(), t, nthreads);
+        }
+        hyb_dense_host(r, work.data());
+        for (int i = p.shape.nstages - 2; i >= 0; --i) {
+            for (int t = 0; t < nthreads; ++t) {
+                hyb_native_phase(i, r, io, work.data(), t, nthreads);
+            }
         }
         return;
     }

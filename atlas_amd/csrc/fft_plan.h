@@ -5,6 +5,9 @@
 //
 // Method per row length n (h = n/2):
 //   DIRECT    n even, h is {2,3,5}-smooth : half-length complex FFT (c2r pre-processing + in-place DIT)
+//   HYBRID    n even, h = A*B, B smooth, A = product of the primes > 5 of h, 7 <= A <= HYB_MAX_A :
+//                                          half-length complex FFT whose radix-A stage is a dense DFT on the matrix
+//                                          cores (fft_core.h: "HYBRID rows"), no Bluestein
 //   BLUESTEIN n even otherwise            : half-length chirp-z with a {2,3,5}-smooth M >= 2h-1
 //   DFT       n odd                       : O(n*modes) direct sum (never hit by Gaussian grids)
 #pragma once
@@ -16,7 +19,7 @@
 namespace atlas_amd {
 namespace fft {
 
-enum FftMethod : int { FFT_DIRECT = 0, FFT_BLUESTEIN = 1, FFT_DFT = 2 };
+enum FftMethod : int { FFT_DIRECT = 0, FFT_BLUESTEIN = 1, FFT_DFT = 2, FFT_HYBRID = 3 };
 
 struct FftRowPlan {
     int n;              // row length (number of longitudes of the global row)
@@ -30,6 +33,17 @@ struct FftRowPlan {
     int64_t off_bhat;   // [M]  DFT_M(conj chirp, wrapped) / M in DIF order (BLUESTEIN)
     int64_t off_bhat_t; // [R_last][M/R_last] the same, transposed for the compile-time specialised kernel
     int ct_f, ct_k;     // M = ct_f << ct_k handled by a specialised kernel instance (ct_k < 0: generic kernel)
+    int hyb_A, hyb_B;   // HYBRID: dense radix and smooth part (h = hyb_A * hyb_B)
+    int hyb_Mt, hyb_Ks; // HYBRID: tiles of the padded (A+1)/2 x (A+1)/2 cos / sin matrices (16 rows, 4 columns)
+    int hyb_raw;        // HYBRID: entries of the LDS staging area for the row's modes (after the padded_size(h) work area)
+    int64_t off_cs;     // HYBRID: [Mt][Ks][64] {cos, sin} operand fragments
+};
+struct PlanOptions {
+    bool specialised_shapes = true;  // compile-time specialised kernel instances where they exist
+    bool hybrid             = true;  // dense-stage rows (HYBRID)
+    int hybrid_max_a        = HYB_MAX_A;
+    int hybrid_min_h        = 64;
+    int max_mode            = 1 << 30;  // highest wavenumber any row can carry (sizes the staging area of HYBRID rows)
 };
 
 struct FftPlanSet {
@@ -41,8 +55,10 @@ struct FftPlanSet {
 bool is_smooth235(int n);
 int next_smooth235(int n);
 int next_bluestein_length(int n);  // smallest {1,3,5}*2^k >= n
-FftShape make_shape(int M);  // M must be {2,3,5}-smooth
+FftShape make_shape(int M, int max_pow2_radix = 16);  // M must be {2,3,5}-smooth
+FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, const PlanOptions& opt);
 FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, bool specialised_shapes = true);
+int hybrid_dense_radix(int h);  // product of the prime factors > 5 of h
 
 // Host execution of one row with exactly the kernel's algorithm (used by CPU tests; NOT a product fallback:
 // nothing in the invtrans path calls it).  X: h+1 (or n/2+1) complex modes (zero beyond mmax); y: n reals.

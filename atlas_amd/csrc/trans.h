@@ -162,6 +162,7 @@ private:
         int nthreads;
         int ct_f, ct_k;  // specialised kernel instance, or ct_k < 0
         bool direct;     // specialised instance is the direct (no Bluestein) kernel
+        bool hybrid = false;  // dense-stage rows (fft_rows_hyb_kernel)
         int nrows;
         int* d_rows;
     };

@@ -25,6 +25,7 @@ hipError_t launch_convert_f64_f32(const double* src, float* dst, size_t n, hipSt
 hipError_t launch_fourier(const FourierParams& p, int lds_bytes, int nthreads, hipStream_t stream);
 hipError_t launch_fourier_ct(const FourierParams& p, int ctf, int ctk, int lds_bytes, int nthreads,
                              hipStream_t stream);
+hipError_t launch_fourier_hyb(const FourierParams& p, int lds_bytes, int nthreads, hipStream_t stream);
 hipError_t launch_fourier_dct(const FourierParams& p, int ctf, int ctk, int lds_bytes, int nthreads,
                               hipStream_t stream);
 hipError_t launch_spectra_prepare(const double* vor, const double* div, const double* sp, double* out, int T, int nvd,
@@ -93,7 +94,18 @@ Trans::Trans(const grid::StructuredGrid& grid, int truncation, const TransConfig
     else {
         lengths = geo_.nx;
     }
-    fftplans_ = fft::make_fft_plans(lengths, use_ct_);
+    {
+        fft::PlanOptions po;
+        po.specialised_shapes = use_ct_;
+        po.max_mode           = geo_.T;
+        if (const char* e = std::getenv("ATLAS_AMD_FFT_HYBRID")) {      // A/B switch: 0 = Bluestein for every awkward row
+            po.hybrid = atoi(e) != 0;
+        }
+        if (const char* e = std::getenv("ATLAS_AMD_FFT_HYB_MAXA")) {    // largest dense radix
+            po.hybrid_max_a = atoi(e);
+        }
+        fftplans_ = fft::make_fft_plans(lengths, po);
+    }
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     own_stream_ = true;
     upload();
@@ -287,6 +299,22 @@ void Trans::upload() {
             by_class[{2, pl.shape.M}].push_back(j);  // specialised direct rows
             continue;
         }
+        if (pl.method == fft::FFT_HYBRID) {
+            // dense-stage rows, bucketed by LDS footprint (workgroups per CU: 8, 6, 4, 3, 2, 1)
+            const int fp = pl.lds_complex;
+            int cls      = 0;
+            for (int c : {1280, 1700, 2560, 3400, 5120, 10240}) {
+                if (fp <= c) {
+                    cls = c;
+                    break;
+                }
+            }
+            if (cls == 0) {
+                throw std::runtime_error("row length " + std::to_string(pl.n) + " does not fit in LDS (160 KiB)");
+            }
+            by_class[{3, cls}].push_back(j);
+            continue;
+        }
         int cls = -1;
         for (int c : class_M) {
             if (pl.lds_complex <= fft::padded_size(c)) {
@@ -316,6 +344,22 @@ void Trans::upload() {
         c.nrows     = (int)it->second.size();
         c.ct_f = c.ct_k = -1;
         c.direct = it->first.first == 2;
+        c.hybrid = it->first.first == 3;
+        if (c.hybrid) {
+            int lds = 0, nthr = 64;
+            for (int j : it->second) {
+                const fft::FftRowPlan& pl = fftplans_.plans[row_plan[j]];
+                lds                       = std::max(lds, pl.lds_complex);
+                // one radix-8 butterfly per worker and stage; enough wavefronts for the dense stage's row tiles
+                nthr = std::max(nthr, std::min(512, (pl.h / 8 + 63) / 64 * 64));
+                nthr = std::max(nthr, 64 * ((pl.hyb_Mt + fft::HYB_UPW - 1) / fft::HYB_UPW));
+            }
+            if (const char* e = std::getenv("ATLAS_AMD_FFT_HYB_NT")) {
+                nthr = std::max(nthr, atoi(e));
+            }
+            c.lds_bytes = lds * 16;
+            c.nthreads  = nthr;
+        }
         if (it->first.first >= 1) {
             const fft::FftRowPlan& pl = fftplans_.plans[row_plan[it->second[0]]];
             c.ct_f                    = pl.ct_f;
@@ -472,7 +516,10 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
             }
             st = stream3_;
         }
-        if (c.ct_k >= 0 && use_ct_) {
+        if (c.hybrid) {
+            HIP_CHECK(launch_fourier_hyb(p, c.lds_bytes, c.nthreads, st));
+        }
+        else if (c.ct_k >= 0 && use_ct_) {
             if (c.direct) {
                 HIP_CHECK(launch_fourier_dct(p, c.ct_f, c.ct_k, c.lds_bytes, c.nthreads, st));
             }
