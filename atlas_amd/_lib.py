@@ -142,6 +142,7 @@ legendre_reference_tables = _sig("atlas_amd__legendre_reference_tables", C.c_int
                                  C.c_size_t, c_void_p, C.c_size_t)
 fft_host_row = _sig("atlas_amd__fft_host_row", C.c_int, C.c_int, c_void_p, C.c_int, c_void_p)
 fft_host_row_generic = _sig("atlas_amd__fft_host_row_generic", C.c_int, C.c_int, c_void_p, C.c_int, c_void_p)
+fft_host_row_hybrid = _sig("atlas_amd__fft_host_row_hybrid", C.c_int, C.c_int, c_void_p, C.c_int, c_void_p)
 
 
 def check(rc):

@@ -40,7 +40,7 @@ struct FftRowPlan {
 };
 struct PlanOptions {
     bool specialised_shapes = true;  // compile-time specialised kernel instances where they exist
-    bool hybrid             = true;  // dense-stage rows (HYBRID)
+    bool hybrid             = false; // dense-stage rows (HYBRID): opt-in (ATLAS_AMD_FFT_HYBRID=1) until it beats Bluestein
     int hybrid_max_a        = HYB_MAX_A;
     int hybrid_min_h        = 64;
     int max_mode            = 1 << 30;  // highest wavenumber any row can carry (sizes the staging area of HYBRID rows)

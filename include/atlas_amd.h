@@ -237,6 +237,9 @@ int atlas_amd__legendre_gen_host_selfcheck(const atlas_amd_Grid* grid, int trunc
 int atlas_amd__fft_host_row(int n, const double* modes, int mmax, double* out);
 /* same through the generic (run-time shape) phase code even where a compile-time specialised instance exists */
 int atlas_amd__fft_host_row_generic(int n, const double* modes, int mmax, double* out);
+/* same with the dense-stage ("hybrid") plan where the row length admits one: h = n/2 = A*B, A the product of the prime
+ * factors > 5 of h (A <= 257), B {2,3,5}-smooth; other lengths take their usual plan */
+int atlas_amd__fft_host_row_hybrid(int n, const double* modes, int mmax, double* out);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * HaloExchange.  Replaces atlas__HaloExchange__* (src/atlas/parallel/HaloExchange.h:429-456).
