@@ -57,6 +57,7 @@ struct FourierParams {
     const long long* rowoff;          // [nlats+1]
     const int* rows;                  // rows handled by this launch (size class)
     int nrows;
+    unsigned nvirt;                   // virtual blocks (row, field slots) of the launch, set by the launcher
     int T;
     int RP;
     int nf;

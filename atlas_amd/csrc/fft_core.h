@@ -711,6 +711,8 @@ struct CtShape {
     static constexpr int K  = K_;
     static constexpr int M  = F_ << K_;
     static constexpr int NS = ct_nstages(F_, K_);
+    // workers per row of the Bluestein kernel: one radix-16 butterfly each in the middle stages
+    static constexpr int NT = (M / 16 + 63) / 64 * 64 < 64 ? 64 : ((M / 16 + 63) / 64 * 64 > 512 ? 512 : (M / 16 + 63) / 64 * 64);
     static constexpr int radix(int i) { return ct_radix(F_, K_, i); }
     static constexpr int L(int i) {
         int l = M;
@@ -768,8 +770,65 @@ AA_HD constexpr int row_num_phases_ct() {
     return 2 * S::NS - 1;
 }
 
-template <class S, class Reader>
-AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCt& r, const Reader& rd, const RowOut& io,
+// ---- the row's kept modes are fetched ONCE per row into an LDS staging area `raw` before phase 0, which needs every
+//      mode twice (X[k] and X[h-k]).  Device: fft_kernel.hip (LDS-DMA gather); host emulation: plain copy.
+AA_HD cplx ct_raw_mode(const cplx* raw, int mmax, int m, int h) {
+    cplx v = m <= mmax ? raw[m] : cplx{0., 0.};
+    if (m == 0 || m == h) {
+        v.im = 0.;   // conventions of row_mode()
+    }
+    return v;
+}
+
+// phase 0 of a specialised Bluestein row, butterfly b: c2r pre-processing + chirp + DIF stage 0 (L = M, one block) in
+// registers.  M >= 2h-1 and M even: h <= M/2, so the inputs q >= NZ = ceil(R0/2) are zero padding for every b.  The
+// table loads are issued in batches of NB elements ahead of a scheduling fence: left alone, the compiler serialises
+// them one round trip at a time to save registers.
+template <class S>
+AA_HD void ct_phase0_compute(int b, const RowTablesCt& r, const cplx* raw, const RowOut& io, cplx* x) {
+    constexpr int M   = S::M;
+    constexpr int R0  = S::radix(0);
+    constexpr int Ls0 = M / R0;
+    constexpr int NZ  = (R0 + 1) / 2;
+    constexpr int NB  = NZ <= 5 ? NZ : (NZ % 5 == 0 ? 5 : (NZ % 4 == 0 ? 4 : (NZ % 3 == 0 ? 3 : 2)));
+    const int h       = r.h;
+    cplx w1           = r.tw[b];
+#pragma unroll
+    for (int q0 = 0; q0 < NZ; q0 += NB) {
+        cplx P[NB], C[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (q0 + i < NZ) {
+                const int k  = b + (q0 + i) * Ls0;
+                const int kc = k < h ? k : h - 1;
+                P[i]         = r.pre[kc * AA_ABL(r, 1)];
+                C[i]         = r.chirp[kc * AA_ABL(r, 1)];
+            }
+        }
+        AA_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (q0 + i < NZ) {
+                const int k  = b + (q0 + i) * Ls0;
+                const int kc = k < h ? k : h - 1;
+                const cplx a = ct_raw_mode(raw, io.mmax, kc, h);
+                const cplx c = cconj(ct_raw_mode(raw, io.mmax, h - kc, h));
+                const cplx z = cmul(c2r_pre(a, c, P[i]), C[i]);
+                x[q0 + i]    = k < h ? z : cplx{0., 0.};
+            }
+        }
+    }
+#pragma unroll
+    for (int q = NZ; q < R0; ++q) x[q] = cplx{0., 0.};
+    bfly<R0>(x, -1);
+    w1.im = -w1.im;
+    twiddle_apply<R0>(x, w1);
+}
+
+// RAW_ALIASES_WORK: the staging area lives inside `work` (device: LDS is the scarce resource), so every worker
+// finishes reading it before anybody writes stage-0 results; needs nt == S::NT.
+template <class S, bool RAW_ALIASES_WORK>
+AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCt& r, const cplx* raw, const RowOut& io,
                         cplx* work) {
     constexpr int M   = S::M;
     constexpr int NS  = S::NS;
@@ -778,48 +837,32 @@ AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCt& r, const Reade
     constexpr int RL  = S::radix(NS - 1);
     const int h       = r.h;
     if (ph == 0) {
-        // ---- fused: load + c2r pre-processing + chirp + DIF stage 0 (L = M, one block)
-        // M >= 2h-1 and M even: h <= M/2, so the inputs q >= NZ = ceil(R0/2) are zero padding for every b.
-        // The global loads are issued in batches of NB elements (4 loads each: X[k], X[h-k], pre, chirp; clamped
-        // addresses, masks applied afterwards) ahead of a scheduling fence: left alone, the compiler serialises
-        // them one round trip at a time to save registers.
-        constexpr int NZ = (R0 + 1) / 2;
-        constexpr int NB = NZ <= 5 ? NZ : (NZ % 5 == 0 ? 5 : (NZ % 4 == 0 ? 4 : (NZ % 3 == 0 ? 3 : 2)));
-        for (int b = t; b < Ls0; b += nt) {
-            cplx x[R0];
-            cplx w1 = r.tw[b];
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (RAW_ALIASES_WORK) {
+            constexpr int NBUT = (Ls0 + S::NT - 1) / S::NT;
+            cplx x[NBUT][R0];
 #pragma unroll
-            for (int q0 = 0; q0 < NZ; q0 += NB) {
-                cplx A[NB], B[NB], P[NB], C[NB];
-#pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    if (q0 + i < NZ) {
-                        const int k  = b + (q0 + i) * Ls0;
-                        const int kc = k < h ? k : h - 1;
-                        A[i]         = rd(row_mode_index(io.mmax, kc));
-                        B[i]         = rd(row_mode_index(io.mmax, h - kc));
-                        P[i]         = r.pre[kc * AA_ABL(r, 1)];
-                        C[i]         = r.chirp[kc * AA_ABL(r, 1)];
-                    }
-                }
-                AA_SCHED_FENCE();
-#pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    if (q0 + i < NZ) {
-                        const int k  = b + (q0 + i) * Ls0;
-                        const int kc = k < h ? k : h - 1;
-                        const cplx a = row_mode_mask(A[i], io.mmax, kc, h);
-                        const cplx c = cconj(row_mode_mask(B[i], io.mmax, h - kc, h));
-                        const cplx z = cmul(c2r_pre(a, c, P[i]), C[i]);
-                        x[q0 + i]    = k < h ? z : cplx{0., 0.};
-                    }
+            for (int ib = 0; ib < NBUT; ++ib) {
+                const int b = t + ib * S::NT;
+                if (b < Ls0) {
+                    ct_phase0_compute<S>(b, r, raw, io, x[ib]);
                 }
             }
+            __syncthreads();
 #pragma unroll
-            for (int q = NZ; q < R0; ++q) x[q] = cplx{0., 0.};
-            bfly<R0>(x, -1);
-            w1.im = -w1.im;
-            twiddle_apply<R0>(x, w1);
+            for (int ib = 0; ib < NBUT; ++ib) {
+                const int b = t + ib * S::NT;
+                if (b < Ls0) {
+#pragma unroll
+                    for (int q = 0; q < R0; ++q) work[PAD(b + q * Ls0)] = x[ib][q];
+                }
+            }
+            return;
+        }
+#endif
+        for (int b = t; b < Ls0; b += nt) {
+            cplx x[R0];
+            ct_phase0_compute<S>(b, r, raw, io, x);
 #pragma unroll
             for (int q = 0; q < R0; ++q) work[PAD(b + q * Ls0)] = x[q];
         }

@@ -49,7 +49,8 @@ struct ModeReaderT {
     const FourierParams& p;
     long long lat_local;
     int f2;
-    __device__ __forceinline__ cplx operator()(int m) const {
+    // address of mode m (fp64 storage: a double*; fp32 storage: element index in floats, see operator())
+    __device__ __forceinline__ const double* locate(int m, long long& o) const {
         const double* base = p.part_base[0];
         int cnt            = p.part_cnt[0];
         int ml             = m;
@@ -67,7 +68,17 @@ struct ModeReaderT {
 #if defined(AA_FFT_ABLATE)
         if (p.abl & 1) ml = 0;
 #endif
-        const long long o = (lat_local * cnt + ml) * p.RP + f2;
+        o = (lat_local * cnt + ml) * p.RP + f2;
+        return base;
+    }
+    __device__ __forceinline__ const double* address(int m) const {   // fp64 storage only
+        long long o;
+        const double* base = locate(m, o);
+        return base + o;
+    }
+    __device__ __forceinline__ cplx operator()(int m) const {
+        long long o;
+        const double* base = locate(m, o);
         if (STORAGE == 1 || (STORAGE == 2 && p.f32)) {  // fp32 intermediate: same element indexing, float storage
             const fft::fpair v = *reinterpret_cast<const fft::fpair*>(reinterpret_cast<const float*>(base) + o);
             return cplx{(double)v.x, (double)v.y};
@@ -192,21 +203,58 @@ __device__ __forceinline__ void for_each_phase(Fn&& fn) {
     }
 }
 
+// Gather of the kept modes X[0..mmax] of one (row, field) into LDS (raw[m], contiguous).  fp64: LDS-DMA, 16 bytes per
+// lane straight from the Fourier intermediate into LDS (no staging registers; destination = wave-uniform base + 16 * lane,
+// so lane l of wave w handles m = sweep * nt + 64 w + l; lanes beyond mmax re-read mode mmax into slots nobody reads).
+// fp32 intermediate: through registers (the 8-byte element has no DMA width).
+template <bool F32>
+__device__ __forceinline__ void gather_modes_to_lds(const FourierParams& p, long long lat_local, int f, int mmax,
+                                                    cplx* raw, int tid, int nt) {
+    const ModeReaderT<(F32 ? 1 : 0)> rd{p, lat_local, 2 * f};
+    if (mmax < 0) {
+        return;
+    }
+    for (int m0 = 0; m0 <= mmax; m0 += nt) {
+        const int m  = m0 + tid;
+        const int mc = m <= mmax ? m : mmax;
+        if constexpr (F32) {
+            const cplx v = rd(mc);
+            if (m <= mmax) {
+                raw[m] = v;
+            }
+        }
+        else {
+            if ((m0 + (tid & ~63)) <= mmax) {   // wave-uniform: this wavefront has at least one live lane
+                const double* src = rd.address(mc);
+                cplx* dst         = raw + m0 + (tid & ~63);   // wave-uniform
+                __builtin_amdgcn_global_load_lds(
+                    reinterpret_cast<const __attribute__((address_space(1))) void*>(reinterpret_cast<uintptr_t>(src)),
+                    reinterpret_cast<__attribute__((address_space(3))) void*>(
+                        static_cast<unsigned>(reinterpret_cast<uintptr_t>(dst))),
+                    16, 0, 0);
+            }
+        }
+    }
+}
+
+// One workgroup of S::NT workers per (row, field).  Every mode of the row is fetched from the Fourier intermediate once,
+// into an LDS staging area that aliases the work array (phase 0 reads it completely before writing its results).
 template <class S, bool F32>
-__global__ void __launch_bounds__(FFT_MAX_NTHR, 3) fft_rows_ct_kernel(FourierParams p) {
+__global__ void __launch_bounds__(S::NT, 3) fft_rows_ct_kernel(FourierParams p) {
     extern __shared__ double lds_raw[];
     cplx* work = reinterpret_cast<cplx*>(lds_raw);
     int row, f;
     if (!fft_block_to_job(p, blockIdx.x, row, f)) {
         return;
     }
+    const int tid      = threadIdx.x;
+    constexpr int nt   = S::NT;
+    constexpr int NPH  = fft::row_num_phases_ct<S>();
+    const bool prof    = p.prof != nullptr && tid == 0;
     const fft::FftRowPlan* pl = p.plans + p.row_plan[row];
     const long long goff      = (long long)f * p.npts + (p.rowoff[row] - p.rowoff[p.lat0]);
-    const int tid             = threadIdx.x;
-    const int nt              = blockDim.x;
     const double scale        = (f < p.scale_uv_fields) ? p.coslatinv[row] : 1.0;
     const int mmax            = p.row_mmax[row];
-    const ModeReaderT<(F32 ? 1 : 0)> rd{p, (long long)(row - p.lat0), 2 * f};
     fft::RowTablesCt r;
 #if defined(AA_FFT_ABLATE)
     r.abl    = p.abl;
@@ -223,17 +271,22 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR, 3) fft_rows_ct_kernel(FourierPar
     io.aligned16 = ((goff & 1) == 0);
     io.f32       = F32 ? 1 : 0;
     io.scale     = scale;
-    constexpr int NPH = fft::row_num_phases_ct<S>();
     unsigned long long tprev = 0;
-    const bool prof = p.prof != nullptr && tid == 0;
     if (prof) {
         tprev = clock64();
+    }
+    gather_modes_to_lds<F32>(p, (long long)(row - p.lat0), f, io.mmax, work, tid, nt);
+    __syncthreads();
+    if (prof) {
+        const unsigned long long tn = clock64();
+        atomicAdd(&p.prof[30], tn - tprev);
+        tprev = tn;
     }
     // compile-time recursion over the phases: `#pragma unroll` gives up on the largest shapes ("unrolled size is too
     // large") and would leave a run-time loop around a switch
     for_each_phase<S, 0>([&](auto phc) {
         constexpr int ph = decltype(phc)::value;
-        fft::row_phase_ct<S>(ph, tid, nt, r, rd, io, work);
+        fft::row_phase_ct<S, true>(ph, tid, nt, r, work, io, work);
         if constexpr (ph < NPH - 1) {
             if constexpr (S::wave_local_middle() && ph >= 1 && ph <= NPH - 3) {
                 // producer and consumer lanes of the next phase are in this wavefront: LDS executes a wavefront's
@@ -407,7 +460,7 @@ hipError_t launch_fourier_hyb(const FourierParams& p, int lds_bytes, int nthread
 }
 
 template <class S, bool F32>
-static hipError_t launch_ct_t(const FourierParams& p, int lds_bytes, int nthreads, unsigned nblk, hipStream_t stream) {
+static hipError_t launch_ct_t(FourierParams p, int lds_bytes, unsigned nblk, hipStream_t stream) {
     static int max_set = 0;
     if (lds_bytes > max_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_ct_kernel<S, F32>),
@@ -417,22 +470,23 @@ static hipError_t launch_ct_t(const FourierParams& p, int lds_bytes, int nthread
         }
         max_set = lds_bytes;
     }
+    const unsigned grid = nblk;
+    p.nvirt             = nblk;
     static const bool debug = std::getenv("ATLAS_AMD_FFT_DEBUG") != nullptr;
     if (debug) {
-        int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fft_rows_ct_kernel<S, F32>, nthreads, lds_bytes);
+        int per_cu = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fft_rows_ct_kernel<S, F32>, S::NT, lds_bytes);
         hipFuncAttributes fa{};
         (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&fft_rows_ct_kernel<S, F32>));
-        std::fprintf(stderr, "[atlas_amd] fft ct M=%d threads=%d lds=%d blocks=%u regs=%d scratch=%zu -> %d workgroups/CU\n",
-                     S::M, nthreads, lds_bytes, nblk, fa.numRegs, (size_t)fa.localSizeBytes, nb);
+        std::fprintf(stderr, "[atlas_amd] fft ct M=%d threads=%d lds=%d rows*fields=%u regs=%d scratch=%zu -> %d workgroups/CU\n",
+                     S::M, S::NT, lds_bytes, nblk, fa.numRegs, (size_t)fa.localSizeBytes, per_cu);
     }
-    hipLaunchKernelGGL((fft_rows_ct_kernel<S, F32>), dim3(nblk), dim3(nthreads), lds_bytes, stream, p);
+    hipLaunchKernelGGL((fft_rows_ct_kernel<S, F32>), dim3(grid), dim3(S::NT), lds_bytes, stream, p);
     return hipGetLastError();
 }
 template <class S>
-static hipError_t launch_ct(const FourierParams& p, int lds_bytes, int nthreads, unsigned nblk, hipStream_t stream) {
-    return p.f32 ? launch_ct_t<S, true>(p, lds_bytes, nthreads, nblk, stream)
-                 : launch_ct_t<S, false>(p, lds_bytes, nthreads, nblk, stream);
+static hipError_t launch_ct(const FourierParams& p, int lds_bytes, unsigned nblk, hipStream_t stream) {
+    return p.f32 ? launch_ct_t<S, true>(p, lds_bytes, nblk, stream) : launch_ct_t<S, false>(p, lds_bytes, nblk, stream);
 }
 
 hipError_t launch_fourier_ct(const FourierParams& p, int ctf, int ctk, int lds_bytes, int nthreads,
@@ -440,7 +494,8 @@ hipError_t launch_fourier_ct(const FourierParams& p, int ctf, int ctk, int lds_b
     const int ngr         = (p.f_end - p.f_begin + FGROUP - 1) / FGROUP;
     const long long units = (long long)p.nrows * ngr;
     const unsigned nblk   = (unsigned)((units + 7) / 8 * 64);
-    AA_CT_DISPATCH(ctf, ctk, return launch_ct<S>(p, lds_bytes, nthreads, nblk, stream))
+    (void)nthreads;   // the specialised Bluestein kernel has a compile-time worker count (CtShape::NT)
+    AA_CT_DISPATCH(ctf, ctk, return launch_ct<S>(p, lds_bytes, nblk, stream))
     return hipErrorInvalidValue;
 }
 

@@ -328,6 +328,11 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, const PlanOptions
     return ps;
 }
 
+template <class S>
+static void row_phase_ct_host(int ph, int t, int nt, const RowTablesCt& r, const cplx* raw, const RowOut& io, cplx* work) {
+    row_phase_ct<S, false>(ph, t, nt, r, raw, io, work);   // staging area separate from the work array
+}
+
 void host_execute_row(const FftPlanSet& ps, int plan, const cplx* X, int mmax, double* y, int nthreads,
                       bool use_specialised) {
     const FftRowPlan& p = ps.plans.at(plan);
@@ -422,9 +427,13 @@ void host_execute_row(const FftPlanSet& ps, int plan, const cplx* X, int mmax, d
         const int ctf = p.ct_f, ctk = p.ct_k;
         bool done = false;
         AA_CT_DISPATCH(ctf, ctk, {
+            std::vector<cplx> rawv(p.h + 1);
+            for (int m = 0; m <= io.mmax; ++m) {
+                rawv[m] = X[m];
+            }
             for (int ph = 0; ph < row_num_phases_ct<S>(); ++ph) {
                 for (int t = 0; t < nthreads; ++t) {
-                    row_phase_ct<S>(ph, t, nthreads, rc, rd, io, work.data());
+                    row_phase_ct_host<S>(ph, t, nthreads, rc, rawv.data(), io, work.data());
                 }
             }
             done = true;
