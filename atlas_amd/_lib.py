@@ -38,6 +38,26 @@ def _sig(name, restype, *argtypes):
 last_error = _sig("atlas_amd__last_error", C.c_char_p)
 version = _sig("atlas_amd__version", C.c_char_p)
 device_count = _sig("atlas_amd__device_count", C.c_int)
+stream_wait_stream = _sig("atlas_amd__stream_wait_stream", C.c_int, c_void_p, c_void_p)
+
+
+class torch_stream_order:
+    """`with torch_stream_order(obj_stream):` -- device tensors handed to the library were produced on torch's current
+    stream and will be consumed there: the object's stream first waits for torch's stream, and torch's stream then waits
+    for what was submitted inside the block (events, no host synchronisation)."""
+
+    def __init__(self, obj_stream):
+        import torch
+        self.obj = obj_stream
+        self.torch = torch.cuda.current_stream().cuda_stream
+
+    def __enter__(self):
+        check(stream_wait_stream(self.obj, self.torch))
+        return self
+
+    def __exit__(self, *exc):
+        check(stream_wait_stream(self.torch, self.obj))
+        return False
 
 Grid_new_gaussian = _sig("atlas_amd__Grid__new_gaussian", c_void_p, C.c_char_p)
 Grid_new_structured = _sig("atlas_amd__Grid__new_structured", c_void_p, C.c_int, c_void_p, c_void_p)

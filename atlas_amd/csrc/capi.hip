@@ -93,6 +93,70 @@ int atlas_amd__device_count(void) {
     return n;
 }
 
+int atlas_amd__stream_wait_stream(void* waiting_stream, void* signalling_stream) {
+    AA_TRY
+    if (waiting_stream != signalling_stream) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            throw std::runtime_error("stream_wait_stream: hipEventCreate failed");
+        }
+        hipError_t r = hipEventRecord(e, (hipStream_t)signalling_stream);
+        if (r == hipSuccess) {
+            r = hipStreamWaitEvent((hipStream_t)waiting_stream, e, 0);
+        }
+        (void)hipEventDestroy(e);   // released once the recorded work has completed
+        if (r != hipSuccess) {
+            throw std::runtime_error(std::string("stream_wait_stream: ") + hipGetErrorString(r));
+        }
+    }
+    AA_CATCH_INT
+}
+
+void* atlas_amd__device_malloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+        (void)hipGetLastError();
+        atlas_amd::set_last_error("device_malloc: hipMalloc failed");
+        return nullptr;
+    }
+    return p;
+}
+int atlas_amd__device_free(void* ptr) {
+    AA_TRY
+    if (ptr && hipFree(ptr) != hipSuccess) {
+        throw std::runtime_error("device_free: hipFree failed");
+    }
+    AA_CATCH_INT
+}
+int atlas_amd__device_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes) {
+    AA_TRY
+    if (bytes && hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        throw std::runtime_error("device_memcpy_h2d failed");
+    }
+    AA_CATCH_INT
+}
+int atlas_amd__device_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes) {
+    AA_TRY
+    if (bytes && hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+        throw std::runtime_error("device_memcpy_d2h failed");
+    }
+    AA_CATCH_INT
+}
+int atlas_amd__device_synchronize(void) {
+    AA_TRY
+    if (hipDeviceSynchronize() != hipSuccess) {
+        throw std::runtime_error("device_synchronize failed");
+    }
+    AA_CATCH_INT
+}
+int atlas_amd__set_device(int device) {
+    AA_TRY
+    if (hipSetDevice(device) != hipSuccess) {
+        throw std::runtime_error("set_device failed");
+    }
+    AA_CATCH_INT
+}
+
 // ---------------------------------------------------------------- Grid
 atlas_amd_Grid* atlas_amd__Grid__new_gaussian(const char* name) {
     AA_TRY
@@ -245,6 +309,7 @@ atlas_amd_Trans* atlas_amd__Trans__new(const atlas_amd_Grid* grid, int truncatio
 }
 void atlas_amd__Trans__delete(atlas_amd_Trans* t) {
     if (t) {
+        t->dist.reset();   // refers to *t->impl
         delete t->impl;
         delete t;
     }
@@ -347,6 +412,29 @@ int atlas_amd__Trans__backend(char** backend, size_t* size) {
     *backend             = (char*)std::malloc(s.size() + 1);
     std::memcpy(*backend, s.c_str(), s.size() + 1);
     AA_CATCH_INT
+}
+int atlas_amd__Trans__handle(const atlas_amd_Trans* t, int* handle) {
+    AA_TRY
+    (void)t;
+    (void)handle;
+    throw std::logic_error("Not implemented: Trans::handle() (TransImpl.cc:20-22; only the IFS backend has one)");
+    AA_CATCH_INT
+}
+const atlas_amd_Spectral* atlas_amd__Trans__spectral(const atlas_amd_Trans* t) {
+    if (!t) {
+        return nullptr;
+    }
+    const_cast<atlas_amd_Trans*>(t)->spectral.truncation = t->impl->truncation();
+    return &t->spectral;
+}
+int atlas_amd__Spectral__truncation(const atlas_amd_Spectral* s) {
+    return s ? s->truncation : -1;
+}
+int64_t atlas_amd__Spectral__nb_spectral_coefficients(const atlas_amd_Spectral* s) {
+    return s ? (int64_t)(s->truncation + 1) * (s->truncation + 2) : 0;
+}
+int64_t atlas_amd__Spectral__nb_spectral_coefficients_global(const atlas_amd_Spectral* s) {
+    return atlas_amd__Spectral__nb_spectral_coefficients(s);
 }
 const atlas_amd_Grid* atlas_amd__Trans__grid(const atlas_amd_Trans* t) {
     return t ? t->grid : nullptr;

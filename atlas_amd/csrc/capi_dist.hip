@@ -1,0 +1,223 @@
+// extern "C" layer of include/atlas_amd.h: communicators, distributed inverse transform, halo exchange between ranks.
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/atlas_amd.h"
+#include "capi_types.h"
+#include "comm.h"
+#include "dist_trans.h"
+#include "halo_exchange.h"
+#include "trans.h"
+
+namespace atlas_amd {
+void set_last_error(const std::string& s);
+}
+
+struct atlas_amd_CommHub {
+    std::shared_ptr<atlas_amd::parallel::LocalHub> hub;
+};
+struct atlas_amd_Comm {
+    std::unique_ptr<atlas_amd::parallel::Comm> impl;
+};
+
+#define DX_TRY try {
+#define DX_CATCH                                    \
+    }                                               \
+    catch (const std::exception& e) {               \
+        atlas_amd::set_last_error(e.what());        \
+        return 1;                                   \
+    }                                               \
+    catch (...) {                                   \
+        atlas_amd::set_last_error("unknown error"); \
+        return 1;                                   \
+    }                                               \
+    return 0;
+#define DX_CATCH_PTR                                \
+    }                                               \
+    catch (const std::exception& e) {               \
+        atlas_amd::set_last_error(e.what());        \
+        return nullptr;                             \
+    }                                               \
+    catch (...) {                                   \
+        atlas_amd::set_last_error("unknown error"); \
+        return nullptr;                             \
+    }
+
+extern "C" {
+
+int atlas_amd__Comm__unique_id_bytes(void) {
+    return atlas_amd::parallel::UNIQUE_ID_BYTES;
+}
+int atlas_amd__Comm__get_unique_id(void* out) {
+    DX_TRY
+    if (!out) {
+        throw std::invalid_argument("Comm::get_unique_id: null argument");
+    }
+    atlas_amd::parallel::rccl_get_unique_id(out);
+    DX_CATCH
+}
+atlas_amd_Comm* atlas_amd__Comm__new_rccl(const void* unique_id, int nranks, int rank) {
+    DX_TRY
+    auto* c = new atlas_amd_Comm();
+    try {
+        c->impl = atlas_amd::parallel::make_rccl_comm(unique_id, nranks, rank);
+    }
+    catch (...) {
+        delete c;
+        throw;
+    }
+    return c;
+    DX_CATCH_PTR
+}
+atlas_amd_CommHub* atlas_amd__CommHub__new(int nranks) {
+    DX_TRY
+    auto* h = new atlas_amd_CommHub();
+    try {
+        h->hub = std::make_shared<atlas_amd::parallel::LocalHub>(nranks);
+    }
+    catch (...) {
+        delete h;
+        throw;
+    }
+    return h;
+    DX_CATCH_PTR
+}
+void atlas_amd__CommHub__delete(atlas_amd_CommHub* h) {
+    delete h;
+}
+atlas_amd_Comm* atlas_amd__Comm__new_local(atlas_amd_CommHub* hub, int rank) {
+    DX_TRY
+    if (!hub) {
+        throw std::invalid_argument("Comm::new_local: null hub");
+    }
+    auto* c = new atlas_amd_Comm();
+    try {
+        c->impl = atlas_amd::parallel::make_local_comm(hub->hub, rank);
+    }
+    catch (...) {
+        delete c;
+        throw;
+    }
+    return c;
+    DX_CATCH_PTR
+}
+void atlas_amd__Comm__delete(atlas_amd_Comm* c) {
+    delete c;
+}
+int atlas_amd__Comm__size(const atlas_amd_Comm* c) {
+    return c && c->impl ? c->impl->size() : 0;
+}
+int atlas_amd__Comm__rank(const atlas_amd_Comm* c) {
+    return c && c->impl ? c->impl->rank() : -1;
+}
+const char* atlas_amd__Comm__kind(const atlas_amd_Comm* c) {
+    return c && c->impl ? c->impl->kind() : "";
+}
+int atlas_amd__Comm__barrier(atlas_amd_Comm* c) {
+    DX_TRY
+    if (!c) {
+        throw std::invalid_argument("Comm::barrier: null communicator");
+    }
+    c->impl->barrier();
+    DX_CATCH
+}
+int atlas_amd__Comm__exchange(atlas_amd_Comm* c, int nsend, const int send_peer[], void* const send_ptr[],
+                              const size_t send_bytes[], int nrecv, const int recv_peer[], void* const recv_ptr[],
+                              const size_t recv_bytes[], void* stream) {
+    DX_TRY
+    if (!c || nsend < 0 || nrecv < 0) {
+        throw std::invalid_argument("Comm::exchange: bad arguments");
+    }
+    std::vector<atlas_amd::parallel::Msg> s(nsend), r(nrecv);
+    for (int i = 0; i < nsend; ++i) {
+        s[i] = atlas_amd::parallel::Msg{send_peer[i], send_ptr[i], send_bytes[i]};
+    }
+    for (int i = 0; i < nrecv; ++i) {
+        r[i] = atlas_amd::parallel::Msg{recv_peer[i], recv_ptr[i], recv_bytes[i]};
+    }
+    c->impl->exchange(s, r, (hipStream_t)stream);
+    DX_CATCH
+}
+
+// ---------------------------------------------------------------- distributed transform
+static atlas_amd::trans::DistributedTrans& dist_of(atlas_amd_Trans* t, atlas_amd_Comm* c) {
+    if (!t || !c || !c->impl) {
+        throw std::invalid_argument("invtrans_distributed: null Trans / Comm");
+    }
+    if (!t->dist || t->dist_comm != c) {
+        t->dist.reset();
+        t->dist.reset(new atlas_amd::trans::DistributedTrans(*t->impl, *c->impl));
+        t->dist_comm = c;
+    }
+    return *t->dist;
+}
+
+int atlas_amd__Trans__invtrans_distributed(atlas_amd_Trans* t, atlas_amd_Comm* c, int nb_fields, const double* sp_dev,
+                                           double* gp_dev) {
+    DX_TRY
+    dist_of(t, c).invtrans(nb_fields, sp_dev, gp_dev);
+    DX_CATCH
+}
+int atlas_amd__Trans__invtrans_distributed_many(atlas_amd_Trans* t, atlas_amd_Comm* c, int ntransforms, int nb_fields,
+                                                const double* const* sp_dev, double* const* gp_dev) {
+    DX_TRY
+    if (ntransforms > 0 && (!sp_dev || !gp_dev)) {
+        throw std::invalid_argument("invtrans_distributed_many: null arrays");
+    }
+    dist_of(t, c).invtrans_many(ntransforms, nb_fields, sp_dev, gp_dev);
+    DX_CATCH
+}
+int atlas_amd__Trans__set_max_message_bytes(atlas_amd_Trans* t, atlas_amd_Comm* c, long long bytes) {
+    DX_TRY
+    if (bytes < 8) {
+        throw std::invalid_argument("set_max_message_bytes: at least 8");
+    }
+    dist_of(t, c).max_message_elems = bytes / 8;
+    DX_CATCH
+}
+int atlas_amd__transpose_messages(int truncation, int RP, int nparts, int part, const int bands[], long long max_message_elems,
+                                  int capacity, int* peer, long long* send_begin, long long* send_end, long long* recv_begin,
+                                  long long* recv_end, int* count) {
+    DX_TRY
+    if (!bands || !count || nparts < 1) {
+        throw std::invalid_argument("transpose_messages: bad arguments");
+    }
+    std::vector<int> b(bands, bands + nparts + 1);
+    const auto plan = atlas_amd::trans::make_transpose_plan(truncation, RP, b, nparts, part);
+    const auto msgs = atlas_amd::trans::transpose_messages(plan, b, RP, nparts, part, max_message_elems);
+    *count          = (int)msgs.size();
+    for (int i = 0; i < (int)msgs.size() && i < capacity; ++i) {
+        peer[i]       = msgs[i].peer;
+        send_begin[i] = msgs[i].send_begin;
+        send_end[i]   = msgs[i].send_end;
+        recv_begin[i] = msgs[i].recv_begin;
+        recv_end[i]   = msgs[i].recv_end;
+    }
+    DX_CATCH
+}
+
+// ---------------------------------------------------------------- halo exchange between ranks
+int atlas_amd__HaloExchange__setup_comm(atlas_amd_HaloExchange* h, atlas_amd_Comm* c, const int part[],
+                                        const int remote_idx[], int base, int size, int halo_begin) {
+    DX_TRY
+    if (!h || !c || !part || !remote_idx) {
+        throw std::invalid_argument("HaloExchange::setup_comm: null argument");
+    }
+    h->impl.setup_comm(*c->impl, part, remote_idx, base, size, halo_begin);
+    DX_CATCH
+}
+int atlas_amd__HaloExchange__execute_comm(atlas_amd_HaloExchange* h, atlas_amd_Comm* c, int dtype, void* field_dev, int rank,
+                                          const int shape[], const long long strides[], int parallel_dim, int adjoint) {
+    DX_TRY
+    if (!h || !c || !field_dev || !shape || !strides) {
+        throw std::invalid_argument("HaloExchange::execute_comm: null argument");
+    }
+    const atlas_amd::parallel::HaloFieldDesc d = h->impl.describe(rank, shape, strides, parallel_dim);
+    h->impl.execute_comm(*c->impl, dtype, field_dev, d, adjoint != 0);
+    DX_CATCH
+}
+
+}  // extern "C"

@@ -163,6 +163,35 @@ int atlas_amd__HaloExchange__execute_adjoint_strided_double(atlas_amd_HaloExchan
     return strided(h, atlas_amd::parallel::HALO_DOUBLE, field, var_strides, var_shape, var_rank, true);
 }
 
+// atlas__HaloExchange__execute[_adjoint]_<T>(This, field, var_rank): declared, never defined in the reference
+// (HaloExchange.h:441-443,453-455); one value per node is the only layout that needs no shape
+static int unstrided(atlas_amd_HaloExchange* h, int dtype, void* field, int var_rank, bool adjoint) {
+    if (var_rank != 0) {
+        atlas_amd::set_last_error("HaloExchange::execute_<T>(field, var_rank): only var_rank == 0 is defined without a shape; "
+                                  "use execute_strided_<T>");
+        return 1;
+    }
+    return strided(h, dtype, field, nullptr, nullptr, 0, adjoint);
+}
+int atlas_amd__HaloExchange__execute_int(atlas_amd_HaloExchange* h, int field[], int var_rank) {
+    return unstrided(h, atlas_amd::parallel::HALO_INT, field, var_rank, false);
+}
+int atlas_amd__HaloExchange__execute_float(atlas_amd_HaloExchange* h, float field[], int var_rank) {
+    return unstrided(h, atlas_amd::parallel::HALO_FLOAT, field, var_rank, false);
+}
+int atlas_amd__HaloExchange__execute_double(atlas_amd_HaloExchange* h, double field[], int var_rank) {
+    return unstrided(h, atlas_amd::parallel::HALO_DOUBLE, field, var_rank, false);
+}
+int atlas_amd__HaloExchange__execute_adjoint_int(atlas_amd_HaloExchange* h, int field[], int var_rank) {
+    return unstrided(h, atlas_amd::parallel::HALO_INT, field, var_rank, true);
+}
+int atlas_amd__HaloExchange__execute_adjoint_float(atlas_amd_HaloExchange* h, float field[], int var_rank) {
+    return unstrided(h, atlas_amd::parallel::HALO_FLOAT, field, var_rank, true);
+}
+int atlas_amd__HaloExchange__execute_adjoint_double(atlas_amd_HaloExchange* h, double field[], int var_rank) {
+    return unstrided(h, atlas_amd::parallel::HALO_DOUBLE, field, var_rank, true);
+}
+
 // general field description: rank, shape[], strides[] (elements), parallel dimension -- HaloExchange::execute<T,RANK,
 // ParallelDim> (HaloExchange.h:151).  op: 0 execute (1 process), 1 execute_adjoint (1 process), 2 pack, 3 unpack,
 // 4 pack_adjoint, 5 unpack_adjoint (+=), 6 zero_halos.  `on_device` != 0: field / buffer are device pointers and the

@@ -10,6 +10,7 @@
 #include <cstddef>
 #include <vector>
 
+#include "comm.h"
 #include "halo_device.h"
 #include "halo_setup.h"
 
@@ -32,6 +33,9 @@ public:
     void setup_begin_device(int nproc, int myproc, const int* part_dev, const int* remote_idx_dev, int base,
                             int parsize, int halo_begin = 0);
     void setup_finish(const int sendcounts[], const int recv_requests[]);
+    // the complete reference setup between the ranks of `comm` (allToAll of the receive counts, allToAllv of the
+    // requested indices: HaloExchange.cc:118,156)
+    void setup_comm(Comm& comm, const int part[], const int remote_idx[], int base, int parsize, int halo_begin = 0);
     bool is_setup() const { return plan_.finished; }
     const HaloPlan& plan() const { return plan_; }
 
@@ -47,6 +51,10 @@ public:
     // complete exchange for one process (periodic / pole duplicates are "ghosts" of the same rank)
     void execute_device(int dtype, void* field, const HaloFieldDesc& d);
     void execute_adjoint_device(int dtype, void* field, const HaloFieldDesc& d);
+    // complete exchange between the ranks of `comm` (HaloExchange.h:191-219: irecv / pack / isend / wait / unpack;
+    // adjoint :227-290): pack kernel -> one grouped send/recv per peer with counts and displacements scaled by var_size
+    // (:318-331) -> unpack kernel, all asynchronous on stream().  A transform running on another stream overlaps it.
+    void execute_comm(Comm& comm, int dtype, void* field, const HaloFieldDesc& d, bool adjoint);
     // host-pointer variants: stage the field through device memory (synchronous)
     void execute_host(int dtype, void* field, int rank, const int shape[], const long long strides[],
                       int parallel_dim, bool adjoint);
@@ -60,7 +68,8 @@ private:
     void* scratch(size_t bytes, int which);
 
     HaloPlan plan_;
-    hipStream_t stream_ = nullptr;
+    bool has_device_    = false;    // a HIP device was found when the object was made (stream 0 is a legal stream)
+    hipStream_t stream_ = nullptr;  // nullptr == the default stream when has_device_
     bool own_stream_    = false;
     int* d_sendmap_     = nullptr;
     int* d_recvmap_     = nullptr;

@@ -34,12 +34,13 @@ HaloExchange::HaloExchange() {
         (void)hipGetLastError();
         return;  // setup (host logic) still works; execute will fail loudly
     }
+    has_device_ = true;
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     own_stream_ = true;
 }
 
 HaloExchange::~HaloExchange() {
-    if (stream_) {
+    if (has_device_) {
         (void)hipStreamSynchronize(stream_);
     }
     for (void* p : {(void*)d_sendmap_, (void*)d_recvmap_, (void*)d_adj_nodes_, (void*)d_adj_start_,
@@ -54,6 +55,9 @@ HaloExchange::~HaloExchange() {
 }
 
 void HaloExchange::set_stream(hipStream_t s) {
+    if (!has_device_) {
+        throw std::runtime_error("HaloExchange: no HIP device");
+    }
     synchronize();
     if (own_stream_ && stream_) {
         (void)hipStreamDestroy(stream_);
@@ -63,7 +67,7 @@ void HaloExchange::set_stream(hipStream_t s) {
 }
 
 void HaloExchange::synchronize() const {
-    if (stream_ || !own_stream_) {
+    if (has_device_) {
         HIP_CHECK(hipStreamSynchronize(stream_));
     }
 }
@@ -80,7 +84,7 @@ void HaloExchange::setup_begin(int nproc, int myproc, const int part[], const in
 
 void HaloExchange::setup_begin_device(int nproc, int myproc, const int* part_dev, const int* ridx_dev, int base,
                                       int parsize, int halo_begin) {
-    if (!stream_) {
+    if (!has_device_) {
         throw std::runtime_error("HaloExchange: no HIP device");
     }
     const int n       = std::max(parsize - halo_begin, 0);
@@ -133,7 +137,7 @@ void HaloExchange::setup_finish(const int sendcounts[], const int recv_requests[
 }
 
 void HaloExchange::upload_maps() {
-    if (!stream_) {
+    if (!has_device_) {
         return;  // no device: host logic only
     }
     synchronize();
@@ -206,7 +210,7 @@ HaloFieldDesc HaloExchange::describe(int rank, const int shape[], const long lon
 
 #define NEED_SETUP()                                                                        \
     if (!plan_.finished) throw std::runtime_error("HaloExchange was not setup"); /* HaloExchange.h:155 */ \
-    if (!stream_ && own_stream_ == false && d_sendmap_ == nullptr) throw std::runtime_error("HaloExchange: no HIP device")
+    if (!has_device_) throw std::runtime_error("HaloExchange: no HIP device")
 
 void HaloExchange::pack_device(int dtype, const void* field, const HaloFieldDesc& d, void* sendbuf) {
     NEED_SETUP();
@@ -253,10 +257,67 @@ void HaloExchange::execute_adjoint_device(int dtype, void* field, const HaloFiel
     zero_halos_device(dtype, field, d);
 }
 
+void HaloExchange::setup_comm(Comm& comm, const int part[], const int remote_idx[], int base, int parsize,
+                              int halo_begin) {
+    const int n = comm.size();
+    halo_setup_local(plan_, n, comm.rank(), part, remote_idx, base, parsize, halo_begin);
+    std::vector<int> sendcounts(n, 0);
+    comm.all_to_all(plan_.recvcounts.data(), sendcounts.data(), 1);                       // HaloExchange.cc:118
+    size_t nreq = 0;
+    for (int c : sendcounts) {
+        nreq += (size_t)c;
+    }
+    std::vector<int> requests(std::max<size_t>(nreq, 1), 0);
+    comm.all_to_allv(plan_.send_requests.data(), plan_.recvcounts.data(), requests.data(), sendcounts.data());   // :156
+    halo_setup_finish(plan_, sendcounts.data(), requests.data());
+    upload_maps();
+}
+
+void HaloExchange::execute_comm(Comm& comm, int dtype, void* field, const HaloFieldDesc& d, bool adjoint) {
+    NEED_SETUP();
+    if (comm.size() != plan_.nproc || comm.rank() != plan_.myproc) {
+        throw std::invalid_argument("HaloExchange::execute: communicator differs from the one of the setup");
+    }
+    const size_t esz = (size_t)d.var_size * halo_dtype_size(dtype);
+    const std::vector<int>& out_cnt = adjoint ? plan_.recvcounts : plan_.sendcounts;
+    const std::vector<int>& out_dsp = adjoint ? plan_.recvdispls : plan_.senddispls;
+    const std::vector<int>& in_cnt  = adjoint ? plan_.sendcounts : plan_.recvcounts;
+    const std::vector<int>& in_dsp  = adjoint ? plan_.senddispls : plan_.recvdispls;
+    const int out_total             = adjoint ? plan_.recvcnt : plan_.sendcnt;
+    const int in_total              = adjoint ? plan_.sendcnt : plan_.recvcnt;
+    char* outbuf = (char*)scratch(std::max<size_t>((size_t)out_total * esz, 16), 0);
+    char* inbuf  = (char*)scratch(std::max<size_t>((size_t)in_total * esz, 16), 1);
+    if (adjoint) {
+        pack_adjoint_device(dtype, field, d, outbuf);
+    }
+    else {
+        pack_device(dtype, field, d, outbuf);
+    }
+    std::vector<Msg> sends, recvs;
+    for (int p = 0; p < plan_.nproc; ++p) {
+        if (out_cnt[p]) {
+            sends.push_back(Msg{p, outbuf + (size_t)out_dsp[p] * esz, (size_t)out_cnt[p] * esz});
+        }
+        if (in_cnt[p]) {
+            recvs.push_back(Msg{p, inbuf + (size_t)in_dsp[p] * esz, (size_t)in_cnt[p] * esz});
+        }
+    }
+    comm.exchange(sends, recvs, stream_);
+    if (adjoint) {
+        unpack_adjoint_device(dtype, field, d, inbuf);
+        zero_halos_device(dtype, field, d);
+    }
+    else {
+        unpack_device(dtype, field, d, inbuf);
+    }
+}
+
 void HaloExchange::execute_host(int dtype, void* field, int rank, const int shape[], const long long strides[],
                                 int parallel_dim, bool adjoint) {
-    NEED_SETUP();
-    if (!stream_) {
+    if (!plan_.finished) {
+        throw std::runtime_error("HaloExchange was not setup");  // HaloExchange.h:155
+    }
+    if (!has_device_) {
         throw std::runtime_error("HaloExchange::execute needs a HIP device; there is no CPU fallback");
     }
     const HaloFieldDesc d = describe(rank, shape, strides, parallel_dim);
@@ -264,6 +325,9 @@ void HaloExchange::execute_host(int dtype, void* field, int rank, const int shap
     for (int i = 0; i < rank; ++i) {
         if (strides[i] < 0) {
             throw std::invalid_argument("HaloExchange: negative strides are not supported");
+        }
+        if (shape[i] <= 0) {
+            return;  // empty field (e.g. a part without points): nothing to exchange
         }
         span += (long long)(shape[i] - 1) * strides[i];
     }

@@ -51,6 +51,17 @@ void halo_setup_local(HaloPlan& plan, int nproc, int myproc, const int part[], c
 }
 
 void halo_setup_finish(HaloPlan& plan, const int sendcounts[], const int recv_requests[]) {
+    if (plan.nproc < 1 || (int)plan.senddispls.size() != plan.nproc || (int)plan.recvcounts.size() != plan.nproc) {
+        throw std::logic_error("HaloExchange::setup_finish called before setup_begin");
+    }
+    if (!sendcounts || (!recv_requests && std::accumulate(sendcounts, sendcounts + plan.nproc, 0) > 0)) {
+        throw std::invalid_argument("HaloExchange::setup_finish: null argument");
+    }
+    for (int p = 0; p < plan.nproc; ++p) {
+        if (sendcounts[p] < 0) {
+            throw std::invalid_argument("HaloExchange::setup_finish: negative send count");
+        }
+    }
     plan.sendcounts.assign(sendcounts, sendcounts + plan.nproc);
     plan.sendcnt = std::accumulate(plan.sendcounts.begin(), plan.sendcounts.end(), 0);
     plan.senddispls[0] = 0;

@@ -40,7 +40,7 @@ struct TransConfig {
     int ndgl = 0, nxmax = 0;          // the grid is a row subset of a global grid with ndgl latitudes / longest row nxmax
                                       // (mirror-band decomposition): what fourier_truncation must see; 0: the grid's own
     int device_tables          = -1;  // Legendre table computed on the device (1) or on the host and uploaded (0);
-                                      // -1: environment variable ATLAS_AMD_TABLES=device|host, default host
+                                      // -1: environment variable ATLAS_AMD_TABLES=device|host, default device
 };
 
 struct StageTimings {

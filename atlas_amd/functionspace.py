@@ -179,7 +179,13 @@ class StructuredColumns:
             lev, sn, sk, sv = shape[1], strides[0], strides[1], strides[2]
         else:
             raise NotImplementedError("vector fields must have rank 2 or 3")   # StructuredColumns.cc:735-741
-        _lib.check(SC_fixup(self._h, dt, ptr, lev, sn, sk, sv, stream))
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream().cuda_stream   # stream-ordered with the tensor's producer
+            _lib.check(SC_fixup(self._h, dt, ptr, lev, sn, sk, sv, stream))
+        else:
+            with _lib.torch_stream_order(stream):
+                _lib.check(SC_fixup(self._h, dt, ptr, lev, sn, sk, sv, stream))
 
     def haloExchange(self, field, vector=False):
         """fs.haloExchange(field): exchange + pole fix-up for fields whose metadata type is 'vector'"""

@@ -1,8 +1,10 @@
 """Host-side mirror of atlas::parallel::HaloExchange (reference: src/atlas/parallel/HaloExchange.h:40-148).
 
 setup() is the reference's index logic (C++ host code behind the C ABI); pack / unpack / adjoint run as HIP kernels;
-the peer-to-peer step uses torch.distributed (backend "nccl" = RCCL send/recv over xGMI on MI355X nodes) where the
-reference uses eckit::mpi iSend/iReceive (HaloExchange.h:333-369).  A single process needs no transport at all."""
+between processes both the setup collectives and the peer-to-peer step run inside the library over its communicator
+(atlas_amd.comm.Comm: RCCL ncclSend / ncclRecv groups over xGMI) where the reference uses eckit::mpi
+(HaloExchange.h:333-369).  A single process needs no transport at all.  For CPU tests of the index logic between real
+processes a torch.distributed (gloo) transport is kept in atlas_amd/parallel_torch.py."""
 import ctypes as C
 
 import numpy as np
@@ -29,6 +31,10 @@ HX_field_op = _sig("atlas_amd__HaloExchange__field_op", c_int, c_void_p, c_int, 
 HX_stream = _sig("atlas_amd__HaloExchange__stream", c_void_p, c_void_p)
 HX_set_stream = _sig("atlas_amd__HaloExchange__set_stream", c_int, c_void_p, c_void_p)
 HX_sync = _sig("atlas_amd__HaloExchange__synchronize", c_int, c_void_p)
+HX_setup_comm = _sig("atlas_amd__HaloExchange__setup_comm", c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                     c_int)
+HX_execute_comm = _sig("atlas_amd__HaloExchange__execute_comm", c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                       c_void_p, c_int, c_int)
 HX_strided = {name: _sig(f"atlas_amd__HaloExchange__execute{adj}_strided_{name}", c_int, c_void_p, c_void_p, c_void_p,
                          c_void_p, c_int)
               for adj in ("", "_adjoint") for name in ("int", "long", "float", "double")} and {
@@ -59,29 +65,6 @@ def _describe(field):
         [s // field.itemsize for s in field.strides], False, field.itemsize
 
 
-def exchange_packed(outbuf, inbuf, out_cnt, out_dsp, in_cnt, in_dsp, var_size, group=None):
-    """the communication step of HaloExchange::execute (HaloExchange.h:191-215: iReceive / iSend per peer with
-    counts and displacements scaled by var_size, :318-331) on packed buffers: one batched send/recv per peer over
-    torch.distributed (RCCL on device tensors; any backend in tests), the rank's own part (periodic / pole duplicates)
-    as a local copy"""
-    import torch.distributed as dist
-    me, ops = dist.get_rank(group), []
-    for peer in range(len(out_cnt)):
-        o = outbuf[int(out_dsp[peer]) * var_size:int(out_dsp[peer] + out_cnt[peer]) * var_size]
-        i = inbuf[int(in_dsp[peer]) * var_size:int(in_dsp[peer] + in_cnt[peer]) * var_size]
-        if peer == me:
-            i.copy_(o)
-            continue
-        g = dist.get_global_rank(group, peer) if group is not None else peer
-        if i.numel():
-            ops.append(dist.P2POp(dist.irecv, i, g, group=group))
-        if o.numel():
-            ops.append(dist.P2POp(dist.isend, o, g, group=group))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-
-
 class HaloExchange:
     def __init__(self, name=""):
         self.name = name
@@ -107,25 +90,19 @@ class HaloExchange:
             _lib.check(HX_setup_hb(self._h, part.ctypes.data, ridx.ctypes.data, int(base), int(size), int(halo_begin)))
             self._is_setup = True
             return
-        import torch
-        import torch.distributed as dist
-        group = None if comm is True else comm
-        nproc, me = dist.get_world_size(group), dist.get_rank(group)
-        _lib.check(HX_setup_begin(self._h, nproc, me, part.ctypes.data, ridx.ctypes.data, int(base), int(size),
-                                  int(halo_begin)))
-        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-        recvcounts = self._get("recvcounts", nproc)
-        sendcounts_t = torch.zeros(nproc, dtype=torch.int32, device=dev)
-        dist.all_to_all_single(sendcounts_t, torch.from_numpy(recvcounts).to(dev), group=group)   # allToAll, :118
-        sendcounts = sendcounts_t.cpu().numpy().astype(np.int32)
-        req = self._get("send_requests", HX_recvcnt(self._h))
-        recv_req_t = torch.zeros(int(sendcounts.sum()), dtype=torch.int32, device=dev)
-        dist.all_to_all_single(recv_req_t, torch.from_numpy(req).to(dev), output_split_sizes=sendcounts.tolist(),
-                               input_split_sizes=recvcounts.tolist(), group=group)                # allToAllv, :156
-        recv_req = np.ascontiguousarray(recv_req_t.cpu().numpy().astype(np.int32))
-        _lib.check(HX_setup_finish(self._h, np.ascontiguousarray(sendcounts).ctypes.data, recv_req.ctypes.data))
-        self._group = group
-        self._dist = True
+        from .comm import Comm
+        if not isinstance(comm, Comm):
+            # a torch.distributed process group (True: the default group)
+            import torch.distributed as dist
+            group = None if comm is True else comm
+            if dist.get_backend(group) != "nccl":
+                from .parallel_torch import setup_over_torch   # CPU tests over gloo
+                setup_over_torch(self, part, ridx, base, size, halo_begin, group)
+                return
+            comm = Comm.rccl_from_torch(group)
+        _lib.check(HX_setup_comm(self._h, comm._h, part.ctypes.data, ridx.ctypes.data, int(base), int(size),
+                                 int(halo_begin)))
+        self._comm = comm
         self._is_setup = True
 
     def setup_emulated(self, nproc, myproc, part, remote_idx, base, size, halo_begin=0, on_device=False):
@@ -185,7 +162,13 @@ class HaloExchange:
         bptr = None
         if buffer is not None:
             bptr = buffer.data_ptr() if _is_torch(buffer) else buffer.ctypes.data
-        _lib.check(HX_field_op(self._h, op, dt, ptr, rank, shp, strd, int(parallel_dim), bptr, int(on_dev)))
+        if on_dev and _is_torch(field):
+            # the tensor was produced on torch's current stream and is consumed there: order the object's stream
+            # after it, and torch's stream after the operation (events only)
+            with _lib.torch_stream_order(HX_stream(self._h)):
+                _lib.check(HX_field_op(self._h, op, dt, ptr, rank, shp, strd, int(parallel_dim), bptr, int(on_dev)))
+        else:
+            _lib.check(HX_field_op(self._h, op, dt, ptr, rank, shp, strd, int(parallel_dim), bptr, int(on_dev)))
 
     def var_size(self, field, parallel_dim=0):
         shape = list(field.shape)
@@ -195,16 +178,22 @@ class HaloExchange:
     def execute(self, field, parallel_dim=0):
         if not self._is_setup:
             raise _lib.AtlasAmdError("HaloExchange was not setup")
+        if getattr(self, "_comm", None) is not None:
+            return self._execute_comm(field, parallel_dim, adjoint=False)
         if getattr(self, "_dist", False) and self.nproc() > 1:
-            return self._execute_distributed(field, parallel_dim, adjoint=False)
+            from .parallel_torch import execute_over_torch
+            return execute_over_torch(self, field, parallel_dim, adjoint=False)
         self._op(OP_EXECUTE, field, parallel_dim)
         return field
 
     def execute_adjoint(self, field, parallel_dim=0):
         if not self._is_setup:
             raise _lib.AtlasAmdError("HaloExchange was not setup")
+        if getattr(self, "_comm", None) is not None:
+            return self._execute_comm(field, parallel_dim, adjoint=True)
         if getattr(self, "_dist", False) and self.nproc() > 1:
-            return self._execute_distributed(field, parallel_dim, adjoint=True)
+            from .parallel_torch import execute_over_torch
+            return execute_over_torch(self, field, parallel_dim, adjoint=True)
         self._op(OP_ADJOINT, field, parallel_dim)
         return field
 
@@ -230,26 +219,16 @@ class HaloExchange:
         import torch
         _lib.check(HX_set_stream(self._h, torch.cuda.current_stream().cuda_stream))
 
-    def _execute_distributed(self, field, parallel_dim, adjoint):
-        """pack -> RCCL send/recv per peer (self part: device copy) -> unpack, on torch's current stream"""
-        import torch
-        import torch.distributed as dist
-        if not (_is_torch(field) and field.is_cuda):
-            raise TypeError("distributed halo exchange needs a CUDA (HIP) tensor")
-        self.use_torch_stream()
-        p = self.plan()
-        vs = self.var_size(field, parallel_dim)
-        out_cnt, in_cnt = (p["recvcounts"], p["sendcounts"]) if adjoint else (p["sendcounts"], p["recvcounts"])
-        out_dsp, in_dsp = (p["recvdispls"], p["senddispls"]) if adjoint else (p["senddispls"], p["recvdispls"])
-        outbuf = torch.empty(int(out_cnt.sum()) * vs, dtype=field.dtype, device=field.device)
-        inbuf = torch.empty(int(in_cnt.sum()) * vs, dtype=field.dtype, device=field.device)
-        (self.pack_adjoint if adjoint else self.pack)(field, outbuf, parallel_dim)
-        exchange_packed(outbuf, inbuf, out_cnt, out_dsp, in_cnt, in_dsp, vs, self._group)
-        if adjoint:
-            self.unpack_adjoint(inbuf, field, parallel_dim)
-            self.zero_halos(field, parallel_dim)
-        else:
-            self.unpack(inbuf, field, parallel_dim)
+    def _execute_comm(self, field, parallel_dim, adjoint):
+        """HaloExchange::execute between the ranks of the communicator, inside the library: pack kernel -> grouped
+        send/recv per peer -> unpack kernel on the object's stream"""
+        dt, ptr, rank, shape, strides, on_dev, _ = _describe(field)
+        if not on_dev:
+            raise TypeError("halo exchange between ranks needs a device (HIP) tensor")
+        shp = (C.c_int * rank)(*shape)
+        strd = (C.c_longlong * rank)(*strides)
+        with _lib.torch_stream_order(HX_stream(self._h)):
+            _lib.check(HX_execute_comm(self._h, self._comm._h, dt, ptr, rank, shp, strd, int(parallel_dim), int(adjoint)))
         return field
 
     # ------------------------------------------------------------------ C-interface style entry points
@@ -261,23 +240,3 @@ class HaloExchange:
         vsh = (C.c_int * max(len(var_shape), 1))(*var_shape)
         fn = HX_strided[("_adjoint" if adjoint else "", name)]
         _lib.check(fn(self._h, field.ctypes.data, vs, vsh, len(var_shape)))
-
-
-def smoke_halo():
-    """tiny single-process halo exchange on cuda:0 (periodic duplicates), checked against the oracle"""
-    import torch
-    from oracle.halo import HaloExchangeOracle
-    n = 40
-    part = np.zeros(n, dtype=np.int32)
-    ridx = np.arange(n, dtype=np.int32)
-    ridx[32:] = np.arange(8)          # nodes 32..39 are periodic copies of nodes 0..7
-    hx = HaloExchange()
-    hx.setup(part, ridx, 0, n)
-    f = torch.arange(n * 5, dtype=torch.float64, device="cuda").reshape(n, 5).contiguous()
-    ref = f.cpu().numpy().copy()
-    orc = [HaloExchangeOracle(0, 1)]
-    HaloExchangeOracle.setup(orc, [part], [ridx], 0, [n])
-    HaloExchangeOracle.execute(orc, [ref])
-    hx.execute(f)
-    hx.synchronize()
-    assert np.array_equal(f.cpu().numpy(), ref), "smoke: halo exchange mismatch"

@@ -101,8 +101,9 @@ class Trans:
                         raise TypeError("need contiguous float32 tensors")
                     if scalar_spectra.numel() < ncoef * nf or gp.numel() < npts * nf:
                         raise ValueError("float32 arrays too small")
-                    _lib.check(_lib.Trans_invtrans_scalar_device_f32(self._h, nf, scalar_spectra.data_ptr(),
-                                                                     gp.data_ptr()))
+                    with _lib.torch_stream_order(self.stream()):
+                        _lib.check(_lib.Trans_invtrans_scalar_device_f32(self._h, nf, scalar_spectra.data_ptr(),
+                                                                         gp.data_ptr()))
                     return gp
             if (not dev and isinstance(gp, np.ndarray) and isinstance(scalar_spectra, np.ndarray)
                     and gp.dtype == np.float32 and scalar_spectra.dtype == np.float32):
@@ -116,8 +117,11 @@ class Trans:
                 raise TypeError("spectra and grid-point arrays must both be host or both be device")
             sp_p = _ptr(scalar_spectra, ncoef * nf, "scalar_spectra")
             gp_p = _ptr(gp, npts * nf, "gp_fields", writable=True)
-            fn = _lib.Trans_invtrans_scalar_device if dev else _lib.Trans_invtrans_scalar
-            _lib.check(fn(self._h, nf, sp_p, gp_p))
+            if dev:
+                with _lib.torch_stream_order(self.stream()):   # torch tensors: stream-ordered with their producers
+                    _lib.check(_lib.Trans_invtrans_scalar_device(self._h, nf, sp_p, gp_p))
+            else:
+                _lib.check(_lib.Trans_invtrans_scalar(self._h, nf, sp_p, gp_p))
             return gp
         if len(args) == 4:
             nvd, vor, div, gp = args
@@ -127,8 +131,11 @@ class Trans:
             vor_p = _ptr(vor, ncoef * nvd, "vorticity_spectra") if nvd > 0 else None
             div_p = _ptr(div, ncoef * nvd, "divergence_spectra") if nvd > 0 else None
             gp_p = _ptr(gp, npts * (ns + 2 * nvd), "gp_fields", writable=True)
-            fn = _lib.Trans_invtrans_device if dev else _lib.Trans_invtrans
-            _lib.check(fn(self._h, ns, sp_p, nvd, vor_p, div_p, gp_p))
+            if dev:
+                with _lib.torch_stream_order(self.stream()):
+                    _lib.check(_lib.Trans_invtrans_device(self._h, ns, sp_p, nvd, vor_p, div_p, gp_p))
+            else:
+                _lib.check(_lib.Trans_invtrans(self._h, ns, sp_p, nvd, vor_p, div_p, gp_p))
             return gp
         raise TypeError("invtrans(nb_scalar, sp, gp) or invtrans(nb_scalar, sp, nb_vordiv, vor, div, gp)")
 
@@ -290,13 +297,15 @@ class Trans:
         return out
 
     def legendre_device(self, truncation_in, nf, spectra, fourier):
-        _lib.check(_lib.Trans_legendre_device(self._h, truncation_in, nf, _ptr(spectra), _ptr(fourier)))
+        with _lib.torch_stream_order(self.stream()):
+            _lib.check(_lib.Trans_legendre_device(self._h, truncation_in, nf, _ptr(spectra), _ptr(fourier)))
 
     def fourier_device(self, nf, nb_vordiv, parts, part_cnt, gp):
         n = len(parts)
         bases = (C.c_void_p * n)(*[_ptr(p) for p in parts])
         cnts = (C.c_int * n)(*[int(c) for c in part_cnt])
-        _lib.check(_lib.Trans_fourier_device(self._h, nf, nb_vordiv, bases, cnts, _ptr(gp)))
+        with _lib.torch_stream_order(self.stream()):
+            _lib.check(_lib.Trans_fourier_device(self._h, nf, nb_vordiv, bases, cnts, _ptr(gp)))
 
 
 class VorDivToUV:

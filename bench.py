@@ -5,16 +5,18 @@ one such transform per GPU with spectra and grid-point arrays resident in HBM.
     python bench.py --gpus N --steps K --warmup W
 N = 1: single MI355X (the whole transform on one device).
 N > 1: launched by torch.distributed.run, one rank per GPU; every step processes N transforms (weak scaling), each
-       transform distributed over all N GPUs and returned in Atlas's latitude bands (atlas_amd/dist.py):
-       N = 8 : Legendre stage sharded by zonal wavenumber, RCCL all-to-all of the Fourier intermediate (m ->
-               latitude-band transpose) pipelined against the neighbouring transforms, Fourier stage on the local band;
-               after the timed region one transform is re-run with the other decomposition and compared bit for bit
-               ("multi_gpu_crosscheck");
-       N < 8 : exchange-free (the transposition would be bound by the one or three xGMI links between 2 or 4 GPUs):
-               every GPU transforms a northern band of rows and its mirror image ("mirror", work 1/N) if that
-               decomposition first reproduces, bit for bit on every rank, the same rows computed through the tested
-               zonal-band crop path ("mirror_selfcheck"); otherwise its own latitude band ("band", Legendre work 2/N).
-       --dist-mode overrides.
+       transform distributed over all N GPUs and returned in Atlas's latitude bands (atlas_amd/dist.py).  The timed
+       decomposition is the one BASELINE configs C3 / C4 name: Legendre stage sharded by zonal wavenumber, m ->
+       latitude-band transposition of the Fourier intermediate over RCCL (ncclSend / ncclRecv groups issued by the library,
+       csrc/comm.hip, on a second HIP stream), pipelined against the neighbouring transforms, Fourier stage on the local
+       band.  torch.distributed only launches the ranks, carries RCCL's 128-byte unique id and the barriers.  After the
+       timed region (a) one transform is re-run with the exchange-free latitude-band decomposition and compared bit for
+       bit ("multi_gpu_crosscheck"), (b) the exchange-free mirror-band decomposition (a northern band of rows and its
+       mirror image per GPU, work 1/N) is timed too and reported as "alt_decomposition" if it first reproduces, bit for
+       bit on every rank, the same rows computed through the zonal-band crop path.
+       --dist-mode band|mirror times one of the exchange-free decompositions instead; --dist-impl torch uses the
+       torch.distributed implementation of the driver (atlas_amd/dist_torch.py; also what the CPU tests of this file
+       run over gloo).
 Prints ONE JSON line (rank 0)."""
 import argparse
 import json
@@ -105,8 +107,11 @@ def main():
                     help="also time the BLAS dgemm + pocketfft variant of the CPU restatement (cpu_baseline_blas)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the distributed driver even with one rank")
     ap.add_argument("--dist-mode", default="auto", choices=["auto", "alltoall", "band", "mirror"],
-                    help="N > 1: wavenumber sharding + RCCL all-to-all, or exchange-free latitude-band sharding "
-                         "(auto: band below 8 ranks, all-to-all at 8; see atlas_amd/dist.py)")
+                    help="N > 1: wavenumber sharding + RCCL transposition (auto, alltoall), or one of the exchange-free "
+                         "decompositions (see atlas_amd/dist.py)")
+    ap.add_argument("--dist-impl", default="auto", choices=["auto", "native", "torch"],
+                    help="N > 1: driver inside the library (RCCL from C++) or the torch.distributed one (auto: native on GPUs)")
+    ap.add_argument("--no-alt", action="store_true", help="N > 1: do not time the alternative (mirror-band) decomposition")
     args = ap.parse_args()
 
     import numpy as np
@@ -144,62 +149,40 @@ def main():
             sync()
     else:
         import torch.distributed as dist
-        from atlas_amd.dist import DistributedTrans
         if on_gpu:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
-        # every rank holds the spectra of the `world` transforms of a step (replicated input; each rank reads only
-        # the wavenumbers it owns)
+        impl = args.dist_impl if args.dist_impl != "auto" else ("native" if on_gpu else "torch")
+        impl_note = None
+        if impl == "native":
+            from atlas_amd.dist import DistributedTrans
+        else:
+            from atlas_amd.dist_torch import DistributedTrans
+        # every rank holds the spectra of the transforms of a step (replicated input, as TransLocal's callers hold it;
+        # each rank reads only the wavenumbers it owns)
         sps = [torch.from_numpy(red_spectra(TRUNC, nf, seed=20251114 + i)).to(DEVICE) for i in range(min(world, 2))]
-        mode, mirror_selfcheck, dtr = args.dist_mode, None, None
-        if mode == "auto" and 1 < world < 8:
-            # Below 8 GPUs the exchange-free decompositions win (the transposition is bound by 1 or 3 xGMI links).  The
-            # mirror-band one keeps the hemisphere sharing (work 1/P instead of 2/P) but was built after round 1's GPU
-            # budget was spent: adopt it only if, on every rank, it reproduces bit for bit the rows computed through the
-            # tested zonal-band crop path; otherwise fall back to the latitude-band decomposition.
-            ok = 0
-            try:
-                dtr = DistributedTrans(g, TRUNC, profile=True, mode="mirror")
-                b0, b1 = dtr.trans.mirror_rows()
-                gp_m = torch.empty(nf * dtr.trans.nb_gridpoints(), dtype=torch.float64, device=DEVICE)
-                dtr.invtrans(nf, sps[0], gp_m)
-                ok, first = 1, 0
-                for j0, j1 in ((b0, b1), (g.ny() - b1, g.ny() - b0)):
-                    tc = atlas_amd.Trans(g, TRUNC, rows=(j0, j1))
-                    tc.use_torch_stream()
-                    n = tc.nb_gridpoints()
-                    gp_c = torch.empty(nf * n, dtype=torch.float64, device=DEVICE)
-                    tc.invtrans(nf, sps[0], gp_c)
-                    sync()
-                    same = torch.equal(gp_m.view(nf, -1)[:, first:first + n], gp_c.view(nf, -1))
-                    ok = ok if (same and bool(torch.isfinite(gp_c).all()) and float(gp_c.abs().max()) > 0.0) else 0
-                    first += n
-                    del tc, gp_c
-                ok = ok if first * nf == gp_m.numel() else 0
-                del gp_m
-            except Exception as e:   # any failure means: do not use it
-                sys.stderr.write(f"[bench] rank {rank}: mirror-band self-check failed: {type(e).__name__}: {e}\n")
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device=DEVICE)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            mirror_selfcheck = {"compared": "mirror-band rows vs the same rows through the zonal-band crop path, "
-                                            f"{nf} fields, every rank", "bitwise_equal_on_all_ranks": bool(int(flag.item()))}
-            if int(flag.item()) == 1:
-                mode = "mirror"
-            else:
-                mode, dtr = "band", None
-            if on_gpu:
-                torch.cuda.empty_cache()
-        if mode != "mirror" or dtr is None:
+        mode = "alltoall" if args.dist_mode == "auto" else args.dist_mode
+        try:
             dtr = DistributedTrans(g, TRUNC, profile=True, mode=mode)
+            ok = 1
+        except Exception as e:   # e.g. RCCL not loadable from the library: every rank falls back together
+            sys.stderr.write(f"[bench] rank {rank}: native distributed driver unavailable: {type(e).__name__}: {e}\n")
+            ok, dtr = 0, None
+            impl_note = f"{type(e).__name__}: {e}"
+        flag = torch.tensor([ok], dtype=torch.int32, device=DEVICE)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if impl != "native":
+                raise SystemExit("distributed driver failed to start")
+            from atlas_amd.dist_torch import DistributedTrans
+            impl, dtr = "torch (fallback)", DistributedTrans(g, TRUNC, profile=True, mode=mode)
         tr = dtr.trans
         gp = torch.zeros(nf * tr.nb_gridpoints(), dtype=torch.float64, device=DEVICE)
-
         gps = [gp] * world
 
         def step():
-            # `world` transforms per step, software-pipelined: RCCL all-to-all of transform i overlaps the Legendre
+            # `world` transforms per step, software-pipelined: the exchange of transform i overlaps the Legendre
             # stage of transform i+1 and the Fourier stage of transform i-1
             dtr.invtrans_many(nf, [sps[i % len(sps)] for i in range(world)], gps)
 
@@ -227,17 +210,14 @@ def main():
     ms_per_step = dt / args.steps * 1e3
 
     # multi-GPU parity evidence (outside the timed region): the transposed decomposition must reproduce, bit for bit,
-    # what the exchange-free latitude-band decomposition computes for this rank's rows (tests/test_gpu_trans.py shows
-    # both equal the single-device result).  Only run when the all-to-all is the timed mode anyway, so that the
-    # exchange-free runs stay free of collectives in the data path; ATLAS_AMD_BENCH_CROSSCHECK=1 forces it.
-    crosscheck = None
-    if use_dist and dtr.mode != "mirror" and ((world > 1 and dtr.mode == "alltoall")
-                                             or os.environ.get("ATLAS_AMD_BENCH_CROSSCHECK") == "1"):
+    # what the exchange-free latitude-band decomposition computes for this rank's rows (tests/test_gpu_trans.py and
+    # tests/test_gpu_dist_native.py show both equal the single-device result).
+    crosscheck, alt = None, None
+    if use_dist and dtr.mode == "alltoall":
         import torch.distributed as dist
-        other = "band" if dtr.mode == "alltoall" else "alltoall"
         ok, err = 0, None
         try:
-            dto = DistributedTrans(g, TRUNC, mode=other)
+            dto = DistributedTrans(g, TRUNC, mode="band")
             gp_a, gp_b = torch.empty_like(gp), torch.empty_like(gp)
             dtr.invtrans(nf, sps[0], gp_a)
             dto.invtrans(nf, sps[0], gp_b)
@@ -249,10 +229,57 @@ def main():
             err = f"{type(e).__name__}: {e}"
         flag = torch.tensor([ok], dtype=torch.int32, device=DEVICE)   # every rank takes part, failed or not
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        crosscheck = {"compared": f"{dtr.mode} vs {other} decomposition, {nf} fields, every rank's latitude band",
+        crosscheck = {"compared": f"alltoall vs band decomposition, {nf} fields, every rank's latitude band",
                       "bitwise_equal_on_all_ranks": bool(int(flag.item()))}
         if err:
             crosscheck["error_on_rank0"] = err
+        if on_gpu:
+            torch.cuda.empty_cache()
+    # the alternative decomposition, timed for comparison: mirror bands (no exchange, hemisphere symmetry kept), adopted
+    # only if every rank reproduces, bit for bit, the same rows through the GPU-tested zonal-band crop path
+    if use_dist and world > 1 and dtr.mode == "alltoall" and not args.no_alt:
+        import torch.distributed as dist
+        ok, dm = 0, None
+        try:
+            dm = DistributedTrans(g, TRUNC, profile=True, mode="mirror")
+            b0, b1 = dm.trans.mirror_rows()
+            gp_m = torch.empty(nf * dm.trans.nb_gridpoints(), dtype=torch.float64, device=DEVICE)
+            dm.invtrans(nf, sps[0], gp_m)
+            ok, first = 1, 0
+            for j0, j1 in ((b0, b1), (g.ny() - b1, g.ny() - b0)):
+                tc = atlas_amd.Trans(g, TRUNC, rows=(j0, j1))
+                n = tc.nb_gridpoints()
+                gp_c = torch.empty(nf * n, dtype=torch.float64, device=DEVICE)
+                tc.invtrans(nf, sps[0], gp_c)
+                tc.synchronize()
+                sync()
+                same = torch.equal(gp_m.view(nf, -1)[:, first:first + n], gp_c.view(nf, -1))
+                ok = ok if (same and bool(torch.isfinite(gp_c).all()) and float(gp_c.abs().max()) > 0.0) else 0
+                first += n
+                del tc, gp_c
+            ok = ok if first * nf == gp_m.numel() else 0
+        except Exception as e:   # any failure means: not reported
+            sys.stderr.write(f"[bench] rank {rank}: mirror-band self-check failed: {type(e).__name__}: {e}\n")
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=DEVICE)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        alt = {"mode": "mirror", "selfcheck_bitwise_equal_on_all_ranks": bool(int(flag.item()))}
+        if int(flag.item()) == 1:
+            asteps = max(1, min(args.steps, 5))
+            for _ in range(1):
+                dm.invtrans_many(nf, [sps[i % len(sps)] for i in range(world)], [gp_m] * world)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(asteps):
+                dm.invtrans_many(nf, [sps[i % len(sps)] for i in range(world)], [gp_m] * world)
+            barrier()
+            adt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=DEVICE)
+            dist.all_reduce(adt, op=dist.ReduceOp.MAX)
+            alt.update({"value": asteps * world / float(adt.item()), "unit": "transforms/s", "steps": asteps,
+                        "ms_per_step": float(adt.item()) / asteps * 1e3,
+                        "note": "exchange-free: every GPU transforms a northern band of rows and its mirror image; output "
+                                "is two row ranges per GPU, not Atlas's contiguous bands"})
+        del dm
 
     if rank == 0:
         leg_ms = tm["legendre_ms"] / max(tm["legendre_calls"], 1)
@@ -295,7 +322,7 @@ def main():
                                    f"per transform, {world} transform(s) per step",
                        "grid": GRID, "truncation": TRUNC, "levels": NLEV,
                        "parallelism": "single GPU" if not use_dist else (
-                           f"m-sharded Legendre + RCCL all-to-all + latitude-band FFT over {world} GPUs"
+                           f"m-sharded Legendre + RCCL m->latitude transposition + latitude-band FFT over {world} GPUs"
                            if dtr.mode == "alltoall" else
                            f"mirror-band sharding of both stages over {world} GPUs (a northern band of rows and its mirror "
                            f"image per GPU: no exchange, hemisphere symmetry kept)" if dtr.mode == "mirror" else
@@ -307,8 +334,10 @@ def main():
         out["roofline"]["kernel"] = dominant["kernel"]
         if crosscheck is not None:
             out["multi_gpu_crosscheck"] = crosscheck
-        if use_dist and mirror_selfcheck is not None:
-            out["mirror_selfcheck"] = mirror_selfcheck
+        if alt is not None:
+            out["alt_decomposition"] = alt
+        if use_dist:
+            out["dist_impl"] = impl if impl_note is None else f"{impl}: {impl_note}"
         if world == 1 and not use_dist and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_fields)
             if args.cpu_baseline_blas:

@@ -37,6 +37,19 @@ const char* atlas_amd__last_error(void);
 const char* atlas_amd__version(void);
 /* number of visible HIP devices (0: the transform cannot run; there is no CPU fallback) */
 int atlas_amd__device_count(void);
+/* stream ordering helper for callers that own their device arrays on another HIP stream: all work submitted to
+ * `waiting_stream` after this call starts after the work submitted to `signalling_stream` before it (event record +
+ * hipStreamWaitEvent, no host synchronisation).  Trans / HaloExchange objects run on their own non-blocking stream
+ * (atlas_amd__Trans__stream / atlas_amd__HaloExchange__stream). */
+int atlas_amd__stream_wait_stream(void* waiting_stream, void* signalling_stream);
+/* device memory for callers without the HIP headers (C / Fortran drivers of the device-pointer entry points): plain
+ * hipMalloc / hipFree / hipMemcpy (synchronous) / hipDeviceSynchronize / hipSetDevice */
+void* atlas_amd__device_malloc(size_t bytes);
+int atlas_amd__device_free(void* ptr);
+int atlas_amd__device_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
+int atlas_amd__device_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
+int atlas_amd__device_synchronize(void);
+int atlas_amd__set_device(int device);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Grid description.  Replaces the `const Grid::Implementation*` argument of atlas__Trans__new
@@ -77,7 +90,7 @@ atlas_amd_Trans* atlas_amd__Trans__new(const atlas_amd_Grid* grid, int truncatio
  *   type=local|mi355x    accepted for atlas option::type compatibility
  *   tables=host|device   where the Legendre table is computed when no cache is given: on the host (OpenMP, then
  *                        uploaded) or on the device from O(T^2) host-prepared inputs (bit-identical; default: the
- *                        environment variable ATLAS_AMD_TABLES, else host)
+ *                        environment variable ATLAS_AMD_TABLES, else device: 0.9 s against 6.7 s at TL1279)
  * legendre_cache / size: optional Legendre cache blob in TransLocal's file layout (TransLocal.cc:608-614), or NULL */
 atlas_amd_Trans* atlas_amd__Trans__new_config(const atlas_amd_Grid* grid, int truncation, const char* config,
                                               const void* legendre_cache, size_t legendre_cache_size);
@@ -134,6 +147,16 @@ int atlas_amd__Trans__set_backend(const char* backend);
 int atlas_amd__Trans__backend(char** backend, size_t* size);
 /* atlas__Trans__grid (TransInterface.h:103): the grid the object was built with (borrowed) */
 const atlas_amd_Grid* atlas_amd__Trans__grid(const atlas_amd_Trans* t);
+/* atlas__Trans__handle (TransInterface.h:98): TransImpl::handle() is ATLAS_NOTIMPLEMENTED for every backend but the IFS
+ * one (TransImpl.cc:20-22), TransLocal included: returns an error whose message starts with "Not implemented" */
+int atlas_amd__Trans__handle(const atlas_amd_Trans* t, int* handle);
+/* atlas__Trans__spectral (TransInterface.h:104): the spectral function space of the transform, functionspace::Spectral
+ * (truncation) (TransLocal.cc:809-814); borrowed, lives as long as the Trans */
+typedef struct atlas_amd_Spectral atlas_amd_Spectral;
+const atlas_amd_Spectral* atlas_amd__Trans__spectral(const atlas_amd_Trans* t);
+int atlas_amd__Spectral__truncation(const atlas_amd_Spectral* s);
+int64_t atlas_amd__Spectral__nb_spectral_coefficients(const atlas_amd_Spectral* s);          /* (T+1)(T+2), Spectral.h:184 */
+int64_t atlas_amd__Spectral__nb_spectral_coefficients_global(const atlas_amd_Spectral* s);
 
 /* Field / FieldSet overloads (TransInterface.h:73-97, TransLocal.cc:818-897).  A field is described by its host data
  * pointer and C-order shape (what array::make_view sees); only rank-1 fields are supported, as in TransLocal, plus the
@@ -242,6 +265,52 @@ int atlas_amd__fft_host_row_generic(int n, const double* modes, int mmax, double
 int atlas_amd__fft_host_row_hybrid(int n, const double* modes, int mmax, double* out);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Communicators: the inter-GPU transport of the library (grouped point-to-point exchanges of device buffers).
+ * Replaces the eckit::mpi communicator behind parallel::HaloExchange (iReceive / iSend per peer,
+ * src/atlas/parallel/HaloExchange.h:191-219,333-369; allToAll / allToAllv of the setup, HaloExchange.cc:118,156).
+ *   rccl  : one process per GPU, ncclSend / ncclRecv groups over xGMI.  One rank calls get_unique_id and the caller's
+ *           control plane (MPI_Bcast in Atlas) hands the bytes to the others; every rank then calls new_rccl with the
+ *           HIP device it will use already current.
+ *   local : N ranks inside one process (one host thread per rank, same device): rendezvous + device copies.  For tests
+ *           and single-process multi-rank drivers. */
+typedef struct atlas_amd_Comm atlas_amd_Comm;
+typedef struct atlas_amd_CommHub atlas_amd_CommHub;
+int atlas_amd__Comm__unique_id_bytes(void);                 /* 128 */
+int atlas_amd__Comm__get_unique_id(void* out);
+atlas_amd_Comm* atlas_amd__Comm__new_rccl(const void* unique_id, int nranks, int rank);
+atlas_amd_CommHub* atlas_amd__CommHub__new(int nranks);
+void atlas_amd__CommHub__delete(atlas_amd_CommHub* hub);
+atlas_amd_Comm* atlas_amd__Comm__new_local(atlas_amd_CommHub* hub, int rank);
+void atlas_amd__Comm__delete(atlas_amd_Comm* comm);
+int atlas_amd__Comm__size(const atlas_amd_Comm* comm);
+int atlas_amd__Comm__rank(const atlas_amd_Comm* comm);
+const char* atlas_amd__Comm__kind(const atlas_amd_Comm* comm);   /* "rccl" | "local" */
+int atlas_amd__Comm__barrier(atlas_amd_Comm* comm);
+/* one grouped exchange of device buffers, asynchronous on `stream`; between two ranks the k-th send of one side is
+ * matched with the k-th receive of the other (same size) */
+int atlas_amd__Comm__exchange(atlas_amd_Comm* comm, int nsend, const int send_peer[], void* const send_ptr[],
+                              const size_t send_bytes[], int nrecv, const int recv_peer[], void* const recv_ptr[],
+                              const size_t recv_bytes[], void* stream);
+
+/* Distributed inverse transform (one rank per GPU): `t` made with config "nparts=<P> part=<p> shard=m" for the
+ * communicator's (size, rank).  Legendre stage on the rank's wavenumbers (m % P == p), m -> latitude transposition of the
+ * Fourier intermediate over the communicator (messages of at most 512 MiB), Fourier stage on the rank's latitude band
+ * (Atlas BandsDistribution rule; atlas_amd__Trans__bands).  sp_dev: the full spectra (replicated, as TransLocal's callers
+ * hold them); gp_dev: nb_fields * atlas_amd__Trans__nb_gridpoints(t) values, the rank's band in StructuredColumns owned
+ * order.  Asynchronous on the Trans stream; the exchange runs on a second stream.  _many pipelines several transforms:
+ * the exchange of transform i overlaps the Legendre stage of i+1 and the Fourier stage of i-1. */
+int atlas_amd__Trans__invtrans_distributed(atlas_amd_Trans* t, atlas_amd_Comm* comm, int nb_fields, const double* sp_dev,
+                                           double* gp_dev);
+int atlas_amd__Trans__invtrans_distributed_many(atlas_amd_Trans* t, atlas_amd_Comm* comm, int ntransforms, int nb_fields,
+                                                const double* const* sp_dev, double* const* gp_dev);
+int atlas_amd__Trans__set_max_message_bytes(atlas_amd_Trans* t, atlas_amd_Comm* comm, long long bytes);
+/* the messages of the transposition for rank `part` (test hook): offsets in doubles into the rank's intermediate and
+ * into its receive buffer */
+int atlas_amd__transpose_messages(int truncation, int RP, int nparts, int part, const int bands[], long long max_message_elems,
+                                  int capacity, int* peer, long long* send_begin, long long* send_end, long long* recv_begin,
+                                  long long* recv_end, int* count);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * HaloExchange.  Replaces atlas__HaloExchange__* (src/atlas/parallel/HaloExchange.h:429-456).
  * dtype codes: 0 int, 1 long, 2 float, 3 double (the four types Atlas instantiates, detail/Packer.cc:71-95).
  * ------------------------------------------------------------------------------------------------------------- */
@@ -294,8 +363,23 @@ int atlas_amd__HaloExchange__execute_adjoint_strided_float(atlas_amd_HaloExchang
 int atlas_amd__HaloExchange__execute_adjoint_strided_double(atlas_amd_HaloExchange* h, double field[],
                                                             const int var_strides[], const int var_shape[],
                                                             int var_rank);
-/* (atlas__HaloExchange__execute_<T>(This, field, var_rank), :441-443/:453-455, are declared but never defined in the
- * reference, so they have no counterpart.) */
+/* atlas__HaloExchange__execute[_adjoint]_{int,float,double}(This, field, var_rank) (:441-443 / :453-455) are declared
+ * but never defined in the reference (no shape is passed).  Provided here for the one case that is well defined without a
+ * shape, var_rank == 0 (one value per node, field[size]); any other var_rank is an error. */
+int atlas_amd__HaloExchange__execute_int(atlas_amd_HaloExchange* h, int field[], int var_rank);
+int atlas_amd__HaloExchange__execute_float(atlas_amd_HaloExchange* h, float field[], int var_rank);
+int atlas_amd__HaloExchange__execute_double(atlas_amd_HaloExchange* h, double field[], int var_rank);
+int atlas_amd__HaloExchange__execute_adjoint_int(atlas_amd_HaloExchange* h, int field[], int var_rank);
+int atlas_amd__HaloExchange__execute_adjoint_float(atlas_amd_HaloExchange* h, float field[], int var_rank);
+int atlas_amd__HaloExchange__execute_adjoint_double(atlas_amd_HaloExchange* h, double field[], int var_rank);
+/* the reference setup and a complete exchange between the ranks of a communicator (HaloExchange.cc:78-172,
+ * HaloExchange.h:191-219 / :227-290): pack kernel -> grouped send/recv per peer -> unpack kernel, asynchronous on the
+ * object's stream (a transform on another stream overlaps it).  field_dev: device pointer, described as in field_op. */
+int atlas_amd__HaloExchange__setup_comm(atlas_amd_HaloExchange* h, atlas_amd_Comm* comm, const int part[],
+                                        const int remote_idx[], int base, int size, int halo_begin);
+int atlas_amd__HaloExchange__execute_comm(atlas_amd_HaloExchange* h, atlas_amd_Comm* comm, int dtype, void* field_dev,
+                                          int rank, const int shape[], const long long strides[], int parallel_dim,
+                                          int adjoint);
 /* general form of HaloExchange::execute<T,RANK,ParallelDim> / the pack and unpack stages (HaloExchange.h:151-290):
  * op 0 execute, 1 execute_adjoint (both: one process), 2 pack(sendmap), 3 unpack(recvmap), 4 pack_adjoint(recvmap),
  * 5 unpack_adjoint(+= at sendmap), 6 zero_halos.  Buffers hold sendcnt*var_size (ops 2,5) or recvcnt*var_size

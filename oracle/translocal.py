@@ -58,6 +58,7 @@ def lib():
         L.orc_invtrans_rows.argtypes = [vp, i, i, vp, i, vp, vp, i]
         L.orc_invtrans_vordiv.argtypes = [vp, i, vp, i, vp, vp, vp, i]
         L.orc_vd2uv.argtypes = [i, i, vp, vp, vp, vp]
+        L.orc_gemm.argtypes = [i, sz, i, vp, vp, vp]
         L.orc_c2r_direct.argtypes = [i, vp, vp]
         L.orc_c2r_fft.argtypes = [i, vp, vp]
         _lib = L
@@ -77,6 +78,18 @@ def legendre_lat(trc, lat_rad):
     vs, vc = np.zeros(trc + 1), np.zeros(trc + 1)
     L.orc_legendre_lat(trc, float(lat_rad), legpol.ctypes.data, zfn.ctypes.data, vs.ctypes.data, vc.ctypes.data)
     return legpol
+
+
+def gemm(A, B):
+    """C = A @ B through the oracle's own GEMM (column-major operands, the contraction of the Legendre stage)"""
+    A = np.asfortranarray(A, dtype=np.float64)
+    B = np.asfortranarray(B, dtype=np.float64)
+    rows, K = A.shape
+    K2, L = B.shape
+    assert K == K2
+    C_ = np.zeros((rows, L), order="F")
+    lib().orc_gemm(rows, K, L, A.ctypes.data, B.ctypes.data, C_.ctypes.data)
+    return np.ascontiguousarray(C_)
 
 
 def c2r_direct(n, half_spectrum):

@@ -340,6 +340,18 @@ static inline size_t orc_pos_fourier(const orc_plan* p, int fld, int imag, int j
  * `trc` is the CALL's truncation (T for scalars, T+1 on the vor/div path); entries are taken only
  * if n <= trc && m < trc (:982).  scl_fourier must be zero-initialised by the caller (:1423-1428).
  * ---------------------------------------------------------------------------------------------- */
+/* a9: C(rows x L) += A(rows x K) * B(K x L), all column-major with leading dimensions rows, K, rows
+ * (MatrixMultiply.tcc:45-68 -> eckit gemm; "generic" backend order: column of C by column, k outer, r inner).
+ * Known-answer test of the reference: src/tests/linalg/test_linalg_dense.cc:117-136. */
+void orc_gemm(int rows, size_t K, int L, const double* A, const double* B, double* C) {
+    for (int c = 0; c < L; ++c) {
+        for (size_t k = 0; k < K; ++k) {
+            const double b = B[(size_t)c * K + k];
+            for (int r = 0; r < rows; ++r) C[(size_t)c * rows + r] += A[k * rows + r] * b;
+        }
+    }
+}
+
 void orc_invtrans_legendre(const orc_plan* p, int trc, int nf, const double* sp, double* scl_fourier) {
     const int T = p->T;
 #pragma omp parallel for schedule(dynamic, 1)
@@ -370,16 +382,8 @@ void orc_invtrans_legendre(const orc_plan* p, int trc, int nf, const double* sp,
             /* C(rows x L) = A(rows x K) * B(K x L), all column-major (:1007-1023; eckit "generic" order) */
             const double* b_sym  = p->leg_sym + p->begin_sym[m] + (size_t)p->nlat0[m] * ks;
             const double* b_asym = p->leg_asym + p->begin_asym[m] + (size_t)p->nlat0[m] * ka;
-            for (int c = 0; c < L; ++c) {
-                for (size_t k = 0; k < ks; ++k) {
-                    double b = b_sym[(size_t)c * ks + k];
-                    for (int r = 0; r < rows; ++r) c_sym[(size_t)c * rows + r] += a_sym[k * rows + r] * b;
-                }
-                for (size_t k = 0; k < ka; ++k) {
-                    double b = b_asym[(size_t)c * ka + k];
-                    for (int r = 0; r < rows; ++r) c_asym[(size_t)c * rows + r] += a_asym[k * rows + r] * b;
-                }
-            }
+            orc_gemm(rows, ks, L, a_sym, b_sym, c_sym);
+            orc_gemm(rows, ka, L, a_asym, b_asym, c_asym);
             /* merge hemispheres (:1031-1080); posFourier :955-957 */
             for (int jlat = 0; jlat < p->nlats_nh; ++jlat) {
                 int c = L - p->nlats_nh + jlat;

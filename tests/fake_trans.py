@@ -47,6 +47,12 @@ class FakeTrans:
     def use_torch_stream(self):
         pass
 
+    def synchronize(self):
+        pass
+
+    def stream(self):
+        return None
+
     def truncation(self):
         return self.T
 

@@ -30,7 +30,7 @@ def _bench_worker(rank, world, port, argv, grid, corrupt_mirror, outdir):
                        "LOCAL_WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
     os.environ.pop("ATLAS_AMD_BENCH_CROSSCHECK", None)
     import atlas_amd
-    import atlas_amd.dist as aadist
+    import atlas_amd.dist_torch as aadist   # what bench.py selects off the GPU (--dist-impl auto)
     import bench
     from fake_trans import FakeTrans
     FakeTrans.corrupt_mirror = corrupt_mirror
@@ -76,20 +76,27 @@ def test_single_gpu_line_has_roofline_and_cpu_baseline(tmp_path):
     assert out["config"]["parallelism"] == "single GPU"
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "transforms/s"
-    assert "multi_gpu_crosscheck" not in out and "mirror_selfcheck" not in out
+    assert "multi_gpu_crosscheck" not in out and "alt_decomposition" not in out
 
 
-def test_two_ranks_adopt_the_mirror_band_decomposition_after_its_self_check(tmp_path):
+def test_two_ranks_time_the_named_decomposition_and_report_the_mirror_bands_beside_it(tmp_path):
+    """N > 1 default: the m-sharded decomposition with the transposition (BASELINE C3 / C4) is the timed one, checked
+    against the band decomposition; the exchange-free mirror-band decomposition is timed as `alt_decomposition` after
+    its bitwise self-check"""
     out = run_bench(tmp_path, 2, ["--gpus", "2", "--steps", "2", "--warmup", "1"])
-    assert out["mirror_selfcheck"]["bitwise_equal_on_all_ranks"] is True
-    assert out["config"]["parallelism"].startswith("mirror-band")
+    assert out["config"]["parallelism"].startswith("m-sharded")
+    assert out["multi_gpu_crosscheck"]["bitwise_equal_on_all_ranks"] is True
+    alt = out["alt_decomposition"]
+    assert alt["mode"] == "mirror" and alt["selfcheck_bitwise_equal_on_all_ranks"] is True and alt["value"] > 0
+    assert out["dist_impl"].startswith("torch")                           # off the GPU; "native" on MI355X
     assert "cpu_baseline" not in out                                      # rank 0 at N = 1 only
 
 
-def test_two_ranks_fall_back_to_latitude_bands_when_the_self_check_fails(tmp_path):
+def test_mirror_bands_are_not_reported_when_their_self_check_fails(tmp_path):
     out = run_bench(tmp_path, 2, ["--gpus", "2", "--steps", "1", "--warmup", "0"], corrupt_mirror=True)
-    assert out["mirror_selfcheck"]["bitwise_equal_on_all_ranks"] is False
-    assert out["config"]["parallelism"].startswith("latitude-band")
+    assert out["config"]["parallelism"].startswith("m-sharded")
+    assert out["alt_decomposition"]["selfcheck_bitwise_equal_on_all_ranks"] is False
+    assert "value" not in out["alt_decomposition"]
 
 
 def test_all_to_all_decomposition_with_cross_check(tmp_path):
@@ -98,14 +105,15 @@ def test_all_to_all_decomposition_with_cross_check(tmp_path):
     out = run_bench(tmp_path, 3, ["--gpus", "3", "--steps", "2", "--warmup", "1", "--dist-mode", "alltoall"])
     assert out["config"]["parallelism"].startswith("m-sharded")
     assert out["multi_gpu_crosscheck"]["bitwise_equal_on_all_ranks"] is True
-    assert "mirror_selfcheck" not in out
 
 
 def test_explicit_modes(tmp_path):
     out = run_bench(tmp_path, 2, ["--gpus", "2", "--steps", "1", "--warmup", "0", "--dist-mode", "band"])
-    assert out["config"]["parallelism"].startswith("latitude-band") and "mirror_selfcheck" not in out
+    assert out["config"]["parallelism"].startswith("latitude-band") and "alt_decomposition" not in out
     out = run_bench(tmp_path, 2, ["--gpus", "2", "--steps", "1", "--warmup", "0", "--dist-mode", "mirror"])
-    assert out["config"]["parallelism"].startswith("mirror-band") and "mirror_selfcheck" not in out
+    assert out["config"]["parallelism"].startswith("mirror-band") and "alt_decomposition" not in out
+    out = run_bench(tmp_path, 2, ["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-alt"])
+    assert out["config"]["parallelism"].startswith("m-sharded") and "alt_decomposition" not in out
 
 
 def test_eight_ranks_auto_is_the_all_to_all_decomposition(tmp_path):

@@ -1,4 +1,4 @@
-"""CPU tests of the multi-GPU decomposition logic (atlas_amd/dist.py):
+"""CPU tests of the multi-GPU decomposition logic (atlas_amd/dist_torch.py (torch.distributed transport; the product path is native: atlas_amd/dist.py)):
   * split sizes / offsets of the m -> latitude transpose and the address formula the FFT kernel uses,
     exercised with a REAL all_to_all_single over gloo with world_size 2 and 3 (CPU tensors);
   * HaloExchange.setup over a gloo process group against the serial oracle."""
@@ -38,7 +38,7 @@ def _bands(nx, nparts):
 
 def _transpose_worker(rank, world, port, T, RP, nx, q, limits=None, async_op=False):
     sys.path.insert(0, ROOT)
-    from atlas_amd.dist import mode_address, owned_wavenumbers, transpose_exchange, transpose_plan
+    from atlas_amd.dist_torch import mode_address, owned_wavenumbers, transpose_exchange, transpose_plan
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     nlats = len(nx)
     bands = _bands(nx, world)
@@ -94,7 +94,7 @@ def test_m_to_latitude_transpose_over_gloo(world):
                                                    (3, 64, False),
                                                    (3, 300, True)])
 def test_bounded_size_exchange_over_gloo(world, limits, async_op):
-    """atlas_amd.dist.transpose_exchange: the single all_to_all_single and the bounded-size point-to-point messages
+    """atlas_amd.dist_torch.transpose_exchange: the single all_to_all_single and the bounded-size point-to-point messages
     must deliver the same transposed intermediate"""
     nx = np.array([20 + 4 * j for j in range(8)] + [20 + 4 * j for j in range(8)][::-1])
     ctx = mp.get_context("spawn")
@@ -111,7 +111,7 @@ def test_bounded_size_exchange_over_gloo(world, limits, async_op):
 
 
 def test_exchange_messages_cover_both_buffers_exactly_once():
-    from atlas_amd.dist import exchange_messages, transpose_plan
+    from atlas_amd.dist_torch import exchange_messages, transpose_plan
     nx = np.array([20 + 4 * j for j in range(40)] + [20 + 4 * j for j in range(40)][::-1])
     T, RP = 47, 32
     for world in (1, 2, 3, 8):
@@ -175,7 +175,8 @@ def _halo_exchange_worker(rank, world, port, gridname, halo, nlev, q, mirror=Fal
     sys.path.insert(0, ROOT)
     import atlas_amd
     from atlas_amd.functionspace import MirrorBandColumns, StructuredColumns
-    from atlas_amd.parallel import HaloExchange, exchange_packed
+    from atlas_amd.parallel import HaloExchange
+    from atlas_amd.parallel_torch import exchange_packed
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     g = atlas_amd.Grid(gridname)
     fs = (MirrorBandColumns if mirror else StructuredColumns)(g, halo=halo, nparts=world, part=rank)
@@ -207,7 +208,7 @@ def _halo_exchange_worker(rank, world, port, gridname, halo, nlev, q, mirror=Fal
 def test_halo_exchange_communication_step_over_gloo(world, gridname, halo, mirror):
     """StructuredColumns partitions (Atlas equal_bands), or the two-range parts of the mirror-band decomposition
     (MirrorBandColumns), in `world` real processes: distributed HaloExchange.setup, then
-    the send/recv step of execute (atlas_amd.parallel.exchange_packed) on packed buffers; afterwards every halo point
+    the send/recv step of execute (atlas_amd.parallel_torch.exchange_packed) on packed buffers; afterwards every halo point
     must hold the value of the point it mirrors (test_structuredcolumns_haloexchange.cc:38-60 in spirit)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -234,3 +235,28 @@ def test_latitude_bands_follow_bands_distribution_rule():
         for q in range(P):
             for j in range(b[q], b[q + 1]):
                 assert bands_partition(int(off[j]), int(off[-1]), P, 1) == q
+
+
+@pytest.mark.parametrize("nparts,maxmsg", [(1, 1 << 26), (2, 1 << 26), (3, 4000), (8, 1 << 26), (8, 900), (5, 128)])
+def test_library_transpose_messages_equal_the_python_plan(nparts, maxmsg):
+    """the message list the library builds for the m -> latitude transposition (csrc/dist_trans.hip, what the RCCL path
+    sends) against the Python formulation that the gloo tests above exercise between real processes"""
+    import atlas_amd
+    from atlas_amd.dist import transpose_messages
+    from atlas_amd.dist_torch import exchange_messages, transpose_plan
+    g = atlas_amd.Grid("O32")
+    T, RP = 31, 16
+    ny = g.ny()
+    nx = np.asarray(g.nx())
+    bands = np.asarray(_bands(nx, nparts), dtype=np.int32)
+    assert bands[0] == 0 and bands[-1] == ny
+    for part in range(nparts):
+        plan = transpose_plan(ny, T, RP, bands, nparts, part)
+        want = exchange_messages(plan, bands, RP, nparts, part, maxmsg)
+        got = transpose_messages(T, RP, bands, nparts, part, maxmsg)
+        assert got == [tuple(int(v) for v in m) for m in want]
+        # every double of the receive buffer is written exactly once
+        cover = np.zeros(sum(plan["out_splits"]), dtype=np.int32)
+        for _, _, _, rb, re in got:
+            cover[rb:re] += 1
+        assert (cover == 1).all()

@@ -1,0 +1,128 @@
+"""The distributed paths that run INSIDE the library (csrc/comm.hip, dist_trans.hip, halo_exchange.hip: execute_comm),
+driven from Python threads: P emulated ranks on one GPU over the "local" communicator, and one rank over real RCCL.
+
+Oracle: the single-device transform (itself compared with the CPU oracle in test_gpu_trans.py) -- the sharded result must
+equal it bit for bit, because every (m, latitude) product and every row goes through the same arithmetic; for the halo
+exchange: the owner's value at every halo node (src/tests/functionspace/test_structuredcolumns_haloexchange.cc:38-60)."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import atlas_amd
+from atlas_amd.comm import Comm, CommHub
+from atlas_amd.dist import DistributedTrans
+from atlas_amd.functionspace import StructuredColumns
+from atlas_amd.parallel import HaloExchange
+from helpers import red_spectra
+
+pytestmark = pytest.mark.gpu
+
+
+def run_ranks(nparts, fn):
+    hub = CommHub(nparts)
+    comms = [hub.comm(r) for r in range(nparts)]
+    out, err = [None] * nparts, [None] * nparts
+
+    def worker(r):
+        try:
+            torch.cuda.set_device(0)
+            out[r] = fn(comms[r])
+        except BaseException as e:  # noqa: BLE001  (reported below)
+            err[r] = e
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(nparts)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(600)
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+@pytest.mark.parametrize("gridname,T,nf,nparts,maxmsg", [("O64", 63, 3, 2, None), ("O64", 63, 5, 3, 8192),
+                                                         ("F32", 31, 4, 4, None), ("O160", 159, 9, 8, 1 << 16)])
+def test_native_distributed_transform_equals_single_device(gridname, T, nf, nparts, maxmsg):
+    g = atlas_amd.Grid(gridname)
+    sps = [torch.from_numpy(red_spectra(T, nf, seed=s)).cuda() for s in (1, 2, 3)]
+    tr = atlas_amd.Trans(g, T)
+    refs = []
+    for sp in sps:
+        gp = torch.zeros(nf * g.size(), dtype=torch.float64, device="cuda")
+        tr.invtrans(nf, sp, gp)
+        tr.synchronize()
+        refs.append(gp.cpu().numpy().reshape(nf, -1))
+    off = np.concatenate([[0], np.cumsum(g.nx())])
+
+    def rank(comm):
+        d = DistributedTrans(g, T, comm=comm, mode="alltoall")
+        if maxmsg:
+            d.set_max_message_bytes(maxmsg)
+        n = d.trans.nb_gridpoints()
+        gps = [torch.zeros(nf * n, dtype=torch.float64, device="cuda") for _ in sps]
+        d.invtrans(nf, sps[0], gps[0])
+        d.trans.synchronize()
+        one = gps[0].cpu().numpy().copy()
+        d.invtrans_many(nf, sps, gps)            # pipelined: exchange of i next to Legendre of i+1 / Fourier of i-1
+        d.trans.synchronize()
+        return d.bands[comm.rank()], d.bands[comm.rank() + 1], one, [x.cpu().numpy() for x in gps]
+
+    for b0, b1, one, many in run_ranks(nparts, rank):
+        sl = slice(off[b0], off[b1])
+        assert np.array_equal(one.reshape(nf, -1), refs[0][:, sl])
+        for got, ref in zip(many, refs):
+            assert np.array_equal(got.reshape(nf, -1), ref[:, sl])
+
+
+@pytest.mark.parametrize("gridname,nparts,halo", [("O16", 2, 1), ("O32", 3, 2), ("F16", 4, 1)])
+def test_native_halo_exchange_between_ranks(gridname, nparts, halo):
+    g = atlas_amd.Grid(gridname)
+
+    def rank(comm):
+        fs = StructuredColumns(g, halo=halo, nparts=nparts, part=comm.rank())
+        hx = HaloExchange()
+        hx.setup(fs.partition(), fs.remote_index(), 0, fs.sizeHalo(), halo_begin=fs.sizeOwned(), comm=comm)
+        gidx = fs.global_index()
+        a = np.where(fs.ghost() == 0, gidx, -1).astype(np.int64)
+        f = torch.from_numpy(np.repeat(a[:, None], 4, axis=1).copy()).cuda()
+        hx.execute(f)
+        hx.synchronize()
+        ok = np.array_equal(f.cpu().numpy()[:, 0], gidx) and np.array_equal(f.cpu().numpy()[:, 3], gidx)
+        # adjoint: halo contributions are added to their owners, halos zeroed (HaloExchange.h:227-290)
+        w = torch.ones(fs.sizeHalo(), 2, dtype=torch.float64, device="cuda")
+        hx.execute_adjoint(w)
+        hx.synchronize()
+        wn = w.cpu().numpy()
+        return ok, float(wn[:, 0].sum()), int((wn[fs.ghost() == 1] != 0).sum()), fs.sizeHalo()
+
+    res = run_ranks(nparts, rank)
+    assert all(r[0] for r in res)
+    assert all(r[2] == 0 for r in res)                                  # halos zeroed
+    assert sum(r[1] for r in res) == sum(r[3] for r in res)             # the adjoint conserves the sum
+
+
+def test_native_paths_over_a_real_rccl_communicator_of_one_rank():
+    g = atlas_amd.Grid("O32")
+    T, nf = 31, 3
+    comm = Comm.rccl(Comm.unique_id(), 1, 0)
+    assert comm.kind() == "rccl" and comm.size() == 1 and comm.rank() == 0
+    comm.barrier()
+    sp = torch.from_numpy(red_spectra(T, nf)).cuda()
+    ref = torch.zeros(nf * g.size(), dtype=torch.float64, device="cuda")
+    atlas_amd.Trans(g, T).invtrans(nf, sp, ref)
+    d = DistributedTrans(g, T, comm=comm, mode="alltoall")
+    gp = torch.zeros_like(ref)
+    d.invtrans_many(nf, [sp, sp], [gp, gp])
+    d.trans.synchronize()
+    torch.cuda.synchronize()
+    assert torch.equal(gp, ref)
+    fs = StructuredColumns(g, halo=2)
+    hx = HaloExchange()
+    hx.setup(fs.partition(), fs.remote_index(), 0, fs.sizeHalo(), halo_begin=fs.sizeOwned(), comm=comm)
+    gidx = fs.global_index()
+    f = torch.from_numpy(np.where(fs.ghost() == 0, gidx, -1).astype(np.int64)).cuda()
+    hx.execute(f)
+    hx.synchronize()
+    assert np.array_equal(f.cpu().numpy(), gidx)

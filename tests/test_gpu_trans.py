@@ -234,9 +234,9 @@ def test_full_size_linearity(trans_full):
                                                   ("O160", 159, 9, 8)])
 def test_sharded_stages_reproduce_single_device_result(gridname, T, nf, nparts):
     """P objects with (nparts=P, part=p) in one process: m-sharded Legendre stage, the all-to-all replaced by device
-    copies that follow atlas_amd.dist.transpose_plan, latitude-band Fourier stage.  Must equal the single-object
+    copies that follow atlas_amd.dist_torch.transpose_plan, latitude-band Fourier stage.  Must equal the single-object
     result bit for bit (same arithmetic per (m, latitude) and per row)."""
-    from atlas_amd.dist import transpose_plan
+    from atlas_amd.dist_torch import transpose_plan
     g, tr1 = get_trans(gridname, T)
     sp = red_spectra(T, nf, seed=5)
     ref = run_device(tr1, nf, sp).reshape(nf, -1)

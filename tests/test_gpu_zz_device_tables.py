@@ -4,8 +4,8 @@
 device memory must equal the host-generated one bit for bit -- the kernels perform the reference's multiplications and
 additions in the reference's order (LegendrePolynomials.cc:85-149) without contraction -- for the whole table and for
 the wavenumber-sharded and latitude-band decompositions; the transform built on it then gives identical results.
-2. The mirror-band decomposition (Trans(shard="mirror"), functionspace.MirrorBandColumns), built after round 1's GPU
-budget was spent: non-strict xfail until it has run on hardware once."""
+2. The mirror-band decomposition (Trans(shard="mirror"), functionspace.MirrorBandColumns) and the adjoint halo exchange
+on the device against the reference's expected arrays."""
 import numpy as np
 import pytest
 
@@ -42,10 +42,8 @@ def test_transform_on_device_generated_table():
 
 
 # ---------------------------------------------------------------- mirror-band decomposition (shard="mirror")
-# Built after the round's GPU budget was spent: the kernels and the crop path it uses are the tested ones, the geometry
-# equivalence is tested on the CPU (tests/test_host_logic.py), but the mode itself has not run on hardware yet --
-# hence non-strict xfail, and a child process so that nothing it does can take the test session down.
-@pytest.mark.xfail(strict=False, reason="shard=mirror has not been run on hardware yet")
+# The kernels and the crop path it uses are the tested ones, the geometry equivalence is tested on the CPU
+# (tests/test_host_logic.py); run in a child process (several Trans objects per part).
 @pytest.mark.parametrize("gridname,T,nf,nparts", [("O64", 63, 3, 2), ("O64", 63, 5, 3), ("F32", 31, 4, 4),
                                                   ("O160", 159, 9, 8)])
 def test_mirror_band_sharding_reproduces_single_device_result(gridname, T, nf, nparts):
@@ -60,7 +58,6 @@ def test_mirror_band_sharding_reproduces_single_device_result(gridname, T, nf, n
     assert r.returncode == 0 and "MIRROR OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.xfail(strict=False, reason="MirrorBandColumns was built after the round's GPU budget was spent")
 @pytest.mark.parametrize("gridname,nparts,halo", [("O16", 2, 2), ("O16", 3, 1)])
 def test_mirror_band_columns_halo_exchange_emulated(gridname, nparts, halo):
     """function space of the mirror-band decomposition (two row ranges per part): after the halo exchange (device pack /
@@ -83,7 +80,6 @@ def test_mirror_band_columns_halo_exchange_emulated(gridname, nparts, halo):
         assert np.array_equal(a.cpu().numpy()[:, 2], f.global_index())
 
 
-@pytest.mark.xfail(strict=False, reason="the adjoint goldens were added after the round's GPU budget was spent")
 @pytest.mark.parametrize("dtype", [np.float64, np.float32, np.int32, np.int64])
 @pytest.mark.parametrize("case", ["rank0_arrview", "rank1", "rank1_strided_v1", "rank1_strided_v2", "rank2", "rank2_l1",
                                   "rank2_l2_v2", "rank2_v2", "rank0_wrap", "rank1_paralleldim1", "rank2_paralleldim2"])

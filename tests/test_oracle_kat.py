@@ -145,5 +145,10 @@ def test_fourier_truncation_known_values():
 
 def test_gemm_known_answer():
     # src/tests/linalg/test_linalg_dense.cc:117-136: [[1,-2],[-4,2]]^2 = [[9,-6],[-12,12]] (column-major C = A*B)
+    # through the oracle's own GEMM (column-major operands, the contraction of the Legendre stage)
     A = np.array([[1., -2.], [-4., 2.]])
-    assert np.array_equal(A @ A, np.array([[9., -6.], [-12., 12.]]))
+    C = oracle.gemm(np.asfortranarray(A), np.asfortranarray(A))
+    assert np.array_equal(C, np.array([[9., -6.], [-12., 12.]]))
+    rng = np.random.default_rng(5)
+    A, B = rng.standard_normal((7, 5)), rng.standard_normal((5, 9))
+    assert np.allclose(oracle.gemm(A, B), A @ B, rtol=1e-14, atol=1e-14)

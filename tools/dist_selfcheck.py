@@ -19,8 +19,8 @@ import torch
 import torch.distributed as dist
 
 import atlas_amd
-import atlas_amd.dist as aadist
-from atlas_amd.dist import DistributedTrans
+import atlas_amd.dist_torch as aadist
+from atlas_amd.dist_torch import DistributedTrans
 from helpers import red_spectra
 
 
