@@ -160,6 +160,10 @@ legendre_reference_sizes = _sig("atlas_amd__legendre_reference_sizes", C.c_int, 
                                 C.POINTER(C.c_size_t), C.POINTER(C.c_size_t))
 legendre_reference_tables = _sig("atlas_amd__legendre_reference_tables", C.c_int, c_void_p, C.c_int, c_void_p,
                                  C.c_size_t, c_void_p, C.c_size_t)
+LegendreCacheCreator_uid = _sig("atlas_amd__LegendreCacheCreator__uid", C.c_int, c_void_p, C.c_int, C.c_int, C.c_char_p,
+                                C.c_size_t)
+LegendreCacheCreator_estimate = _sig("atlas_amd__LegendreCacheCreator__estimate", C.c_int64, C.c_int)
+LegendreCacheCreator_supported = _sig("atlas_amd__LegendreCacheCreator__supported", C.c_int, c_void_p)
 fft_host_row = _sig("atlas_amd__fft_host_row", C.c_int, C.c_int, c_void_p, C.c_int, c_void_p)
 fft_host_row_generic = _sig("atlas_amd__fft_host_row_generic", C.c_int, C.c_int, c_void_p, C.c_int, c_void_p)
 fft_host_row_hybrid = _sig("atlas_amd__fft_host_row_hybrid", C.c_int, C.c_int, c_void_p, C.c_int, c_void_p)

@@ -10,6 +10,8 @@
 
 #include "../../include/atlas_amd.h"
 #include "capi_types.h"
+#include "equal_regions.h"
+#include "legendre_cache_uid.h"
 #include "fft_plan.h"
 #include "gaussian.h"
 #include "legendre_host.h"
@@ -154,6 +156,54 @@ int atlas_amd__set_device(int device) {
     if (hipSetDevice(device) != hipSuccess) {
         throw std::runtime_error("set_device failed");
     }
+    AA_CATCH_INT
+}
+
+int atlas_amd__LegendreCacheCreator__uid(const atlas_amd_Grid* grid, int truncation, int flt, char* out, size_t capacity) {
+    AA_TRY
+    if (!grid || !out || capacity == 0) {
+        throw std::invalid_argument("LegendreCacheCreator::uid: null argument");
+    }
+    const std::string s = atlas_amd::trans::legendre_cache_uid(grid->g, truncation, flt != 0);
+    if (s.size() + 1 > capacity) {
+        throw std::invalid_argument("LegendreCacheCreator::uid: buffer too small");
+    }
+    std::memcpy(out, s.c_str(), s.size() + 1);
+    AA_CATCH_INT
+}
+int64_t atlas_amd__LegendreCacheCreator__estimate(int truncation) {
+    return atlas_amd::trans::legendre_cache_estimate(truncation);
+}
+int atlas_amd__LegendreCacheCreator__supported(const atlas_amd_Grid* grid) {
+    return grid != nullptr;   // structured grid without projection (LegendreCacheCreatorLocal.cc:140-148): all this library has
+}
+
+int atlas_amd__eq_caps(int nb_regions, int capacity, int regions_per_zone[], double zone_colatitudes[], int* nb_zones) {
+    AA_TRY
+    if (!nb_zones) {
+        throw std::invalid_argument("eq_caps: null argument");
+    }
+    std::vector<int> r;
+    std::vector<double> c;
+    atlas_amd::grid::eq_caps(nb_regions, r, c);
+    *nb_zones = (int)r.size();
+    for (int i = 0; i < (int)r.size() && i < capacity; ++i) {
+        if (regions_per_zone) {
+            regions_per_zone[i] = r[i];
+        }
+        if (zone_colatitudes) {
+            zone_colatitudes[i] = c[i];
+        }
+    }
+    AA_CATCH_INT
+}
+int atlas_amd__equal_regions_partition(const atlas_amd_Grid* grid, int nb_parts, int partition_out[]) {
+    AA_TRY
+    if (!grid || !partition_out) {
+        throw std::invalid_argument("equal_regions_partition: null argument");
+    }
+    const std::vector<int> p = atlas_amd::grid::equal_regions_partition(grid->g, nb_parts);
+    std::copy(p.begin(), p.end(), partition_out);
     AA_CATCH_INT
 }
 

@@ -229,12 +229,40 @@ StructuredGrid make_gaussian_grid(const std::string& name) {
         g.regular = false;
         g.name    = "O" + std::to_string(N);
     }
+    else if (kind == 'N' || kind == 'n') {
+        // classic reduced Gaussian grid: tabulated points per latitude (src/atlas/grid/detail/pl/classic_gaussian/N*.cc)
+        std::vector<int> pl;
+        if (!classic_gaussian_pl(N, pl)) {
+            throw std::invalid_argument("classic reduced Gaussian grid '" + name +
+                                        "' is not tabulated (N16 ... N8000 as in Atlas); pass nx[]/lat[] explicitly");
+        }
+        for (int j = 0; j < N; ++j) {
+            g.nx[j]             = pl[j];
+            g.nx[2 * N - 1 - j] = pl[j];
+        }
+        g.regular = false;
+        g.name    = "N" + std::to_string(N);
+    }
     else {
-        throw std::invalid_argument(
-            "unsupported grid '" + name +
-            "': only F<N> and O<N> are generated here; pass nx[]/lat[] explicitly for classic N<N> or other grids");
+        throw std::invalid_argument("unsupported grid '" + name +
+                                    "': F<N>, O<N> and the tabulated classic N<N> are known by name; pass nx[]/lat[] "
+                                    "explicitly for other grids");
     }
     return g;
+}
+
+bool classic_gaussian_pl(int N, std::vector<int>& pl) {
+#include "classic_pl.inc"
+    for (const auto& e : kClassicPlIndex) {
+        if (e[0] == N) {
+            pl.clear();
+            for (int i = e[1]; i < e[1] + e[2]; ++i) {
+                pl.insert(pl.end(), (size_t)kClassicPlPairs[i][1], kClassicPlPairs[i][0]);
+            }
+            return (int)pl.size() == N;
+        }
+    }
+    return false;
 }
 
 StructuredGrid make_reduced_gaussian_grid(int N, const int pl[], int npl) {

@@ -35,6 +35,8 @@ struct StructuredGrid {
 constexpr int kMaxGaussianN = 16000;
 
 bool gaussian_latitudes_tabulated(int N);
+// points per latitude (north pole -> equator) of the classic reduced Gaussian grid N<N>, if tabulated
+bool classic_gaussian_pl(int N, std::vector<int>& pl);
 void gaussian_latitudes_npole_equator(int N, double lats[]);
 void gaussian_latitudes_npole_spole(int N, double lats[]);
 

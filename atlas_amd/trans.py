@@ -335,24 +335,21 @@ class VorDivToUV:
         return U, V
 
 
-def _md5_10(data):
-    """truncate(eckit::MD5(...).digest()) (LegendreCacheCreatorLocal.cc:34-37): first 10 hex digits"""
-    import hashlib
-    return hashlib.md5(data).hexdigest()[:10]
-
-
 def legendre_cache_grid_hash(y_degrees):
     """hash(const Grid&) for structured grids (LegendreCacheCreatorLocal.cc:40-53): MD5 over std::lround(y * 1e8) of every
-    row, each added as a 64-bit integer.  (eckit::MD5's streaming rules are pinned by the uid strings the reference's own
-    test expects, src/tests/trans/test_trans.cc:600-696: tests/test_host_logic.py.)"""
-    import struct
-    buf = b"".join(struct.pack("<q", int(np.floor(abs(v) * 1.e8 + 0.5)) * (1 if v >= 0 else -1)) for v in y_degrees)
-    return _md5_10(buf)
+    row, each added as a 64-bit integer (csrc/legendre_cache_uid.cpp).  Pinned by the uid strings the reference's own test
+    expects, src/tests/trans/test_trans.cc:600-696: tests/test_host_logic.py."""
+    y = np.ascontiguousarray(y_degrees, dtype=np.float64)
+    g = StructuredGrid(nx=[4] * len(y), y=y)
+    uid = LegendreCacheCreator(g, 0).uid()
+    if not uid.startswith("local-T0-grid-"):
+        raise ValueError("these rows form a named family (L / S grid): no grid hash in their uid")
+    return uid[len("local-T0-grid-"):len("local-T0-grid-") + 10]
 
 
 class LegendreCacheCreator:
     """atlas::trans::LegendreCacheCreator for type "local" (src/atlas/trans/LegendreCacheCreator.h:30-111,
-    local/LegendreCacheCreatorLocal.cc:66-165)"""
+    local/LegendreCacheCreatorLocal.cc:66-165), through the C ABI (atlas_amd__LegendreCacheCreator__*)"""
 
     def __init__(self, grid, truncation, flt=False):
         if isinstance(grid, str):
@@ -360,29 +357,15 @@ class LegendreCacheCreator:
         self.grid, self._truncation, self._flt = grid, int(truncation), bool(flt)
 
     def supported(self):
-        return True     # structured grid without projection (LegendreCacheCreatorLocal.cc:140-148); all this package has
+        return bool(_lib.LegendreCacheCreator_supported(self.grid._h))
 
     def uid(self):
-        g, s = self.grid, f"local-T{self._truncation}-"
-        y = g.y()
-        name = getattr(g, "name", "")
-        if name[:1] in ("F", "O", "N") and name[1:].isdigit():
-            s += f"GaussianN{int(name[1:])}"                       # same cache for any global Gaussian grid
-        elif g.regular() and np.allclose(np.diff(y), y[1] - y[0]) and abs(y[0] + y[-1]) < 1e-9:
-            dy_2 = 90.0 / g.ny()
-            if abs(y[0] - 90.0) < 1e-9:
-                s += f"L-ny{g.ny()}"
-            elif abs(y[0] - (90.0 - dy_2)) < 1e-9:
-                s += f"S-ny{g.ny()}"
-            else:
-                s += "grid-" + legendre_cache_grid_hash(y)
-        else:
-            s += "grid-" + legendre_cache_grid_hash(y)             # give_up(): no reuse across grids
-        return s + "-OPT" + _md5_10(b"flt" + (b"\x01" if self._flt else b"\x00"))
+        buf = C.create_string_buffer(256)
+        _lib.check(_lib.LegendreCacheCreator_uid(self.grid._h, self._truncation, int(self._flt), buf, 256))
+        return buf.value.decode()
 
     def estimate(self):
-        T = self._truncation
-        return (T * T * T) // 2 * 8                                 # LegendreCacheCreatorLocal.cc:162-164
+        return int(_lib.LegendreCacheCreator_estimate(self._truncation))          # LegendreCacheCreatorLocal.cc:162-164
 
     def create(self, path=None):
         """create() -> cache bytes (np.uint8), create(path) -> writes the file TransLocal's write_legendre would

@@ -264,6 +264,22 @@ int atlas_amd__fft_host_row_generic(int n, const double* modes, int mmax, double
  * factors > 5 of h (A <= 257), B {2,3,5}-smooth; other lengths take their usual plan */
 int atlas_amd__fft_host_row_hybrid(int n, const double* modes, int mmax, double* out);
 
+/* atlas::trans::LegendreCacheCreator, type "local" (src/atlas/trans/LegendreCacheCreator.h:30-111,
+ * local/LegendreCacheCreatorLocal.cc:66-165): uid = "local-T<T>-GaussianN<N>|L-ny<ny>|S-ny<ny>|grid-<md5>-OPT<md5>" (expected
+ * strings: src/tests/trans/test_trans.cc:600-696), estimate = T^3/2*8 bytes.  create() is
+ * atlas_amd__Trans__legendre_cache_export on a Trans of the same (grid, truncation). */
+int atlas_amd__LegendreCacheCreator__uid(const atlas_amd_Grid* grid, int truncation, int flt, char* out, size_t capacity);
+int64_t atlas_amd__LegendreCacheCreator__estimate(int truncation);
+int atlas_amd__LegendreCacheCreator__supported(const atlas_amd_Grid* grid);
+
+/* grid::Partitioner("equal_regions", N) for structured grids, Atlas's default (EqualRegionsPartitioner.cc:70-347,443-605):
+ * eq_caps = Leopardi's zones north -> south (regions per zone, colatitude of each zone's southern edge; expected values of
+ * src/tests/mesh/test_rgg.cc:103-165); partition_out[npts] = part of every grid point in global order, the explicit
+ * grid::Distribution atlas_amd__StructuredColumns__new_distribution accepts
+ * (src/tests/functionspace/test_structuredcolumns.cc:87-106: O8 on 5 parts). */
+int atlas_amd__eq_caps(int nb_regions, int capacity, int regions_per_zone[], double zone_colatitudes[], int* nb_zones);
+int atlas_amd__equal_regions_partition(const atlas_amd_Grid* grid, int nb_parts, int partition_out[]);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Communicators: the inter-GPU transport of the library (grouped point-to-point exchanges of device buffers).
  * Replaces the eckit::mpi communicator behind parallel::HaloExchange (iReceive / iSend per peer,

@@ -126,3 +126,50 @@ def test_native_paths_over_a_real_rccl_communicator_of_one_rank():
     hx.execute(f)
     hx.synchronize()
     assert np.array_equal(f.cpu().numpy(), gidx)
+
+
+def test_config_C3_TL639_O640_137_levels_on_four_ranks():
+    """BASELINE config C3 at its own size (TL639 -> O640, 137 levels, 4 latitude-band parts, m-sharded Legendre stage +
+    transposition + halo exchange), the four ranks emulated as threads on one GPU: bands equal the single-device transform
+    bit for bit (sampled rows of which are checked against the oracle), and after the halo exchange of the band fields
+    every halo node of every part holds its owner's value."""
+    import oracle
+    from helpers import compute_rms
+    g = atlas_amd.Grid("O640")
+    T, nf, nparts = 639, 137, 4
+    sp_h = red_spectra(T, nf, seed=5)
+    sp = torch.from_numpy(sp_h).cuda()
+    ref = torch.zeros(nf * g.size(), dtype=torch.float64, device="cuda")
+    tr = atlas_amd.Trans(g, T)
+    tr.invtrans(nf, sp, ref)
+    tr.synchronize()
+    del tr
+    ref = ref.view(nf, -1)
+    off = np.concatenate([[0], np.cumsum(g.nx())])
+    rows = [0, 319, 640, 1279]
+    op = oracle.OraclePlan(T, g.nx(), g.y(), with_tables=False)
+    for r, want in zip(rows, op.invtrans_rows(nf, sp_h, rows, use_fft=True)):
+        assert compute_rms(ref[:, off[r]:off[r + 1]].cpu().numpy(), want) < 1e-12, r
+
+    def rank(comm):
+        d = DistributedTrans(g, T, comm=comm, mode="alltoall")
+        n = d.trans.nb_gridpoints()
+        gp = torch.zeros(nf * n, dtype=torch.float64, device="cuda")
+        d.invtrans(nf, sp, gp)
+        d.trans.synchronize()
+        b0, b1 = d.bands[comm.rank()], d.bands[comm.rank() + 1]
+        same = torch.equal(gp.view(nf, -1), ref[:, off[b0]:off[b1]])
+        # the band as a StructuredColumns field (nodes x levels), halo exchange between the ranks
+        fs = StructuredColumns(g, halo=1, nparts=nparts, part=comm.rank(), distribution="row_bands")
+        assert fs.sizeOwned() == n
+        hx = HaloExchange()
+        hx.setup(fs.partition(), fs.remote_index(), 0, fs.sizeHalo(), halo_begin=fs.sizeOwned(), comm=comm)
+        f = torch.full((fs.sizeHalo(), nf), float("nan"), dtype=torch.float64, device="cuda")
+        f[:n] = gp.view(nf, -1).t()
+        hx.execute(f)
+        hx.synchronize()
+        gi = torch.from_numpy(fs.global_index() - 1).cuda()
+        return same, torch.equal(f, ref.t()[gi])
+
+    for same, halo_ok in run_ranks(nparts, rank):
+        assert same and halo_ok

@@ -429,3 +429,90 @@ def test_fp32_variant_against_fp64(gridname, T, nf):
     host = np.full(nf * g.size(), np.nan, dtype=np.float32)       # host-pointer entry point
     tr.invtrans(nf, sp32, host)
     assert np.array_equal(host, gp.cpu().numpy())
+
+
+# ---------------------------------------------------------------- BASELINE configs at their own sizes
+def test_config_C4_batch_of_ten_transforms_sampled_rows(trans_full):
+    """BASELINE config C4's call: TL1279 -> O1280, 10 x 137 = 1370 fields in ONE invtrans (18 GB of spectra, 72 GB of
+    grid points, all resident): sampled rows of sampled fields against the oracle, and field independence against the
+    137-field call."""
+    g, tr = trans_full
+    T, nf = 1279, 1370
+    rng = np.random.default_rng(4)
+    sp = torch.from_numpy(red_spectra(T, 137, seed=21)).cuda().reshape(-1, 137).repeat(1, 10).contiguous().reshape(-1)
+    gp = torch.empty(nf * g.size(), dtype=torch.float64, device="cuda")
+    tr.invtrans(nf, sp, gp)
+    tr.synchronize()
+    gp137 = torch.empty(137 * g.size(), dtype=torch.float64, device="cuda")
+    tr.invtrans(137, dev(red_spectra(T, 137, seed=21)), gp137)
+    tr.synchronize()
+    v, v137 = gp.view(nf, -1), gp137.view(137, -1)
+    for f in (0, 136, 137, 700, 1369):                 # field f of the batch == field f % 137 of the single transform
+        assert torch.equal(v[f], v137[f % 137]), f
+    rows = [3, 1279, 2100]
+    fields = [5, 640, 1368]
+    op = oracle.OraclePlan(T, g.nx(), g.y(), with_tables=False)
+    off = np.concatenate([[0], np.cumsum(g.nx())])
+    sub = np.ascontiguousarray(sp.view(-1, nf)[:, fields].cpu().numpy()).reshape(-1)
+    for r, ref in zip(rows, op.invtrans_rows(len(fields), sub, rows, use_fft=True)):
+        got = v[fields][:, off[r]:off[r + 1]].cpu().numpy()
+        assert compute_rms(got, ref) < 1e-12, r
+    del gp, sp, gp137
+    torch.cuda.empty_cache()
+
+
+def test_config_C5_fp32_on_F1280_137_levels_against_the_oracle():
+    """BASELINE config C5: TL1279 -> F1280 (N1280's latitudes, full grid), 137 levels, fp32 storage + fp32 MFMA Legendre
+    stage.  Oracle: the fp64 CPU restatement on the float-rounded spectra, sampled rows.  Tolerance 2e-6 rel-RMS (fp32
+    products accumulated over up to 640 terms of O(1) magnitude: eps_32 * sqrt(K) ~ 1.5e-6)."""
+    g = atlas_amd.Grid("F1280")
+    T, nf = 1279, 137
+    tr = atlas_amd.Trans(g, T)
+    sp32 = red_spectra(T, nf, seed=61).astype(np.float32)
+    gp = torch.full((nf * g.size(),), float("nan"), dtype=torch.float32, device="cuda")
+    tr.invtrans(nf, torch.from_numpy(sp32).cuda(), gp)
+    tr.synchronize()
+    assert bool(torch.isfinite(gp).all())
+    rows = [0, 11, 1279, 1280, 2559]
+    op = oracle.OraclePlan(T, g.nx(), g.y(), with_tables=False)
+    off = np.concatenate([[0], np.cumsum(g.nx())])
+    v = gp.view(nf, -1)
+    for r, ref in zip(rows, op.invtrans_rows(nf, sp32.astype(np.float64), rows, use_fft=True)):
+        got = v[:, off[r]:off[r + 1]].cpu().numpy().astype(np.float64)
+        assert compute_rms(got, ref) < 2e-6, r
+
+
+def test_classic_reduced_gaussian_grid_against_oracle():
+    """N<n> by name (BASELINE C5 writes "N1280"): TL63 -> N64 and sampled rows of TL1279 -> N1280"""
+    g = atlas_amd.Grid("N64")
+    T, nf = 63, 3
+    sp = red_spectra(T, nf, seed=71)
+    gp = run_device(atlas_amd.Trans(g, T), nf, sp)
+    assert compute_rms(gp, oracle.OraclePlan(T, g.nx(), g.y()).invtrans(nf, sp, use_fft=True)) < 1e-13
+    g = atlas_amd.Grid("N1280")
+    T, nf = 1279, 5
+    sp = red_spectra(T, nf, seed=72)
+    gp = run_device(atlas_amd.Trans(g, T), nf, sp).reshape(nf, -1)
+    rows = [0, 300, 1279, 2559]
+    op = oracle.OraclePlan(T, g.nx(), g.y(), with_tables=False)
+    off = np.concatenate([[0], np.cumsum(g.nx())])
+    for r, ref in zip(rows, op.invtrans_rows(nf, sp, rows, use_fft=True)):
+        assert compute_rms(gp[:, off[r]:off[r + 1]], ref) < 1e-12, r
+
+
+def test_hybrid_fourier_rows_equal_the_bluestein_rows(monkeypatch):
+    """the dense-stage ("hybrid", opt-in) Fourier kernel -- radix-A DFT on the fp64 matrix cores + radix-{2..9} stages --
+    against the Bluestein kernels on every row of O320 / TL319 and against the oracle on sampled rows"""
+    g = atlas_amd.Grid("O320")
+    T, nf = 319, 9
+    sp = red_spectra(T, nf, seed=81)
+    monkeypatch.setenv("ATLAS_AMD_FFT_HYBRID", "0")
+    a = run_device(atlas_amd.Trans(g, T), nf, sp)
+    monkeypatch.setenv("ATLAS_AMD_FFT_HYBRID", "1")
+    b = run_device(atlas_amd.Trans(g, T), nf, sp)
+    assert compute_rms(b, a) < 1e-14 and not np.array_equal(a, b)      # different arithmetic, same transform
+    rows = [40, 63, 200, 319, 500]
+    op = oracle.OraclePlan(T, g.nx(), g.y(), with_tables=False)
+    off = np.concatenate([[0], np.cumsum(g.nx())])
+    for r, ref in zip(rows, op.invtrans_rows(nf, sp, rows, use_fft=True)):
+        assert compute_rms(b.reshape(nf, -1)[:, off[r]:off[r + 1]], ref) < 1e-13, r

@@ -282,8 +282,9 @@ def test_legendre_cache_creator_uid_pinned_by_reference_goldens():
     (src/tests/trans/test_trans.cc:600-696): "-OPT4189816c2e" for flt=false, and "grid-800ac12540 / 0915e0f040 /
     7c400822f0" for F320 / F640 / F1280 cropped to latitudes [-20, 20], "grid-7824deccdf / 7d1771559e" for L90 / L900.
     Reproducing them also pins the Gaussian latitudes of those rows to 1e-8 degrees."""
-    from atlas_amd.trans import LegendreCacheCreator, legendre_cache_grid_hash, _md5_10
-    assert _md5_10(b"flt" + b"\x00") == "4189816c2e"
+    from atlas_amd.trans import LegendreCacheCreator, legendre_cache_grid_hash
+    assert LegendreCacheCreator("O32", 31).uid().endswith("-OPT4189816c2e")      # MD5("flt" + '\0'), 10 digits
+    assert LegendreCacheCreator("O32", 31, flt=True).uid()[-10:] != "4189816c2e"
     for N, want in ((320, "800ac12540"), (640, "0915e0f040"), (1280, "7c400822f0")):
         y = np.array(atlas_amd.gaussian_latitudes(N))
         assert legendre_cache_grid_hash(y[(y >= -20) & (y <= 20)]) == want, N
@@ -297,3 +298,24 @@ def test_legendre_cache_creator_uid_pinned_by_reference_goldens():
     g = atlas_amd.StructuredGrid(nx=[72] * 36, y=87.5 - 5.0 * np.arange(36))
     assert LegendreCacheCreator(g, 20).uid() == "local-T20-S-ny36-OPT4189816c2e"
     assert LegendreCacheCreator("O32", 31).estimate() == 31 ** 3 // 2 * 8
+
+
+def test_classic_reduced_gaussian_grids_by_name():
+    """N<n>: the tabulated points-per-latitude of the classic reduced Gaussian grids (src/atlas/grid/detail/pl/
+    classic_gaussian/N*.cc; data, no formula) against tests/golden/classic_pl.json (SHA-256 of every table, number of
+    points), written from the reference's tables by tools/gen_classic_pl.py.  BASELINE config C5 names N1280."""
+    import hashlib
+    import json
+    fix = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "classic_pl.json")))
+    assert {"N32", "N640", "N1280", "N8000"} <= set(fix)
+    for name, f in fix.items():
+        g = atlas_amd.Grid(name)
+        N = int(name[1:])
+        nx = np.asarray(g.nx())
+        assert g.ny() == 2 * N and np.array_equal(nx[:N], nx[::-1][:N])            # symmetric about the equator
+        assert hashlib.sha256(nx[:N].astype("<i4").tobytes()).hexdigest() == f["sha256"], name
+        assert g.size() == f["npts"] and int(nx.max()) == f["nxmax"] == 4 * N
+        assert np.allclose(g.y(), atlas_amd.gaussian_latitudes(N))                 # the latitudes of F<N> / O<N>
+    assert atlas_amd.Grid("N1280").size() == 8505906 and atlas_amd.Grid("N640").size() == 2140702
+    with pytest.raises(Exception):
+        atlas_amd.Grid("N17")                                                       # not tabulated

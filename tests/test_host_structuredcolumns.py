@@ -220,3 +220,26 @@ def test_equal_regions_partitioner_goldens_and_structuredcolumns():
         pp, ridx, gi = fs.partition(), fs.remote_index(), fs.global_index()
         for n in range(fs.sizeOwned(), fs.sizeHalo()):
             assert fss[pp[n]].global_index()[ridx[n]] == gi[n]
+
+
+def test_equal_regions_partition_of_O8_over_five_parts_is_the_reference_vector():
+    """the expected array of src/tests/functionspace/test_structuredcolumns.cc:87-106 (partition of every point of O8 with
+    the default partitioner on 5 MPI tasks; tests/golden/equal_regions_O8_5.json), from the library (C++) and from the
+    numpy restatement in oracle/; StructuredColumns built on it owns exactly those points"""
+    import json
+    import os
+    from atlas_amd.partitioner import EqualRegionsPartitioner
+    from oracle.partitioner import EqualRegionsPartitioner as OraclePartitioner
+    fix = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "equal_regions_O8_5.json")))
+    g = atlas_amd.Grid(fix["grid"])
+    want = np.asarray(fix["partition"], dtype=np.int32)
+    assert want.size == g.size() == 544
+    got = EqualRegionsPartitioner(fix["nparts"]).partition(g)
+    assert np.array_equal(got, want)
+    assert np.array_equal(OraclePartitioner(fix["nparts"]).partition(g), want)
+    for N in (2, 3, 7, 12, 40):
+        assert np.array_equal(EqualRegionsPartitioner(N).partition(g), OraclePartitioner(N).partition(g))
+    for p in range(fix["nparts"]):
+        fs = StructuredColumns(g, halo=0, nparts=fix["nparts"], part=p, distribution="equal_regions")
+        assert fs.sizeOwned() == int((want == p).sum())
+        assert np.array_equal(np.sort(fs.global_index()[:fs.sizeOwned()]) - 1, np.nonzero(want == p)[0])
