@@ -15,6 +15,7 @@
 // against the reference tables in the development container).  tests/golden/gaussian_latitudes.json
 // pins a SHA-256 of every tabulated N.
 #include "gaussian.h"
+#include "legendre_series.h"
 
 #include <algorithm>
 #include <cmath>
@@ -101,64 +102,45 @@ void tabulated_latitudes(int N, double lats[]) {
     }
 }
 
-// --- Newton iteration in double precision, as the reference does for non-tabulated N -----------------------------
-// Latitudes.cc:227-273 (series coefficients + first guess), :100-135 (one Newton step), :170-210 (loop, tol 1000 eps)
+// --- Newton iteration in double precision, what the reference does for a Gaussian number it has no table for ---------
+// The latitudes are the roots of P_2N, found on its cosine series in the colatitude (legendre_series.h).  To return the
+// reference's doubles bit for bit the first guess, the update and the stopping rule are the reference's (Latitudes.cc:
+// 227-273 series and first guess, :100-135 one step, :170-210 loop: one more step after |step| <= 1000 eps, at most 21),
+// and every sum runs in ascending wavenumber.
 void newton_latitudes(int N, double lats[]) {
-    const size_t kdgl = 2 * (size_t)N;
-    std::vector<double> zzfn(N + 1);
+    const int degree = 2 * N;
+    std::vector<double> series(degree + 1, 0.);
     {
-        std::vector<double> zfn(kdgl + 1);
-        const double zfn0 = 2.;
-        zfn[0]            = zfn0;
-        for (size_t jn = 1; jn <= kdgl; ++jn) {
-            zfn[jn] = zfn0;
-            for (size_t jgl = 1; jgl <= jn; ++jgl) {
-                zfn[jn] *= std::sqrt(1. - 0.25 / (static_cast<double>(jgl * jgl)));
-            }
-            size_t iodd = jn % 2;
-            for (size_t jgl = 2; jgl <= jn - iodd; jgl += 2) {
-                zfn[jn - jgl] = zfn[jn - jgl + 2] * static_cast<double>((jgl - 1) * (2 * jn - jgl + 2)) /
-                                static_cast<double>(jgl * (2 * jn - jgl + 1));
-            }
+        double lead = 2.;
+        for (int j = 1; j <= degree; ++j) {
+            lead = legendre_series_lead(lead, j);
         }
-        size_t iodd = kdgl % 2;
-        for (size_t jgl = iodd, ik = iodd; jgl <= kdgl; jgl += 2, ++ik) {
-            zzfn[ik] = zfn[jgl];
-        }
+        legendre_series_row(degree, lead, series.data());   // even entries: s(2N, 0), s(2N, 2), ...
     }
-    const double ztol = std::numeric_limits<double>::epsilon() * 1000.;
-    for (int jgl = 0; jgl < N; ++jgl) {
-        double z    = (4. * (jgl + 1.) - 1.) * M_PI / (4. * 2. * N + 2.);
-        double zx   = (z + 1. / (std::tan(z) * (8. * (2. * N) * (2. * N))));
-        bool tol_ok = false;
-        double zxn  = zx;
-        for (int it = 1; it <= 21; ++it) {
-            // one Newton step on the cosine series of P_2N (kodd = 0)
-            double zdlk   = 0.5 * zzfn[0];
-            double zdlldn = 0.;
-            size_t ik     = 1;
-            for (size_t jn = 2; jn <= kdgl; jn += 2) {
-                zdlk += zzfn[ik] * std::cos(static_cast<double>(jn) * zx);
-                zdlldn -= zzfn[ik] * static_cast<double>(jn) * std::sin(static_cast<double>(jn) * zx);
-                ++ik;
+    const double tolerance = std::numeric_limits<double>::epsilon() * 1000.;
+    for (int root = 0; root < N; ++root) {
+        const double guess = (4. * (root + 1.) - 1.) * M_PI / (4. * 2. * N + 2.);
+        double colat       = (guess + 1. / (std::tan(guess) * (8. * (2. * N) * (2. * N))));
+        bool converged     = false;
+        for (int iteration = 1; iteration <= 21; ++iteration) {
+            double value = 0.5 * series[0];
+            double slope = 0.;
+            for (int k = 2; k <= degree; k += 2) {
+                const double kd = static_cast<double>(k);
+                value += series[k] * std::cos(kd * colat);
+                slope -= series[k] * kd * std::sin(kd * colat);
             }
-            double zmod = 0.;
-            if (zdlldn != 0) {
-                zmod = -zdlk / zdlldn;
-            }
-            zxn = zx + zmod;
-            zx  = zxn;
-            if (tol_ok) {
+            const double step = slope != 0 ? -value / slope : 0.;
+            colat             = colat + step;
+            if (converged) {
                 break;
             }
-            if (std::abs(zmod) <= ztol) {
-                tol_ok = true;
-            }
+            converged = std::abs(step) <= tolerance;
         }
-        if (!tol_ok) {
+        if (!converged) {
             throw std::runtime_error("Could not converge gaussian latitude");
         }
-        lats[jgl] = 90. - zxn * (180. / M_PI);
+        lats[root] = 90. - colat * (180. / M_PI);
     }
 }
 

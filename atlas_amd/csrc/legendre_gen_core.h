@@ -45,7 +45,7 @@ struct LegendreGenParams {
     const double* vcos;  // cos(j * colatitude), j = 0..trc
     const double* vsin;
     const double* diag;  // P(m,m), m = 0..trc (m = 0, 1 unused)
-    const double* zdlx;  // [lat_pitch] sin(latitude) as the reference computes it (cos of the colatitude; 1 at a pole)
+    const double* mu;    // [lat_pitch] sin(latitude) as the reference computes it (cos of the colatitude; 1 at a pole)
     const int* mstop;    // [lat_pitch] highest m whose rows include this latitude (-1: none)
     // work arrays
     double* col01;  // [2][trc+1][lat_pitch]   P(0,n), P(1,n)
@@ -67,15 +67,17 @@ LG_HD size_t lg_idx(int trc, int m, int n) {
 LG_HD void legendre_series_point(const double* z /* zfn row of jn */, int jn, double sq, const double* vcos,
                                  const double* vsin, size_t pitch, double& p0, double& p1) {
 #pragma clang fp contract(off)
-    const int iodd = jn & 1;
-    double zdlk    = iodd ? 0. : 0.5 * z[0];
-    double zdlldn  = 0.0;
-    for (int jk = 2 - iodd; jk <= jn; jk += 2) {
-        zdlk   = zdlk + z[jk] * vcos[size_t(jk) * pitch];
-        zdlldn = zdlldn + sq * z[jk] * jk * vsin[size_t(jk) * pitch];
+    // value: sum of s(n,k) cos(k colat), half weight on k = 0; derivative term: sum of s(n,k) k sin(k colat) scaled by
+    // 1/sqrt(n(n+1)); terms in ascending k, each added to the running sum (the reference's order)
+    const int odd  = jn & 1;
+    double value   = odd ? 0. : 0.5 * z[0];
+    double slope   = 0.0;
+    for (int k = 2 - odd; k <= jn; k += 2) {
+        value = value + z[k] * vcos[size_t(k) * pitch];
+        slope = slope + sq * z[k] * k * vsin[size_t(k) * pitch];
     }
-    p0 = zdlk;
-    p1 = zdlldn;
+    p0 = value;
+    p1 = slope;
 }
 
 // one (latitude, n) pair of the series stage; n = 0 holds the constant P(0,0) = 1
@@ -137,7 +139,7 @@ LG_HD void legendre_chain(const LegendreGenParams& g, int lat, int parity) {
     if (mstop < parity) {
         return;
     }
-    const double x = g.zdlx[lat];
+    const double x = g.mu[lat];
     double* buf[2] = {g.rows + size_t(parity * 2 + 0) * size_t(trc + 1) * pitch + lat,
                       g.rows + size_t(parity * 2 + 1) * size_t(trc + 1) * pitch + lat};
     // first row of the chain: the series column

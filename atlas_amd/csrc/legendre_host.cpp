@@ -3,6 +3,7 @@
 #include "legendre_host.h"
 
 #include "legendre_gen_core.h"
+#include "legendre_series.h"
 
 #include <algorithm>
 #include <cmath>
@@ -14,84 +15,75 @@ namespace trans {
 
 LegendreEvaluator::LegendreEvaluator(int trc): trc_(trc), tri_(size_t(trc + 2) * size_t(trc + 1) / 2) {
     const size_t ld = size_t(trc) + 1;
+    // series coefficients of every degree (legendre_series.h; LegendrePolynomials.cc:24-45)
     zfn_.assign(ld * ld, 0.);
-    // compute_zfn (LegendrePolynomials.cc:24-45)
-    zfn_[0] = 2.;
-    for (int jn = 1; jn <= trc; ++jn) {
-        double zfnn = zfn_[0];
-        for (int jgl = 1; jgl <= jn; ++jgl) {
-            zfnn *= std::sqrt(1. - 0.25 / (double(jgl) * double(jgl)));
-        }
-        const int iodd      = jn % 2;
-        zfn_[jn * ld + jn]  = zfnn;
-        for (int jgl = 2; jgl <= jn - iodd; jgl += 2) {
-            const double zfjn       = ((jgl - 1.) * (2. * jn - jgl + 2.));
-            const double zfjd       = (jgl * (2. * jn - jgl + 1.));
-            zfn_[jn * ld + jn - jgl] = zfn_[jn * ld + jn - jgl + 2] * zfjn / zfjd;
-        }
+    double lead = 2.;
+    zfn_[0]     = lead;
+    for (int n = 1; n <= trc; ++n) {
+        lead = legendre_series_lead(lead, n);
+        legendre_series_row(n, lead, &zfn_[size_t(n) * ld]);
     }
-    // side effect of the odd-n branch of compute_legendre_polynomials_lat (:102)
-    for (int jn = 1; jn <= trc; jn += 2) {
-        zfn_[jn * ld + 0] = 0.;
+    // odd degrees have no constant term; the reference clears it while evaluating the first latitude (:102)
+    for (int n = 1; n <= trc; n += 2) {
+        zfn_[size_t(n) * ld] = 0.;
     }
     sq1_.assign(ld, 0.);
     diag_.assign(ld, 0.);
-    for (int jn = 1; jn <= trc; ++jn) {
-        sq1_[jn]  = 1. / std::sqrt(jn * (jn + 1.));
-        diag_[jn] = std::sqrt((2. * jn + 1.) / (2. * jn));
+    for (int n = 1; n <= trc; ++n) {
+        sq1_[n]  = 1. / std::sqrt(n * (n + 1.));
+        diag_[n] = std::sqrt((2. * n + 1.) / (2. * n));
     }
-    // Belousov (17) coefficients (:136-149); independent of latitude
+    // the three coefficients of the recurrence (m-2, n-2), (m-2, n-1), (m, n-1) -> (m, n) (:136-149), one triple per
+    // (m, n), latitude independent.  Numerators and denominators are products of small integers (exact in double), so
+    // each coefficient is one division and one square root.
     ca_.assign(tri_, 0.);
     cb_.assign(tri_, 0.);
     cc_.assign(tri_, 0.);
-    for (int jn = 3; jn <= trc; ++jn) {
-        for (int jm = 2; jm < jn; ++jm) {
-            const double cn = ((2. * jn + 1.) * (jn + jm - 3.) * (jn + jm - 1.));
-            const double cd = ((2. * jn - 3.) * (jn + jm - 2.) * (jn + jm));
-            const double dn = ((2. * jn + 1.) * (jn - jm + 1.) * (jn + jm - 1.));
-            const double dd = ((2. * jn - 1.) * (jn + jm - 2.) * (jn + jm));
-            const double en = ((2. * jn + 1.) * (jn - jm));
-            const double ed = ((2. * jn - 1.) * (jn + jm));
-            const size_t i  = idxmn(trc, jm, jn);
-            ca_[i]          = std::sqrt(cn / cd);
-            cb_[i]          = std::sqrt(dn / dd);
-            cc_[i]          = std::sqrt(en / ed);
+    for (int n = 3; n <= trc; ++n) {
+        const double up = 2. * n + 1., mid = 2. * n - 1., low = 2. * n - 3.;
+        for (int m = 2; m < n; ++m) {
+            const double sum = n + m, dif = n - m;
+            const size_t i   = idxmn(trc, m, n);
+            ca_[i]           = std::sqrt((up * (sum - 3.) * (sum - 1.)) / (low * (sum - 2.) * sum));
+            cb_[i]           = std::sqrt((up * (dif + 1.) * (sum - 1.)) / (mid * (sum - 2.) * sum));
+            cc_[i]           = std::sqrt((up * dif) / (mid * sum));
         }
     }
 }
 
-void LegendreEvaluator::colatitude_terms(double lat, double* vsin, double* vcos, size_t stride, double& zdlx_out,
-                                         double& sint_out, double& zdl1sita_out) const {
-    const double zdlx1      = (M_PI_2 - lat);
-    double zdlx             = std::cos(zdlx1);
-    volatile double zdlsita = std::sqrt(1. - zdlx * zdlx);
+void LegendreEvaluator::colatitude_terms(double lat, double* vsin, double* vcos, size_t stride, double& mu_out,
+                                         double& sin_colat_out, double& inv_sin_colat_out) const {
+    const double colat        = (M_PI_2 - lat);
+    double mu                 = std::cos(colat);                 // sin(latitude) as the reference obtains it (:60)
+    volatile double sin_colat = std::sqrt(1. - mu * mu);         // volatile as in the reference (:61): no re-association
     for (int j = 1; j <= trc_; j++) {
-        vsin[size_t(j) * stride] = std::sin(j * zdlx1);
-        vcos[size_t(j) * stride] = std::cos(j * zdlx1);
+        vsin[size_t(j) * stride] = std::sin(j * colat);
+        vcos[size_t(j) * stride] = std::cos(j * colat);
     }
-    double zdl1sita = 0.;
-    if (std::abs(zdlsita) <= std::sqrt(std::numeric_limits<double>::epsilon())) {
-        zdlx    = 1.;
-        zdlsita = 0.;
+    double inv = 0.;
+    if (std::abs(sin_colat) <= std::sqrt(std::numeric_limits<double>::epsilon())) {   // at a pole (:64-72)
+        mu        = 1.;
+        sin_colat = 0.;
     }
     else {
-        zdl1sita = 1. / zdlsita;
+        inv = 1. / sin_colat;
     }
-    zdlx_out     = zdlx;
-    sint_out     = zdlsita;
-    zdl1sita_out = zdl1sita;
+    mu_out            = mu;
+    sin_colat_out     = sin_colat;
+    inv_sin_colat_out = inv;
 }
 
-void LegendreEvaluator::diagonal(double p11, double sint, double zdl1sita, double* diag, size_t stride) const {
-    const double zdls = zdl1sita * std::numeric_limits<double>::min();
-    double prev       = p11;
-    for (int jn = 2; jn <= trc_; ++jn) {
-        double v = prev * sint * diag_[jn];
-        if (std::abs(v) < zdls) {
+void LegendreEvaluator::diagonal(double p11, double sin_colat, double inv_sin_colat, double* diag, size_t stride) const {
+    // P(m, m) = P(m-1, m-1) * sin(colat) * sqrt((2m+1)/2m), flushed to zero below the underflow guard (:122-130)
+    const double guard = inv_sin_colat * std::numeric_limits<double>::min();
+    double prev        = p11;
+    for (int m = 2; m <= trc_; ++m) {
+        double v = prev * sin_colat * diag_[m];
+        if (std::abs(v) < guard) {
             v = 0.0;
         }
-        diag[size_t(jn) * stride] = v;
-        prev                      = v;
+        diag[size_t(m) * stride] = v;
+        prev                     = v;
     }
 }
 
@@ -100,60 +92,40 @@ void LegendreEvaluator::evaluate(double lat, double* legpol, double* scratch) co
     const size_t ld = size_t(trc) + 1;
     double* vsin    = scratch;
     double* vcos    = scratch + ld;
-    // 1. first two columns (:58-115)
-    double zdlx, zdlsita_, zdl1sita;
-    colatitude_terms(lat, vsin, vcos, 1, zdlx, zdlsita_, zdl1sita);
-    const double zdlsita     = zdlsita_;
+    // 1. columns m = 0 and m = 1: cosine series of P_n and its derivative (:85-115), shared with the device generator
+    double mu, sin_colat, inv_sin_colat;
+    colatitude_terms(lat, vsin, vcos, 1, mu, sin_colat, inv_sin_colat);
     legpol[idxmn(trc, 0, 0)] = 1.;
-    for (int jn = 2; jn <= trc; jn += 2) {
-        const double* z = &zfn_[jn * ld];
-        double zdlk     = 0.5 * z[0];
-        double zdlldn   = 0.0;
-        const double sq = sq1_[jn];
-        for (int jk = 2; jk <= jn; jk += 2) {
-            zdlk   = zdlk + z[jk] * vcos[jk];
-            zdlldn = zdlldn + sq * z[jk] * jk * vsin[jk];
-        }
-        legpol[idxmn(trc, 0, jn)] = zdlk;
-        legpol[idxmn(trc, 1, jn)] = zdlldn;
+    for (int n = 1; n <= trc; ++n) {
+        double p0, p1;
+        legendre_series_point(&zfn_[size_t(n) * ld], n, sq1_[n], vcos, vsin, 1, p0, p1);
+        legpol[idxmn(trc, 0, n)] = p0;
+        legpol[idxmn(trc, 1, n)] = p1;
     }
-    for (int jn = 1; jn <= trc; jn += 2) {
-        const double* z = &zfn_[jn * ld];
-        double zdlk     = 0.;
-        double zdlldn   = 0.0;
-        const double sq = sq1_[jn];
-        for (int jk = 1; jk <= jn; jk += 2) {
-            zdlk   = zdlk + z[jk] * vcos[jk];
-            zdlldn = zdlldn + sq * z[jk] * jk * vsin[jk];
+    // 2. diagonal
+    {
+        const double guard = inv_sin_colat * std::numeric_limits<double>::min();
+        for (int m = 2; m <= trc; ++m) {
+            double v = legpol[idxmn(trc, m - 1, m - 1)] * sin_colat * diag_[m];
+            if (std::abs(v) < guard) {
+                v = 0.0;
+            }
+            legpol[idxmn(trc, m, m)] = v;
         }
-        legpol[idxmn(trc, 0, jn)] = zdlk;
-        legpol[idxmn(trc, 1, jn)] = zdlldn;
     }
-    // 2. diagonal (:122-130)
-    const double zdls = zdl1sita * std::numeric_limits<double>::min();
-    const double sint = zdlsita;
-    for (int jn = 2; jn <= trc; ++jn) {
-        double v = legpol[idxmn(trc, jn - 1, jn - 1)] * sint * diag_[jn];
-        if (std::abs(v) < zdls) {
-            v = 0.0;
-        }
-        legpol[idxmn(trc, jn, jn)] = v;
-    }
-    // 3. general recurrence (:136-149).  The reference iterates n outer / m inner; the data dependencies
-    //    (m-2,n-2), (m-2,n-1), (m,n-1) allow m outer / n inner, which is contiguous in the packed triangle and
-    //    performs the identical operations on identical operands.
-    for (int jm = 2; jm < trc; ++jm) {
-        const size_t base   = idxmn(trc, jm, jm);      // (jm, jm)
-        const size_t basem2 = idxmn(trc, jm - 2, jm - 2);  // (jm-2, jm-2)
-        double* p           = legpol + base;           // p[n-jm]
-        const double* q     = legpol + basem2;         // q[n-(jm-2)]
-        const double* a     = ca_.data() + base;
-        const double* b     = cb_.data() + base;
-        const double* c     = cc_.data() + base;
-        for (int jn = std::max(3, jm + 1); jn <= trc; ++jn) {
-            const int i = jn - jm;
-            // (m-2, n-2) -> q[n-2-(m-2)] = q[i];  (m-2, n-1) -> q[i+1];  (m, n-1) -> p[i-1]
-            p[i] = a[i] * q[i] - b[i] * q[i + 1] * zdlx + c[i] * p[i - 1] * zdlx;
+    // 3. everything else.  The reference walks n outer / m inner; the dependencies (m-2,n-2), (m-2,n-1), (m,n-1) allow
+    //    m outer / n inner, which is contiguous in the packed triangle and applies the identical operations to the
+    //    identical operands.
+    for (int m = 2; m < trc; ++m) {
+        const size_t row   = idxmn(trc, m, m);
+        double* p          = legpol + row;                        // p[n - m]       = P(m, n)
+        const double* q    = legpol + idxmn(trc, m - 2, m - 2);   // q[n - (m - 2)] = P(m - 2, n)
+        const double* a    = ca_.data() + row;
+        const double* b    = cb_.data() + row;
+        const double* c    = cc_.data() + row;
+        for (int n = std::max(3, m + 1); n <= trc; ++n) {
+            const int i = n - m;
+            p[i]        = a[i] * q[i] - b[i] * q[i + 1] * mu + c[i] * p[i - 1] * mu;
         }
     }
 }
@@ -277,20 +249,20 @@ LegendreGenInputs prepare_legendre_gen(const TransGeometry& geo, const LegendreW
     in.vcos.assign(ld * pitch, 0.);
     in.vsin.assign(ld * pitch, 0.);
     in.diag.assign(ld * pitch, 0.);
-    in.zdlx.assign(pitch, 0.);
+    in.mu.assign(pitch, 0.);
     in.mstop.assign(pitch, -1);
 #pragma omp parallel for schedule(static)
     for (int jlat = 0; jlat < in.nlats; ++jlat) {
-        double zdlx, sint, zdl1sita;
-        ev.colatitude_terms(geo.lats_leg[jlat], in.vsin.data() + jlat, in.vcos.data() + jlat, pitch, zdlx, sint,
-                            zdl1sita);
-        in.zdlx[jlat] = zdlx;
+        double mu, sint, inv_sin_colat;
+        ev.colatitude_terms(geo.lats_leg[jlat], in.vsin.data() + jlat, in.vcos.data() + jlat, pitch, mu, sint,
+                            inv_sin_colat);
+        in.mu[jlat] = mu;
         // P(1,1): the n = 1 term of the series (the kernel computes the same value into its column)
         double p01, p11;
         legendre_series_point(in.zfn.data() + ld, 1, in.sq1[1], in.vcos.data() + jlat, in.vsin.data() + jlat, pitch, p01,
                               p11);
         in.diag[pitch + jlat] = p11;
-        ev.diagonal(p11, sint, zdl1sita, in.diag.data() + jlat, pitch);
+        ev.diagonal(p11, sint, inv_sin_colat, in.diag.data() + jlat, pitch);
         in.mstop[jlat] = geo.mmax_leg[jlat] < geo.T ? geo.mmax_leg[jlat] : geo.T;
     }
     in.nlat0           = geo.nlat0;
@@ -310,7 +282,7 @@ void compute_legendre_table_tiled_emulated(const TransGeometry& geo, const Legen
     LegendreGenParams g;
     g.trc = in.trc, g.T = in.T, g.nlats = in.nlats, g.lat_pitch = in.lat_pitch;
     g.zfn = in.zfn.data(), g.sq1 = in.sq1.data(), g.ca = in.ca.data(), g.cb = in.cb.data(), g.cc = in.cc.data();
-    g.vcos = in.vcos.data(), g.vsin = in.vsin.data(), g.diag = in.diag.data(), g.zdlx = in.zdlx.data();
+    g.vcos = in.vcos.data(), g.vsin = in.vsin.data(), g.diag = in.diag.data(), g.mu = in.mu.data();
     g.mstop = in.mstop.data();
     g.col01 = col01.data(), g.rows = rows.data(), g.table = table;
     g.nlat0 = in.nlat0.data(), g.first_item_of_m = in.first_item_of_m.data();

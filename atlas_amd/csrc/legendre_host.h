@@ -22,12 +22,12 @@ public:
     // legpol: packed triangle of size triangle_size(); scratch: 2*(trc+1) doubles
     void evaluate(double lat_rad, double* legpol, double* scratch) const;
     // the latitude-dependent scalars and cos/sin tables at the head of compute_legendre_polynomials_lat
-    // (LegendrePolynomials.cc:58-83): vsin[j*stride], vcos[j*stride] for j = 1..trc; zdlx = sin(lat) (1 at a pole),
-    // sint = cos(lat) (0 at a pole), zdl1sita = 1/sint (0 at a pole)
-    void colatitude_terms(double lat_rad, double* vsin, double* vcos, size_t stride, double& zdlx, double& sint,
-                          double& zdl1sita) const;
+    // (LegendrePolynomials.cc:58-83): vsin[j*stride], vcos[j*stride] for j = 1..trc; mu = sin(lat) (1 at a pole),
+    // sint = cos(lat) (0 at a pole), inv_sin_colat = 1/sint (0 at a pole)
+    void colatitude_terms(double lat_rad, double* vsin, double* vcos, size_t stride, double& mu, double& sint,
+                          double& inv_sin_colat) const;
     // P(m,m) for m = 2..trc from P(1,1) (:122-130), written to diag[m*stride]
-    void diagonal(double p11, double sint, double zdl1sita, double* diag, size_t stride) const;
+    void diagonal(double p11, double sint, double inv_sin_colat, double* diag, size_t stride) const;
     const std::vector<double>& zfn() const { return zfn_; }
     const std::vector<double>& sq1() const { return sq1_; }
     const std::vector<double>& ca() const { return ca_; }
@@ -55,7 +55,7 @@ void compute_legendre_table_tiled(const TransGeometry& geo, const LegendreWork& 
 struct LegendreGenParams;
 struct LegendreGenInputs {
     int trc = 0, T = 0, nlats = 0, lat_pitch = 0;
-    std::vector<double> zfn, sq1, ca, cb, cc, vcos, vsin, diag, zdlx;
+    std::vector<double> zfn, sq1, ca, cb, cc, vcos, vsin, diag, mu;
     std::vector<int> mstop, nlat0, first_item_of_m, item_kpad;
     std::vector<long long> item_p_off;
     size_t col01_doubles() const { return size_t(2) * size_t(trc + 1) * size_t(lat_pitch); }

@@ -196,7 +196,7 @@ void Trans::generate_table_on_device() {
     LegendreGenParams g;
     g.trc = in.trc, g.T = in.T, g.nlats = in.nlats, g.lat_pitch = in.lat_pitch;
     g.zfn = up(in.zfn), g.sq1 = up(in.sq1), g.ca = up(in.ca), g.cb = up(in.cb), g.cc = up(in.cc);
-    g.vcos = up(in.vcos), g.vsin = up(in.vsin), g.diag = up(in.diag), g.zdlx = up(in.zdlx);
+    g.vcos = up(in.vcos), g.vsin = up(in.vsin), g.diag = up(in.diag), g.mu = up(in.mu);
     g.mstop = up(in.mstop);
     g.nlat0 = up(in.nlat0), g.first_item_of_m = up(in.first_item_of_m);
     g.item_p_off = up(in.item_p_off), g.item_kpad = up(in.item_kpad);
