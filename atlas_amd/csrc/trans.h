@@ -179,6 +179,12 @@ private:
     unsigned long long* d_prof_ = nullptr;
     size_t vd_cap_      = 0;
     void ensure(double*& ptr, size_t& cap, size_t n);
+    // host-pointer pipeline (pinned staging)
+    void invtrans_host_pipelined(int nb_fields, const double* sp_host, double* gp_host);
+    double* pin_[2]          = {nullptr, nullptr};
+    hipEvent_t pin_ev_[2]    = {nullptr, nullptr};
+    hipEvent_t stage_ev_     = nullptr;
+    hipStream_t copy_stream_ = nullptr;
     std::vector<hipEvent_t> events_;  // pairs (begin, end)
     std::vector<int> ev_kind_;        // 0 legendre, 1 fourier, per pair
     size_t ev_used_ = 0;

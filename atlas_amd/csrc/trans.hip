@@ -1,6 +1,7 @@
 // See trans.h.  Host code of the MI355X TransLocal replacement: builds the plan, uploads the tables once,
 // launches the two kernels per call on the object's HIP stream.
 #include "trans.h"
+#include "host_copy.h"
 
 #include <algorithm>
 #include <cmath>
@@ -148,6 +149,14 @@ Trans::~Trans() {
     }
     if (stream2_) {
         (void)hipStreamDestroy(stream2_);
+    }
+    if (pin_[0]) {
+        for (int i = 0; i < 2; ++i) {
+            (void)hipHostFree(pin_[i]);
+            (void)hipEventDestroy(pin_ev_[i]);
+        }
+        (void)hipStreamDestroy(copy_stream_);
+        (void)hipEventDestroy(stage_ev_);
     }
     if (stream3_) {
         (void)hipStreamDestroy(stream3_);
@@ -698,9 +707,85 @@ void Trans::invtrans(int nb_scalar_fields, const double scalar_spectra[], double
     const size_t ngp = (size_t)nb_gridpoints() * (size_t)nb_scalar_fields;  // all points, or the rows of a crop
     ensure(d_sp_, sp_cap_, nsp);
     ensure(d_gp_, gp_cap_, ngp);
+    // measured (tools/bench_host.py, gpurun_out/r02/bench_host.txt): 180.4 ms without and 180.7 ms with the staging pipeline at
+    // TL1279 / O1280 / 137 levels = 50 GB/s of the ~57 GB/s link either way -- the runtime's own pageable path already
+    // streams at the link rate and the 18 ms of compute are a tenth of the transfer; the pipeline stays opt-in.
+    static const bool pipe_env = std::getenv("ATLAS_AMD_HOST_PIPELINE") ? atoi(std::getenv("ATLAS_AMD_HOST_PIPELINE")) != 0 : false;
+    if (pipe_env && nb_scalar_fields >= 16 && ngp * sizeof(double) >= (size_t(256) << 20) && fourier_parts() == 1) {
+        invtrans_host_pipelined(nb_scalar_fields, scalar_spectra, gp_fields);
+        return;
+    }
     HIP_CHECK(hipMemcpyAsync(d_sp_, scalar_spectra, nsp * sizeof(double), hipMemcpyHostToDevice, stream_));
     invtrans_uv_device(geo_.T, nb_scalar_fields, 0, d_sp_, d_gp_);
     HIP_CHECK(hipMemcpyAsync(gp_fields, d_gp_, ngp * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    synchronize();
+}
+
+// Host arrays in, host arrays out (what atlas__Trans__invtrans_scalar callers pass): 1.8 GB up and 7.2 GB down per 137
+// levels at TL1279 / O1280 against 18 ms of compute, i.e. bound by PCIe.  The transfers go through pinned staging buffers
+// in pieces so that (a) both directions run at the link rate instead of the pageable rate, (b) the caller-side copies
+// (multi-threaded) overlap the DMA, (c) the grid points of a group of fields leave the device while the Fourier stage of
+// the next group runs.
+void Trans::invtrans_host_pipelined(int nf, const double* sp_host, double* gp_host) {
+    const size_t nsp  = nb_spectral_coefficients() * (size_t)nf;
+    const size_t npts = (size_t)nb_gridpoints();
+    const size_t piece = size_t(64) << 20;   // doubles per staging buffer (512 MiB)
+    if (!pin_[0]) {
+        for (int i = 0; i < 2; ++i) {
+            HIP_CHECK(hipHostMalloc((void**)&pin_[i], piece * sizeof(double), hipHostMallocDefault));
+            HIP_CHECK(hipEventCreateWithFlags(&pin_ev_[i], hipEventDisableTiming));
+        }
+        HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&stage_ev_, hipEventDisableTiming));
+    }
+    // ---- spectra up: caller -> pinned (threads) -> device, two buffers in flight
+    int k = 0;
+    for (size_t o = 0; o < nsp; o += piece, ++k) {
+        const size_t n = std::min(piece, nsp - o);
+        const int b    = k & 1;
+        if (k >= 2) {
+            HIP_CHECK(hipEventSynchronize(pin_ev_[b]));   // the DMA out of this buffer has finished
+        }
+        parallel_copy(pin_[b], sp_host + o, n * sizeof(double));
+        HIP_CHECK(hipMemcpyAsync(d_sp_ + o, pin_[b], n * sizeof(double), hipMemcpyHostToDevice, stream_));
+        HIP_CHECK(hipEventRecord(pin_ev_[b], stream_));
+    }
+    // ---- Legendre stage for all fields, Fourier stage by groups of fields, grid points down group by group
+    double* F = fourier_buffer(nf);
+    legendre_device(geo_.T, nf, d_sp_, F);
+    const double* base[1] = {F};
+    const int cnt[1]      = {m_cnt_};
+    const int group       = std::max(8, (int)(piece / npts) / 8 * 8);   // fields per staging buffer, whole groups of 8
+    if ((size_t)group * npts > piece) {
+        throw std::logic_error("host pipeline: a group of 8 fields does not fit the staging buffer");
+    }
+    HIP_CHECK(hipStreamSynchronize(stream_));   // the staging buffers are free again (spectra uploaded)
+    struct Pending {
+        int f0, f1, buf;
+    };
+    std::vector<Pending> pending;
+    k = 0;
+    for (int f0 = 0; f0 < nf; f0 += group, ++k) {
+        const int f1 = std::min(nf, f0 + group);
+        const int b  = k & 1;
+        fourier_fields(nf, 0, base, cnt, d_gp_, f0, f1, stream_);
+        HIP_CHECK(hipEventRecord(stage_ev_, stream_));
+        if (k >= 2) {   // the previous content of this buffer must have reached the caller's array
+            const Pending p = pending[k - 2];
+            HIP_CHECK(hipEventSynchronize(pin_ev_[p.buf]));
+            parallel_copy(gp_host + (size_t)p.f0 * npts, pin_[p.buf], (size_t)(p.f1 - p.f0) * npts * sizeof(double));
+        }
+        HIP_CHECK(hipStreamWaitEvent(copy_stream_, stage_ev_, 0));
+        HIP_CHECK(hipMemcpyAsync(pin_[b], d_gp_ + (size_t)f0 * npts, (size_t)(f1 - f0) * npts * sizeof(double),
+                                 hipMemcpyDeviceToHost, copy_stream_));
+        HIP_CHECK(hipEventRecord(pin_ev_[b], copy_stream_));
+        pending.push_back(Pending{f0, f1, b});
+    }
+    for (size_t i = pending.size() >= 2 ? pending.size() - 2 : 0; i < pending.size(); ++i) {
+        const Pending p = pending[i];
+        HIP_CHECK(hipEventSynchronize(pin_ev_[p.buf]));
+        parallel_copy(gp_host + (size_t)p.f0 * npts, pin_[p.buf], (size_t)(p.f1 - p.f0) * npts * sizeof(double));
+    }
     synchronize();
 }
 

@@ -44,14 +44,34 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X spec, dense fp64 matrix (v_mfma_f64_16x1
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+KERNEL_SOURCES = ("legendre_kernel.hip", "fft_kernel.hip", "fft_core.h", "fft_plan.cpp", "trans.hip", "trans_plan.cpp")
+
+
+def kernel_source_digest():
+    """SHA-256 over the sources that determine the two stages' memory traffic: a PMC measurement is attached to a bench
+    line only if it was taken on exactly these sources (tools/prof_round_summary.py stamps the profile with it)"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "atlas_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def measured_traffic():
     """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); collected by tools/prof_pmc.sh, not at bench time."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
-        return {}
-    with open(path) as f:
-        return json.load(f).get("traffic_bytes_per_launch", {})
+    MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE; tools/prof_round.sh).  PMC counters cannot be read from
+    inside the timed process, so the figures come from the newest committed profile -- and only if it carries the digest
+    of the kernel sources this run was built from; a stale profile yields null, not an old number."""
+    import glob
+    best = {}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("kernel_source_sha256") == kernel_source_digest():
+            best = dict(d.get("traffic_bytes_per_launch", {}))
+            best["_profile"] = os.path.basename(path)
+    return best
 
 
 def cpu_baseline(sample_fields=8):
@@ -91,9 +111,16 @@ def cpu_baseline_blas(sample_fields=8):
     t0 = time.perf_counter()
     invtrans_blas(op, sample_fields, sp)
     dt = time.perf_counter() - t0
-    return {"value": (sample_fields / NLEV) / dt, "unit": "transforms/s", "cores": os.cpu_count() or 1, "kind": "port",
-            "sample": f"{sample_fields} of {NLEV} levels in {dt:.2f} s, numpy/OpenBLAS dgemm + scipy pocketfft "
-                      f"(oracle/translocal_blas.py); scaled by {NLEV}/{sample_fields}"}
+    try:
+        from threadpoolctl import threadpool_info
+        blas_threads = max([int(i.get("num_threads", 1)) for i in threadpool_info() if i.get("user_api") == "blas"] or [1])
+    except Exception:
+        blas_threads = os.cpu_count() or 1
+    return {"value": (sample_fields / NLEV) / dt, "unit": "transforms/s", "cores": blas_threads, "kind": "port",
+            "sample": f"{sample_fields} of {NLEV} levels of one TL{TRUNC}->{GRID} transform in {dt:.2f} s: the reference's "
+                      f"algorithm with library kernels -- per-m dgemm pairs (numpy/OpenBLAS, {blas_threads} threads) + per-row "
+                      f"pocketfft c2r (scipy.fft) -- i.e. TransLocal with eckit 'lapack' + pocketfft "
+                      f"(oracle/translocal_blas.py; tables built beforehand); scaled by {NLEV}/{sample_fields}"}
 
 
 def main():
@@ -103,8 +130,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-fields", type=int, default=24)
-    ap.add_argument("--cpu-baseline-blas", action="store_true",
-                    help="also time the BLAS dgemm + pocketfft variant of the CPU restatement (cpu_baseline_blas)")
+    ap.add_argument("--cpu-baseline-naive", action="store_true",
+                    help="also time the plain-loop restatement (oracle/translocal_oracle.c, OpenMP) as cpu_baseline_naive")
+    ap.add_argument("--cpu-baseline-blas", action="store_true", help=argparse.SUPPRESS)   # the default now
     ap.add_argument("--force-dist", action="store_true", help="exercise the distributed driver even with one rank")
     ap.add_argument("--dist-mode", default="auto", choices=["auto", "alltoall", "band", "mirror"],
                     help="N > 1: wavenumber sharding + RCCL transposition (auto, alltoall), or one of the exchange-free "
@@ -299,7 +327,7 @@ def main():
             fft_bytes = (kept_modes * nf * 16 + nf * g.size() * 8) / world
         leg_tf = leg_flops / (leg_ms * 1e-3) / 1e12 if leg_ms > 0 else 0.0
         fft_gbs = fft_bytes / (fft_ms * 1e-3) / 1e9 if fft_ms > 0 else 0.0
-        traffic = measured_traffic() if world == 1 else {}     # the PMC passes were taken on the single-GPU workload
+        traffic = measured_traffic() if world == 1 and not use_dist else {}   # PMC passes: the single-GPU workload
         kernels = [
             # one launch per transform: the single largest kernel of the path (rocprofv3 --stats agrees, profiles/)
             {"kernel": "legendre_kernel", "launches_per_transform": 1, "bound": "mfma", "achieved": leg_tf,
@@ -332,6 +360,9 @@ def main():
             "roofline_kernels": kernels,
         }
         out["roofline"]["kernel"] = dominant["kernel"]
+        out["roofline"]["traffic_source"] = (f"profiles/{traffic['_profile']} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same "
+                                             f"kernel sources)" if traffic.get("_profile") else
+                                             "none: no committed PMC profile matches these kernel sources")
         if crosscheck is not None:
             out["multi_gpu_crosscheck"] = crosscheck
         if alt is not None:
@@ -339,9 +370,9 @@ def main():
         if use_dist:
             out["dist_impl"] = impl if impl_note is None else f"{impl}: {impl_note}"
         if world == 1 and not use_dist and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_fields)
-            if args.cpu_baseline_blas:
-                out["cpu_baseline_blas"] = cpu_baseline_blas(args.cpu_sample_fields)
+            out["cpu_baseline"] = cpu_baseline_blas(args.cpu_sample_fields)
+            if args.cpu_baseline_naive:
+                out["cpu_baseline_naive"] = cpu_baseline(args.cpu_sample_fields)
     if use_dist:
         import torch.distributed as dist
         dist.barrier()

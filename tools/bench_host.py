@@ -1,0 +1,33 @@
+"""Dev tool (GPU box): the host-pointer entry point (host arrays in / out, what atlas__Trans__invtrans_scalar callers pass)
+at TL1279 -> O1280, 137 levels: wall time and PCIe rate with and without the pinned staging pipeline, result compared bit
+for bit with the device-pointer path."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch, atlas_amd
+from helpers import red_spectra
+grid, T, nf = "O1280", 1279, 137
+g = atlas_amd.Grid(grid)
+sp = red_spectra(T, nf)
+ref = torch.zeros(nf * g.size(), dtype=torch.float64, device="cuda")
+tr = atlas_amd.Trans(g, T)
+tr.invtrans(nf, torch.from_numpy(sp).cuda(), ref)
+tr.synchronize()
+ref = ref.cpu().numpy()
+del tr
+nbytes = sp.nbytes + ref.nbytes
+for pipe in ("0", "1"):
+    os.environ["ATLAS_AMD_HOST_PIPELINE"] = pipe
+    tr = atlas_amd.Trans(g, T)
+    gp = np.zeros(nf * g.size())
+    tr.invtrans(nf, sp, gp)
+    ts = []
+    for _ in range(3):
+        gp[:] = 0
+        t0 = time.perf_counter()
+        tr.invtrans(nf, sp, gp)
+        ts.append(time.perf_counter() - t0)
+    print(f"ATLAS_AMD_HOST_PIPELINE={pipe}: {min(ts) * 1e3:.1f} ms per transform (host arrays), "
+          f"{nbytes / min(ts) / 1e9:.1f} GB/s over PCIe (1.8 GB up + 7.2 GB down), bitwise equal to the device path: "
+          f"{np.array_equal(gp, ref)}", flush=True)
+    del tr

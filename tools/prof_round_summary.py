@@ -72,7 +72,14 @@ for st, cs in stage.items():
         wr = cs["WRITE_SIZE"] * 1e3 / ntr
         traffic[st] = rd + wr
         detail[st] = {"read_bytes(2xFETCH_SIZE)": rd, "write_bytes(WRITE_SIZE)": wr}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    import bench
+    digest = bench.kernel_source_digest()
+except Exception:  # noqa: BLE001
+    digest = None
 out = {"traffic_bytes_per_launch": traffic, "detail": detail, "transforms_profiled": ntr,
+       "kernel_source_sha256": digest,
        "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes over bench.py --steps 2 --warmup 1; "
                "FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B); fourier_stage = sum over the row-class "
                "launches of one transform"}
