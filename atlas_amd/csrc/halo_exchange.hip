@@ -1,6 +1,8 @@
 // See halo_exchange.h.
 #include "halo_exchange.h"
 
+#include "trace.h"
+
 #include <cstring>
 #include <sstream>
 #include <stdexcept>
@@ -235,6 +237,7 @@ void HaloExchange::zero_halos_device(int dtype, void* field, const HaloFieldDesc
 }
 
 void HaloExchange::execute_device(int dtype, void* field, const HaloFieldDesc& d) {
+    TraceRange trace("HaloExchange::execute[device]");   // HaloExchange.h:153
     NEED_SETUP();
     if (plan_.nproc != 1) {
         throw std::logic_error("execute_device: multi-process exchange is driven by the caller (pack / send / unpack)");
@@ -246,6 +249,7 @@ void HaloExchange::execute_device(int dtype, void* field, const HaloFieldDesc& d
 }
 
 void HaloExchange::execute_adjoint_device(int dtype, void* field, const HaloFieldDesc& d) {
+    TraceRange trace("HaloExchange::execute_adjoint[device]");   // HaloExchange.h:232
     NEED_SETUP();
     if (plan_.nproc != 1) {
         throw std::logic_error("execute_adjoint_device: multi-process exchange is driven by the caller");
@@ -274,6 +278,7 @@ void HaloExchange::setup_comm(Comm& comm, const int part[], const int remote_idx
 }
 
 void HaloExchange::execute_comm(Comm& comm, int dtype, void* field, const HaloFieldDesc& d, bool adjoint) {
+    TraceRange trace(adjoint ? "HaloExchange::execute_adjoint[device]" : "HaloExchange::execute[device]");
     NEED_SETUP();
     if (comm.size() != plan_.nproc || comm.rank() != plan_.myproc) {
         throw std::invalid_argument("HaloExchange::execute: communicator differs from the one of the setup");

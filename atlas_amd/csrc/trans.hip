@@ -2,6 +2,7 @@
 // launches the two kernels per call on the object's HIP stream.
 #include "trans.h"
 #include "host_copy.h"
+#include "trace.h"
 
 #include <algorithm>
 #include <cmath>
@@ -458,6 +459,7 @@ void Trans::legendre_chunks(int trc_in, int nb_fields, const double* sp_dev, dou
     p.m_cnt  = m_cnt_;
     p.row_begin = cfg_.by_band ? band_begin() : 0;
     p.row_end   = cfg_.by_band ? band_end() : geo_.nlats;
+    TraceRange trace("Inverse Legendre Transform (GEMM)");   // TransLocal.cc:948
     timed_begin(0);
     if (!work_.items.empty()) {
         HIP_CHECK(launch_legendre(p, (int)work_.items.size(), chunk0, nrun, stream_));
@@ -499,6 +501,8 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
     p.coslatinv       = d_coslatinv_;
     p.prof            = d_prof_;
     p.abl             = std::getenv("ATLAS_AMD_FFT_ABLATE") ? atoi(std::getenv("ATLAS_AMD_FFT_ABLATE")) : 0;
+    TraceRange trace(geo_.regular ? "Inverse Fourier Transform (mi355x, RegularGrid)"      // TransLocal.cc:1107
+                                  : "Inverse Fourier Transform (mi355x, ReducedGrid)");    // TransLocal.cc:1159
     timed_begin(1, stream);
     static const int only_m = std::getenv("ATLAS_AMD_FFT_ONLY_M") ? atoi(std::getenv("ATLAS_AMD_FFT_ONLY_M")) : 0;
     // Row-length classes with few workgroups (the four longest rows, the polar caps) cannot fill 256 CUs on their own:
@@ -561,6 +565,7 @@ void Trans::invtrans_uv_device(int trc_in, int nb_fields, int nb_vordiv, const d
     if (nb_fields <= 0) {
         return;
     }
+    TraceRange trace("invtrans_uv structured");   // TransLocal.cc:1418
     if (fourier_parts() != 1) {
         throw std::logic_error("invtrans_uv_device on a wavenumber-sharded Trans: use legendre_device / exchange / fourier_device");
     }
