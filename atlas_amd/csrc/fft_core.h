@@ -1136,46 +1136,94 @@ AA_HD void hyb_gather(const RowTablesHyb& r, const Reader& rd, const RowOut& io,
 }
 
 AA_HD cplx hyb_fold(const RowTablesHyb& r, const RowOut& io, const cplx* raw, int k, cplx pre) {
-    const int k2 = r.h - k;
-    const cplx a = k <= io.mmax ? raw[k] : cplx{0., 0.};
-    const cplx b = k2 <= io.mmax ? cconj(raw[k2]) : cplx{0., 0.};
+    const cplx a = ct_raw_mode(raw, io.mmax, k, r.h);
+    const cplx b = cconj(ct_raw_mode(raw, io.mmax, r.h - k, r.h));
     return c2r_pre(a, b, pre);
 }
 
-// one (group, q) item of the fold + split
-AA_HD void hyb_fold_item(const RowTablesHyb& r, const RowOut& io, const cplx* raw, cplx* work, int gf, int gA, int q) {
+// fold + symmetric split.  Worker t owns one native digit combination gf (consecutive workers: consecutive gf, so the
+// table loads and the staging reads of a wavefront are contiguous) and every `per`-th q.  The table values of the first
+// HYB_FOLD_NB items are requested ahead of time (`hyb_fold_prefetch`, issued next to the mode gather, whose latency then
+// hides theirs); the rest in batches of HYB_FOLD_NB, loads first.
+constexpr int HYB_FOLD_NB = 4;
+struct HybFoldWork {
+    int gf, gA, q0, per;            // per == 0: this worker has no items
+    cplx p1[HYB_FOLD_NB], p2[HYB_FOLD_NB];
+};
+
+AA_HD void hyb_fold_loads(const RowTablesHyb& r, const HybFoldWork& w, int qb, cplx* p1, cplx* p2) {
+    const int A = r.A, B = r.B, Kp = r.Kp;
+#pragma unroll
+    for (int i = 0; i < HYB_FOLD_NB; ++i) {
+        int q = qb + i * w.per;
+        q     = q < Kp ? q : Kp - 1;
+        p1[i] = r.pre[w.gf + B * q];
+        p2[i] = r.pre[w.gf + B * (q ? A - q : 0)];
+    }
+}
+
+AA_HD void hyb_fold_prefetch(const RowTablesHyb& r, int t, int nt, HybFoldWork& w) {
+    const int B = r.B;
+    w.per       = nt / B;
+    w.q0        = w.per ? t / B : 0;
+    w.gf        = w.per ? t - w.q0 * B : 0;
+    if (w.per == 0 || w.q0 >= w.per) {
+        w.per = 0;
+        return;
+    }
+    w.gA = pos_of_freq(*r.shape, w.gf);   // = g * A: position of the group's first element
+    hyb_fold_loads(r, w, w.q0, w.p1, w.p2);
+}
+
+AA_HD void hyb_fold_item(const RowTablesHyb& r, const RowOut& io, const cplx* raw, cplx* work, int gf, int gA, int q,
+                         cplx pre1, cplx pre2) {
     const int A = r.A, B = r.B;
-    const int k  = gf + B * q;
-    const cplx z = hyb_fold(r, io, raw, k, r.pre[k]);
+    const cplx z = hyb_fold(r, io, raw, gf + B * q, pre1);
     if (q == 0) {
         work[PAD(gA)] = z;
     }
     else {
-        const int k2  = gf + B * (A - q);
-        const cplx z2 = hyb_fold(r, io, raw, k2, r.pre[k2]);
+        const cplx z2         = hyb_fold(r, io, raw, gf + B * (A - q), pre2);
         work[PAD(gA + q)]     = cadd(z, z2);
         work[PAD(gA + A - q)] = csub(z, z2);
     }
 }
 
-AA_HD void hyb_fold_split(const RowTablesHyb& r, const RowOut& io, const cplx* raw, cplx* work, int t, int nt) {
+AA_HD void hyb_fold_split(const RowTablesHyb& r, const RowOut& io, const cplx* raw, cplx* work, int t, int nt,
+                          const HybFoldWork& w) {
     const int B = r.B, Kp = r.Kp;
-    const int per = nt / B;   // workers per native digit combination gf (consecutive workers: consecutive gf)
-    if (per >= 1) {
-        const int q0 = t / B;
-        const int gf = t - q0 * B;
-        if (q0 < per) {
-            const int gA = pos_of_freq(*r.shape, gf);   // = g * A: position of the group's first element
-            for (int q = q0; q < Kp; q += per) {
-                hyb_fold_item(r, io, raw, work, gf, gA, q);
-            }
-        }
-    }
-    else {
+    if (nt / B == 0) {   // more native digit combinations than workers (tiny A): plain loops
         for (int gf = t; gf < B; gf += nt) {
             const int gA = pos_of_freq(*r.shape, gf);
             for (int q = 0; q < Kp; ++q) {
-                hyb_fold_item(r, io, raw, work, gf, gA, q);
+                hyb_fold_item(r, io, raw, work, gf, gA, q, r.pre[gf + B * q], r.pre[gf + B * (q ? r.A - q : 0)]);
+            }
+        }
+        return;
+    }
+    if (w.per == 0) {
+        return;
+    }
+    bool first = true;
+    for (int qb = w.q0; qb < Kp; qb += HYB_FOLD_NB * w.per) {
+        cplx p1[HYB_FOLD_NB], p2[HYB_FOLD_NB];
+        if (first) {
+#pragma unroll
+            for (int i = 0; i < HYB_FOLD_NB; ++i) {
+                p1[i] = w.p1[i];
+                p2[i] = w.p2[i];
+            }
+            first = false;
+        }
+        else {
+            hyb_fold_loads(r, w, qb, p1, p2);
+            AA_SCHED_FENCE();
+        }
+#pragma unroll
+        for (int i = 0; i < HYB_FOLD_NB; ++i) {
+            const int q = qb + i * w.per;
+            if (q < Kp) {
+                hyb_fold_item(r, io, raw, work, w.gf, w.gA, q, p1[i], p2[i]);
             }
         }
     }

@@ -385,7 +385,6 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR, 4) fft_rows_hyb_kernel(FourierPa
     const int nt              = blockDim.x;
     const double scale        = (f < p.scale_uv_fields) ? p.coslatinv[row] : 1.0;
     const int mmax            = p.row_mmax[row];
-    const ModeReaderT<(F32 ? 1 : 0)> rd{p, (long long)(row - p.lat0), 2 * f};
     fft::RowTablesHyb r;
     r.n     = pl->n;
     r.h     = pl->h;
@@ -417,10 +416,12 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR, 4) fft_rows_hyb_kernel(FourierPa
         }
     };
     stamp(-1);
-    fft::hyb_gather(r, rd, io, raw, tid, nt);
+    gather_modes_to_lds<F32>(p, (long long)(row - p.lat0), f, io.mmax, raw, tid, nt);
+    fft::HybFoldWork fw;
+    fft::hyb_fold_prefetch(r, tid, nt, fw);   // table values of the fold: in flight next to the gather
     __syncthreads();
     stamp(0);
-    fft::hyb_fold_split(r, io, raw, work, tid, nt);
+    fft::hyb_fold_split(r, io, raw, work, tid, nt, fw);
     __syncthreads();
     stamp(1);
     fft::hyb_dense_device(r, work, tid, nt);

@@ -269,7 +269,7 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, const PlanOptions
             const int A = p.hyb_A, Kp = (A + 1) / 2;
             p.hyb_Mt    = (Kp + 15) / 16;
             p.hyb_Ks    = (Kp + 3) / 4;
-            p.hyb_raw   = std::min(h, opt.max_mode) + 1;
+            p.hyb_raw   = (std::min(h, opt.max_mode) + 1 + 63) / 64 * 64;   // the device gather writes whole 64-lane granules
             p.lds_complex += p.hyb_raw;
             p.off_cs    = (int64_t)ps.table.size();
             for (int mt = 0; mt < p.hyb_Mt; ++mt) {
@@ -368,7 +368,9 @@ void host_execute_row(const FftPlanSet& ps, int plan, const cplx* X, int mmax, d
             hyb_gather(r, rd, io, raw.data(), t, nthreads);
         }
         for (int t = 0; t < nthreads; ++t) {
-            hyb_fold_split(r, io, raw.data(), work.data(), t, nthreads);
+            HybFoldWork fw;
+            hyb_fold_prefetch(r, t, nthreads, fw);
+            hyb_fold_split(r, io, raw.data(), work.data(), t, nthreads, fw);
         }
         hyb_dense_host(r, work.data());
         for (int i = p.shape.nstages - 2; i >= 0; --i) {
