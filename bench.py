@@ -107,9 +107,10 @@ def cpu_baseline_blas(sample_fields=8):
     g = atlas_amd.Grid(GRID)
     op = oracle.OraclePlan(TRUNC, g.nx(), g.y(), with_tables=True)
     sp = red_spectra(TRUNC, sample_fields)
-    invtrans_blas(op, 1, np.ascontiguousarray(sp.reshape(-1, sample_fields)[:, :1]).reshape(-1))   # warm-up
+    workers = os.cpu_count() or 1
+    invtrans_blas(op, 1, np.ascontiguousarray(sp.reshape(-1, sample_fields)[:, :1]).reshape(-1), workers=workers)   # warm-up
     t0 = time.perf_counter()
-    invtrans_blas(op, sample_fields, sp)
+    invtrans_blas(op, sample_fields, sp, workers=workers)
     dt = time.perf_counter() - t0
     try:
         from threadpoolctl import threadpool_info
@@ -119,7 +120,7 @@ def cpu_baseline_blas(sample_fields=8):
     return {"value": (sample_fields / NLEV) / dt, "unit": "transforms/s", "cores": blas_threads, "kind": "port",
             "sample": f"{sample_fields} of {NLEV} levels of one TL{TRUNC}->{GRID} transform in {dt:.2f} s: the reference's "
                       f"algorithm with library kernels -- per-m dgemm pairs (numpy/OpenBLAS, {blas_threads} threads) + per-row "
-                      f"pocketfft c2r (scipy.fft) -- i.e. TransLocal with eckit 'lapack' + pocketfft "
+                      f"pocketfft c2r (scipy.fft, {workers} workers) -- i.e. TransLocal with eckit 'lapack' + pocketfft "
                       f"(oracle/translocal_blas.py; tables built beforehand); scaled by {NLEV}/{sample_fields}"}
 
 
@@ -129,7 +130,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-fields", type=int, default=24)
+    ap.add_argument("--cpu-sample-fields", type=int, default=NLEV,
+                    help="levels of the transform the CPU baseline runs (default: all 137 -- the dgemm shapes of the real call)")
     ap.add_argument("--cpu-baseline-naive", action="store_true",
                     help="also time the plain-loop restatement (oracle/translocal_oracle.c, OpenMP) as cpu_baseline_naive")
     ap.add_argument("--cpu-baseline-blas", action="store_true", help=argparse.SUPPRESS)   # the default now
@@ -372,7 +374,7 @@ def main():
         if world == 1 and not use_dist and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_blas(args.cpu_sample_fields)
             if args.cpu_baseline_naive:
-                out["cpu_baseline_naive"] = cpu_baseline(args.cpu_sample_fields)
+                out["cpu_baseline_naive"] = cpu_baseline(min(args.cpu_sample_fields, 24))
     if use_dist:
         import torch.distributed as dist
         dist.barrier()
