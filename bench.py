@@ -166,6 +166,7 @@ def main():
     g = atlas_amd.Grid(GRID)
 
     use_dist = world > 1 or args.force_dist
+    crosscheck = None
     if not use_dist:
         tr = atlas_amd.Trans(g, TRUNC, profile=True)
         tr.use_torch_stream()
@@ -209,6 +210,44 @@ def main():
             impl, dtr = "torch (fallback)", DistributedTrans(g, TRUNC, profile=True, mode=mode)
         tr = dtr.trans
         gp = torch.zeros(nf * tr.nb_gridpoints(), dtype=torch.float64, device=DEVICE)
+
+        # multi-GPU parity evidence, BEFORE the timed region so that a wrong transport cannot produce a timed number: the
+        # transposed decomposition must reproduce, bit for bit, what the exchange-free latitude-band decomposition
+        # computes for this rank's rows (tests/test_gpu_trans.py and tests/test_gpu_dist_native.py show both equal the
+        # single-device result).  If the library's own driver fails it, every rank switches to the torch.distributed
+        # driver together and the JSON line says so.
+        def crosscheck_against_bands(d, cls):
+            ok, err = 0, None
+            try:
+                dto = cls(g, TRUNC, mode="band")
+                gp_a, gp_b = torch.empty_like(gp), torch.empty_like(gp)
+                d.invtrans(nf, sps[0], gp_a)
+                dto.invtrans(nf, sps[0], gp_b)
+                sync()
+                ok = int(bool(torch.equal(gp_a, gp_b)) and bool(torch.isfinite(gp_a).all())
+                         and float(gp_a.abs().max()) > 0.0)
+                del dto, gp_a, gp_b
+            except Exception as e:  # the check must never cost the measurement
+                err = f"{type(e).__name__}: {e}"
+            flag = torch.tensor([ok], dtype=torch.int32, device=DEVICE)   # every rank takes part, failed or not
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            out = {"compared": f"alltoall vs band decomposition, {nf} fields, every rank's latitude band, before the "
+                               f"timed region", "bitwise_equal_on_all_ranks": bool(int(flag.item()))}
+            if err:
+                out["error_on_rank0"] = err
+            if on_gpu:
+                torch.cuda.empty_cache()
+            return out
+
+        if dtr.mode == "alltoall":
+            crosscheck = crosscheck_against_bands(dtr, DistributedTrans)
+            if not crosscheck["bitwise_equal_on_all_ranks"] and impl == "native":
+                from atlas_amd.dist_torch import DistributedTrans
+                impl_note = "the library's driver failed the cross-check against the band decomposition: " + \
+                            crosscheck.get("error_on_rank0", "results differ")
+                impl, dtr = "torch (fallback)", DistributedTrans(g, TRUNC, profile=True, mode=mode)
+                tr = dtr.trans
+                crosscheck = crosscheck_against_bands(dtr, DistributedTrans)
         gps = [gp] * world
 
         def step():
@@ -239,32 +278,7 @@ def main():
     transforms = args.steps * world
     ms_per_step = dt / args.steps * 1e3
 
-    # multi-GPU parity evidence (outside the timed region): the transposed decomposition must reproduce, bit for bit,
-    # what the exchange-free latitude-band decomposition computes for this rank's rows (tests/test_gpu_trans.py and
-    # tests/test_gpu_dist_native.py show both equal the single-device result).
-    crosscheck, alt = None, None
-    if use_dist and dtr.mode == "alltoall":
-        import torch.distributed as dist
-        ok, err = 0, None
-        try:
-            dto = DistributedTrans(g, TRUNC, mode="band")
-            gp_a, gp_b = torch.empty_like(gp), torch.empty_like(gp)
-            dtr.invtrans(nf, sps[0], gp_a)
-            dto.invtrans(nf, sps[0], gp_b)
-            sync()
-            ok = int(bool(torch.equal(gp_a, gp_b)) and bool(torch.isfinite(gp_a).all())
-                     and float(gp_a.abs().max()) > 0.0)
-            del dto, gp_a, gp_b
-        except Exception as e:  # the check must never cost the measurement
-            err = f"{type(e).__name__}: {e}"
-        flag = torch.tensor([ok], dtype=torch.int32, device=DEVICE)   # every rank takes part, failed or not
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        crosscheck = {"compared": f"alltoall vs band decomposition, {nf} fields, every rank's latitude band",
-                      "bitwise_equal_on_all_ranks": bool(int(flag.item()))}
-        if err:
-            crosscheck["error_on_rank0"] = err
-        if on_gpu:
-            torch.cuda.empty_cache()
+    alt = None
     # the alternative decomposition, timed for comparison: mirror bands (no exchange, hemisphere symmetry kept), adopted
     # only if every rank reproduces, bit for bit, the same rows through the GPU-tested zonal-band crop path
     if use_dist and world > 1 and dtr.mode == "alltoall" and not args.no_alt:
