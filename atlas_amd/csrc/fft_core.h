@@ -207,28 +207,28 @@ AA_HD void bfly9(cplx* x, int dir) {
         for (int q1 = 0; q1 < 3; ++q1) x[3 * q1 + q0] = u[q1];
     }
 }
-// exp(dir * 2 pi i k / 120), k in [0,120): the index is a compile-time constant after unrolling, so the entries
+// exp(dir * 2 pi i k / 360), k in [0,360): the index is a compile-time constant after unrolling, so the entries
 // become literal operands
-AA_HD cplx cmul_root120(cplx a, int k, int dir) {
-    constexpr double tab[120][2] = {
-#include "fft_roots120.inc"
+AA_HD cplx cmul_root360(cplx a, int k, int dir) {
+    constexpr double tab[360][2] = {
+#include "fft_roots360.inc"
     };
     if (k == 0) return a;
-    if (k == 30) return cmuli(a, dir);
-    if (k == 60) return cplx{-a.re, -a.im};
-    if (k == 90) return cmuli(a, -dir);
+    if (k == 90) return cmuli(a, dir);
+    if (k == 180) return cplx{-a.re, -a.im};
+    if (k == 270) return cmuli(a, -dir);
     return cmulw(a, tab[k][0], tab[k][1], dir);
 }
 
 template <int R>
 AA_HD void bfly(cplx* x, int dir);
 
-// composite radix R = R1 * R2 (R1 odd, R2 a power of two), Cooley-Tukey inside registers:
+// composite radix R = R1 * R2 (R a divisor of 360), Cooley-Tukey inside registers:
 // p = R2 p1 + p0, q = R1 q1 + q0:  w_R^{pq} = w_R1^{p1 q0} w_R^{p0 q0} w_R2^{p0 q1}
 template <int R1, int R2>
 AA_HD void bfly_comp(cplx* x, int dir) {
     constexpr int R = R1 * R2;
-    static_assert(120 % R == 0, "root table covers divisors of 120");
+    static_assert(360 % R == 0, "root table covers divisors of 360");
     cplx t[R2][R1];
 #pragma unroll
     for (int p0 = 0; p0 < R2; ++p0) {
@@ -237,7 +237,7 @@ AA_HD void bfly_comp(cplx* x, int dir) {
         for (int p1 = 0; p1 < R1; ++p1) u[p1] = x[R2 * p1 + p0];
         bfly<R1>(u, dir);
 #pragma unroll
-        for (int q0 = 0; q0 < R1; ++q0) t[p0][q0] = cmul_root120(u[q0], ((p0 * q0) % R) * (120 / R), dir);
+        for (int q0 = 0; q0 < R1; ++q0) t[p0][q0] = cmul_root360(u[q0], ((p0 * q0) % R) * (360 / R), dir);
     }
 #pragma unroll
     for (int q0 = 0; q0 < R1; ++q0) {
@@ -264,6 +264,8 @@ AA_HD void bfly(cplx* x, int dir) {
     else if constexpr (R == 12) bfly_comp<3, 4>(x, dir);
     else if constexpr (R == 20) bfly_comp<5, 4>(x, dir);
     else if constexpr (R == 24) bfly_comp<3, 8>(x, dir);
+    else if constexpr (R == 15) bfly_comp<3, 5>(x, dir);
+    else if constexpr (R == 18) bfly_comp<9, 2>(x, dir);
     else static_assert(R == 2, "unsupported radix");
 }
 
@@ -403,7 +405,9 @@ AA_HD void bluestein_mid(cplx* d, int M, const cplx* __restrict__ bhat, int t, i
         case 10: { constexpr int RR = 10; CALL; } break; \
         case 12: { constexpr int RR = 12; CALL; } break; \
         case 20: { constexpr int RR = 20; CALL; } break; \
-        case 24: { constexpr int RR = 24; CALL; } break;
+        case 24: { constexpr int RR = 24; CALL; } break; \
+        case 15: { constexpr int RR = 15; CALL; } break; \
+        case 18: { constexpr int RR = 18; CALL; } break;
 #endif
 #define AA_RADIX_SWITCH(R, CALL)                         \
     switch (R) {                                         \
@@ -677,7 +681,7 @@ AA_HD void row_phase(int ph, int t, int nt, const RowTables& r, const Reader& rd
 // trips for a 3-stage length instead of 6.  The filter spectrum is read through a [q][butterfly] transposed copy so
 // that the lanes of one load instruction are contiguous.
 // stage list of the specialised M = F * 2^K transform (DIF order); 0 past the end.
-//   M = R0 * 256 with R0 = F * 2^(K-8) <= 24 :  [R0, 16, 16]   (R0 = 1: [16, 16])
+//   M = R0 * 256 with R0 = F * 2^(K-8) <= 24 :  [R0, 16, 16]   (R0 = 1: [16, 16]); F in {1, 3, 5, 9, 15}
 //       one composite first stage (fused with the load; a 3/5-point DFT times a 2/4/8-point DFT in registers),
 //       then R0 independent 256-point blocks: their forward stages, the filter multiply and their inverse stages
 //       only move data between the 16 lanes that own the block (wave-local, no workgroup barrier)
@@ -1063,7 +1067,8 @@ AA_HD void row_phase_dct(int ph, int t, int nt, const RowTablesCt& r, const Read
 
 // the (F, K) instances that exist (kernel and host emulation use the same list)
 AA_HD constexpr bool ct_supported(int f, int k) {
-    return (f == 1 && k >= 8 && k <= 13) || (f == 3 && k >= 7 && k <= 11) || (f == 5 && k >= 6 && k <= 10);
+    return (f == 1 && k >= 8 && k <= 13) || (f == 3 && k >= 7 && k <= 11) || (f == 5 && k >= 6 && k <= 10) ||
+           (f == 9 && k >= 8 && k <= 9) || (f == 15 && k == 8);   // 2304, 4608, 3840: tighter Bluestein lengths
 }
 #define AA_CT_CASE(FF, KK, CALL)                         \
     if (ctf == FF && ctk == KK) {                        \
@@ -1074,7 +1079,8 @@ AA_HD constexpr bool ct_supported(int f, int k) {
     AA_CT_CASE(1, 8, CALL) AA_CT_CASE(1, 9, CALL) AA_CT_CASE(1, 10, CALL) AA_CT_CASE(1, 11, CALL)               \
     AA_CT_CASE(1, 12, CALL) AA_CT_CASE(1, 13, CALL) AA_CT_CASE(3, 7, CALL) AA_CT_CASE(3, 8, CALL)               \
     AA_CT_CASE(3, 9, CALL) AA_CT_CASE(3, 10, CALL) AA_CT_CASE(3, 11, CALL) AA_CT_CASE(5, 6, CALL)               \
-    AA_CT_CASE(5, 7, CALL) AA_CT_CASE(5, 8, CALL) AA_CT_CASE(5, 9, CALL) AA_CT_CASE(5, 10, CALL)
+    AA_CT_CASE(5, 7, CALL) AA_CT_CASE(5, 8, CALL) AA_CT_CASE(5, 9, CALL) AA_CT_CASE(5, 10, CALL)               \
+    AA_CT_CASE(9, 8, CALL) AA_CT_CASE(9, 9, CALL) AA_CT_CASE(15, 8, CALL)
 
 // ======================================================================================================
 // HYBRID rows: h = A * B with B {2,3,5}-smooth and A the product of the prime factors > 5 of h (A odd, <= HYB_MAX_A).

@@ -66,13 +66,22 @@ int next_smooth235(int n) {
 // followed by radix-16/8/4/2 stages
 int next_bluestein_length(int n) {
     int best = 0;
-    for (int f : {1, 3, 5}) {  // 9*2^k was measured slower (radix-9 first stage) than the next {1,3,5}*2^k
+    for (int f : {1, 3, 5}) {
         int m = f;
         while (m < n) {
             m *= 2;
         }
         if (best == 0 || m < best) {
             best = m;
+        }
+    }
+    // the three extra lengths with a specialised [R0, 16, 16] instance: 9*256, 15*256, 18*256
+    const bool finer = std::getenv("ATLAS_AMD_FFT_FINER_M") ? atoi(std::getenv("ATLAS_AMD_FFT_FINER_M")) != 0 : true;
+    if (finer) {
+        for (int m : {2304, 3840, 4608}) {
+            if (m >= n && m < best) {
+                best = m;
+            }
         }
     }
     return best;
@@ -212,7 +221,7 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, const PlanOptions
             p.method = FFT_DIRECT;
             // h itself a length of the specialised family?  (regular grids: every row)
             if (specialised_shapes) {
-                for (int f : {1, 3, 5}) {
+                for (int f : {1, 3, 5, 9, 15}) {
                     if (h % f == 0) {
                         const int k = ilog2_exact(h / f);
                         if (k >= 0 && ct_supported(f, k)) {
@@ -246,7 +255,7 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, const PlanOptions
             const int Mb = next_bluestein_length(2 * h - 1);
             // M = F * 2^K with a specialised instance?
             if (specialised_shapes) {
-                for (int f : {1, 3, 5}) {
+                for (int f : {1, 3, 5, 9, 15}) {
                     if (Mb % f == 0) {
                         const int k = ilog2_exact(Mb / f);
                         if (k >= 0 && ct_supported(f, k)) {

@@ -210,7 +210,9 @@ def test_full_size_sampled_rows_against_oracle(trans_full):
     T, nf = 1279, 137
     sp = red_spectra(T, nf)
     gp = run_device(tr, nf, sp).reshape(nf, -1)
-    rows = [0, 1, 639, 1275, 1279, 1280, 2000, 2559]   # 1275: n = 5120, h = 2560 -> specialised direct kernel
+    # 1275: n = 5120, h = 2560 -> specialised direct kernel; 540 / 900 / 1100: Bluestein lengths 2304 / 3840 / 4608
+    # ([9,16,16], [15,16,16], [18,16,16]); 1147: h = 2304 itself -> direct kernel of that shape
+    rows = [0, 1, 540, 639, 900, 1100, 1147, 1275, 1279, 1280, 2000, 2559]
     op = oracle.OraclePlan(T, g.nx(), g.y(), with_tables=False)
     off = np.concatenate([[0], np.cumsum(g.nx())])
     for r, ref in zip(rows, op.invtrans_rows(nf, sp, rows, use_fft=True)):

@@ -160,6 +160,8 @@ def test_device_table_generator_code_matches_host_generator(gridname, T, nparts,
 
 ROW_LENGTHS = [20, 24, 28, 32, 36, 44, 52, 60, 64, 68, 76, 100, 128, 148, 192, 256, 260, 300, 404, 500, 1004, 1280,
                2048, 2560, 4 * 1283, 5120, 5136, 21, 35, 45,
+               # Bluestein lengths 2304, 3840, 4608 ([9,16,16], [15,16,16], [18,16,16]) and the same as direct lengths
+               2 * 1090, 2 * 1810, 2 * 2210, 2 * 2304, 2 * 3840, 2 * 4608,
                # h = n/2 in the specialised family F*2^K: the direct (no Bluestein) specialised phases
                512, 640, 768, 1536, 3072, 6144, 8192, 10240]
 
