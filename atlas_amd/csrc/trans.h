@@ -136,8 +136,9 @@ private:
     hipStream_t stream_ = nullptr;
     hipStream_t stream2_ = nullptr;            // Fourier stage of the pipelined transform
     hipStream_t ev_stream_ = nullptr;
-    hipStream_t stream3_ = nullptr;            // side stream for the row-length classes with few workgroups
-    hipEvent_t side_fork_ = nullptr, side_join_ = nullptr;
+    std::vector<hipStream_t> side_streams_;     // the row-length classes of the Fourier stage are dealt to several streams
+    std::vector<hipEvent_t> side_joins_;
+    hipEvent_t side_fork_ = nullptr;
     std::vector<hipEvent_t> pipe_events_;
     int pipeline_ = 1;                          // pieces of the Legendre/Fourier software pipeline (1: off)
     bool own_stream_    = false;

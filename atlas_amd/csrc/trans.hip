@@ -159,10 +159,14 @@ Trans::~Trans() {
         (void)hipStreamDestroy(copy_stream_);
         (void)hipEventDestroy(stage_ev_);
     }
-    if (stream3_) {
-        (void)hipStreamDestroy(stream3_);
+    for (auto st : side_streams_) {
+        (void)hipStreamDestroy(st);
+    }
+    for (auto ev : side_joins_) {
+        (void)hipEventDestroy(ev);
+    }
+    if (side_fork_) {
         (void)hipEventDestroy(side_fork_);
-        (void)hipEventDestroy(side_join_);
     }
     if (own_stream_ && stream_) {
         (void)hipStreamDestroy(stream_);
@@ -505,30 +509,46 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
                                   : "Inverse Fourier Transform (mi355x, ReducedGrid)");    // TransLocal.cc:1159
     timed_begin(1, stream);
     static const int only_m = std::getenv("ATLAS_AMD_FFT_ONLY_M") ? atoi(std::getenv("ATLAS_AMD_FFT_ONLY_M")) : 0;
-    // Row-length classes with few workgroups (the four longest rows, the polar caps) cannot fill 256 CUs on their own:
-    // they go to a side stream and share the device with the big classes instead of each adding a launch tail.
-    static const bool side_env = std::getenv("ATLAS_AMD_FFT_SIDE") ? atoi(std::getenv("ATLAS_AMD_FFT_SIDE")) != 0 : true;
-    const long long groups     = (f_end - f_begin + 7) / 8;
-    bool side_used             = false;
+    // The row-length classes are independent launches.  Run back to back on one stream each ends in a tail (the last
+    // workgroups of a class leave CUs idle); dealt round robin to a few streams the tail of one class is filled by the
+    // next and workgroups of different LDS footprints share a CU.  Measured on TL1279/O1280/137 levels (25 classes, in
+    // descending row length): 9.3 ms on one stream, 8.9 / 8.6 / 8.0 / 8.3 / 8.6 ms on 2 / 3 / 4 / 5 / 6-8 streams; 150 random
+    // orders and stream assignments found nothing below the round robin over four (profiles/r02_fft_streams.txt).
+    // ATLAS_AMD_FFT_STREAMS overrides.  All streams fork from and join the caller's stream through events.
+    const int nstreams_env = std::getenv("ATLAS_AMD_FFT_STREAMS") ? atoi(std::getenv("ATLAS_AMD_FFT_STREAMS")) : 4;
+    const int nstreams = std::max(1, std::min(nstreams_env, 8));
+    while ((int)side_streams_.size() < nstreams - 1) {
+        hipStream_t st;
+        hipEvent_t ev;
+        HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        side_streams_.push_back(st);
+        side_joins_.push_back(ev);
+    }
+    if (nstreams > 1 && !side_fork_) {
+        HIP_CHECK(hipEventCreateWithFlags(&side_fork_, hipEventDisableTiming));
+    }
+    std::vector<char> used(nstreams, 0);
+    bool forked = false;
+    int next    = 0;
     for (const SizeClass& c : classes_) {
         p.rows  = c.d_rows;
         p.nrows = c.nrows;
         if (only_m && c.lds_bytes != fft::padded_size(only_m) * 16) {  // dev tool (tools/fft_phase_prof.py): one class
             continue;
         }
+        const int si = next++ % nstreams;
         hipStream_t st = stream;
-        if (side_env && (long long)c.nrows * groups * 8 <= 9000) {
-            if (!side_used) {
-                if (!stream3_) {
-                    HIP_CHECK(hipStreamCreateWithFlags(&stream3_, hipStreamNonBlocking));
-                    HIP_CHECK(hipEventCreateWithFlags(&side_fork_, hipEventDisableTiming));
-                    HIP_CHECK(hipEventCreateWithFlags(&side_join_, hipEventDisableTiming));
-                }
+        if (si > 0) {
+            if (!forked) {
                 HIP_CHECK(hipEventRecord(side_fork_, stream));
-                HIP_CHECK(hipStreamWaitEvent(stream3_, side_fork_, 0));
-                side_used = true;
+                forked = true;
             }
-            st = stream3_;
+            st = side_streams_[si - 1];
+            if (!used[si]) {
+                HIP_CHECK(hipStreamWaitEvent(st, side_fork_, 0));
+                used[si] = 1;
+            }
         }
         if (c.hybrid) {
             HIP_CHECK(launch_fourier_hyb(p, c.lds_bytes, c.nthreads, st));
@@ -545,9 +565,11 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
             HIP_CHECK(launch_fourier(p, c.lds_bytes, c.nthreads, st));
         }
     }
-    if (side_used) {
-        HIP_CHECK(hipEventRecord(side_join_, stream3_));
-        HIP_CHECK(hipStreamWaitEvent(stream, side_join_, 0));
+    for (int si = 1; si < nstreams; ++si) {
+        if (used[si]) {
+            HIP_CHECK(hipEventRecord(side_joins_[si - 1], side_streams_[si - 1]));
+            HIP_CHECK(hipStreamWaitEvent(stream, side_joins_[si - 1], 0));
+        }
     }
     timed_end();
 }
