@@ -39,6 +39,14 @@ last_error = _sig("atlas_amd__last_error", C.c_char_p)
 version = _sig("atlas_amd__version", C.c_char_p)
 device_count = _sig("atlas_amd__device_count", C.c_int)
 stream_wait_stream = _sig("atlas_amd__stream_wait_stream", C.c_int, c_void_p, c_void_p)
+_diag_mfma_f64_rate = _sig("atlas_amd__diag_mfma_f64_rate", C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double))
+
+
+def diag_mfma_f64_rate(target_ms=25.0, repeats=3):
+    """TFLOP/s the current device sustains on v_mfma_f64_16x16x4_f64 alone (measurement aid, csrc/diag.hip)"""
+    out = C.c_double(0.0)
+    check(_diag_mfma_f64_rate(float(target_ms), int(repeats), C.byref(out)))
+    return out.value
 
 
 class torch_stream_order:

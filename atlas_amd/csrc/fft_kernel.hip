@@ -471,6 +471,11 @@ static hipError_t launch_ct_t(FourierParams p, int lds_bytes, unsigned nblk, hip
         }
         max_set = lds_bytes;
     }
+    if (const char* e = std::getenv("ATLAS_AMD_FFT_LDS_PAD")) {  // dev tool: occupancy sensitivity (more LDS per workgroup)
+        lds_bytes += atoi(e);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_ct_kernel<S, F32>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    }
     const unsigned grid = nblk;
     p.nvirt             = nblk;
     static const bool debug = std::getenv("ATLAS_AMD_FFT_DEBUG") != nullptr;

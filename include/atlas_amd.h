@@ -50,6 +50,9 @@ int atlas_amd__device_memcpy_h2d(void* dst_dev, const void* src_host, size_t byt
 int atlas_amd__device_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
 int atlas_amd__device_synchronize(void);
 int atlas_amd__set_device(int device);
+/* measurement aid (bench.py): TFLOP/s this device sustains on v_mfma_f64_16x16x4_f64 alone, best of `repeats` kernels of
+ * about target_ms each on the current device's default stream (4 wavefronts per SIMD, random operands) */
+int atlas_amd__diag_mfma_f64_rate(double target_ms, int repeats, double* tflops_out);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Grid description.  Replaces the `const Grid::Implementation*` argument of atlas__Trans__new
