@@ -40,6 +40,7 @@ struct LegendreParamsT {
     int nchunks; // column chunks per item (filled in by the launcher)
     int chunk0;  // first column chunk of this launch
     int nchunks_run;  // column chunks computed by this launch (pipelined transform: a subset)
+    int abl;          // dev switch of the role-split kernel (ATLAS_AMD_LEG_ABLATE): parts left out, results then wrong; 0 in production
 };
 using LegendreParams    = LegendreParamsT<double>;
 using LegendreParamsF32 = LegendreParamsT<float>;   // fp32 variant (BASELINE config C5)

@@ -188,11 +188,15 @@ void Trans::synchronize() const {
 
 // Legendre table computed on the device (legendre_gen_kernel.hip) from O(T^2) host-prepared inputs: no host
 // generation of the O(T^2 N) table, no multi-GB upload
+static constexpr size_t kTableSlack = 16 * 64;  // doubles
+
 void Trans::generate_table_on_device() {
     const LegendreGenInputs in = prepare_legendre_gen(geo_, work_);
     const size_t n             = (size_t)work_.table_doubles;
-    HIP_CHECK(hipMalloc((void**)&d_P_, std::max<size_t>(n, 1) * sizeof(double)));
-    HIP_CHECK(hipMemsetAsync(d_P_, 0, std::max<size_t>(n, 1) * sizeof(double), stream_));  // K / latitude padding
+    // + kTableSlack: the deep-stage Legendre kernel stages whole 12 / 16-row stages and may read (never use) up to 8 rows
+    // past the last item's block
+    HIP_CHECK(hipMalloc((void**)&d_P_, (n + kTableSlack) * sizeof(double)));
+    HIP_CHECK(hipMemsetAsync(d_P_, 0, (n + kTableSlack) * sizeof(double), stream_));  // K / latitude padding
     struct Scratch {  // device buffers that only live for the generation, released on every exit path
         std::vector<void*> ptrs;
         void push_back(void* p) { ptrs.push_back(p); }
@@ -265,7 +269,9 @@ void Trans::upload() {
         else {
             compute_legendre_table_tiled(geo_, work_, host);
         }
-        d_P_ = dev_upload(host, n);
+        HIP_CHECK(hipMalloc((void**)&d_P_, (n + kTableSlack) * sizeof(double)));
+        HIP_CHECK(hipMemcpy(d_P_, host, n * sizeof(double), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemset(d_P_ + n, 0, kTableSlack * sizeof(double)));
         free(host);
     }
     {

@@ -27,8 +27,9 @@ class StructuredGrid:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
-            _lib.Grid_delete(h)
+        delete = getattr(_lib, "Grid_delete", None) if _lib is not None else None   # module globals go first at interpreter exit
+        if h and delete is not None:
+            delete(h)
             self._h = None
 
     def ny(self):

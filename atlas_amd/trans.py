@@ -63,8 +63,9 @@ class Trans:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
-            _lib.Trans_delete(h)
+        delete = getattr(_lib, "Trans_delete", None) if _lib is not None else None   # module globals go first at interpreter exit
+        if h and delete is not None:
+            delete(h)
             self._h = None
 
     # ---- atlas::trans::TransImpl accessors (TransImpl.h:38-60) ----

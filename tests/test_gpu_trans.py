@@ -518,3 +518,48 @@ def test_hybrid_fourier_rows_equal_the_bluestein_rows(monkeypatch):
     off = np.concatenate([[0], np.cumsum(g.nx())])
     for r, ref in zip(rows, op.invtrans_rows(nf, sp, rows, use_fft=True)):
         assert compute_rms(b.reshape(nf, -1)[:, off[r]:off[r + 1]], ref) < 1e-13, r
+
+
+@pytest.mark.parametrize("case", ["scalar_O160_nf40", "vordiv_F64", "sharded_O160_nf44", "band_O160_nf42", "scalar_O64_nf137"])
+def test_legendre_kernel_variants_are_bitwise_equal(case, monkeypatch):
+    """The 96-column workgroup of the Legendre stage (field counts whose 16-column tiles come in sixes: nf 33..48, 81..96,
+    129..144, ...) has three implementations of the same arithmetic in the same order: the generic template ("classic"),
+    the default without vector-ALU work in its stage loop ("lean") and the role-split experiment ("split").
+    ATLAS_AMD_LEG_KERNEL is read at every launch; every entry point that reaches the stage must give identical bits."""
+    outs = {}
+    for kernel in ("classic", "lean", "split"):
+        monkeypatch.setenv("ATLAS_AMD_LEG_KERNEL", kernel)
+        if case.startswith("scalar"):
+            gridname, T, nf = ("O160", 159, 40) if "O160" in case else ("O64", 63, 137)
+            g, tr = get_trans(gridname, T)
+            outs[kernel] = run_device(tr, nf, red_spectra(T, nf, seed=11))
+        elif case == "vordiv_F64":
+            T, ns, nvd = 63, 6, 17          # 2 * 17 wind fields + 6 scalars = 40 fields in one Legendre launch
+            g, tr = get_trans("F64", T)
+            sp, vor, div = red_spectra(T, ns, 1), red_spectra(T, nvd, 2), red_spectra(T, nvd, 3)
+            gp = torch.zeros((ns + 2 * nvd) * g.size(), dtype=torch.float64, device="cuda")
+            tr.invtrans(ns, dev(sp), nvd, dev(vor), dev(div), gp)
+            tr.synchronize()
+            outs[kernel] = gp.cpu().numpy()
+        elif case == "sharded_O160_nf44":
+            T, nf, nparts = 159, 44, 3
+            g = atlas_amd.Grid("O160")
+            sp_d, parts = dev(red_spectra(T, nf, seed=12)), []
+            for part in range(nparts):
+                tr = atlas_amd.Trans(g, T, nparts=nparts, part=part)
+                f = torch.zeros(tr.fourier_size(nf), dtype=torch.float64, device="cuda")
+                tr.legendre_device(T, nf, sp_d, f)
+                tr.synchronize()
+                parts.append(f.cpu().numpy())
+            outs[kernel] = np.concatenate(parts)
+        else:
+            T, nf, rows = 159, 42, (200, 320)
+            g = atlas_amd.Grid("O160")
+            tr = atlas_amd.Trans(g, T, rows=rows)
+            gp = torch.zeros(nf * tr.nb_gridpoints(), dtype=torch.float64, device="cuda")
+            tr.invtrans(nf, dev(red_spectra(T, nf, seed=13)), gp)
+            tr.synchronize()
+            outs[kernel] = gp.cpu().numpy()
+    assert float(np.abs(outs["classic"]).max()) > 0
+    assert np.array_equal(outs["classic"], outs["lean"])
+    assert np.array_equal(outs["classic"], outs["split"])
