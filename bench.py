@@ -349,7 +349,8 @@ def main():
         traffic = measured_traffic() if world == 1 and not use_dist else {}   # PMC passes: the single-GPU workload
         kernels = [
             # one launch per transform: the single largest kernel of the path (rocprofv3 --stats agrees, profiles/)
-            {"kernel": "legendre_kernel", "launches_per_transform": 1, "bound": "mfma", "achieved": leg_tf,
+            {"kernel": "legendre_kernel_lean" if NLEV == 137 and os.environ.get("ATLAS_AMD_LEG_KERNEL", "lean") == "lean"
+                       else "legendre_kernel", "launches_per_transform": 1, "bound": "mfma", "achieved": leg_tf,
              "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": leg_tf / FP64_MFMA_PEAK_TFLOPS,
              "avg_ms": leg_ms, "traffic": traffic.get("legendre_kernel")},
             # the Fourier stage is one launch per row-length class (fft_rows_ct_kernel<CtShape<F,K>> /
