@@ -326,8 +326,7 @@ __global__ void __launch_bounds__(512, 4) legendre_kernel_lean(LegendreParams p)
     using RT = RealTraits<double>;
     using acc_t = typename RT::acc_t;
     constexpr int RTW = 3, NTHR = 512;
-    extern __shared__ double lds_raw[];
-    double* lds = lds_raw;
+    // dynamic LDS: L::BYTES, addressed from 0 by the inline asm below
 
     const int nchunks   = p.nchunks_run;
     const int bx        = blockIdx.x & 7;
@@ -663,7 +662,6 @@ __global__ void __launch_bounds__(768, 6) legendre_kernel_v2(LegendreParams p) {
     using L  = LegLds2<KS, PRING>;
     using RT = RealTraits<double>;
     using acc_t = typename RT::acc_t;
-    using vec_t = typename RT::vec_t;
     constexpr int RTW = 3;
     static_assert(PRING == 4 || PRING == 5, "the waits below are written for three or four stages in flight");
     extern __shared__ double lds_raw[];

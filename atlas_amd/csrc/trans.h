@@ -52,6 +52,7 @@ class Trans {
 public:
     Trans(const grid::StructuredGrid& grid, int truncation, const TransConfig& cfg = TransConfig());
     ~Trans();
+    void release() noexcept;   // frees every device resource (destructor; constructor that throws)
     Trans(const Trans&)            = delete;
     Trans& operator=(const Trans&) = delete;
 

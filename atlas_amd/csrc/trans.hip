@@ -108,16 +108,31 @@ Trans::Trans(const grid::StructuredGrid& grid, int truncation, const TransConfig
         }
         fftplans_ = fft::make_fft_plans(lengths, po);
     }
-    HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    own_stream_ = true;
-    upload();
+    // upload() allocates the table and every plan buffer and can throw (cache size, row length, out of memory): the
+    // destructor does not run for a constructor that throws, so release what exists before passing the error on
+    try {
+        HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        own_stream_ = true;
+        upload();
+    }
+    catch (...) {
+        release();
+        throw;
+    }
 }
 
 Trans::~Trans() {
-    (void)hipStreamSynchronize(stream_);
-    auto fr = [](void* p) {
+    release();
+}
+
+void Trans::release() noexcept {
+    if (stream_) {
+        (void)hipStreamSynchronize(stream_);
+    }
+    auto fr = [](auto*& p) {
         if (p) {
             (void)hipFree(p);
+            p = nullptr;
         }
     };
     fr(d_P_);
@@ -136,6 +151,7 @@ Trans::~Trans() {
     for (auto& c : classes_) {
         fr(c.d_rows);
     }
+    classes_.clear();
     fr(d_fourier_);
     fr(d_sp_);
     fr(d_gp_);
@@ -145,16 +161,20 @@ Trans::~Trans() {
     for (auto& e : events_) {
         (void)hipEventDestroy(e);
     }
+    events_.clear();
     for (auto& e : pipe_events_) {
         (void)hipEventDestroy(e);
     }
+    pipe_events_.clear();
     if (stream2_) {
         (void)hipStreamDestroy(stream2_);
+        stream2_ = nullptr;
     }
     if (pin_[0]) {
         for (int i = 0; i < 2; ++i) {
             (void)hipHostFree(pin_[i]);
             (void)hipEventDestroy(pin_ev_[i]);
+            pin_[i] = nullptr;
         }
         (void)hipStreamDestroy(copy_stream_);
         (void)hipEventDestroy(stage_ev_);
@@ -162,15 +182,19 @@ Trans::~Trans() {
     for (auto st : side_streams_) {
         (void)hipStreamDestroy(st);
     }
+    side_streams_.clear();
     for (auto ev : side_joins_) {
         (void)hipEventDestroy(ev);
     }
+    side_joins_.clear();
     if (side_fork_) {
         (void)hipEventDestroy(side_fork_);
+        side_fork_ = nullptr;
     }
     if (own_stream_ && stream_) {
         (void)hipStreamDestroy(stream_);
     }
+    stream_ = nullptr;
 }
 
 void Trans::set_stream(hipStream_t s) {
@@ -419,11 +443,16 @@ double* Trans::fourier_buffer(int nb_fields) {
     return d_fourier_;
 }
 
+static constexpr size_t kMaxPendingTimings = 1024;   // (begin, end) event pairs held before they are folded into timings_
+
 void Trans::timed_begin(int kind, hipStream_t s) {
     if (!profile_) {
         return;
     }
     ev_stream_ = s ? s : stream_;
+    if (ev_used_ >= 2 * kMaxPendingTimings) {
+        collect_timings();   // a caller that never asks for timings() keeps a bounded number of events
+    }
     while (events_.size() < ev_used_ + 2) {
         hipEvent_t e;
         HIP_CHECK(hipEventCreate(&e));

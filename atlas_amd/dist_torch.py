@@ -99,10 +99,12 @@ def transpose_exchange(F, R, plan, bands, RP, nparts, part, group=None, async_op
         if peer == part:
             R[rb:re].copy_(Ff[sb:se])
         else:
+            # P2POp addresses the peer by its GLOBAL rank, also inside a sub-group (as parallel_torch.exchange_packed does)
+            gpeer = dist.get_global_rank(group, peer) if group is not None else peer
             if se > sb:
-                ops.append(dist.P2POp(dist.isend, Ff[sb:se], peer, group))
+                ops.append(dist.P2POp(dist.isend, Ff[sb:se], gpeer, group))
             if re > rb:
-                ops.append(dist.P2POp(dist.irecv, R[rb:re], peer, group))
+                ops.append(dist.P2POp(dist.irecv, R[rb:re], gpeer, group))
     works = dist.batch_isend_irecv(ops) if ops else []
     if async_op:
         return list(works)

@@ -110,6 +110,52 @@ def test_bounded_size_exchange_over_gloo(world, limits, async_op):
     assert all(ok for _, ok, _ in res)
 
 
+def _subgroup_worker(grank, gworld, members, port, T, RP, nx, q, limits):
+    """ranks `members` of a larger world form the transform's group; the others only take part in new_group()"""
+    sys.path.insert(0, ROOT)
+    from atlas_amd.dist_torch import mode_address, owned_wavenumbers, transpose_exchange, transpose_plan
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=grank, world_size=gworld)
+    group = dist.new_group(ranks=members)
+    ok = True
+    if grank in members:
+        world, rank = len(members), members.index(grank)
+        nlats = len(nx)
+        bands = _bands(nx, world)
+        plan = transpose_plan(nlats, T, RP, bands, world, rank)
+        cnt = owned_wavenumbers(T, world, rank)
+        F = torch.zeros(nlats, cnt, RP, dtype=torch.float64)
+        for ml in range(cnt):
+            m = rank + ml * world
+            F[:, ml, :] = (torch.arange(nlats, dtype=torch.float64)[:, None] * 1e6 + m * 1e3
+                           + torch.arange(RP, dtype=torch.float64)[None, :])
+        R = torch.full((sum(plan["out_splits"]),), -1.0, dtype=torch.float64)
+        transpose_exchange(F, R, plan, bands, RP, world, rank, group=group, max_message_elems=limits)
+        for lat in range(bands[rank], bands[rank + 1]):
+            for m in range(T + 1):
+                a = mode_address(plan, RP, lat - bands[rank], m, world)
+                ok = ok and np.array_equal(R[a:a + RP].numpy(), lat * 1e6 + m * 1e3 + np.arange(RP))
+    q.put((grank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("limits", [1 << 26, 100])
+def test_exchange_inside_a_sub_group_addresses_peers_by_global_rank(limits):
+    """group-local rank 1 is global rank 2: the bounded-size point-to-point path must translate (P2POp takes global ranks),
+    and must deliver what the single all_to_all_single delivers"""
+    nx = np.array([20 + 4 * j for j in range(8)] + [20 + 4 * j for j in range(8)][::-1])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_subgroup_worker, args=(r, 3, [0, 2], port, 11, 16, nx, q, limits)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(3)]
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok in res)
+
+
 def test_exchange_messages_cover_both_buffers_exactly_once():
     from atlas_amd.dist_torch import exchange_messages, transpose_plan
     nx = np.array([20 + 4 * j for j in range(40)] + [20 + 4 * j for j in range(40)][::-1])

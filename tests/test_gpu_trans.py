@@ -563,3 +563,19 @@ def test_legendre_kernel_variants_are_bitwise_equal(case, monkeypatch):
     assert float(np.abs(outs["classic"]).max()) > 0
     assert np.array_equal(outs["classic"], outs["lean"])
     assert np.array_equal(outs["classic"], outs["split"])
+
+
+def test_a_constructor_that_throws_releases_its_device_memory():
+    """TransLocal's constructor can fail after allocating (a Legendre cache of the wrong size is detected in upload()):
+    the stream and the buffers allocated so far must be released, or a caller probing cache files exhausts HBM."""
+    T = 159
+    g, tr = get_trans("O160", T)
+    blob = tr.legendre_cache()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(40):
+        with pytest.raises(_lib.AtlasAmdError):
+            atlas_amd.Trans(g, T, legendre_cache=blob[:-8])
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20, (free0, free1)   # plans and row tables of one object are a few MB; 40 leaks would be far more
