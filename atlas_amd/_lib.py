@@ -76,6 +76,8 @@ Grid_size = _sig("atlas_amd__Grid__size", C.c_int64, c_void_p)
 Grid_regular = _sig("atlas_amd__Grid__regular", C.c_int, c_void_p)
 Grid_nx = _sig("atlas_amd__Grid__nx", C.c_int, c_void_p, c_void_p)
 Grid_y = _sig("atlas_amd__Grid__y", C.c_int, c_void_p, c_void_p)
+Grid_crop_to_domain = _sig("atlas_amd__Grid__crop_to_domain", C.c_int, c_void_p, C.c_double, C.c_double, C.c_double, C.c_double,
+                           C.POINTER(C.c_int), C.POINTER(C.c_int), c_void_p, c_void_p, C.c_int)
 gaussian_latitudes_npole_spole = _sig("atlas_amd__gaussian_latitudes_npole_spole", C.c_int, C.c_int, c_void_p)
 
 Trans_new = _sig("atlas_amd__Trans__new", c_void_p, c_void_p, C.c_int)

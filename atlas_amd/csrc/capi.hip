@@ -10,6 +10,7 @@
 
 #include "../../include/atlas_amd.h"
 #include "capi_types.h"
+#include "domain_crop.h"
 #include "equal_regions.h"
 #include "legendre_cache_uid.h"
 #include "fft_plan.h"
@@ -300,6 +301,33 @@ atlas_amd_Trans* atlas_amd__Trans__new_config(const atlas_amd_Grid* grid, int tr
             cfg.row_begin = std::stoi(kv.second.substr(0, colon));
             cfg.row_end   = std::stoi(kv.second.substr(colon + 1));
         }
+        else if (kv.first == "domain") {  // "west,east,south,north": RectangularDomain crop of the (global) grid
+            double b[4];
+            size_t pos = 0;
+            std::string v = kv.second;
+            for (int i = 0; i < 4; ++i) {
+                size_t used = 0;
+                b[i]        = std::stod(v.substr(pos), &used);
+                pos += used;
+                if (i < 3) {
+                    if (pos >= v.size() || v[pos] != ',') {
+                        throw std::invalid_argument("domain must be 'west,east,south,north'");
+                    }
+                    ++pos;
+                }
+            }
+            const grid::DomainCrop c = grid::crop_to_domain(grid->g, b[0], b[1], b[2], b[3]);
+            cfg.row_begin = c.row_begin;
+            cfg.row_end   = c.row_end;
+            bool whole    = true;
+            for (size_t r = 0; r < c.n.size(); ++r) {
+                whole = whole && c.i0[r] == 0 && c.n[r] == grid->g.nx[c.row_begin + r];
+            }
+            if (!whole) {
+                cfg.win_i0 = c.i0;
+                cfg.win_n  = c.n;
+            }
+        }
         else if (kv.first == "shard") {
             if (kv.second != "m" && kv.second != "band" && kv.second != "mirror") {
                 throw std::invalid_argument(
@@ -369,6 +397,24 @@ int atlas_amd__Trans__truncation(const atlas_amd_Trans* t) {
 }
 int64_t atlas_amd__Trans__nb_gridpoints(const atlas_amd_Trans* t) {
     return t->impl->nb_gridpoints();
+}
+int atlas_amd__Grid__crop_to_domain(const atlas_amd_Grid* grid, double west, double east, double south, double north,
+                                    int* row_begin, int* row_end, int first_index[], int count[], int capacity) {
+    AA_TRY
+    if (!grid || !row_begin || !row_end) {
+        throw std::invalid_argument("crop_to_domain: NULL argument");
+    }
+    const grid::DomainCrop c = grid::crop_to_domain(grid->g, west, east, south, north);
+    *row_begin = c.row_begin;
+    *row_end   = c.row_end;
+    if (first_index && count) {
+        if (capacity < c.row_end - c.row_begin) {
+            throw std::invalid_argument("crop_to_domain: arrays too short for the rows of the domain");
+        }
+        std::copy(c.i0.begin(), c.i0.end(), first_index);
+        std::copy(c.n.begin(), c.n.end(), count);
+    }
+    AA_CATCH_INT
 }
 int64_t atlas_amd__Trans__nb_gridpoints_global(const atlas_amd_Trans* t) {
     return t->impl->nb_gridpoints_global();

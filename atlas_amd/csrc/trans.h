@@ -39,6 +39,8 @@ struct TransConfig {
                                          // true = latitude-band sharding of both stages (no exchange, 2x Legendre work)
     int ndgl = 0, nxmax = 0;          // the grid is a row subset of a global grid with ndgl latitudes / longest row nxmax
                                       // (mirror-band decomposition): what fourier_truncation must see; 0: the grid's own
+    std::vector<int> win_i0, win_n;   // per row of [row_begin, row_end): keep the win_n points starting at index win_i0,
+                                      // wrapping around (a RectangularDomain crop, TransLocal.cc:1120-1135); empty: whole rows
     int device_tables          = -1;  // Legendre table computed on the device (1) or on the host and uploaded (0);
                                       // -1: environment variable ATLAS_AMD_TABLES=device|host, default device
 };
@@ -57,7 +59,10 @@ public:
     Trans& operator=(const Trans&) = delete;
 
     int truncation() const { return geo_.T; }
-    int64_t nb_gridpoints() const { return geo_.rowoff[band_end()] - geo_.rowoff[band_begin()]; }
+    // points of the output: the rows of the band, or of their longitude windows
+    int64_t nb_gridpoints() const { return windowed() ? win_npts_ : band_points(); }
+    int64_t band_points() const { return geo_.rowoff[band_end()] - geo_.rowoff[band_begin()]; }
+    bool windowed() const { return !cfg_.win_n.empty(); }
     int64_t nb_gridpoints_global() const { return geo_.npts; }
     size_t nb_spectral_coefficients() const { return size_t(geo_.T + 1) * size_t(geo_.T + 2); }  // TransLocal.h:90
     const TransGeometry& geometry() const { return geo_; }
@@ -175,6 +180,12 @@ private:
     size_t sp_cap_      = 0;
     double* d_gp_       = nullptr;
     size_t gp_cap_      = 0;
+    double* d_gpfull_   = nullptr;  // whole rows of a longitude-window crop, before the window is copied out
+    size_t gpfull_cap_  = 0;
+    int* d_win_i0_      = nullptr;
+    int* d_win_n_       = nullptr;
+    long long* d_win_off_ = nullptr;
+    int64_t win_npts_   = 0;
     double* d_all_      = nullptr;  // combined (U,V,scalar) spectra of the vor/div path
     size_t all_cap_     = 0;
     double* d_vd_       = nullptr;  // host-API staging of vor ++ div

@@ -20,6 +20,9 @@ namespace atlas_amd {
 namespace trans {
 
 hipError_t launch_legendre(const LegendreParams& p, int nitems, int chunk0, int nrun, hipStream_t stream);
+hipError_t launch_window_crop(const double* full, double* out, const long long* rowoff, const int* win_i0, const int* win_n,
+                              const long long* win_off, int nrows, long long npts_full, long long npts_out, int f_begin,
+                              int f_end, hipStream_t stream);
 hipError_t launch_legendre_gen(const LegendreGenParams& g, hipStream_t stream);
 void legendre_tiling(int nf, int& rtw, int& nrg, int& nchunks);
 hipError_t launch_legendre_f32(const LegendreParamsF32& p, int nitems, int chunk0, int nrun, hipStream_t stream);
@@ -83,6 +86,21 @@ Trans::Trans(const grid::StructuredGrid& grid, int truncation, const TransConfig
     }
     else {
         bands_ = latitude_bands(geo_, cfg.nparts);
+    }
+    if (!cfg.win_n.empty()) {
+        // longitude windows (RectangularDomain crop): per row of rows=j0:j1
+        const int nrows = cfg.row_end - cfg.row_begin;
+        if (nrows <= 0 || (int)cfg.win_n.size() != nrows || (int)cfg.win_i0.size() != nrows) {
+            throw std::invalid_argument("Trans: longitude windows need rows=j0:j1 and one (first index, count) per row");
+        }
+        win_npts_ = 0;
+        for (int r = 0; r < nrows; ++r) {
+            const int nx = geo_.nx[cfg.row_begin + r];
+            if (cfg.win_i0[r] < 0 || cfg.win_i0[r] >= nx || cfg.win_n[r] < 1 || cfg.win_n[r] > nx) {
+                throw std::invalid_argument("Trans: longitude window outside its row");
+            }
+            win_npts_ += cfg.win_n[r];
+        }
     }
     work_ = make_legendre_work(geo_, cfg.nparts, cfg.part, cfg_.by_band, cfg.row_begin, cfg.row_end);
     m_cnt_ = 0;
@@ -156,6 +174,10 @@ void Trans::release() noexcept {
     fr(d_sp_);
     fr(d_gp_);
     fr(d_all_);
+    fr(d_gpfull_);
+    fr(d_win_i0_);
+    fr(d_win_n_);
+    fr(d_win_off_);
     fr(d_prof_);
     fr(d_vd_);
     for (auto& e : events_) {
@@ -329,6 +351,15 @@ void Trans::upload() {
     d_coslatinv_ = dev_upload(coslatinv.data(), coslatinv.size());
     std::vector<long long> rowoff(geo_.rowoff.begin(), geo_.rowoff.end());
     d_rowoff_ = dev_upload(rowoff.data(), rowoff.size());
+    if (windowed()) {
+        std::vector<long long> woff(cfg_.win_n.size() + 1, 0);
+        for (size_t r = 0; r < cfg_.win_n.size(); ++r) {
+            woff[r + 1] = woff[r] + cfg_.win_n[r];
+        }
+        d_win_i0_  = dev_upload(cfg_.win_i0.data(), cfg_.win_i0.size());
+        d_win_n_   = dev_upload(cfg_.win_n.data(), cfg_.win_n.size());
+        d_win_off_ = dev_upload(woff.data(), woff.size());
+    }
     // ---- launch classes for the rows of the local latitude band ----
     // Bluestein rows whose length M = F*2^K has a compile-time specialised kernel instance form one class per M;
     // everything else (short rows, {2,3,5}-smooth rows, odd rows) goes to the generic kernel, bucketed by LDS need.
@@ -524,6 +555,23 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
     p.nparts          = fourier_parts();
     p.lat0            = band_begin();
     p.gp              = gp_dev;
+    if (windowed()) {
+        // whole rows first (TransLocal.cc:1120-1135 does the same: full-length c2r, then the window is copied out)
+        if (f32) {
+            throw std::logic_error("fp32 invtrans of a longitude-window crop is not implemented");
+        }
+        const size_t need = (size_t)nb_fields * (size_t)band_points();
+        if (need > gpfull_cap_) {
+            HIP_CHECK(hipStreamSynchronize(stream));
+            if (d_gpfull_) {
+                HIP_CHECK(hipFree(d_gpfull_));
+                d_gpfull_ = nullptr;
+            }
+            HIP_CHECK(hipMalloc((void**)&d_gpfull_, need * sizeof(double)));
+            gpfull_cap_ = need;
+        }
+        p.gp = d_gpfull_;
+    }
     p.plans           = (const fft::FftRowPlan*)d_fftplans_;
     p.table           = (const fft::cplx*)d_ffttable_;
     p.row_plan        = d_row_plan_;
@@ -605,6 +653,10 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
             HIP_CHECK(hipEventRecord(side_joins_[si - 1], side_streams_[si - 1]));
             HIP_CHECK(hipStreamWaitEvent(stream, side_joins_[si - 1], 0));
         }
+    }
+    if (windowed()) {
+        HIP_CHECK(launch_window_crop(d_gpfull_, gp_dev, d_rowoff_ + band_begin(), d_win_i0_, d_win_n_, d_win_off_,
+                                     band_end() - band_begin(), band_points(), win_npts_, f_begin, f_end, stream));
     }
     timed_end();
 }
@@ -773,7 +825,7 @@ void Trans::invtrans(int nb_scalar_fields, const double scalar_spectra[], double
     // TL1279 / O1280 / 137 levels = 50 GB/s of the ~57 GB/s link either way -- the runtime's own pageable path already
     // streams at the link rate and the 18 ms of compute are a tenth of the transfer; the pipeline stays opt-in.
     static const bool pipe_env = std::getenv("ATLAS_AMD_HOST_PIPELINE") ? atoi(std::getenv("ATLAS_AMD_HOST_PIPELINE")) != 0 : false;
-    if (pipe_env && nb_scalar_fields >= 16 && ngp * sizeof(double) >= (size_t(256) << 20) && fourier_parts() == 1) {
+    if (pipe_env && nb_scalar_fields >= 16 && ngp * sizeof(double) >= (size_t(256) << 20) && fourier_parts() == 1 && !windowed()) {
         invtrans_host_pipelined(nb_scalar_fields, scalar_spectra, gp_fields);
         return;
     }

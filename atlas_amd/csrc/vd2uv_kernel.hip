@@ -180,5 +180,36 @@ hipError_t launch_spectra_prepare(const double* vor, const double* div, const do
     return hipGetLastError();
 }
 
+// ---- longitude-window crop (RectangularDomain): out[f][win_off[r] + i] = full[f][rowoff[r] - rowoff[0] + (win_i0[r] + i) mod n_r]
+// One workgroup per (row, field); HBM-bound copy of the kept points (TransLocal.cc:1123-1131 does this on the host).
+__global__ void __launch_bounds__(256) window_crop_kernel(const double* __restrict__ full, double* __restrict__ out,
+                                                          const long long* __restrict__ rowoff, const int* __restrict__ win_i0,
+                                                          const int* __restrict__ win_n, const long long* __restrict__ win_off,
+                                                          long long npts_full, long long npts_out, int f_begin) {
+    const int r        = blockIdx.x;
+    const int f        = f_begin + blockIdx.y;
+    const int n        = (int)(rowoff[r + 1] - rowoff[r]);
+    const int i0       = win_i0[r];
+    const int cnt      = win_n[r];
+    const double* src  = full + (long long)f * npts_full + (rowoff[r] - rowoff[0]);
+    double* dst        = out + (long long)f * npts_out + win_off[r];
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+        int j = i0 + i;
+        j     = j >= n ? j - n : j;
+        dst[i] = src[j];
+    }
+}
+
+hipError_t launch_window_crop(const double* full, double* out, const long long* rowoff, const int* win_i0, const int* win_n,
+                              const long long* win_off, int nrows, long long npts_full, long long npts_out, int f_begin,
+                              int f_end, hipStream_t stream) {
+    if (nrows <= 0 || f_end <= f_begin) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(window_crop_kernel, dim3(nrows, f_end - f_begin), dim3(256), 0, stream, full, out, rowoff, win_i0, win_n,
+                       win_off, npts_full, npts_out, f_begin);
+    return hipGetLastError();
+}
+
 }  // namespace trans
 }  // namespace atlas_amd

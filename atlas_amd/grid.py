@@ -32,6 +32,18 @@ class StructuredGrid:
             delete(h)
             self._h = None
 
+    def crop_to_domain(self, west, east, south, north):
+        """atlas::Grid(grid, RectangularDomain({west, east}, {south, north})): ((row_begin, row_end), first global index
+        of every kept row, number of points of every kept row (taken with wrap-around))"""
+        import ctypes as C
+        j0, j1 = C.c_int(0), C.c_int(0)
+        i0 = np.zeros(self.ny(), dtype=np.int32)
+        n = np.zeros(self.ny(), dtype=np.int32)
+        _lib.check(_lib.Grid_crop_to_domain(self._h, float(west), float(east), float(south), float(north), C.byref(j0),
+                                            C.byref(j1), i0.ctypes.data, n.ctypes.data, int(self.ny())))
+        k = j1.value - j0.value
+        return (j0.value, j1.value), i0[:k].copy(), n[:k].copy()
+
     def ny(self):
         return len(self._nx)
 

@@ -40,7 +40,7 @@ class Trans:
     """trans::Trans(grid, truncation, config) with option::type("local") semantics, running on an MI355X."""
 
     def __init__(self, grid, truncation, profile=False, nparts=1, part=0, legendre_cache=None, shard="m", rows=None,
-                 tables=None):
+                 tables=None, domain=None):
         if isinstance(grid, str):
             grid = StructuredGrid(name=grid)
         self.grid = grid
@@ -53,6 +53,10 @@ class Trans:
             cfg += f";tables={tables}"
         if rows is not None:   # (j0, j1): zonal-band crop of the grid (regional domain that keeps whole latitude rows)
             cfg += f";rows={int(rows[0])}:{int(rows[1])}"
+        if domain is not None:  # (west, east, south, north): trans::Trans(grid, RectangularDomain, truncation)
+            if rows is not None:
+                raise ValueError("give rows= or domain=, not both")
+            cfg += ";domain=" + ",".join(repr(float(v)) for v in domain)
         cache_ptr, cache_size = None, 0
         if legendre_cache is not None:
             self._cache = np.ascontiguousarray(np.frombuffer(legendre_cache, dtype=np.uint8))
@@ -60,6 +64,9 @@ class Trans:
         self._h = _lib.check_ptr(_lib.Trans_new_config(grid._h, int(truncation), cfg.encode(), cache_ptr, cache_size))
         self.nparts, self.part, self.shard = int(nparts), int(part), shard
         self.rows = rows
+        self.domain = domain
+        if domain is not None:
+            self.rows, self.window_first, self.window_count = grid.crop_to_domain(*domain)
 
     def __del__(self):
         h = getattr(self, "_h", None)

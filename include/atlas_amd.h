@@ -100,6 +100,15 @@ atlas_amd_Trans* atlas_amd__Trans__new_config(const atlas_amd_Grid* grid, int tr
 void atlas_amd__Trans__delete(atlas_amd_Trans* t);                           /* atlas__Trans__delete      :55 */
 int atlas_amd__Trans__truncation(const atlas_amd_Trans* t);                  /* atlas__Trans__truncation  :99 */
 int64_t atlas_amd__Trans__nb_gridpoints(const atlas_amd_Trans* t);           /* local band (== global for nparts=1) */
+/* RectangularDomain crop of a global structured grid (atlas::Grid(grid, domain), src/atlas/grid/detail/grid/Structured.cc:
+ * 390-560): the rows [row_begin, row_end) whose latitude lies in [south, north] and per row the run of count[r] points
+ * starting at global index first_index[r] (wrapping around) whose longitude, normalised to [west, west + 360), lies in
+ * [west, east]; bounds inclusive with the reference's tolerance of 1e-6 degrees.  first_index / count may be NULL (rows
+ * only), else they hold at least `capacity` >= row_end - row_begin entries.  A Trans for the crop: config key
+ * "domain=west,east,south,north" of atlas_amd__Trans__new_config (trans::Trans(grid, domain, truncation),
+ * TransLocal.cc:394-470); its grid points are the windows row by row. */
+int atlas_amd__Grid__crop_to_domain(const atlas_amd_Grid* grid, double west, double east, double south, double north,
+                                    int* row_begin, int* row_end, int first_index[], int count[], int capacity);
 int64_t atlas_amd__Trans__nb_gridpoints_global(const atlas_amd_Trans* t);
 int64_t atlas_amd__Trans__nb_spectral_coefficients(const atlas_amd_Trans* t); /* (T+1)(T+2), TransLocal.h:90 */
 

@@ -23,6 +23,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
@@ -103,6 +104,10 @@ public:
 
 private:
     std::string text_;
+};
+// atlas::RectangularDomain({west, east}, {south, north}) in degrees
+struct RectangularDomain {
+    double west, east, south, north;
 };
 namespace option {
 inline Config type(const std::string& t) {  // atlas::option::type
@@ -196,6 +201,17 @@ public:
 
     Trans(const StructuredGrid& grid, int truncation, const Config& config = Config()) {
         h_ = atlas_amd__Trans__new_config(grid.handle(), truncation, config.str().c_str(), nullptr, 0);
+        if (!h_) {
+            detail::raise();
+        }
+    }
+    // trans::Trans(global_grid, domain, truncation, config) (Trans.h, TransLocal.cc:394-470): the rows and the longitude
+    // window of every row that the domain contains; the output holds those points row by row
+    Trans(const StructuredGrid& grid, const RectangularDomain& domain, int truncation, const Config& config = Config()) {
+        char text[160];
+        std::snprintf(text, sizeof(text), "%.17g,%.17g,%.17g,%.17g", domain.west, domain.east, domain.south, domain.north);
+        const Config c = config | Config("domain", std::string(text));
+        h_             = atlas_amd__Trans__new_config(grid.handle(), truncation, c.str().c_str(), nullptr, 0);
         if (!h_) {
             detail::raise();
         }

@@ -174,6 +174,51 @@ static void case_invtrans_analytic(const std::string& gridname) {
     }
 }
 
+// test_transgeneral.cc:751-954 "test_trans_domain": the analytic harmonics on the points of a RectangularDomain crop of O64
+static void case_invtrans_domain_analytic() {
+    const int T = 63;
+    StructuredGrid g("O64");
+    const RectangularDomain domain{-5., 5., -2.5, 0.};   // test_transgeneral.cc:760-762
+    trans::Trans trans(g, domain, T, option::type("local"));
+    const std::vector<int> nx   = g.nx();
+    const std::vector<double> y = g.y();
+    // the points of the crop, from the grid definition: rows with south <= y <= north, longitudes k dx in [west, east]
+    std::vector<std::pair<double, double>> pts;   // (lat, lon) in radians
+    for (int j = 0; j < g.ny(); ++j) {
+        if (y[j] < domain.south - 1e-6 || y[j] > domain.north + 1e-6) continue;
+        const double dx = 360. / nx[j];
+        for (int k = -nx[j]; k <= nx[j]; ++k) {
+            if (k * dx >= domain.west - 1e-6 && k * dx <= domain.east + 1e-6) {
+                pts.push_back({y[j] * M_PI / 180., k * dx * M_PI / 180.});
+            }
+        }
+    }
+    EXPECT(pts.size() == 14 && trans.nb_gridpoints() == pts.size());
+    const int nm[6][2] = {{0, 0}, {1, 0}, {1, 1}, {2, 1}, {3, 2}, {3, 3}};
+    std::vector<std::pair<int, int>> cases;
+    for (int c = 0; c < 6; ++c) {
+        cases.push_back({c, 0});
+        if (nm[c][1] > 0) cases.push_back({c, 1});
+    }
+    const int nf = int(cases.size());
+    std::vector<double> sp(trans.nb_spectral_coefficients() * nf, 0.), gp(pts.size() * nf, -999.);
+    for (int f = 0; f < nf; ++f) {
+        const int n = nm[cases[f].first][0], m = nm[cases[f].first][1];
+        const size_t pos = size_t(2 * T + 3 - m) * m / 2 + (n - m);
+        sp[(2 * pos + cases[f].second) * nf + f] = 1.;
+    }
+    trans.invtrans(nf, sp.data(), gp.data());
+    for (int f = 0; f < nf; ++f) {
+        const int n = nm[cases[f].first][0], m = nm[cases[f].first][1], imag = cases[f].second;
+        std::vector<double> ref, got(gp.begin() + size_t(f) * pts.size(), gp.begin() + size_t(f + 1) * pts.size());
+        for (const auto& pt : pts) {
+            const double P = legendre_closed_form(n, m, pt.first);
+            ref.push_back(imag == 0 ? P * std::cos(m * pt.second) * (m > 0 ? 2. : 1.) : -2. * P * std::sin(m * pt.second));
+        }
+        EXPECT(rel_rms(got, ref) < 1e-13);
+    }
+}
+
 static void case_vordiv2wind_and_not_implemented() {
     const int T = 31;
     StructuredGrid g("F32");
@@ -248,6 +293,7 @@ int main(int argc, char** argv) {
         {"halo_index_logic", case_halo_index_logic, false},
         {"invtrans_analytic_F32", [] { case_invtrans_analytic("F32"); }, true},
         {"invtrans_analytic_O32", [] { case_invtrans_analytic("O32"); }, true},
+        {"invtrans_domain_analytic", case_invtrans_domain_analytic, true},
         {"vordiv2wind_and_not_implemented", case_vordiv2wind_and_not_implemented, true},
         {"halo_exchange_on_structured_columns", case_halo_exchange_on_structured_columns, true},
     };

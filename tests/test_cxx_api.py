@@ -54,7 +54,7 @@ def test_c_header_compiles_as_c(tmp_path):
 def test_cxx_interface_on_device(cxx_binary):
     out = _run(cxx_binary)
     assert "0 failure(s)" in out
-    for case in ("invtrans_analytic_F32", "invtrans_analytic_O32", "vordiv2wind_and_not_implemented",
+    for case in ("invtrans_analytic_F32", "invtrans_analytic_O32", "invtrans_domain_analytic", "vordiv2wind_and_not_implemented",
                  "halo_exchange_on_structured_columns"):
         assert f"ok     {case}" in out
 

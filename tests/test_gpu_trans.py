@@ -579,3 +579,46 @@ def test_a_constructor_that_throws_releases_its_device_memory():
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 64 << 20, (free0, free1)   # plans and row tables of one object are a few MB; 40 leaks would be far more
+
+
+@pytest.mark.parametrize("gridname,T,domain", [("O64", 63, (-5., 5., -2.5, 0.)),      # test_transgeneral.cc:760-767
+                                               ("F32", 31, (0., 90., 0., 90.)),        # :1343
+                                               ("O160", 159, (350., 372., -20., 35.)),
+                                               ("O64", 63, (0., 10., -90., -10.))])   # :1154 (southern hemisphere)
+def test_rectangular_domain_crop_is_the_window_of_the_global_transform(gridname, T, domain):
+    """trans::Trans(global_grid, domain, truncation) (TransLocal.cc:394-470, 1120-1135): the rows inside the domain are
+    transformed at full length and the longitude window is kept, wrapping around.  Must equal, bit for bit, the same
+    points of the global transform; the point list is rebuilt here from the grid definition, not from the library."""
+    g, tr_global = get_trans(gridname, T)
+    nf = 3
+    sp = red_spectra(T, nf, seed=21)
+    ref = run_device(tr_global, nf, sp).reshape(nf, -1)
+    west, east, south, north = domain
+    nx, y = g.nx(), g.y()
+    off = np.concatenate([[0], np.cumsum(nx)])
+    idx = []
+    for j in range(len(nx)):
+        if south - 1e-6 <= y[j] <= north + 1e-6:
+            dx = 360.0 / nx[j]
+            lon = np.arange(-2 * nx[j], 2 * nx[j] + 1) * dx        # more than one period either side
+            k = np.arange(-2 * nx[j], 2 * nx[j] + 1)[(lon >= west - 1e-6) & (lon <= east + 1e-6)][:nx[j]]
+            assert len(k) > 0 and np.all(np.diff(k) == 1)
+            idx.extend(off[j] + (k % nx[j]))
+    idx = np.array(idx)
+    tr = atlas_amd.Trans(g, T, domain=domain)
+    assert tr.nb_gridpoints() == len(idx) and int(tr.window_count.sum()) == len(idx)
+    gp = torch.zeros(nf * len(idx), dtype=torch.float64, device="cuda")
+    tr.invtrans(nf, dev(sp), gp)
+    tr.synchronize()
+    assert np.array_equal(gp.cpu().numpy().reshape(nf, -1), ref[:, idx])
+    # host entry point and the vor/div path on the same crop
+    gp_h = np.zeros(nf * len(idx))
+    tr.invtrans(nf, sp, gp_h)
+    assert np.array_equal(gp_h.reshape(nf, -1), ref[:, idx])
+    ns, nvd = 1, 1
+    s1, vor, div = red_spectra(T, ns, 31), red_spectra(T, nvd, 32), red_spectra(T, nvd, 33)
+    full = np.zeros((ns + 2 * nvd) * g.size())
+    tr_global.invtrans(ns, s1, nvd, vor, div, full)
+    crop = np.zeros((ns + 2 * nvd) * len(idx))
+    tr.invtrans(ns, s1, nvd, vor, div, crop)
+    assert np.array_equal(crop.reshape(ns + 2 * nvd, -1), full.reshape(ns + 2 * nvd, -1)[:, idx])

@@ -321,3 +321,36 @@ def test_classic_reduced_gaussian_grids_by_name():
     assert atlas_amd.Grid("N1280").size() == 8505906 and atlas_amd.Grid("N640").size() == 2140702
     with pytest.raises(Exception):
         atlas_amd.Grid("N17")                                                       # not tabulated
+
+
+def test_rectangular_domain_crop_of_a_global_grid():
+    """atlas::Grid(global_grid, RectangularDomain) (Structured.cc:390-560) through atlas_amd__Grid__crop_to_domain.
+    Expectations derived by hand from the grid definitions: O64 rows 64 / 65 are the latitudes -0.70 / -2.10 with 272 / 268
+    points (dx = 1.3235 / 1.3433 degrees): [-5, 5] holds the points k dx, k = -3..3, i.e. 7 points from index nx - 3."""
+    import atlas_amd
+    g = atlas_amd.Grid("O64")
+    (j0, j1), i0, n = g.crop_to_domain(-5., 5., -2.5, 0.)      # the domain of test_transgeneral.cc:760-767
+    assert (j0, j1) == (64, 66) and list(i0) == [269, 265] and list(n) == [7, 7]
+    assert -2.5 <= g.y()[65] < g.y()[64] <= 0.
+    # a zonal band keeps whole rows from index 0; a full circle that starts at -180 starts at the row's middle point
+    (j0, j1), i0, n = g.crop_to_domain(0., 360., -3., 3.)
+    assert (j0, j1) == (62, 66) and list(i0) == [0] * 4 and list(n) == list(g.nx()[62:66])
+    (j0, j1), i0, n = g.crop_to_domain(-180., 180., 80., 90.)
+    assert j0 == 0 and list(n) == list(g.nx()[:j1]) and list(i0) == [v // 2 for v in g.nx()[:j1]]
+    # inclusive bounds (tolerance 1e-6 degrees, RectangularDomain.cc:99-103): F32 has dx = 2.8125, 90 = 32 dx
+    f = atlas_amd.Grid("F32")
+    (j0, j1), i0, n = f.crop_to_domain(0., 90., 0., 90.)       # the domain of test_transgeneral.cc:1343
+    assert (j0, j1) == (0, 32) and set(i0) == {0} and set(n) == {33}
+    (j0, j1), i0, n = f.crop_to_domain(1e-7, 90. - 1e-7, 0., 90.)
+    assert set(i0) == {0} and set(n) == {33}
+    (j0, j1), i0, n = f.crop_to_domain(1e-4, 90. - 1e-4, 0., 90.)
+    assert set(i0) == {1} and set(n) == {31}
+    # wrap-around across longitude 0 and errors
+    (j0, j1), i0, n = f.crop_to_domain(350., 370., -10., 10.)
+    assert set(i0) == {125} and set(n) == {7}                  # 351.5625 .. 368.4375
+    with pytest.raises(_lib.AtlasAmdError):
+        g.crop_to_domain(0., 10., 0.1, 0.2)                    # no latitude inside
+    with pytest.raises(_lib.AtlasAmdError):
+        g.crop_to_domain(0.3, 0.4, -10., 10.)                  # no point of a row inside
+    with pytest.raises(_lib.AtlasAmdError):
+        g.crop_to_domain(10., 0., -10., 10.)
