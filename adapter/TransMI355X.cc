@@ -10,6 +10,7 @@
 // Registration mirrors TransLocal's (TransLocal.cc:57, builder template detail/TransFactory.h:114-129); the backend is
 // selected with option::type("mi355x") or Trans::backend("mi355x") (TransFactory.cc:228-252); Fortran callers reach it
 // through the unchanged atlas__Trans__* symbols (atlas_Trans_module.F90:156-177,312-334).
+#include <cstdio>
 #include <string>
 #include <vector>
 
@@ -155,20 +156,27 @@ TransMI355X::TransMI355X(const Cache& cache, const Grid& grid, const Domain& dom
     if (!agrid_) {
         throw_Exception(atlas_amd__last_error(), Here());
     }
-    // regional domains that keep whole latitude rows (the nested case of TransLocal.cc:394-470): rows j0..j1-1 of the
-    // global grid; other crops are not supported by this backend
+    // crops of a global grid (the nested case of TransLocal.cc:394-470): the library works out rows and longitude windows
+    // from the domain's bounds with Atlas's own rule (atlas_amd__Grid__crop_to_domain = Structured.cc:390-560); the
+    // cropped grid built above must agree with it
     std::string cfg;
     StructuredGrid gs(grid_);
-    if (gs && gs.ny() != g.ny()) {
-        idx_t j0 = 0;
-        while (j0 < g.ny() && g.y(j0) > gs.y(0) + 1.e-10) {
-            ++j0;
+    if (gs && !domain.global()) {
+        RectangularDomain rd(domain);
+        ATLAS_ASSERT(rd, "the mi355x Trans backend supports rectangular (or zonal band) domains");
+        char text[160];
+        std::snprintf(text, sizeof(text), "domain=%.17g,%.17g,%.17g,%.17g", rd.xmin(), rd.xmax(), rd.ymin(), rd.ymax());
+        cfg = text;
+        int j0 = 0, j1 = 0;
+        std::vector<int> i0(g.ny()), cnt(g.ny());
+        if (atlas_amd__Grid__crop_to_domain(agrid_, rd.xmin(), rd.xmax(), rd.ymin(), rd.ymax(), &j0, &j1, i0.data(), cnt.data(),
+                                            int(g.ny())) != 0) {
+            throw_Exception(atlas_amd__last_error(), Here());
         }
-        ATLAS_ASSERT(j0 + gs.ny() <= g.ny(), "cropped domain is not a row range of the global grid");
+        ATLAS_ASSERT(j1 - j0 == gs.ny(), "row range of the crop differs from Grid(grid, domain)");
         for (idx_t j = 0; j < gs.ny(); ++j) {
-            ATLAS_ASSERT(gs.nx(j) == g.nx(j0 + j), "the mi355x backend supports crops that keep whole rows only");
+            ATLAS_ASSERT(gs.nx(j) == cnt[j], "longitude window of the crop differs from Grid(grid, domain)");
         }
-        cfg = "rows=" + std::to_string(j0) + ":" + std::to_string(j0 + gs.ny());
     }
     const void* blob = cache.legendre() ? cache.legendre().data() : nullptr;   // trans/Cache.h:98-136
     const size_t len = cache.legendre() ? cache.legendre().size() : 0;
