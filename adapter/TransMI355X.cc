@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "atlas/array.h"
+#include "atlas/domain.h"
 #include "atlas/field/Field.h"
 #include "atlas/field/FieldSet.h"
 #include "atlas/functionspace/Spectral.h"

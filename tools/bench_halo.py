@@ -35,10 +35,31 @@ for nparts, halo in ((4, 1), (8, 1), (8, 2), (1, 2)):
         return (time.perf_counter() - t0) / reps
     tp = timed(lambda: hx.pack(field, sbuf))
     tu = timed(lambda: hx.unpack(rbuf, field))
+    # cold calls: the touched rows of the warm loop above (tens of MB) sit in the 256 MiB Infinity Cache; before every
+    # timed call a 1 GiB buffer is overwritten (evicts L2 and the Infinity Cache), the call is timed alone with events
+    flush = torch.empty(1 << 27, dtype=torch.float64, device="cuda")
+    def cold(fn, reps=9):
+        ts = []
+        for i in range(reps):
+            flush.fill_(float(i))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e-3)
+        return float(np.median(ts))
+    cp = cold(lambda: hx.pack(field, sbuf))
+    cu = cold(lambda: hx.unpack(rbuf, field))
+    del flush
     rec = {"grid": grid, "levels": lev, "nparts": nparts, "part": part, "halo": halo, "size_owned": fs.sizeOwned(),
            "size_halo": fs.sizeHalo(), "send_nodes": nsend, "recv_nodes": nrecv,
            "pack_us": tp * 1e6, "unpack_us": tu * 1e6,
-           "pack_GBs": 2 * nsend * lev * 8 / tp / 1e9, "unpack_GBs": 2 * nrecv * lev * 8 / tu / 1e9}
+           "pack_GBs": 2 * nsend * lev * 8 / tp / 1e9, "unpack_GBs": 2 * nrecv * lev * 8 / tu / 1e9,
+           "cold_pack_us": cp * 1e6, "cold_unpack_us": cu * 1e6,
+           "cold_pack_GBs": 2 * nsend * lev * 8 / cp / 1e9, "cold_unpack_GBs": 2 * nrecv * lev * 8 / cu / 1e9,
+           "note": "warm = 20 back-to-back calls on the same field (cache-resident rows); cold = median of 9 single calls, "
+                   "each after a 1 GiB overwrite; bytes = 2 x packed bytes (read + write)"}
     out.append(rec)
     print(json.dumps(rec), flush=True)
     del fss, hxs
