@@ -170,6 +170,24 @@ int atlas_amd__Trans__invtrans_distributed_many(atlas_amd_Trans* t, atlas_amd_Co
     dist_of(t, c).invtrans_many(ntransforms, nb_fields, sp_dev, gp_dev);
     DX_CATCH
 }
+int atlas_amd__Trans__invtrans_distributed_many_halo(atlas_amd_Trans* t, atlas_amd_Comm* c, int ntransforms, int nb_fields,
+                                                     const double* const* sp_dev, double* const* gp_dev,
+                                                     atlas_amd_HaloExchange* hx, double* const* field_dev) {
+    DX_TRY
+    if (ntransforms > 0 && (!sp_dev || !gp_dev || !field_dev)) {
+        throw std::invalid_argument("invtrans_distributed_many_halo: null arrays");
+    }
+    if (!hx) {
+        throw std::invalid_argument("invtrans_distributed_many_halo: null halo exchange");
+    }
+    for (int i = 1; i < ntransforms; ++i) {
+        if (gp_dev[i] == gp_dev[i - 1] || field_dev[i] == field_dev[i - 1]) {
+            throw std::invalid_argument("invtrans_distributed_many_halo: consecutive transforms need distinct output buffers");
+        }
+    }
+    dist_of(t, c).invtrans_many_halo(ntransforms, nb_fields, sp_dev, gp_dev, hx->impl, field_dev);
+    DX_CATCH
+}
 int atlas_amd__Trans__set_max_message_bytes(atlas_amd_Trans* t, atlas_amd_Comm* c, long long bytes) {
     DX_TRY
     if (bytes < 8) {

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "comm.h"
+#include "halo_exchange.h"
 #include "trans.h"
 
 namespace atlas_amd {
@@ -53,6 +54,12 @@ public:
     // Trans stream.
     void invtrans(int nb_fields, const double* sp_dev, double* gp_dev);
     void invtrans_many(int ntransforms, int nb_fields, const double* const* sp_dev, double* const* gp_dev);
+    // invtrans_many + per transform, on the communication stream (i.e. beside the Legendre stage of the transforms that
+    // follow): its grid points transposed into the owned part of a StructuredColumns field [size_halo][nb_fields] whose
+    // partition is this rank's latitude band, then that field's halo exchange between the ranks (HaloExchange.h:191-219).
+    // The Trans stream waits for the last exchange.
+    void invtrans_many_halo(int ntransforms, int nb_fields, const double* const* sp_dev, double* const* gp_dev,
+                            parallel::HaloExchange& hx, double* const* field_dev);
     hipStream_t comm_stream() const { return comm_stream_; }
     int64_t max_message_elems = int64_t(1) << 26;   // 512 MiB of doubles
 
@@ -67,6 +74,7 @@ private:
     void legendre(int nb_fields, const double* sp_dev, Slot& s);
     void exchange(Slot& s);
     void fourier(int nb_fields, Slot& s, double* gp_dev);
+    void halo(int nb_fields, Slot& s, const double* gp_dev, parallel::HaloExchange& hx, double* field_dev);
 
     Trans& trans_;
     parallel::Comm& comm_;

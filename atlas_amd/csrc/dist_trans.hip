@@ -185,5 +185,44 @@ void DistributedTrans::invtrans_many(int ntransforms, int nb_fields, const doubl
     fourier(nb_fields, slot_[(ntransforms - 1) & 1], gp_dev[ntransforms - 1]);
 }
 
+hipError_t launch_gp_to_field(const double* gp, double* field, long long npts, int nf, hipStream_t stream);
+
+void DistributedTrans::halo(int nb_fields, Slot& s, const double* gp_dev, parallel::HaloExchange& hx, double* field_dev) {
+    HIP_CHECK(hipStreamWaitEvent(comm_stream_, s.fourier_done, 0));
+    const long long npts = trans_.nb_gridpoints();
+    HIP_CHECK(launch_gp_to_field(gp_dev, field_dev, npts, nb_fields, comm_stream_));
+    const int shape[2]         = {hx.plan().parsize, nb_fields};
+    const long long strides[2] = {nb_fields, 1};
+    hx.execute_comm_on(comm_, parallel::HALO_DOUBLE, field_dev, hx.describe(2, shape, strides, 0), false, comm_stream_);
+}
+
+void DistributedTrans::invtrans_many_halo(int ntransforms, int nb_fields, const double* const* sp_dev, double* const* gp_dev,
+                                          parallel::HaloExchange& hx, double* const* field_dev) {
+    if (ntransforms <= 0 || nb_fields <= 0) {
+        return;
+    }
+    if (!hx.is_setup() || hx.plan().parsize < trans_.nb_gridpoints()) {
+        throw std::invalid_argument("invtrans_many_halo: the halo exchange must be set up on a partition that owns this rank's band");
+    }
+    ensure(nb_fields);
+    // Trans stream:  L(0) | L(1) F(0) | L(2) F(1) | ...           communication stream:  X(0) | X(1) H(0) | X(2) H(1) | ...
+    // H(i-1) waits for F(i-1), which precedes L(i+1) on the Trans stream: the exchange runs beside that Legendre stage.
+    for (int i = 0; i < ntransforms; ++i) {
+        Slot& s = slot_[i & 1];
+        legendre(nb_fields, sp_dev[i], s);
+        exchange(s);
+        if (i > 0) {
+            fourier(nb_fields, slot_[(i - 1) & 1], gp_dev[i - 1]);
+            halo(nb_fields, slot_[(i - 1) & 1], gp_dev[i - 1], hx, field_dev[i - 1]);
+        }
+    }
+    Slot& last = slot_[(ntransforms - 1) & 1];
+    fourier(nb_fields, last, gp_dev[ntransforms - 1]);
+    halo(nb_fields, last, gp_dev[ntransforms - 1], hx, field_dev[ntransforms - 1]);
+    // the call completes on the Trans stream
+    HIP_CHECK(hipEventRecord(last.exchange_done, comm_stream_));
+    HIP_CHECK(hipStreamWaitEvent(trans_.stream(), last.exchange_done, 0));
+}
+
 }  // namespace trans
 }  // namespace atlas_amd

@@ -55,6 +55,9 @@ public:
     // adjoint :227-290): pack kernel -> one grouped send/recv per peer with counts and displacements scaled by var_size
     // (:318-331) -> unpack kernel, all asynchronous on stream().  A transform running on another stream overlaps it.
     void execute_comm(Comm& comm, int dtype, void* field, const HaloFieldDesc& d, bool adjoint);
+    // the same on a stream of the caller's (a driver that orders the exchange itself, e.g. behind a transform's Fourier
+    // stage); the object's scratch buffers are in use until that stream has passed the call
+    void execute_comm_on(Comm& comm, int dtype, void* field, const HaloFieldDesc& d, bool adjoint, hipStream_t s);
     // host-pointer variants: stage the field through device memory (synchronous)
     void execute_host(int dtype, void* field, int rank, const int shape[], const long long strides[],
                       int parallel_dim, bool adjoint);

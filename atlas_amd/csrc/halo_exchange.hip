@@ -317,6 +317,16 @@ void HaloExchange::execute_comm(Comm& comm, int dtype, void* field, const HaloFi
     }
 }
 
+void HaloExchange::execute_comm_on(Comm& comm, int dtype, void* field, const HaloFieldDesc& d, bool adjoint, hipStream_t s) {
+    struct Swap {   // the kernels and the exchange below launch on stream_
+        hipStream_t& ref;
+        hipStream_t keep;
+        Swap(hipStream_t& r, hipStream_t s) : ref(r), keep(r) { ref = s; }
+        ~Swap() { ref = keep; }
+    } swap(stream_, s);
+    execute_comm(comm, dtype, field, d, adjoint);
+}
+
 void HaloExchange::execute_host(int dtype, void* field, int rank, const int shape[], const long long strides[],
                                 int parallel_dim, bool adjoint) {
     if (!plan_.finished) {

@@ -200,6 +200,38 @@ __global__ void __launch_bounds__(256) window_crop_kernel(const double* __restri
     }
 }
 
+// ---- grid points of a band, field-major [nf][npts], into the owned part of a StructuredColumns field [point][nf]
+// (the layout of a levels field on the function space): tiled transpose through LDS, HBM-bound
+__global__ void __launch_bounds__(256) gp_to_field_kernel(const double* __restrict__ gp, double* __restrict__ field, long long npts,
+                                                          int nf) {
+    __shared__ double tile[32][33];
+    const long long p0 = (long long)blockIdx.x * 32;
+    const int f0       = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) {   // rows = fields, columns = points (contiguous in gp)
+        const int f       = f0 + r;
+        const long long p = p0 + tx;
+        tile[r][tx]       = (f < nf && p < npts) ? gp[(long long)f * npts + p] : 0.;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {   // rows = points, columns = fields (contiguous in field)
+        const long long p = p0 + r;
+        const int f       = f0 + tx;
+        if (p < npts && f < nf) {
+            field[p * nf + f] = tile[tx][r];
+        }
+    }
+}
+
+hipError_t launch_gp_to_field(const double* gp, double* field, long long npts, int nf, hipStream_t stream) {
+    if (npts <= 0 || nf <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(gp_to_field_kernel, dim3((unsigned)((npts + 31) / 32), (unsigned)((nf + 31) / 32)), dim3(256), 0, stream, gp,
+                       field, npts, nf);
+    return hipGetLastError();
+}
+
 hipError_t launch_window_crop(const double* full, double* out, const long long* rowoff, const int* win_i0, const int* win_n,
                               const long long* win_off, int nrows, long long npts_full, long long npts_out, int f_begin,
                               int f_end, hipStream_t stream) {

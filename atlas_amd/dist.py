@@ -29,6 +29,8 @@ c_void_p, c_int = C.c_void_p, C.c_int
 _sig = _lib._sig
 Trans_invtrans_distributed = _sig("atlas_amd__Trans__invtrans_distributed", c_int, c_void_p, c_void_p, c_int, c_void_p,
                                   c_void_p)
+Trans_invtrans_distributed_many_halo = _sig("atlas_amd__Trans__invtrans_distributed_many_halo", c_int, c_void_p, c_void_p,
+                                           c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p)
 Trans_invtrans_distributed_many = _sig("atlas_amd__Trans__invtrans_distributed_many", c_int, c_void_p, c_void_p, c_int,
                                        c_int, c_void_p, c_void_p)
 Trans_set_max_message_bytes = _sig("atlas_amd__Trans__set_max_message_bytes", c_int, c_void_p, c_void_p, C.c_longlong)
@@ -108,3 +110,17 @@ class DistributedTrans:
         with _lib.torch_stream_order(self.trans.stream()):
             _lib.check(Trans_invtrans_distributed_many(self.trans._h, self.comm._h, n, int(nf), spp, gpp))
         return gps
+
+    def invtrans_many_halo(self, nf, sps, gps, hx, fields):
+        """invtrans_many whose outputs also go, transposed, into the StructuredColumns fields `fields[i]` of shape
+        (size_halo, nf) on this rank's band partition, followed by their halo exchange (`hx`: a parallel.HaloExchange set up
+        on the same communicator) -- on the communication stream, beside the Legendre stage of the next transforms."""
+        if self.mode != "alltoall":
+            raise NotImplementedError("invtrans_many_halo needs the wavenumber-sharded decomposition")
+        n = len(sps)
+        spp = (c_void_p * n)(*[s.data_ptr() for s in sps])
+        gpp = (c_void_p * n)(*[g.data_ptr() for g in gps])
+        fpp = (c_void_p * n)(*[f.data_ptr() for f in fields])
+        with _lib.torch_stream_order(self.trans.stream()):
+            _lib.check(Trans_invtrans_distributed_many_halo(self.trans._h, self.comm._h, n, int(nf), spp, gpp, hx._h, fpp))
+        return fields

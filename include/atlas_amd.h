@@ -331,6 +331,16 @@ int atlas_amd__Trans__invtrans_distributed(atlas_amd_Trans* t, atlas_amd_Comm* c
                                            double* gp_dev);
 int atlas_amd__Trans__invtrans_distributed_many(atlas_amd_Trans* t, atlas_amd_Comm* comm, int ntransforms, int nb_fields,
                                                 const double* const* sp_dev, double* const* gp_dev);
+/* invtrans_distributed_many + per transform, on the library's communication stream -- i.e. beside the Legendre stage of
+ * the transforms that follow: the band's grid points transposed into the owned part of field_dev[i], a StructuredColumns
+ * field [size_halo][nb_fields] of doubles on the partition that owns this rank's latitude band (the row_bands distribution
+ * of the same number of parts), and that field's halo exchange between the ranks (parallel::HaloExchange::execute,
+ * HaloExchange.h:191-219).  hx must have been set up with atlas_amd__HaloExchange__setup_comm on the same communicator.
+ * Consecutive transforms need distinct gp_dev / field_dev buffers (reuse with period two is ordered by the pipeline).
+ * Asynchronous: complete when the Trans stream is (atlas_amd__Trans__synchronize). */
+int atlas_amd__Trans__invtrans_distributed_many_halo(atlas_amd_Trans* t, atlas_amd_Comm* c, int ntransforms, int nb_fields,
+                                                     const double* const* sp_dev, double* const* gp_dev,
+                                                     atlas_amd_HaloExchange* hx, double* const* field_dev);
 int atlas_amd__Trans__set_max_message_bytes(atlas_amd_Trans* t, atlas_amd_Comm* comm, long long bytes);
 /* the messages of the transposition for rank `part` (test hook): offsets in doubles into the rank's intermediate and
  * into its receive buffer */

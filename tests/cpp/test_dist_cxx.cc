@@ -52,7 +52,8 @@ struct RankResult {
 };
 
 static void run_rank(atlas_amd_Comm* comm, const atlas_amd_Grid* grid, int T, int nf, const std::vector<double>& sp_a,
-                     const std::vector<double>& sp_b, RankResult* out) {
+                     const std::vector<double>& sp_b, const std::vector<double>& ref_a, const std::vector<double>& ref_b,
+                     RankResult* out) {
     const int P = atlas_amd__Comm__size(comm), r = atlas_amd__Comm__rank(comm);
     const std::string cfg = "nparts=" + std::to_string(P) + ";part=" + std::to_string(r) + ";shard=m";
     atlas_amd_Trans* t    = atlas_amd__Trans__new_config(grid, T, cfg.c_str(), nullptr, 0);
@@ -126,6 +127,42 @@ static void run_rank(atlas_amd_Comm* comm, const atlas_amd_Grid* grid, int T, in
         }
         out->halo_ok = ok;
         EXPECT(ok);
+        // ---- three transforms (a, b, a) whose outputs go straight into StructuredColumns fields [size_halo][nf] with
+        // their halo exchange, in one pipelined call: owned part = this band's grid points, halo part = the owner's
+        // values, i.e. the global transform at the node's global index
+        {
+            const int64_t npts_g = atlas_amd__Grid__size(grid);
+            double* d_gpc = (double*)atlas_amd__device_malloc((size_t)npt * nf * 8);
+            double* d_fld[3];
+            for (double*& f : d_fld) {
+                f = (double*)atlas_amd__device_malloc((size_t)n * nf * 8);
+                EXPECT(f != nullptr);
+            }
+            const double* sps[3] = {d_spa, d_spb, d_spa};
+            double* gps[3]       = {d_gpa, d_gpb, d_gpc};
+            EXPECT(atlas_amd__Trans__invtrans_distributed_many_halo(t, comm, 3, nf, sps, gps, hx, d_fld) == 0);
+            EXPECT(atlas_amd__Trans__synchronize(t) == 0);
+            std::vector<double> fld((size_t)n * nf);
+            bool fields_ok = true;
+            for (int k = 0; k < 3; ++k) {
+                const std::vector<double>& ref = k == 1 ? ref_b : ref_a;
+                EXPECT(atlas_amd__device_memcpy_d2h(fld.data(), d_fld[k], fld.size() * 8) == 0);
+                for (int i = 0; i < n && fields_ok; ++i) {
+                    for (int f = 0; f < nf; ++f) {
+                        fields_ok = fields_ok && fld[(size_t)i * nf + f] == ref[(size_t)f * npts_g + (gidx[i] - 1)];
+                    }
+                }
+            }
+            EXPECT(fields_ok);
+            out->halo_ok = out->halo_ok && fields_ok;
+            // the same buffer for consecutive transforms is refused
+            double* same[2] = {d_gpa, d_gpa};
+            EXPECT(atlas_amd__Trans__invtrans_distributed_many_halo(t, comm, 2, nf, sps, same, hx, d_fld) != 0);
+            for (double* f : d_fld) {
+                atlas_amd__device_free(f);
+            }
+            atlas_amd__device_free(d_gpc);
+        }
         atlas_amd__device_free(d_f);
         atlas_amd__HaloExchange__delete(hx);
         atlas_amd__StructuredColumns__delete(fs);
@@ -193,7 +230,8 @@ int main(int argc, char** argv) {
         std::vector<RankResult> res(P);
         std::vector<std::thread> th;
         for (int r = 0; r < P; ++r) {
-            th.emplace_back(run_rank, comms[r], grid, T, nf, std::cref(sp_a), std::cref(sp_b), &res[r]);
+            th.emplace_back(run_rank, comms[r], grid, T, nf, std::cref(sp_a), std::cref(sp_b), std::cref(ref_a), std::cref(ref_b),
+                            &res[r]);
         }
         for (auto& t : th) {
             t.join();
@@ -213,7 +251,7 @@ int main(int argc, char** argv) {
         if (c) {
             EXPECT(std::string(atlas_amd__Comm__kind(c)) == "rccl");
             std::vector<RankResult> res(1);
-            run_rank(c, grid, T, nf, sp_a, sp_b, &res[0]);
+            run_rank(c, grid, T, nf, sp_a, sp_b, ref_a, ref_b, &res[0]);
             check_bands(res, "distributed transform + halo exchange, 1 rank over RCCL");
             atlas_amd__Comm__delete(c);
         }
