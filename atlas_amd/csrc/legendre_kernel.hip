@@ -623,6 +623,289 @@ static hipError_t launch_lean(LegendreParams p, int nitems, int nchunks, int chu
     return hipGetLastError();
 }
 
+// ---- legendre_kernel<3, 2, double> with both operands staged by LDS-DMA -------------------------------------------------
+// Same tiling, MFMA roles and summation order as legendre_kernel<3, 2> (bit-identical results).  No staging registers and no
+// staging instructions besides two or three global_load_lds_dwordx4 per wavefront and stage:
+//   * table: wavefront w moves rows 2w, 2w+1 of the stage tile [2 parities x 8 wavenumbers][64 latitudes];
+//   * spectra: the stage tile [16 rows][96 columns] in 16-byte units.  Real and imaginary part of a field lie nf doubles
+//     apart in memory, neighbouring fields of the same part are contiguous: the columns of the tile are the real parts of
+//     the chunk's 48 fields followed by their imaginary parts, so that consecutive lanes of a DMA instruction read
+//     consecutive memory (interleaved runs are not coalesced: 1.2 ms of MFMA time for this launch).  Column group rg of the
+//     workgroup then holds part rg, and the epilogue stores every other double of F.  A unit
+//     whose second field does not exist (odd nf) reads 8 bytes into the following run, which is inside the array (the last
+//     wavenumber's block is never transformed, TransLocal.cc:982) and lands in a padding column.
+// Rings of 4 stage slots for each operand (80 KB per workgroup, 2 workgroups per CU), requested three stages ahead, rows of
+// exactly 64 / 96 doubles with the 16-element groups of odd rows swapped pairwise (conflict-free fragment reads, see the
+// role-split kernel below).  LDS reads are inline asm with immediate offsets: the compiler, which drains vmcnt before any
+// LDS access of a wavefront with LDS-DMA in flight, does not see them; waits are counted by hand; barriers are raw.
+__global__ void __launch_bounds__(512, 4) legendre_kernel_dma(LegendreParams p) {
+    using RT = RealTraits<double>;
+    using acc_t = typename RT::acc_t;
+    constexpr int RTW = 3, KS = 8, RING = 4, SC = 96;
+    constexpr int P_SLOT = 2 * KS * BN;          // doubles
+    constexpr int S_SLOT = 2 * KS * SC;
+    constexpr int S_BASE = RING * P_SLOT;
+
+    const int nchunks   = p.nchunks_run;
+    const int bx        = blockIdx.x & 7;
+    const int bq        = blockIdx.x >> 3;
+    const int chunk     = p.chunk0 + bq % nchunks;
+    const int item_slot = (bq / nchunks) * 8 + bx;
+    if (item_slot >= p.nitems) {
+        return;
+    }
+    const LegendreItemDev it = p.items[item_slot];
+    if (it.m < 0) {
+        return;
+    }
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lt   = wave & 3;
+    const int rg   = wave >> 2;
+    const int m    = it.m;
+    const int nf   = p.nf;
+    const int trc  = p.trc_in;
+    const int r0   = chunk * SC;
+    const int TL   = p.T + 1;
+    const int ntop0 = TL - ((TL - m) & 1);
+    const int ntop1 = TL - 1 + ((TL - m) & 1);
+    const int nmax  = trc < TL ? trc : TL;
+    const bool m_ok = m < trc;
+    const long long ioff = (long long)(2 * trc + 3 - m) * m / 2 * nf * 2;
+    const double* __restrict__ sp = p.sp + ioff;
+    const double* __restrict__ Pb = p.P + it.p_off;
+    const int kpad   = it.kpad;
+    const int nstage = kpad / KS;
+
+    // ---- staging: this wavefront's DMA instructions of a stage ----
+    // table rows 2 wave, 2 wave + 1: lane l delivers row 2 wave + (l >> 5), LDS doubles 2 (l & 31) .. of it, i.e. latitudes
+    // c, c + 1 with c = 2 (l & 31) ^ (16 on the odd row)
+    const unsigned pvo = 8u * (unsigned)((lane >> 5) * BN + ((2 * (lane & 31)) ^ ((lane >> 5) << 4)));
+    const int ppar = wave >> 2, pk0 = (2 * wave) & 7;
+    const double* pbase = Pb + ((long long)ppar * kpad + pk0) * BN;   // + s KS BN per stage (requested in order)
+    // spectra instruction d = 3 a + cc covers units 64 d .. 64 d + 63 of [16 rows][48 units]: rows 4 a .. 4 a + 3
+    auto spectra_lane_offset = [&](int cc) {   // bytes from the lowest-wavenumber row (local row 3) of the row group
+        const int e    = 64 * cc + lane;
+        const int rl   = e / 48, up = e - rl * 48;            // local row 0..3, physical unit
+        const int cl   = (((up >> 3) ^ (rl & 1)) << 4) + ((2 * up) & 15);   // logical column (even)
+        int f          = (r0 >> 1) + cl % 48;                 // columns 0..47: real parts of 48 fields, 48..95: imaginary parts
+        const int im   = cl / 48;
+        f              = f < nf ? f : nf - 1;
+        return 8u * (unsigned)((3 - rl) * 4 * nf + im * nf + f);
+    };
+    auto spectra_lane_row = [&](int cc) { return (64 * cc + lane) / 48; };
+    const int sd0 = wave, sd1 = wave + 8;                     // instructions of this wavefront (sd1 only for wave < 4)
+    const bool two = wave < 4;
+    const unsigned svo0 = spectra_lane_offset(sd0 % 3), svo1 = spectra_lane_offset(sd1 % 3);
+    const int srl0 = spectra_lane_row(sd0 % 3), srl1 = spectra_lane_row(sd1 % 3);
+    const long long sstride = (long long)4 * KS * nf;         // doubles per stage (2 KS wavenumbers down)
+    // lowest wavenumber of row group a (rows 4a .. 4a+3 of the tile) in stage 0; its row base; requested in order
+    auto group_nlow0 = [&](int a) { return ((a >> 1) ? ntop1 : ntop0) - 2 * (4 * (a & 1) + 3); };
+    int nlow0 = group_nlow0(sd0 / 3), nlow1 = group_nlow0(sd1 / 3);
+    const double* sb0 = sp + (long long)(nlow0 - m) * 2 * nf;
+    const double* sb1 = sp + (long long)(nlow1 - m) * 2 * nf;
+    int issued = 0;   // stages requested so far
+
+    auto dma_saddr = [&](unsigned voff, const double* base, unsigned lds_bytes) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds_bytes) : "memory");
+    };
+    auto dma_vaddr = [&](const void* addr, unsigned lds_bytes) {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(addr), "s"(lds_bytes) : "memory");
+    };
+    auto spectra_dma = [&](int s, int d, unsigned voff, int rl, const double* base, int nlow_s0, unsigned slot_bytes) {
+        const int nlow = nlow_s0 - 2 * KS * s;
+        const unsigned dst = slot_bytes + (unsigned)(d * 1024);
+        if (m_ok && nlow >= m && nlow + 6 <= nmax) {   // uniform: the four rows of the group lie inside [m, nmax]
+            dma_saddr(voff, base, dst);
+        }
+        else {
+            const int n      = nlow + 2 * (3 - rl);
+            const bool valid = m_ok && n >= m && n <= nmax;
+            const char* a    = valid ? reinterpret_cast<const char*>(base) + voff : reinterpret_cast<const char*>(p.zero);
+            dma_vaddr(a, dst);
+        }
+    };
+    auto issue_stage = [&](int s) {   // s == issued
+        const unsigned ring = (unsigned)(s & (RING - 1));
+        if (!(p.abl & 2)) {
+            dma_saddr(pvo, pbase, 8u * (ring * P_SLOT + (unsigned)(2 * wave * BN)));
+        }
+        if (!(p.abl & 4)) {
+            spectra_dma(s, sd0, svo0, srl0, sb0, nlow0, 8u * (S_BASE + ring * S_SLOT));
+            if (two) {
+                spectra_dma(s, sd1, svo1, srl1, sb1, nlow1, 8u * (S_BASE + ring * S_SLOT));
+            }
+        }
+        pbase += KS * BN;
+        sb0 -= sstride;
+        sb1 -= sstride;
+        issued = s + 1;
+    };
+    // this wavefront's DMAs of stage t have landed when at most those of the stages requested after t are outstanding
+    auto wait_landed = [&](int t) {
+        const int later = issued - 1 - t;
+        if (two) {
+            if (later >= 2) {
+                AA_WAIT_VMCNT(6);
+            }
+            else if (later == 1) {
+                AA_WAIT_VMCNT(3);
+            }
+            else {
+                AA_WAIT_VMCNT(0);
+            }
+        }
+        else {
+            if (later >= 2) {
+                AA_WAIT_VMCNT(4);
+            }
+            else if (later == 1) {
+                AA_WAIT_VMCNT(2);
+            }
+            else {
+                AA_WAIT_VMCNT(0);
+            }
+        }
+    };
+
+    acc_t acc[2][RTW];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < RTW; ++j) acc[q][j] = acc_t{0, 0, 0, 0};
+    const int x        = (lane >> 4) & 1;
+    const unsigned a_b = 8u * (unsigned)((lane >> 4) * BN + ((lt ^ x) << 4) + (lane & 15));
+    unsigned b_b[RTW];
+#pragma unroll
+    for (int j = 0; j < RTW; ++j) {
+        b_b[j] = 8u * (unsigned)(S_BASE + (lane >> 4) * SC + (((rg * RTW + j) ^ x) << 4) + (lane & 15));
+    }
+    const bool lat_active = lt * 16 < it.nrows;
+
+    auto mma_steps = [&](auto slotc) {
+        constexpr int SLOT = decltype(slotc)::value;
+        constexpr int NKS  = KS / 4;
+        double a[2], b[2][RTW];
+        auto fetch = [&](int t, int set) {
+            const int par = t / NKS, ks = t % NKS;
+            const unsigned ab = a_b;
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a[set]) : "v"(ab), "n"((SLOT * P_SLOT + (par * KS + ks * 4) * BN) * 8) : "memory");
+#pragma unroll
+            for (int j = 0; j < RTW; ++j) {
+                const unsigned bb = b_b[j];
+                asm volatile("ds_read_b64 %0, %1 offset:%2"
+                             : "=v"(b[set][j])
+                             : "v"(bb), "n"((SLOT * S_SLOT + (par * KS + ks * 4) * SC) * 8)
+                             : "memory");
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int t = 0; t < 2 * NKS; ++t) {
+            if (t + 1 < 2 * NKS) {
+                fetch(t + 1, (t + 1) & 1);
+                __builtin_amdgcn_s_waitcnt((15) | (3 << 14) | (7 << 4) | ((1 + RTW) << 8));   // lgkmcnt(1 + RTW)
+            }
+            else {
+                AA_WAIT_LGKMCNT0();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < RTW; ++j) {
+                acc[t / NKS][j] = RT::mma(a[t & 1], b[t & 1][j], acc[t / NKS][j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    for (int t = 0; t < 3 && t < nstage; ++t) {
+        issue_stage(t);
+    }
+    wait_landed(0);
+    __builtin_amdgcn_s_barrier();   // stage 0 is in LDS
+    auto run_stage = [&](int s, auto slotc) {
+        if (s + 3 < nstage) {
+            issue_stage(s + 3);     // slot (s + 3) % 4 was read during stage s - 1
+        }
+        if (lat_active) {
+            mma_steps(slotc);
+        }
+        if (s + 1 < nstage) {
+            wait_landed(s + 1);
+        }
+        __builtin_amdgcn_s_barrier();
+    };
+    for (int s = 0; s < nstage; s += 4) {
+        run_stage(s, std::integral_constant<int, 0>{});
+        if (s + 1 < nstage) {
+            run_stage(s + 1, std::integral_constant<int, 1>{});
+        }
+        if (s + 2 < nstage) {
+            run_stage(s + 2, std::integral_constant<int, 2>{});
+        }
+        if (s + 3 < nstage) {
+            run_stage(s + 3, std::integral_constant<int, 3>{});
+        }
+    }
+
+    // ---- epilogue: merge hemispheres and store; column c of the tile is field 2 (c / 4) + (c & 1), part (c >> 1) & 1 ----
+    const int nlats  = p.nlats;
+    const int jleg0  = p.nlat0[m] + it.tile * BN;
+    const long long RP = p.RP;
+    const int ml       = m / p.m_div;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int c = lt * 16 + RT::row_of(lane, g);
+        if (c < it.nrows) {
+            const int jn = jleg0 + c;
+            const int js = nlats - 1 - jn;
+            const bool st_n = jn != js && jn >= p.row_begin && jn < p.row_end;
+            const bool st_s = js >= p.row_begin && js < p.row_end;
+            double* fn     = p.F + ((long long)(jn - p.row_begin) * p.m_cnt + ml) * RP;
+            double* fs     = p.F + ((long long)(js - p.row_begin) * p.m_cnt + ml) * RP;
+#pragma unroll
+            for (int j = 0; j < RTW; ++j) {
+                const int r  = r0 + 2 * (16 * j + (lane & 15)) + rg;   // column group rg holds part rg of fields 16 j + ..
+                if (r < RP) {
+                    double sy = acc[0][j][g], as = acc[1][j][g];
+                    if ((m == 0 && (r & 1)) || r >= 2 * nf) {   // n_imag = 1 for m = 0; padding columns hold zeros
+                        sy = 0;
+                        as = 0;
+                    }
+                    if (st_n) {
+                        fn[r] = sy + as;
+                    }
+                    if (st_s) {
+                        fs[r] = sy - as;
+                    }
+                }
+            }
+        }
+    }
+}
+
+static hipError_t launch_dma(LegendreParams p, int nitems, int nchunks, int chunk0, int nrun, hipStream_t stream) {
+    constexpr int BYTES = 4 * (2 * 8 * BN + 2 * 8 * 96) * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&legendre_kernel_dma),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+        if (e != hipSuccess) {
+            return e;
+        }
+        attr_set = true;
+    }
+    p.nitems        = nitems;
+    p.nchunks       = nchunks;
+    p.chunk0        = chunk0;
+    p.nchunks_run   = nrun;
+    p.abl           = std::getenv("ATLAS_AMD_LEG_ABLATE") ? atoi(std::getenv("ATLAS_AMD_LEG_ABLATE")) : 0;
+    const int slots = (nitems + 7) / 8;
+    hipLaunchKernelGGL(legendre_kernel_dma, dim3(slots * nrun * 8), dim3(512), BYTES, stream, p);
+    return hipGetLastError();
+}
+
 // ---- role-split variant for the 96-column workgroup (RTW = 3, NRG = 2, fp64) ------------------------------------------
 // Same tiling, MFMA roles and summation order as legendre_kernel<3, 2> (results are bit-identical), different division of
 // labour: the workgroup has 10 wavefronts, 8 that only read fragments from LDS and issue MFMAs, and 2 that only stage.
@@ -1164,6 +1447,9 @@ hipError_t launch_legendre(const LegendreParams& p, int nitems, int chunk0, int 
         }
         if (k == "split") {
             return launch_v2<8, 4>(p, nitems, nchunks, chunk0, nrun, stream);
+        }
+        if (k == "dma") {
+            return launch_dma(p, nitems, nchunks, chunk0, nrun, stream);
         }
     }
     return launch_legendre_t<double>(p, nitems, chunk0, nrun, stream);

@@ -524,10 +524,11 @@ def test_hybrid_fourier_rows_equal_the_bluestein_rows(monkeypatch):
 def test_legendre_kernel_variants_are_bitwise_equal(case, monkeypatch):
     """The 96-column workgroup of the Legendre stage (field counts whose 16-column tiles come in sixes: nf 33..48, 81..96,
     129..144, ...) has three implementations of the same arithmetic in the same order: the generic template ("classic"),
-    the default without vector-ALU work in its stage loop ("lean") and the role-split experiment ("split").
+    the default without vector-ALU work in its stage loop ("lean"), the role-split experiment ("split") and the variant that
+    stages both operands by LDS-DMA ("dma").
     ATLAS_AMD_LEG_KERNEL is read at every launch; every entry point that reaches the stage must give identical bits."""
     outs = {}
-    for kernel in ("classic", "lean", "split"):
+    for kernel in ("classic", "lean", "split", "dma"):
         monkeypatch.setenv("ATLAS_AMD_LEG_KERNEL", kernel)
         if case.startswith("scalar"):
             gridname, T, nf = ("O160", 159, 40) if "O160" in case else ("O64", 63, 137)
@@ -563,6 +564,7 @@ def test_legendre_kernel_variants_are_bitwise_equal(case, monkeypatch):
     assert float(np.abs(outs["classic"]).max()) > 0
     assert np.array_equal(outs["classic"], outs["lean"])
     assert np.array_equal(outs["classic"], outs["split"])
+    assert np.array_equal(outs["classic"], outs["dma"])
 
 
 def test_a_constructor_that_throws_releases_its_device_memory():
