@@ -3,6 +3,7 @@
 
 #include <cstring>
 #include <map>
+#include <memory>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -16,6 +17,7 @@
 #include "fft_plan.h"
 #include "gaussian.h"
 #include "legendre_host.h"
+#include "regional_trans.h"
 #include "trans.h"
 #include "trans_plan.h"
 
@@ -398,6 +400,54 @@ int atlas_amd__Trans__truncation(const atlas_amd_Trans* t) {
 int64_t atlas_amd__Trans__nb_gridpoints(const atlas_amd_Trans* t) {
     return t->impl->nb_gridpoints();
 }
+// ---------------------------------------------------------------- regional (non-nested) targets
+struct atlas_amd_RegionalTrans {
+    std::unique_ptr<trans::RegionalTrans> impl;
+};
+atlas_amd_RegionalTrans* atlas_amd__RegionalTrans__new(int nlon, double west, double dlon, int nlat, const double lats[],
+                                                       int truncation) {
+    AA_TRY
+    if (!lats || nlat < 1) {
+        throw std::invalid_argument("RegionalTrans: needs latitudes");
+    }
+    auto* h = new atlas_amd_RegionalTrans;
+    try {
+        h->impl.reset(new trans::RegionalTrans(nlon, west, dlon, std::vector<double>(lats, lats + nlat), truncation));
+    }
+    catch (...) {
+        delete h;
+        throw;
+    }
+    return h;
+    AA_CATCH_PTR
+}
+void atlas_amd__RegionalTrans__delete(atlas_amd_RegionalTrans* t) {
+    delete t;
+}
+int64_t atlas_amd__RegionalTrans__nb_gridpoints(const atlas_amd_RegionalTrans* t) {
+    return t->impl->nb_gridpoints();
+}
+int atlas_amd__RegionalTrans__invtrans_scalar(atlas_amd_RegionalTrans* t, int nb_fields, const double scalar_spectra[],
+                                              double gp_fields[]) {
+    AA_TRY
+    t->impl->invtrans(nb_fields, scalar_spectra, gp_fields);
+    AA_CATCH_INT
+}
+int atlas_amd__RegionalTrans__invtrans_scalar_device(atlas_amd_RegionalTrans* t, int nb_fields, const double* sp_dev,
+                                                     double* gp_dev) {
+    AA_TRY
+    t->impl->invtrans_scalar_device(nb_fields, sp_dev, gp_dev);
+    AA_CATCH_INT
+}
+int atlas_amd__RegionalTrans__synchronize(atlas_amd_RegionalTrans* t) {
+    AA_TRY
+    t->impl->synchronize();
+    AA_CATCH_INT
+}
+void* atlas_amd__RegionalTrans__stream(const atlas_amd_RegionalTrans* t) {
+    return (void*)t->impl->stream();
+}
+
 int atlas_amd__Grid__crop_to_domain(const atlas_amd_Grid* grid, double west, double east, double south, double north,
                                     int* row_begin, int* row_end, int first_index[], int count[], int capacity) {
     AA_TRY

@@ -1,0 +1,180 @@
+// See regional_trans.h.
+#include "regional_trans.h"
+
+#include <algorithm>
+#include <cmath>
+#include <stdexcept>
+#include <string>
+
+#include "gaussian.h"
+#include "trans_plan.h"
+
+namespace atlas_amd {
+namespace trans {
+
+namespace {
+
+#define RT_CHECK(call)                                                                                                \
+    do {                                                                                                              \
+        hipError_t e_ = (call);                                                                                       \
+        if (e_ != hipSuccess) {                                                                                       \
+            throw std::runtime_error(std::string("HIP error '") + hipGetErrorString(e_) + "' in " #call);              \
+        }                                                                                                             \
+    } while (0)
+
+// gp[f][row][lon] = sum_m  C[m][lon] Re F(row, m, f) + S[m][lon] Im F(row, m, f)
+// One workgroup per (target row, field): the row's 2 (T + 1) Fourier coefficients of the field go to LDS once, every
+// thread then owns longitudes i, i + 256, ...  Reads of the table are contiguous in the longitude.
+__global__ void __launch_bounds__(256) regional_dft_kernel(const double* __restrict__ F, const int* __restrict__ rowsel,
+                                                           const double* __restrict__ table, double* __restrict__ gp, int T, int m_cnt,
+                                                           int RP, int nlon, int nlat) {
+    extern __shared__ double coef[];   // [T + 1][2]
+    const int row = blockIdx.x, f = blockIdx.y;
+    const double* src = F + (long long)rowsel[row] * m_cnt * RP + 2 * f;
+    for (int m = threadIdx.x; m <= T; m += blockDim.x) {
+        coef[2 * m]     = src[(long long)m * RP];
+        coef[2 * m + 1] = src[(long long)m * RP + 1];
+    }
+    __syncthreads();
+    double* out = gp + ((long long)f * nlat + row) * nlon;
+    for (int i = threadIdx.x; i < nlon; i += blockDim.x) {
+        double acc = 0.;
+        for (int m = 0; m <= T; ++m) {
+            acc += table[(long long)(2 * m) * nlon + i] * coef[2 * m];
+            acc += table[(long long)(2 * m + 1) * nlon + i] * coef[2 * m + 1];
+        }
+        out[i] = acc;
+    }
+}
+
+}  // namespace
+
+RegionalTrans::RegionalTrans(int nlon, double west, double dlon, const std::vector<double>& lats_deg, int truncation) :
+    T_(truncation), nlon_(nlon) {
+    if (nlon < 1 || lats_deg.empty() || truncation < 0) {
+        throw std::invalid_argument("RegionalTrans: needs nlon >= 1, at least one latitude and truncation >= 0");
+    }
+    // the symmetric latitude set: |latitudes| (clamped as TransLocal.cc:537-543), north -> equator, then their mirror images
+    std::vector<double> a;
+    for (double y : lats_deg) {
+        if (!(y >= -90. && y <= 90.)) {
+            throw std::invalid_argument("RegionalTrans: latitude outside [-90, 90]");
+        }
+        a.push_back(std::min(std::fabs(y), kLatPole));
+    }
+    std::sort(a.begin(), a.end(), [](double p, double q) { return p > q; });
+    a.erase(std::unique(a.begin(), a.end(), [](double p, double q) { return std::fabs(p - q) < 1.e-12; }), a.end());
+    const bool equator = std::fabs(a.back()) < 1.e-12;
+    grid::StructuredGrid sym;
+    sym.name = "regional";
+    for (size_t k = 0; k < a.size(); ++k) {
+        sym.y.push_back(equator && k + 1 == a.size() ? 0. : a[k]);
+    }
+    for (int k = (int)a.size() - 1 - (equator ? 1 : 0); k >= 0; --k) {
+        sym.y.push_back(-a[k]);
+    }
+    // a regular row length for which no wavenumber is truncated at any latitude (TransLocal.cc:463-468: nlat0 = 0)
+    sym.nx.assign(sym.y.size(), 4 * (truncation + 1));
+    sym.regular = true;
+    auto row_of = [&](double y) {
+        const double v = std::min(std::fabs(y), kLatPole);
+        int k          = 0;
+        while (k < (int)a.size() && std::fabs(a[k] - v) >= 1.e-12) {
+            ++k;
+        }
+        return y >= 0 || (equator && k == (int)a.size() - 1) ? k : (int)sym.y.size() - 1 - k;
+    };
+    std::vector<int> rows;
+    for (double y : lats_deg) {
+        rows.push_back(row_of(y));
+    }
+    TransConfig cfg;
+    cfg.row_begin = *std::min_element(rows.begin(), rows.end());
+    cfg.row_end   = *std::max_element(rows.begin(), rows.end()) + 1;
+    inner_.reset(new Trans(sym, truncation, cfg));
+    for (int m = 0; m <= truncation; ++m) {
+        if (inner_->geometry().nlat0[m] != 0) {
+            throw std::logic_error("RegionalTrans: internal latitude set truncates wavenumber " + std::to_string(m));
+        }
+    }
+    for (int r : rows) {
+        rowsel_.push_back(r - cfg.row_begin);
+    }
+    // Fourier matrix (TransLocal.cc:719-738), computed on the host with the same libm calls
+    std::vector<double> table((size_t)2 * (truncation + 1) * nlon);
+    for (int m = 0; m <= truncation; ++m) {
+        const double factor = m > 0 ? 2. : 1.;
+        for (int i = 0; i < nlon; ++i) {
+            const double lon                   = (west + i * dlon) * (M_PI / 180.);
+            table[(size_t)(2 * m) * nlon + i]     = +std::cos(m * lon) * factor;
+            table[(size_t)(2 * m + 1) * nlon + i] = -std::sin(m * lon) * factor;
+        }
+    }
+    try {
+        RT_CHECK(hipMalloc((void**)&d_table_, table.size() * sizeof(double)));
+        RT_CHECK(hipMemcpy(d_table_, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice));
+        RT_CHECK(hipMalloc((void**)&d_rowsel_, rowsel_.size() * sizeof(int)));
+        RT_CHECK(hipMemcpy(d_rowsel_, rowsel_.data(), rowsel_.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    catch (...) {
+        (void)hipFree(d_table_);
+        (void)hipFree(d_rowsel_);
+        throw;
+    }
+}
+
+RegionalTrans::~RegionalTrans() {
+    if (inner_) {
+        (void)hipStreamSynchronize(inner_->stream());
+    }
+    (void)hipFree(d_table_);
+    (void)hipFree(d_rowsel_);
+    (void)hipFree(d_sp_);
+    (void)hipFree(d_gp_);
+}
+
+void RegionalTrans::invtrans_scalar_device(int nb_fields, const double* sp_dev, double* gp_dev) {
+    if (nb_fields <= 0) {
+        return;
+    }
+    double* F = inner_->fourier_buffer(nb_fields);
+    inner_->legendre_device(T_, nb_fields, sp_dev, F);
+    const size_t lds = (size_t)2 * (T_ + 1) * sizeof(double);
+    if (lds > 160 * 1024) {
+        throw std::runtime_error("RegionalTrans: truncation too large for the direct Fourier kernel");
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&regional_dft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(regional_dft_kernel, dim3(nlat(), nb_fields), dim3(256), lds, inner_->stream(), F, d_rowsel_, d_table_, gp_dev,
+                       T_, T_ + 1, inner_->fourier_row_pitch(nb_fields), nlon_, nlat());
+    RT_CHECK(hipGetLastError());
+}
+
+void RegionalTrans::invtrans(int nb_fields, const double* scalar_spectra, double* gp_fields) {
+    if (nb_fields <= 0) {
+        return;
+    }
+    const size_t nsp = nb_spectral_coefficients() * (size_t)nb_fields, ngp = (size_t)nb_gridpoints() * (size_t)nb_fields;
+    auto ensure = [&](double*& ptr, size_t& cap, size_t n) {
+        if (n > cap) {
+            synchronize();
+            (void)hipFree(ptr);
+            ptr = nullptr;
+            RT_CHECK(hipMalloc((void**)&ptr, n * sizeof(double)));
+            cap = n;
+        }
+    };
+    ensure(d_sp_, sp_cap_, nsp);
+    ensure(d_gp_, gp_cap_, ngp);
+    RT_CHECK(hipMemcpyAsync(d_sp_, scalar_spectra, nsp * sizeof(double), hipMemcpyHostToDevice, inner_->stream()));
+    invtrans_scalar_device(nb_fields, d_sp_, d_gp_);
+    RT_CHECK(hipMemcpyAsync(gp_fields, d_gp_, ngp * sizeof(double), hipMemcpyDeviceToHost, inner_->stream()));
+    synchronize();
+}
+
+}  // namespace trans
+}  // namespace atlas_amd

@@ -384,3 +384,52 @@ class LegendreCacheCreator:
         with open(path, "wb") as f:
             f.write(blob.tobytes())
         return path
+
+
+_RT_new = _lib._sig("atlas_amd__RegionalTrans__new", C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_int)
+_RT_delete = _lib._sig("atlas_amd__RegionalTrans__delete", None, C.c_void_p)
+_RT_npts = _lib._sig("atlas_amd__RegionalTrans__nb_gridpoints", C.c_int64, C.c_void_p)
+_RT_invtrans = _lib._sig("atlas_amd__RegionalTrans__invtrans_scalar", C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)
+_RT_invtrans_dev = _lib._sig("atlas_amd__RegionalTrans__invtrans_scalar_device", C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                             C.c_void_p)
+_RT_sync = _lib._sig("atlas_amd__RegionalTrans__synchronize", C.c_int, C.c_void_p)
+_RT_stream = _lib._sig("atlas_amd__RegionalTrans__stream", C.c_void_p, C.c_void_p)
+
+
+class RegionalTrans:
+    """trans::Trans for a regular longitude-latitude target that is not a crop of a global grid (TransLocal's no_nest branch):
+    latitudes `lats` (degrees, any order), longitudes west + i * dlon for i < nlon.  Scalar fields; grid points
+    [field][lat][lon]."""
+
+    def __init__(self, nlon, west, dlon, lats, truncation):
+        self._lats = np.ascontiguousarray(lats, dtype=np.float64)
+        self.nlon, self.nlat, self.truncation = int(nlon), int(self._lats.size), int(truncation)
+        self._h = _lib.check_ptr(_RT_new(self.nlon, float(west), float(dlon), self.nlat, self._lats.ctypes.data, self.truncation))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h and _RT_delete is not None:
+            _RT_delete(h)
+            self._h = None
+
+    def nb_gridpoints(self):
+        return int(_RT_npts(self._h))
+
+    def stream(self):
+        return _RT_stream(self._h)
+
+    def synchronize(self):
+        _lib.check(_RT_sync(self._h))
+
+    def invtrans(self, nb_fields, scalar_spectra, gp_fields):
+        """host arrays (numpy) or device arrays (torch, asynchronous, ordered against torch's current stream)"""
+        if isinstance(scalar_spectra, np.ndarray):
+            sp = np.ascontiguousarray(scalar_spectra, dtype=np.float64)
+            assert gp_fields.dtype == np.float64 and gp_fields.flags.c_contiguous
+            assert gp_fields.size == nb_fields * self.nb_gridpoints()
+            _lib.check(_RT_invtrans(self._h, int(nb_fields), sp.ctypes.data, gp_fields.ctypes.data))
+            return gp_fields
+        assert gp_fields.numel() == nb_fields * self.nb_gridpoints()
+        with _lib.torch_stream_order(self.stream()):
+            _lib.check(_RT_invtrans_dev(self._h, int(nb_fields), scalar_spectra.data_ptr(), gp_fields.data_ptr()))
+        return gp_fields

@@ -100,6 +100,24 @@ atlas_amd_Trans* atlas_amd__Trans__new_config(const atlas_amd_Grid* grid, int tr
 void atlas_amd__Trans__delete(atlas_amd_Trans* t);                           /* atlas__Trans__delete      :55 */
 int atlas_amd__Trans__truncation(const atlas_amd_Trans* t);                  /* atlas__Trans__truncation  :99 */
 int64_t atlas_amd__Trans__nb_gridpoints(const atlas_amd_Trans* t);           /* local band (== global for nparts=1) */
+/* Targets that are NOT a crop of a global grid: a regular longitude-latitude grid with arbitrary latitudes (degrees, in the
+ * order of its rows) and equally spaced longitudes west + i * dlon, i < nlon -- TransLocal's "no_nest" branch
+ * (src/atlas/trans/local/TransLocal.cc:394-406: no hemisphere symmetry of the target, no Fourier truncation towards the poles,
+ * :535-557 Legendre polynomials at the grid's own latitudes, :719-738,1139-1148 Fourier stage as a matrix product).  Scalar
+ * fields; grid points gp[lon + nlon * (lat + nlat * field)] as the reference; spectra as atlas__Trans__invtrans_scalar.  The
+ * device-pointer variant is asynchronous on atlas_amd__RegionalTrans__stream. */
+typedef struct atlas_amd_RegionalTrans atlas_amd_RegionalTrans;
+atlas_amd_RegionalTrans* atlas_amd__RegionalTrans__new(int nlon, double west, double dlon, int nlat, const double lats[],
+                                                       int truncation);
+void atlas_amd__RegionalTrans__delete(atlas_amd_RegionalTrans* t);
+int64_t atlas_amd__RegionalTrans__nb_gridpoints(const atlas_amd_RegionalTrans* t);
+int atlas_amd__RegionalTrans__invtrans_scalar(atlas_amd_RegionalTrans* t, int nb_fields, const double scalar_spectra[],
+                                              double gp_fields[]);
+int atlas_amd__RegionalTrans__invtrans_scalar_device(atlas_amd_RegionalTrans* t, int nb_fields, const double* sp_dev,
+                                                     double* gp_dev);
+int atlas_amd__RegionalTrans__synchronize(atlas_amd_RegionalTrans* t);
+void* atlas_amd__RegionalTrans__stream(const atlas_amd_RegionalTrans* t);
+
 /* RectangularDomain crop of a global structured grid (atlas::Grid(grid, domain), src/atlas/grid/detail/grid/Structured.cc:
  * 390-560): the rows [row_begin, row_end) whose latitude lies in [south, north] and per row the run of count[r] points
  * starting at global index first_index[r] (wrapping around) whose longitude, normalised to [west, west + 360), lies in

@@ -208,3 +208,28 @@ def vd2uv(trc, nf, vor, div):
     V = np.zeros_like(vor)
     lib().orc_vd2uv(int(trc), int(nf), vor.ctypes.data, div.ctypes.data, U.ctypes.data, V.ctypes.data)
     return U, V
+
+
+def invtrans_regional(truncation, lats_deg, lons_deg, nf, sp):
+    """TransLocal's branch for a regular target that is not a crop of a global grid (no_nest), restated with numpy on top of
+    the oracle's Legendre recurrence: Legendre polynomials at the target's own latitudes, clamped to +-89.9999999
+    (TransLocal.cc:535-557); every wavenumber kept at every latitude (nlat0 = 0, :463-468) except m = truncation, which the
+    Legendre stage never transforms (jm < truncation, :982); Fourier stage = matrix cos(m lon) * factor, -sin(m lon) * factor
+    with factor 2 for m > 0 (:719-738) times the Fourier coefficients (:1139-1148).
+    sp: [(n, m) position][re, im][field] as atlas__Trans__invtrans_scalar; returns gp[field][lat][lon]."""
+    T = int(truncation)
+    sp = np.asarray(sp, dtype=np.float64).reshape((T + 1) * (T + 2) // 2, 2, nf)
+    lats = np.clip(np.asarray(lats_deg, dtype=np.float64), -89.9999999, 89.9999999) * (np.pi / 180.0)
+    lons = np.asarray(lons_deg, dtype=np.float64) * (np.pi / 180.0)
+    gp = np.zeros((nf, len(lats), len(lons)))
+    for j, lat in enumerate(lats):
+        leg = legendre_lat(T, lat)
+        for m in range(T):                       # jm < truncation
+            b = (2 * T + 3 - m) * m // 2
+            P = leg[b:b + T - m + 1]             # n = m .. T
+            re = P @ sp[b:b + T - m + 1, 0, :]
+            im = P @ sp[b:b + T - m + 1, 1, :]
+            factor = 2.0 if m > 0 else 1.0
+            c, s_ = np.cos(m * lons) * factor, -np.sin(m * lons) * factor
+            gp[:, j, :] += re[:, None] * c[None, :] + (im[:, None] * s_[None, :] if m > 0 else 0.0)
+    return gp

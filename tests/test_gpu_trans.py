@@ -624,3 +624,50 @@ def test_rectangular_domain_crop_is_the_window_of_the_global_transform(gridname,
     crop = np.zeros((ns + 2 * nvd) * len(idx))
     tr.invtrans(ns, s1, nvd, vor, div, crop)
     assert np.array_equal(crop.reshape(ns + 2 * nvd, -1), full.reshape(ns + 2 * nvd, -1)[:, idx])
+
+
+@pytest.mark.parametrize("case", ["northern_box", "across_equator_unsorted", "with_equator_and_poles"])
+def test_regional_target_that_is_not_a_crop_of_a_global_grid(case):
+    """TransLocal's no_nest branch (TransLocal.cc:394-406,535-557,719-738,1139-1148) through atlas_amd__RegionalTrans__*:
+    arbitrary latitudes, longitudes west + i * dlon.  Against the oracle's restatement of that branch (rel-RMS 1e-13), and
+    on points that are points of a global regular grid against the global transform."""
+    T, nf = 63, 5
+    sp = red_spectra(T, nf, seed=41)
+    if case == "northern_box":
+        lats, west, dlon, nlon = 61.25 - 0.37 * np.arange(23), -12.5, 0.61, 41
+    elif case == "across_equator_unsorted":
+        lats, west, dlon, nlon = np.array([-7.1, 12.0, 3.3, -3.3, 25.5, -40.25, 0.4]), 170.0, 1.7, 30   # wraps past 180
+    else:
+        lats, west, dlon, nlon = np.array([90.0, 45.0, 0.0, -45.0, -90.0, 10.0, -10.0]), 0.0, 11.25, 32
+    rt = atlas_amd.RegionalTrans(nlon, west, dlon, lats, T)
+    assert rt.nb_gridpoints() == nlon * len(lats)
+    lons = west + dlon * np.arange(nlon)
+    want = oracle.invtrans_regional(T, lats, lons, nf, sp)
+    # Latitude -90: the reference's Legendre routine replaces cos(colatitude) by +1 within a metre of EITHER pole
+    # (LegendrePolynomials.cc:74-77), which is wrong at the south pole when the latitude is not mirrored first (this branch
+    # does not mirror).  The library returns the mirror image of the north-pole polynomials, Pbar_n^m(-x) = (-1)^(n+m)
+    # Pbar_n^m(x): expected value = the oracle at +90 with the spectra's signs flipped accordingly.
+    for j in np.flatnonzero(lats < -89.99):
+        flip = np.concatenate([[(-1.0) ** (n + m) for n in range(m, T + 1)] for m in range(T + 1)])
+        spf = (sp.reshape(-1, 2, nf) * flip[:, None, None]).ravel()
+        want[:, j, :] = oracle.invtrans_regional(T, [-lats[j]], lons, nf, spf)[:, 0, :]
+    gp = torch.zeros(nf * nlon * len(lats), dtype=torch.float64, device="cuda")
+    rt.invtrans(nf, dev(sp), gp)
+    rt.synchronize()
+    got = gp.cpu().numpy().reshape(nf, len(lats), nlon)
+    assert compute_rms(got.ravel(), want.ravel()) < 1e-13
+    gp_h = np.zeros(nf * nlon * len(lats))
+    rt.invtrans(nf, sp, gp_h)
+    assert np.array_equal(gp_h.reshape(got.shape), got)
+    if case == "with_equator_and_poles":
+        return
+    # points of the global regular grid F64: the global transform there (FFT path) within rounding
+    g, tr = get_trans("F64", T)
+    ref = run_device(tr, nf, sp).reshape(nf, g.ny(), -1)
+    rows, i0, step, n = [5, 31, 64, 100, 127], 7, 3, 40
+    rt2 = atlas_amd.RegionalTrans(n, i0 * 360.0 / 256, step * 360.0 / 256, g.y()[rows], T)
+    gp2 = torch.zeros(nf * n * len(rows), dtype=torch.float64, device="cuda")
+    rt2.invtrans(nf, dev(sp), gp2)
+    rt2.synchronize()
+    sel = ref[:, rows][:, :, i0 + step * np.arange(n)]
+    assert compute_rms(gp2.cpu().numpy(), sel.ravel()) < 1e-13

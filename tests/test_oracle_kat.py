@@ -175,3 +175,34 @@ def test_legendre_functions_at_high_degree_against_mpmath():
         worst = max(worst, abs(got - s["value"]))
         assert abs(got - s["value"]) <= 5e-12 * max(1.0, abs(s["value"])), (n, m, lat, got, s["value"])
     assert worst > 0.0      # two different computations, not the same number twice
+
+
+def test_regional_no_fft_branch_restatement_is_pinned_by_the_global_oracle():
+    """oracle.invtrans_regional restates TransLocal's no_nest branch (Legendre polynomials at the target's latitudes + DFT as a
+    matrix product, TransLocal.cc:394-406,535-557,719-738,1139-1148).  On a target whose points are points of a global
+    regular Gaussian grid it must give what the pinned global oracle gives there -- and the closed forms quoted by
+    test_transgeneral.cc:117-272 at arbitrary points."""
+    import math
+    import oracle
+    from helpers import CLOSED_FORMS, red_spectra
+    T, N, nf = 31, 32, 3
+    x, _ = np.polynomial.legendre.leggauss(2 * N)
+    lat = np.degrees(np.arcsin(x[::-1]))
+    nx = np.full(2 * N, 4 * N, dtype=np.int32)
+    op = oracle.OraclePlan(T, nx, lat)
+    sp = red_spectra(T, nf, seed=7)
+    ref = op.invtrans(nf, sp).reshape(nf, 2 * N, 4 * N)
+    rows, cols = [3, 17, 40, 63], np.arange(5, 50, 3)
+    got = oracle.invtrans_regional(T, lat[rows], cols * (360.0 / (4 * N)), nf, sp)
+    want = ref[:, rows][:, :, cols]
+    assert np.sqrt(((got - want) ** 2).sum() / (want ** 2).sum()) < 1e-13
+    lats, lons = np.array([71.3, 12.0, -33.33, -80.5]), 10.0 + 0.7 * np.arange(9)
+    for (n, m), form in CLOSED_FORMS.items():
+        for imag in ((0, 1) if m > 0 else (0,)):
+            sp1 = np.zeros(((T + 1) * (T + 2) // 2, 2, 1))
+            sp1[(2 * T + 3 - m) * m // 2 + n - m, imag, 0] = 1.0
+            got = oracle.invtrans_regional(T, lats, lons, 1, sp1)[0]
+            P = np.array([form(math.sin(math.radians(v)), math.cos(math.radians(v))) for v in lats])
+            lam = np.radians(lons)
+            want = P[:, None] * ((2.0 if m > 0 else 1.0) * (np.cos(m * lam) if imag == 0 else -np.sin(m * lam)))[None, :]
+            assert np.abs(got - want).max() < 1e-13 * max(1.0, np.abs(want).max()), (n, m, imag)
