@@ -186,6 +186,29 @@ inline std::vector<double> gaussian_latitudes_npole_spole(int N) {
 // ---------------------------------------------------------------------------------------------------------------------
 namespace trans {
 
+// trans::Trans for a regular longitude-latitude target that is not a crop of a global grid (TransLocal's no_nest branch,
+// TransLocal.cc:394-406): latitudes in degrees in row order, longitudes west + i * dlon.  Scalar fields.
+class RegionalTrans {
+public:
+    RegionalTrans(int nlon, double west, double dlon, const std::vector<double>& lats, int truncation) {
+        h_ = atlas_amd__RegionalTrans__new(nlon, west, dlon, int(lats.size()), lats.data(), truncation);
+        if (!h_) {
+            detail::raise();
+        }
+    }
+    RegionalTrans(const RegionalTrans&)            = delete;
+    RegionalTrans& operator=(const RegionalTrans&) = delete;
+    ~RegionalTrans() { atlas_amd__RegionalTrans__delete(h_); }
+    size_t nb_gridpoints() const { return size_t(atlas_amd__RegionalTrans__nb_gridpoints(h_)); }
+    // gp_fields[lon + nlon * (lat + nlat * field)]
+    void invtrans(int nb_scalar_fields, const double scalar_spectra[], double gp_fields[]) const {
+        detail::check(atlas_amd__RegionalTrans__invtrans_scalar(h_, nb_scalar_fields, scalar_spectra, gp_fields));
+    }
+
+private:
+    atlas_amd_RegionalTrans* h_ = nullptr;
+};
+
 class Trans {
 public:
     static bool hasBackend(const std::string& backend) { return atlas_amd__Trans__has_backend(backend.c_str()) != 0; }
