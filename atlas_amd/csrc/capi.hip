@@ -439,6 +439,13 @@ int atlas_amd__RegionalTrans__invtrans_scalar_device(atlas_amd_RegionalTrans* t,
     t->impl->invtrans_scalar_device(nb_fields, sp_dev, gp_dev);
     AA_CATCH_INT
 }
+int atlas_amd__RegionalTrans__invtrans_vordiv(atlas_amd_RegionalTrans* t, int nb_scalar_fields, const double scalar_spectra[],
+                                              int nb_vordiv_fields, const double vorticity_spectra[],
+                                              const double divergence_spectra[], double gp_fields[]) {
+    AA_TRY
+    t->impl->invtrans(nb_scalar_fields, scalar_spectra, nb_vordiv_fields, vorticity_spectra, divergence_spectra, gp_fields);
+    AA_CATCH_INT
+}
 int atlas_amd__RegionalTrans__synchronize(atlas_amd_RegionalTrans* t) {
     AA_TRY
     t->impl->synchronize();

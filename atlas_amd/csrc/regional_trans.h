@@ -43,6 +43,11 @@ public:
     // TransLocal::invtrans(nb_scalar_fields, scalar_spectra, gp_fields) for this target: device / host pointers
     void invtrans_scalar_device(int nb_fields, const double* sp_dev, double* gp_dev);
     void invtrans(int nb_fields, const double* scalar_spectra, double* gp_fields);
+    // TransLocal::invtrans(nb_scalar, sp, nb_vordiv, vor, div, gp): gp = [u fields][v fields][scalar fields] (TransLocal.cc:
+    // 1523-1597: truncation extended by one, vd2uv, u and v divided by cos(lat))
+    void invtrans_vordiv_device(int nb_scalar, const double* sp_dev, int nb_vordiv, const double* vor_dev, const double* div_dev,
+                                double* gp_dev);
+    void invtrans(int nb_scalar, const double* sp, int nb_vordiv, const double* vor, const double* div, double* gp);
 
 private:
     int T_ = 0, nlon_ = 0;
@@ -50,9 +55,14 @@ private:
     std::vector<int> rowsel_;           // per target row: row of the inner object's Fourier intermediate
     int* d_rowsel_     = nullptr;
     double* d_table_   = nullptr;       // [T+1][2][nlon]: cos(m lon) * factor, -sin(m lon) * factor
+    double* d_scale_   = nullptr;       // per target row: 1 / cos(latitude), latitude clamped as TransLocal.cc:1449-1456
     double* d_sp_      = nullptr;
     double* d_gp_      = nullptr;
-    size_t sp_cap_ = 0, gp_cap_ = 0;
+    double* d_all_     = nullptr;       // combined (U, V, scalar) spectra of truncation T + 1
+    double* d_vd_      = nullptr;       // host-API staging of vor ++ div
+    size_t sp_cap_ = 0, gp_cap_ = 0, all_cap_ = 0, vd_cap_ = 0;
+    void dft(int trc_in, int nb_fields, int nb_vordiv, const double* F, double* gp_dev);
+    void ensure(double*& ptr, size_t& cap, size_t n);
 };
 
 }  // namespace trans

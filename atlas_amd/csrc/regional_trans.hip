@@ -27,7 +27,8 @@ namespace {
 // thread then owns longitudes i, i + 256, ...  Reads of the table are contiguous in the longitude.
 __global__ void __launch_bounds__(256) regional_dft_kernel(const double* __restrict__ F, const int* __restrict__ rowsel,
                                                            const double* __restrict__ table, double* __restrict__ gp, int T, int m_cnt,
-                                                           int RP, int nlon, int nlat) {
+                                                           int RP, int nlon, int nlat, const double* __restrict__ rowscale,
+                                                           int nscaled) {
     extern __shared__ double coef[];   // [T + 1][2]
     const int row = blockIdx.x, f = blockIdx.y;
     const double* src = F + (long long)rowsel[row] * m_cnt * RP + 2 * f;
@@ -36,14 +37,15 @@ __global__ void __launch_bounds__(256) regional_dft_kernel(const double* __restr
         coef[2 * m + 1] = src[(long long)m * RP + 1];
     }
     __syncthreads();
-    double* out = gp + ((long long)f * nlat + row) * nlon;
+    double* out        = gp + ((long long)f * nlat + row) * nlon;
+    const double scale = f < nscaled ? rowscale[row] : 1.;   // u, v fields of the vor/div path: 1 / cos(lat)
     for (int i = threadIdx.x; i < nlon; i += blockDim.x) {
         double acc = 0.;
         for (int m = 0; m <= T; ++m) {
             acc += table[(long long)(2 * m) * nlon + i] * coef[2 * m];
             acc += table[(long long)(2 * m + 1) * nlon + i] * coef[2 * m + 1];
         }
-        out[i] = acc;
+        out[i] = acc * scale;
     }
 }
 
@@ -110,7 +112,14 @@ RegionalTrans::RegionalTrans(int nlon, double west, double dlon, const std::vect
             table[(size_t)(2 * m + 1) * nlon + i] = -std::sin(m * lon) * factor;
         }
     }
+    std::vector<double> scale;
+    for (double y : lats_deg) {
+        const double lat = std::max(std::min(y, kLatPole), -kLatPole);
+        scale.push_back(1. / std::cos(lat * (M_PI / 180.)));
+    }
     try {
+        RT_CHECK(hipMalloc((void**)&d_scale_, scale.size() * sizeof(double)));
+        RT_CHECK(hipMemcpy(d_scale_, scale.data(), scale.size() * sizeof(double), hipMemcpyHostToDevice));
         RT_CHECK(hipMalloc((void**)&d_table_, table.size() * sizeof(double)));
         RT_CHECK(hipMemcpy(d_table_, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice));
         RT_CHECK(hipMalloc((void**)&d_rowsel_, rowsel_.size() * sizeof(int)));
@@ -119,6 +128,7 @@ RegionalTrans::RegionalTrans(int nlon, double west, double dlon, const std::vect
     catch (...) {
         (void)hipFree(d_table_);
         (void)hipFree(d_rowsel_);
+        (void)hipFree(d_scale_);
         throw;
     }
 }
@@ -129,16 +139,15 @@ RegionalTrans::~RegionalTrans() {
     }
     (void)hipFree(d_table_);
     (void)hipFree(d_rowsel_);
+    (void)hipFree(d_scale_);
     (void)hipFree(d_sp_);
     (void)hipFree(d_gp_);
+    (void)hipFree(d_all_);
+    (void)hipFree(d_vd_);
 }
 
-void RegionalTrans::invtrans_scalar_device(int nb_fields, const double* sp_dev, double* gp_dev) {
-    if (nb_fields <= 0) {
-        return;
-    }
-    double* F = inner_->fourier_buffer(nb_fields);
-    inner_->legendre_device(T_, nb_fields, sp_dev, F);
+void RegionalTrans::dft(int trc_in, int nb_fields, int nb_vordiv, const double* F, double* gp_dev) {
+    (void)trc_in;   // the Legendre stage left zeros for the wavenumbers it does not transform
     const size_t lds = (size_t)2 * (T_ + 1) * sizeof(double);
     if (lds > 160 * 1024) {
         throw std::runtime_error("RegionalTrans: truncation too large for the direct Fourier kernel");
@@ -150,8 +159,67 @@ void RegionalTrans::invtrans_scalar_device(int nb_fields, const double* sp_dev, 
         attr_set = true;
     }
     hipLaunchKernelGGL(regional_dft_kernel, dim3(nlat(), nb_fields), dim3(256), lds, inner_->stream(), F, d_rowsel_, d_table_, gp_dev,
-                       T_, T_ + 1, inner_->fourier_row_pitch(nb_fields), nlon_, nlat());
+                       T_, T_ + 1, inner_->fourier_row_pitch(nb_fields), nlon_, nlat(), d_scale_, 2 * nb_vordiv);
     RT_CHECK(hipGetLastError());
+}
+
+void RegionalTrans::invtrans_scalar_device(int nb_fields, const double* sp_dev, double* gp_dev) {
+    if (nb_fields <= 0) {
+        return;
+    }
+    double* F = inner_->fourier_buffer(nb_fields);
+    inner_->legendre_device(T_, nb_fields, sp_dev, F);
+    dft(T_, nb_fields, 0, F, gp_dev);
+}
+
+hipError_t launch_spectra_prepare(const double* vor, const double* div, const double* sp, double* out, int T, int nvd, int ns,
+                                  hipStream_t stream);
+
+void RegionalTrans::invtrans_vordiv_device(int nb_scalar, const double* sp_dev, int nb_vordiv, const double* vor_dev,
+                                           const double* div_dev, double* gp_dev) {
+    if (nb_vordiv <= 0) {
+        invtrans_scalar_device(nb_scalar, sp_dev, gp_dev);
+        return;
+    }
+    const int nall    = 2 * nb_vordiv + nb_scalar;
+    const size_t nout = size_t(T_ + 2) * size_t(T_ + 3) * size_t(nall);
+    ensure(d_all_, all_cap_, nout);
+    RT_CHECK(launch_spectra_prepare(vor_dev, div_dev, sp_dev, d_all_, T_, nb_vordiv, nb_scalar, inner_->stream()));
+    double* F = inner_->fourier_buffer(nall);
+    inner_->legendre_device(T_ + 1, nall, d_all_, F);   // TransLocal.cc:1590
+    dft(T_ + 1, nall, nb_vordiv, F, gp_dev);
+}
+
+void RegionalTrans::ensure(double*& ptr, size_t& cap, size_t n) {
+    if (n > cap) {
+        synchronize();
+        (void)hipFree(ptr);
+        ptr = nullptr;
+        RT_CHECK(hipMalloc((void**)&ptr, n * sizeof(double)));
+        cap = n;
+    }
+}
+
+void RegionalTrans::invtrans(int nb_scalar, const double* sp, int nb_vordiv, const double* vor, const double* div, double* gp) {
+    if (nb_vordiv <= 0) {
+        invtrans(nb_scalar, sp, gp);
+        return;
+    }
+    const size_t nspec = nb_spectral_coefficients();
+    const size_t ngp   = (size_t)nb_gridpoints() * (size_t)(2 * nb_vordiv + nb_scalar);
+    ensure(d_sp_, sp_cap_, std::max<size_t>(nspec * (size_t)nb_scalar, 1));
+    ensure(d_vd_, vd_cap_, 2 * nspec * (size_t)nb_vordiv);
+    ensure(d_gp_, gp_cap_, ngp);
+    if (nb_scalar > 0) {
+        RT_CHECK(hipMemcpyAsync(d_sp_, sp, nspec * nb_scalar * sizeof(double), hipMemcpyHostToDevice, inner_->stream()));
+    }
+    double* d_vor = d_vd_;
+    double* d_div = d_vd_ + nspec * (size_t)nb_vordiv;
+    RT_CHECK(hipMemcpyAsync(d_vor, vor, nspec * nb_vordiv * sizeof(double), hipMemcpyHostToDevice, inner_->stream()));
+    RT_CHECK(hipMemcpyAsync(d_div, div, nspec * nb_vordiv * sizeof(double), hipMemcpyHostToDevice, inner_->stream()));
+    invtrans_vordiv_device(nb_scalar, nb_scalar > 0 ? d_sp_ : nullptr, nb_vordiv, d_vor, d_div, d_gp_);
+    RT_CHECK(hipMemcpyAsync(gp, d_gp_, ngp * sizeof(double), hipMemcpyDeviceToHost, inner_->stream()));
+    synchronize();
 }
 
 void RegionalTrans::invtrans(int nb_fields, const double* scalar_spectra, double* gp_fields) {
@@ -159,15 +227,6 @@ void RegionalTrans::invtrans(int nb_fields, const double* scalar_spectra, double
         return;
     }
     const size_t nsp = nb_spectral_coefficients() * (size_t)nb_fields, ngp = (size_t)nb_gridpoints() * (size_t)nb_fields;
-    auto ensure = [&](double*& ptr, size_t& cap, size_t n) {
-        if (n > cap) {
-            synchronize();
-            (void)hipFree(ptr);
-            ptr = nullptr;
-            RT_CHECK(hipMalloc((void**)&ptr, n * sizeof(double)));
-            cap = n;
-        }
-    };
     ensure(d_sp_, sp_cap_, nsp);
     ensure(d_gp_, gp_cap_, ngp);
     RT_CHECK(hipMemcpyAsync(d_sp_, scalar_spectra, nsp * sizeof(double), hipMemcpyHostToDevice, inner_->stream()));

@@ -392,6 +392,8 @@ _RT_npts = _lib._sig("atlas_amd__RegionalTrans__nb_gridpoints", C.c_int64, C.c_v
 _RT_invtrans = _lib._sig("atlas_amd__RegionalTrans__invtrans_scalar", C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)
 _RT_invtrans_dev = _lib._sig("atlas_amd__RegionalTrans__invtrans_scalar_device", C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                              C.c_void_p)
+_RT_invtrans_vd = _lib._sig("atlas_amd__RegionalTrans__invtrans_vordiv", C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                            C.c_void_p, C.c_void_p, C.c_void_p)
 _RT_sync = _lib._sig("atlas_amd__RegionalTrans__synchronize", C.c_int, C.c_void_p)
 _RT_stream = _lib._sig("atlas_amd__RegionalTrans__stream", C.c_void_p, C.c_void_p)
 
@@ -432,4 +434,14 @@ class RegionalTrans:
         assert gp_fields.numel() == nb_fields * self.nb_gridpoints()
         with _lib.torch_stream_order(self.stream()):
             _lib.check(_RT_invtrans_dev(self._h, int(nb_fields), scalar_spectra.data_ptr(), gp_fields.data_ptr()))
+        return gp_fields
+
+    def invtrans_vordiv(self, nb_scalar, scalar_spectra, nb_vordiv, vorticity_spectra, divergence_spectra, gp_fields):
+        """host arrays: gp = [u fields][v fields][scalar fields], each [lat][lon]"""
+        sp = np.ascontiguousarray(scalar_spectra, dtype=np.float64) if nb_scalar > 0 else None
+        vor = np.ascontiguousarray(vorticity_spectra, dtype=np.float64)
+        div = np.ascontiguousarray(divergence_spectra, dtype=np.float64)
+        assert gp_fields.dtype == np.float64 and gp_fields.size == (nb_scalar + 2 * nb_vordiv) * self.nb_gridpoints()
+        _lib.check(_RT_invtrans_vd(self._h, int(nb_scalar), sp.ctypes.data if sp is not None else None, int(nb_vordiv),
+                                   vor.ctypes.data, div.ctypes.data, gp_fields.ctypes.data))
         return gp_fields

@@ -115,6 +115,10 @@ int atlas_amd__RegionalTrans__invtrans_scalar(atlas_amd_RegionalTrans* t, int nb
                                               double gp_fields[]);
 int atlas_amd__RegionalTrans__invtrans_scalar_device(atlas_amd_RegionalTrans* t, int nb_fields, const double* sp_dev,
                                                      double* gp_dev);
+/* as atlas__Trans__invtrans: gp = [u fields][v fields][scalar fields] (TransLocal.cc:1523-1597) */
+int atlas_amd__RegionalTrans__invtrans_vordiv(atlas_amd_RegionalTrans* t, int nb_scalar_fields, const double scalar_spectra[],
+                                              int nb_vordiv_fields, const double vorticity_spectra[],
+                                              const double divergence_spectra[], double gp_fields[]);
 int atlas_amd__RegionalTrans__synchronize(atlas_amd_RegionalTrans* t);
 void* atlas_amd__RegionalTrans__stream(const atlas_amd_RegionalTrans* t);
 

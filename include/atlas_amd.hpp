@@ -204,6 +204,11 @@ public:
     void invtrans(int nb_scalar_fields, const double scalar_spectra[], double gp_fields[]) const {
         detail::check(atlas_amd__RegionalTrans__invtrans_scalar(h_, nb_scalar_fields, scalar_spectra, gp_fields));
     }
+    void invtrans(int nb_scalar_fields, const double scalar_spectra[], int nb_vordiv_fields, const double vorticity_spectra[],
+                  const double divergence_spectra[], double gp_fields[]) const {
+        detail::check(atlas_amd__RegionalTrans__invtrans_vordiv(h_, nb_scalar_fields, scalar_spectra, nb_vordiv_fields,
+                                                                vorticity_spectra, divergence_spectra, gp_fields));
+    }
 
 private:
     atlas_amd_RegionalTrans* h_ = nullptr;

@@ -210,26 +210,57 @@ def vd2uv(trc, nf, vor, div):
     return U, V
 
 
-def invtrans_regional(truncation, lats_deg, lons_deg, nf, sp):
+def invtrans_regional(truncation, lats_deg, lons_deg, nf, sp, trc_in=None, nb_vordiv=0):
     """TransLocal's branch for a regular target that is not a crop of a global grid (no_nest), restated with numpy on top of
-    the oracle's Legendre recurrence: Legendre polynomials at the target's own latitudes, clamped to +-89.9999999
-    (TransLocal.cc:535-557); every wavenumber kept at every latitude (nlat0 = 0, :463-468) except m = truncation, which the
-    Legendre stage never transforms (jm < truncation, :982); Fourier stage = matrix cos(m lon) * factor, -sin(m lon) * factor
-    with factor 2 for m > 0 (:719-738) times the Fourier coefficients (:1139-1148).
-    sp: [(n, m) position][re, im][field] as atlas__Trans__invtrans_scalar; returns gp[field][lat][lon]."""
+    the oracle's Legendre recurrence: Legendre polynomials of truncation + 1 at the target's own latitudes, clamped to
+    +-89.9999999 (TransLocal.cc:535-557); every wavenumber kept at every latitude (nlat0 = 0, :463-468) except m >= trc_in,
+    which the Legendre stage never transforms (jm < truncation, :982); Fourier stage = matrix cos(m lon) * factor,
+    -sin(m lon) * factor with factor 2 for m > 0 (:719-738) times the Fourier coefficients (:1139-1148); the first
+    2 nb_vordiv fields (u, v) are divided by cos(lat) (:1443-1469).
+    sp: [(n, m) position of truncation trc_in][re, im][field]; returns gp[field][lat][lon]."""
     T = int(truncation)
-    sp = np.asarray(sp, dtype=np.float64).reshape((T + 1) * (T + 2) // 2, 2, nf)
+    trc = T if trc_in is None else int(trc_in)
+    TL = T + 1
+    sp = np.asarray(sp, dtype=np.float64).reshape((trc + 1) * (trc + 2) // 2, 2, nf)
     lats = np.clip(np.asarray(lats_deg, dtype=np.float64), -89.9999999, 89.9999999) * (np.pi / 180.0)
     lons = np.asarray(lons_deg, dtype=np.float64) * (np.pi / 180.0)
+    nmax = min(trc, TL)
     gp = np.zeros((nf, len(lats), len(lons)))
     for j, lat in enumerate(lats):
-        leg = legendre_lat(T, lat)
-        for m in range(T):                       # jm < truncation
-            b = (2 * T + 3 - m) * m // 2
-            P = leg[b:b + T - m + 1]             # n = m .. T
-            re = P @ sp[b:b + T - m + 1, 0, :]
-            im = P @ sp[b:b + T - m + 1, 1, :]
+        leg = legendre_lat(TL, lat)
+        for m in range(min(trc, T + 1)):         # jm < truncation of the input, and at most T
+            bl = (2 * TL + 3 - m) * m // 2       # table position of (m, m)
+            bs = (2 * trc + 3 - m) * m // 2      # spectra position of (m, m)
+            cnt = nmax - m + 1
+            P = leg[bl:bl + cnt]                 # n = m .. nmax
+            re = P @ sp[bs:bs + cnt, 0, :]
+            im = P @ sp[bs:bs + cnt, 1, :]
             factor = 2.0 if m > 0 else 1.0
             c, s_ = np.cos(m * lons) * factor, -np.sin(m * lons) * factor
             gp[:, j, :] += re[:, None] * c[None, :] + (im[:, None] * s_[None, :] if m > 0 else 0.0)
+        if nb_vordiv > 0:
+            gp[:2 * nb_vordiv, j, :] /= np.cos(lat)
     return gp
+
+
+def invtrans_regional_vordiv(truncation, lats_deg, lons_deg, ns, sp, nvd, vor, div):
+    """TransLocal::invtrans(ns, sp, nvd, vor, div, gp) for such a target: extend_truncation to T + 1 (TransLocal.cc:1496-1519),
+    vd2uv there (VorDivToUVLocal.cc:62-184), fields interleaved [U..][V..][scalars..] per coefficient (:1523-1597), then the
+    scalar path with the 1 / cos(lat) scaling of u and v.  Returns gp[2 nvd + ns][lat][lon]."""
+    T = int(truncation)
+
+    def extend(a, nf):
+        a = np.asarray(a, dtype=np.float64).reshape((T + 1) * (T + 2) // 2, 2, nf)
+        out = np.zeros(((T + 2) * (T + 3) // 2, 2, nf))
+        for m in range(T + 1):
+            b0, b1 = (2 * T + 3 - m) * m // 2, (2 * (T + 1) + 3 - m) * m // 2
+            out[b1:b1 + T - m + 1] = a[b0:b0 + T - m + 1]
+        return out
+
+    ve, de = extend(vor, nvd), extend(div, nvd)
+    U, V = vd2uv(T + 1, nvd, ve.ravel(), de.ravel())
+    parts = [U.reshape(-1, 2, nvd), V.reshape(-1, 2, nvd)]
+    if ns > 0:
+        parts.append(extend(sp, ns))
+    allsp = np.concatenate(parts, axis=2)
+    return invtrans_regional(T, lats_deg, lons_deg, 2 * nvd + ns, allsp, trc_in=T + 1, nb_vordiv=nvd)

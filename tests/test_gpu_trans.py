@@ -659,6 +659,15 @@ def test_regional_target_that_is_not_a_crop_of_a_global_grid(case):
     gp_h = np.zeros(nf * nlon * len(lats))
     rt.invtrans(nf, sp, gp_h)
     assert np.array_equal(gp_h.reshape(got.shape), got)
+    # vor/div path (TransLocal.cc:1523-1597) on the same target; the poles are left out (1 / cos(lat) of the clamped latitude
+    # amplifies the rounding of u and v there by 6e8)
+    if case != "with_equator_and_poles":
+        ns, nvd = 2, 2
+        s1, vor, div = red_spectra(T, ns, 51), red_spectra(T, nvd, 52), red_spectra(T, nvd, 53)
+        want_vd = oracle.invtrans_regional_vordiv(T, lats, lons, ns, s1, nvd, vor, div)
+        gp_vd = np.zeros((ns + 2 * nvd) * nlon * len(lats))
+        rt.invtrans_vordiv(ns, s1, nvd, vor, div, gp_vd)
+        assert compute_rms(gp_vd, want_vd.ravel()) < 1e-12
     if case == "with_equator_and_poles":
         return
     # points of the global regular grid F64: the global transform there (FFT path) within rounding

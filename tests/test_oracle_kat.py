@@ -196,6 +196,13 @@ def test_regional_no_fft_branch_restatement_is_pinned_by_the_global_oracle():
     got = oracle.invtrans_regional(T, lat[rows], cols * (360.0 / (4 * N)), nf, sp)
     want = ref[:, rows][:, :, cols]
     assert np.sqrt(((got - want) ** 2).sum() / (want ** 2).sum()) < 1e-13
+    # the vor/div path of the same branch against the global oracle's
+    ns, nvd = 2, 2
+    s1, vor, div = red_spectra(T, ns, 1), red_spectra(T, nvd, 2), red_spectra(T, nvd, 3)
+    ref = op.invtrans_vordiv(ns, s1, nvd, vor, div).reshape(ns + 2 * nvd, 2 * N, 4 * N)
+    got = oracle.invtrans_regional_vordiv(T, lat[rows], cols * (360.0 / (4 * N)), ns, s1, nvd, vor, div)
+    want = ref[:, rows][:, :, cols]
+    assert np.sqrt(((got - want) ** 2).sum() / (want ** 2).sum()) < 1e-13
     lats, lons = np.array([71.3, 12.0, -33.33, -80.5]), 10.0 + 0.7 * np.arange(9)
     for (n, m), form in CLOSED_FORMS.items():
         for imag in ((0, 1) if m > 0 else (0,)):
