@@ -421,6 +421,24 @@ atlas_amd_RegionalTrans* atlas_amd__RegionalTrans__new(int nlon, double west, do
     return h;
     AA_CATCH_PTR
 }
+atlas_amd_RegionalTrans* atlas_amd__RegionalTrans__new_unstructured(int npts, const double lons[], const double lats[],
+                                                                    int truncation) {
+    AA_TRY
+    if (!lons || !lats || npts < 1) {
+        throw std::invalid_argument("RegionalTrans: needs points");
+    }
+    auto* h = new atlas_amd_RegionalTrans;
+    try {
+        h->impl.reset(new trans::RegionalTrans(std::vector<double>(lons, lons + npts), std::vector<double>(lats, lats + npts),
+                                               truncation));
+    }
+    catch (...) {
+        delete h;
+        throw;
+    }
+    return h;
+    AA_CATCH_PTR
+}
 void atlas_amd__RegionalTrans__delete(atlas_amd_RegionalTrans* t) {
     delete t;
 }

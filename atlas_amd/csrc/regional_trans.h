@@ -28,6 +28,10 @@ class RegionalTrans {
 public:
     // latitudes in degrees in the order of the target's rows (any order), longitudes west + i * dlon, i < nlon
     RegionalTrans(int nlon, double west, double dlon, const std::vector<double>& lats_deg, int truncation);
+    // unstructured target: a list of (lon, lat) points in degrees (TransLocal.cc:741-790, 1293-1420: Legendre polynomials at
+    // every point's latitude, Fourier sum evaluated point by point, grid points gp[point + npts * field]; u and v divided by
+    // the cosine of the point's own, unclamped latitude :1277-1283)
+    RegionalTrans(const std::vector<double>& lons_deg, const std::vector<double>& lats_deg, int truncation);
     ~RegionalTrans();
     RegionalTrans(const RegionalTrans&)            = delete;
     RegionalTrans& operator=(const RegionalTrans&) = delete;
@@ -35,7 +39,8 @@ public:
     int truncation() const { return T_; }
     int nlon() const { return nlon_; }
     int nlat() const { return (int)rowsel_.size(); }
-    int64_t nb_gridpoints() const { return (int64_t)nlon_ * nlat(); }
+    bool unstructured() const { return d_lon_ != nullptr; }
+    int64_t nb_gridpoints() const { return unstructured() ? (int64_t)rowsel_.size() : (int64_t)nlon_ * nlat(); }
     size_t nb_spectral_coefficients() const { return (size_t)(T_ + 1) * (T_ + 2); }
     hipStream_t stream() const { return inner_->stream(); }
     void synchronize() const { inner_->synchronize(); }
@@ -55,6 +60,8 @@ private:
     std::vector<int> rowsel_;           // per target row: row of the inner object's Fourier intermediate
     int* d_rowsel_     = nullptr;
     double* d_table_   = nullptr;       // [T+1][2][nlon]: cos(m lon) * factor, -sin(m lon) * factor
+    double* d_lon_     = nullptr;       // unstructured target: longitude of every point in radians
+    void make_inner(const std::vector<double>& lats_deg, bool clamp_scale);
     double* d_scale_   = nullptr;       // per target row: 1 / cos(latitude), latitude clamped as TransLocal.cc:1449-1456
     double* d_sp_      = nullptr;
     double* d_gp_      = nullptr;

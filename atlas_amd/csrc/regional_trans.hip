@@ -49,14 +49,49 @@ __global__ void __launch_bounds__(256) regional_dft_kernel(const double* __restr
     }
 }
 
+// unstructured target: gp[f][point] = sum_m factor (cos(m lon) Re F - sin(m lon) Im F)(row of the point, m, f)
+// One thread per point and group of 8 fields: the sine and cosine of m lon are computed once per wavenumber.
+constexpr int PFG = 8;
+__global__ void __launch_bounds__(256) points_dft_kernel(const double* __restrict__ F, const int* __restrict__ rowsel,
+                                                         const double* __restrict__ lon, double* __restrict__ gp, int T, int m_cnt, int RP,
+                                                         long long npts, int nf, const double* __restrict__ scale, int nscaled) {
+    const long long pt = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int f0       = blockIdx.y * PFG;
+    if (pt >= npts) {
+        return;
+    }
+    const double* src = F + (long long)rowsel[pt] * m_cnt * RP + 2 * f0;
+    const double lam  = lon[pt];
+    double acc[PFG];
+#pragma unroll
+    for (int k = 0; k < PFG; ++k) {
+        acc[k] = 0.;
+    }
+    for (int m = 0; m <= T; ++m) {
+        double sn, cs;
+        sincos(m * lam, &sn, &cs);
+        const double fr = m > 0 ? 2. * cs : 1., fi = m > 0 ? -2. * sn : 0.;   // TransLocal.cc:1253-1259
+        const double* c = src + (long long)m * RP;
+#pragma unroll
+        for (int k = 0; k < PFG; ++k) {
+            if (f0 + k < nf) {
+                acc[k] += fr * c[2 * k] + fi * c[2 * k + 1];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PFG; ++k) {
+        if (f0 + k < nf) {
+            gp[(long long)(f0 + k) * npts + pt] = acc[k] * (f0 + k < nscaled ? scale[pt] : 1.);
+        }
+    }
+}
+
 }  // namespace
 
-RegionalTrans::RegionalTrans(int nlon, double west, double dlon, const std::vector<double>& lats_deg, int truncation) :
-    T_(truncation), nlon_(nlon) {
-    if (nlon < 1 || lats_deg.empty() || truncation < 0) {
-        throw std::invalid_argument("RegionalTrans: needs nlon >= 1, at least one latitude and truncation >= 0");
-    }
-    // the symmetric latitude set: |latitudes| (clamped as TransLocal.cc:537-543), north -> equator, then their mirror images
+// the symmetric latitude set: |latitudes| (clamped as TransLocal.cc:537-543), north -> equator, then their mirror images; the
+// inner object's Legendre stage covers the row range the target needs; rowsel_ maps target rows / points to its rows
+void RegionalTrans::make_inner(const std::vector<double>& lats_deg, bool clamp_scale) {
     std::vector<double> a;
     for (double y : lats_deg) {
         if (!(y >= -90. && y <= 90.)) {
@@ -76,14 +111,22 @@ RegionalTrans::RegionalTrans(int nlon, double west, double dlon, const std::vect
         sym.y.push_back(-a[k]);
     }
     // a regular row length for which no wavenumber is truncated at any latitude (TransLocal.cc:463-468: nlat0 = 0)
-    sym.nx.assign(sym.y.size(), 4 * (truncation + 1));
+    sym.nx.assign(sym.y.size(), 4 * (T_ + 1));
     sym.regular = true;
     auto row_of = [&](double y) {
         const double v = std::min(std::fabs(y), kLatPole);
-        int k          = 0;
-        while (k < (int)a.size() && std::fabs(a[k] - v) >= 1.e-12) {
-            ++k;
+        // a is sorted descending: binary search for the entry within the merge tolerance
+        int lo = 0, hi = (int)a.size() - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) / 2;
+            if (a[mid] > v + 1.e-12) {
+                lo = mid + 1;
+            }
+            else {
+                hi = mid;
+            }
         }
+        const int k = lo;
         return y >= 0 || (equator && k == (int)a.size() - 1) ? k : (int)sym.y.size() - 1 - k;
     };
     std::vector<int> rows;
@@ -93,14 +136,30 @@ RegionalTrans::RegionalTrans(int nlon, double west, double dlon, const std::vect
     TransConfig cfg;
     cfg.row_begin = *std::min_element(rows.begin(), rows.end());
     cfg.row_end   = *std::max_element(rows.begin(), rows.end()) + 1;
-    inner_.reset(new Trans(sym, truncation, cfg));
-    for (int m = 0; m <= truncation; ++m) {
+    inner_.reset(new Trans(sym, T_, cfg));
+    for (int m = 0; m <= T_; ++m) {
         if (inner_->geometry().nlat0[m] != 0) {
             throw std::logic_error("RegionalTrans: internal latitude set truncates wavenumber " + std::to_string(m));
         }
     }
     for (int r : rows) {
         rowsel_.push_back(r - cfg.row_begin);
+    }
+    std::vector<double> scale;
+    for (double y : lats_deg) {
+        const double lat = clamp_scale ? std::max(std::min(y, kLatPole), -kLatPole) : y;
+        scale.push_back(1. / std::cos(lat * (M_PI / 180.)));
+    }
+    RT_CHECK(hipMalloc((void**)&d_scale_, scale.size() * sizeof(double)));
+    RT_CHECK(hipMemcpy(d_scale_, scale.data(), scale.size() * sizeof(double), hipMemcpyHostToDevice));
+    RT_CHECK(hipMalloc((void**)&d_rowsel_, rowsel_.size() * sizeof(int)));
+    RT_CHECK(hipMemcpy(d_rowsel_, rowsel_.data(), rowsel_.size() * sizeof(int), hipMemcpyHostToDevice));
+}
+
+RegionalTrans::RegionalTrans(int nlon, double west, double dlon, const std::vector<double>& lats_deg, int truncation) :
+    T_(truncation), nlon_(nlon) {
+    if (nlon < 1 || lats_deg.empty() || truncation < 0) {
+        throw std::invalid_argument("RegionalTrans: needs nlon >= 1, at least one latitude and truncation >= 0");
     }
     // Fourier matrix (TransLocal.cc:719-738), computed on the host with the same libm calls
     std::vector<double> table((size_t)2 * (truncation + 1) * nlon);
@@ -112,21 +171,35 @@ RegionalTrans::RegionalTrans(int nlon, double west, double dlon, const std::vect
             table[(size_t)(2 * m + 1) * nlon + i] = -std::sin(m * lon) * factor;
         }
     }
-    std::vector<double> scale;
-    for (double y : lats_deg) {
-        const double lat = std::max(std::min(y, kLatPole), -kLatPole);
-        scale.push_back(1. / std::cos(lat * (M_PI / 180.)));
-    }
     try {
-        RT_CHECK(hipMalloc((void**)&d_scale_, scale.size() * sizeof(double)));
-        RT_CHECK(hipMemcpy(d_scale_, scale.data(), scale.size() * sizeof(double), hipMemcpyHostToDevice));
+        make_inner(lats_deg, true);
         RT_CHECK(hipMalloc((void**)&d_table_, table.size() * sizeof(double)));
         RT_CHECK(hipMemcpy(d_table_, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice));
-        RT_CHECK(hipMalloc((void**)&d_rowsel_, rowsel_.size() * sizeof(int)));
-        RT_CHECK(hipMemcpy(d_rowsel_, rowsel_.data(), rowsel_.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     catch (...) {
         (void)hipFree(d_table_);
+        (void)hipFree(d_rowsel_);
+        (void)hipFree(d_scale_);
+        throw;
+    }
+}
+
+RegionalTrans::RegionalTrans(const std::vector<double>& lons_deg, const std::vector<double>& lats_deg, int truncation) :
+    T_(truncation), nlon_(0) {
+    if (lons_deg.empty() || lons_deg.size() != lats_deg.size() || truncation < 0) {
+        throw std::invalid_argument("RegionalTrans: needs as many longitudes as latitudes, at least one, and truncation >= 0");
+    }
+    std::vector<double> lon;
+    for (double v : lons_deg) {
+        lon.push_back(v * (M_PI / 180.));
+    }
+    try {
+        make_inner(lats_deg, false);
+        RT_CHECK(hipMalloc((void**)&d_lon_, lon.size() * sizeof(double)));
+        RT_CHECK(hipMemcpy(d_lon_, lon.data(), lon.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    catch (...) {
+        (void)hipFree(d_lon_);
         (void)hipFree(d_rowsel_);
         (void)hipFree(d_scale_);
         throw;
@@ -138,6 +211,7 @@ RegionalTrans::~RegionalTrans() {
         (void)hipStreamSynchronize(inner_->stream());
     }
     (void)hipFree(d_table_);
+    (void)hipFree(d_lon_);
     (void)hipFree(d_rowsel_);
     (void)hipFree(d_scale_);
     (void)hipFree(d_sp_);
@@ -148,6 +222,14 @@ RegionalTrans::~RegionalTrans() {
 
 void RegionalTrans::dft(int trc_in, int nb_fields, int nb_vordiv, const double* F, double* gp_dev) {
     (void)trc_in;   // the Legendre stage left zeros for the wavenumbers it does not transform
+    if (unstructured()) {
+        const long long npts = nb_gridpoints();
+        hipLaunchKernelGGL(points_dft_kernel, dim3((unsigned)((npts + 255) / 256), (unsigned)((nb_fields + PFG - 1) / PFG)), dim3(256), 0,
+                           inner_->stream(), F, d_rowsel_, d_lon_, gp_dev, T_, T_ + 1, inner_->fourier_row_pitch(nb_fields), npts,
+                           nb_fields, d_scale_, 2 * nb_vordiv);
+        RT_CHECK(hipGetLastError());
+        return;
+    }
     const size_t lds = (size_t)2 * (T_ + 1) * sizeof(double);
     if (lds > 160 * 1024) {
         throw std::runtime_error("RegionalTrans: truncation too large for the direct Fourier kernel");

@@ -387,6 +387,7 @@ class LegendreCacheCreator:
 
 
 _RT_new = _lib._sig("atlas_amd__RegionalTrans__new", C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_int)
+_RT_new_points = _lib._sig("atlas_amd__RegionalTrans__new_unstructured", C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int)
 _RT_delete = _lib._sig("atlas_amd__RegionalTrans__delete", None, C.c_void_p)
 _RT_npts = _lib._sig("atlas_amd__RegionalTrans__nb_gridpoints", C.c_int64, C.c_void_p)
 _RT_invtrans = _lib._sig("atlas_amd__RegionalTrans__invtrans_scalar", C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)
@@ -407,6 +408,17 @@ class RegionalTrans:
         self._lats = np.ascontiguousarray(lats, dtype=np.float64)
         self.nlon, self.nlat, self.truncation = int(nlon), int(self._lats.size), int(truncation)
         self._h = _lib.check_ptr(_RT_new(self.nlon, float(west), float(dlon), self.nlat, self._lats.ctypes.data, self.truncation))
+
+    @classmethod
+    def unstructured(cls, lons, lats, truncation):
+        """target = a list of (lon, lat) points in degrees (TransLocal's unstructured path); grid points [field][point]"""
+        self = cls.__new__(cls)
+        self._lons = np.ascontiguousarray(lons, dtype=np.float64)
+        self._lats = np.ascontiguousarray(lats, dtype=np.float64)
+        assert self._lons.size == self._lats.size
+        self.nlon, self.nlat, self.truncation = 0, int(self._lats.size), int(truncation)
+        self._h = _lib.check_ptr(_RT_new_points(self.nlat, self._lons.ctypes.data, self._lats.ctypes.data, self.truncation))
+        return self
 
     def __del__(self):
         h = getattr(self, "_h", None)

@@ -109,6 +109,12 @@ int64_t atlas_amd__Trans__nb_gridpoints(const atlas_amd_Trans* t);           /* 
 typedef struct atlas_amd_RegionalTrans atlas_amd_RegionalTrans;
 atlas_amd_RegionalTrans* atlas_amd__RegionalTrans__new(int nlon, double west, double dlon, int nlat, const double lats[],
                                                        int truncation);
+/* unstructured target: npts points (lon, lat) in degrees -- TransLocal's unstructured path (TransLocal.cc:741-790, 1200-1420):
+ * Legendre polynomials at every point's latitude, the Fourier sum evaluated point by point; grid points gp[point + npts *
+ * field]; u and v of the vor/div path divided by the cosine of the point's latitude.  Points at the poles are evaluated at
+ * +-89.9999999 degrees like the structured paths. */
+atlas_amd_RegionalTrans* atlas_amd__RegionalTrans__new_unstructured(int npts, const double lons[], const double lats[],
+                                                                    int truncation);
 void atlas_amd__RegionalTrans__delete(atlas_amd_RegionalTrans* t);
 int64_t atlas_amd__RegionalTrans__nb_gridpoints(const atlas_amd_RegionalTrans* t);
 int atlas_amd__RegionalTrans__invtrans_scalar(atlas_amd_RegionalTrans* t, int nb_fields, const double scalar_spectra[],

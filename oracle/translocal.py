@@ -264,3 +264,14 @@ def invtrans_regional_vordiv(truncation, lats_deg, lons_deg, ns, sp, nvd, vor, d
         parts.append(extend(sp, ns))
     allsp = np.concatenate(parts, axis=2)
     return invtrans_regional(T, lats_deg, lons_deg, 2 * nvd + ns, allsp, trc_in=T + 1, nb_vordiv=nvd)
+
+
+def invtrans_unstructured(truncation, lons_deg, lats_deg, nf, sp, trc_in=None, nb_vordiv=0):
+    """TransLocal's unstructured path (TransLocal.cc:1200-1291): per point the Legendre polynomials at its latitude and
+    the Fourier sum 1, 2 cos(m lon), -2 sin(m lon) over jm < truncation; u and v divided by cos(lat) of the point.
+    Returns gp[field][point].  (Restated on the regional formulation above, one point at a time.)"""
+    lons, lats = np.asarray(lons_deg, dtype=np.float64), np.asarray(lats_deg, dtype=np.float64)
+    out = np.zeros((nf, len(lons)))
+    for i in range(len(lons)):
+        out[:, i] = invtrans_regional(truncation, [lats[i]], [lons[i]], nf, sp, trc_in=trc_in, nb_vordiv=nb_vordiv)[:, 0, 0]
+    return out

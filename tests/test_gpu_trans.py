@@ -680,3 +680,49 @@ def test_regional_target_that_is_not_a_crop_of_a_global_grid(case):
     rt2.synchronize()
     sel = ref[:, rows][:, :, i0 + step * np.arange(n)]
     assert compute_rms(gp2.cpu().numpy(), sel.ravel()) < 1e-13
+
+
+def test_unstructured_target_points():
+    """TransLocal's unstructured path (TransLocal.cc:741-790, 1200-1420; compared there with the structured result in
+    test_transgeneral.cc:1336-1490): a list of (lon, lat) points.  Against the oracle's per-point restatement, and the points
+    of a structured grid must reproduce the structured transform within rounding."""
+    T, nf = 63, 11
+    sp = red_spectra(T, nf, seed=61)
+    rng = np.random.default_rng(5)
+    lons, lats = rng.uniform(-180.0, 540.0, 300), rng.uniform(-89.0, 89.0, 300)
+    lats[:7] = [0.0, 45.0, -45.0, 45.0, 12.5, -12.5, 0.0]        # repeated and mirrored latitudes, the equator
+    ut = atlas_amd.RegionalTrans.unstructured(lons, lats, T)
+    assert ut.nb_gridpoints() == 300
+    gp = np.zeros(nf * 300)
+    ut.invtrans(nf, sp, gp)
+    want = oracle.invtrans_unstructured(T, lons, lats, nf, sp)
+    assert compute_rms(gp, want.ravel()) < 1e-13
+    gp_d = torch.zeros(nf * 300, dtype=torch.float64, device="cuda")
+    ut.invtrans(nf, dev(sp), gp_d)
+    ut.synchronize()
+    assert np.array_equal(gp_d.cpu().numpy(), gp)
+    # every point of O32 as an unstructured target (test_transgeneral.cc:1336-1490 does this with a cropped grid)
+    g, tr = get_trans("O32", T)
+    nx, y = g.nx(), g.y()
+    plon = np.concatenate([np.arange(n) * (360.0 / n) for n in nx])
+    plat = np.concatenate([np.full(n, v) for n, v in zip(nx, y)])
+    ref = run_device(tr, nf, sp)
+    ut2 = atlas_amd.RegionalTrans.unstructured(plon, plat, T)
+    gp2 = np.zeros(nf * len(plon))
+    ut2.invtrans(nf, sp, gp2)
+    # the structured path truncates the Fourier sum towards the poles (nlat0), the unstructured one does not: compare where
+    # every wavenumber is kept
+    full = np.array([oracle.fourier_truncation(T, int(nx[j]), int(nx.max()), len(nx), math.radians(y[j]), False) >= T
+                     for j in range(len(nx))])
+    keep = np.concatenate([np.full(n, k) for n, k in zip(nx, full)])
+    assert keep.sum() > 1000
+    assert compute_rms(gp2.reshape(nf, -1)[:, keep].ravel(), ref.reshape(nf, -1)[:, keep].ravel()) < 1e-13
+    # vor/div -> u, v
+    ns, nvd = 1, 2
+    s1, vor, div = red_spectra(T, ns, 71), red_spectra(T, nvd, 72), red_spectra(T, nvd, 73)
+    parts = oracle.invtrans_regional_vordiv   # per point through the regional restatement
+    want_vd = np.stack([parts(T, [lats[i]], [lons[i]], ns, s1, nvd, vor, div)[:, 0, 0] for i in range(40)], axis=1)
+    ut3 = atlas_amd.RegionalTrans.unstructured(lons[:40], lats[:40], T)
+    gp3 = np.zeros((ns + 2 * nvd) * 40)
+    ut3.invtrans_vordiv(ns, s1, nvd, vor, div, gp3)
+    assert compute_rms(gp3, want_vd.ravel()) < 1e-12
