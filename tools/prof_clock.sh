@@ -2,9 +2,9 @@
 # Dev tool (GPU box): effective shader clock of each kernel = GRBM_GUI_ACTIVE / kernel duration
 export TMPDIR=/tmp
 R=$PWD
-mkdir -p $R/gpurun_out/clk
+rm -rf $R/gpurun_out/clk; mkdir -p $R/gpurun_out/clk
 cd /tmp
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE GRBM_COUNT -d $R/gpurun_out/clk --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/clk/bench.log 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE GRBM_COUNT -d $R/gpurun_out/clk --output-format csv -- python $R/bench.py --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline > $R/gpurun_out/clk/bench.log 2>&1
 cd $R
 python3 - << 'PY'
 import csv, glob, collections
