@@ -7,6 +7,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libatlas_amd.so")
+if os.environ.get("ATLAS_AMD_LIB"):   # dev builds of the same library (tools/: trace / ablation variants), never a fallback
+    LIB_PATH = os.path.abspath(os.environ["ATLAS_AMD_LIB"])
 
 
 class AtlasAmdError(RuntimeError):
@@ -163,6 +165,7 @@ legendre_gen_host_selfcheck = _sig("atlas_amd__legendre_gen_host_selfcheck", C.c
 Trans_timings = _sig("atlas_amd__Trans__timings", C.c_int, c_void_p, c_void_p, C.c_int)
 Trans_set_profile = _sig("atlas_amd__Trans__set_profile", C.c_int, c_void_p, C.c_int)
 Trans_fft_phase_profile = _sig("atlas_amd__Trans__fft_phase_profile", C.c_int, c_void_p, C.c_int, c_void_p)
+Trans_fft_trace = _sig("atlas_amd__Trans__fft_trace", C.c_int, c_void_p, C.c_ulonglong, c_void_p)
 
 fourier_truncation = _sig("atlas_amd__fourier_truncation", C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                           C.c_int)

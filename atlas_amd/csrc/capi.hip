@@ -881,6 +881,12 @@ int atlas_amd__Trans__fft_phase_profile(atlas_amd_Trans* t, int enable, unsigned
     AA_CATCH_INT
 }
 
+int atlas_amd__Trans__fft_trace(atlas_amd_Trans* t, unsigned long long words, unsigned long long* out) {
+    AA_TRY
+    t->impl->fft_trace(words, out);
+    AA_CATCH_INT
+}
+
 // ---------------------------------------------------------------- host-only helpers
 int atlas_amd__fourier_truncation(int truncation, int nx, int nxmax, int ndgl, double lat_rad, int fullgrid) {
     return trans::fourier_truncation(truncation, nx, nxmax, ndgl, lat_rad, fullgrid != 0);

@@ -69,6 +69,8 @@ struct FourierParams {
     const double* coslatinv;          // [nlats]
     int abl;                          // dev builds (-DAA_FFT_ABLATE) only: access-ablation bits, see fft_core.h
     unsigned long long* prof;         // optional [64] per-phase cycle accumulators (dev profiling), else null
+    unsigned long long* trace;        // dev builds (-DAA_FFT_TRACE) only: 8 words per wavefront (hardware id, s_memtime at the
+    unsigned long long trace_cap;     // phase boundaries), slot = (block * waves per workgroup + wave) * 8; capacity in words
 };
 
 }  // namespace trans

@@ -376,6 +376,33 @@ AA_HD void dit_stage(cplx* d, int M, int L, int lsh, const cplx* __restrict__ tw
     }
 }
 
+// the same two stages for one butterfly with the stage twiddle w1 = tw[j * tws] supplied by the caller (the specialised
+// device path loads it once per row and keeps it: the DIF and the DIT stage of one level use the same entry)
+template <int R>
+AA_HD void dif_butterfly_w(cplx* d, int base, int Ls, cplx w1, int dir) {
+    cplx x[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) x[q] = d[PAD(base + q * Ls)];
+    bfly<R>(x, dir);
+    d[PAD(base)] = x[0];
+    if (dir < 0) w1.im = -w1.im;
+    twiddle_apply<R>(x, w1);
+#pragma unroll
+    for (int q = 1; q < R; ++q) d[PAD(base + q * Ls)] = x[q];
+}
+template <int R>
+AA_HD void dit_butterfly_w(cplx* d, int base, int Ls, cplx w1, int dir) {
+    cplx x[R];
+    x[0] = d[PAD(base)];
+    if (dir < 0) w1.im = -w1.im;
+#pragma unroll
+    for (int q = 1; q < R; ++q) x[q] = d[PAD(base + q * Ls)];
+    twiddle_apply<R>(x, w1);
+    bfly<R>(x, dir);
+#pragma unroll
+    for (int q = 0; q < R; ++q) d[PAD(base + q * Ls)] = x[q];
+}
+
 // fused middle of the Bluestein convolution: the last DIF stage and the first DIT stage act on the same contiguous
 // groups of R elements (L = R, no twiddles), so forward butterfly, filter multiply and inverse butterfly happen in
 // registers with one LDS read and one LDS write.
@@ -715,8 +742,20 @@ struct CtShape {
     static constexpr int K  = K_;
     static constexpr int M  = F_ << K_;
     static constexpr int NS = ct_nstages(F_, K_);
-    // workers per row of the Bluestein kernel: one radix-16 butterfly each in the middle stages
-    static constexpr int NT = (M / 16 + 63) / 64 * 64 < 64 ? 64 : ((M / 16 + 63) / 64 * 64 > 512 ? 512 : (M / 16 + 63) / 64 * 64);
+    // workers per row of the Bluestein kernel: one radix-16 butterfly each in the middle stages.  Never 5 or 6 wavefronts:
+    // a workgroup is only launched onto a CU whose every SIMD has registers for ceil(waves / 4) of its wavefronts, so two
+    // 5-wavefront workgroups of 168 registers never share a CU although their 10 wavefronts would fit (per-wavefront trace,
+    // profiles/r03_fft_trace.txt: one workgroup resident 68-82 % of the time for M = 5120 / 4608, two for M = 4096 / 3840).
+    // With 4 wavefronts the butterflies beyond 256 of the middle stages are a second round of the first wavefront(s).
+    static constexpr int NT0 = (M / 16 + 63) / 64 * 64 < 64 ? 64 : ((M / 16 + 63) / 64 * 64 > 512 ? 512 : (M / 16 + 63) / 64 * 64);
+#if defined(AA_FFT_KEEP_5WAVE)
+    static constexpr int NT = NT0;
+#else
+    static constexpr int NT = (NT0 == 320 || NT0 == 384) ? 256 : NT0;
+#endif
+    // wavefronts per SIMD the kernel is compiled for: the LDS footprint M * 16 allows two workgroups per CU above
+    // 53 KiB (two wavefronts per SIMD at most: 256 registers), three below
+    static constexpr int WPS = (M * 16 > 53248) ? 2 : 3;
     static constexpr int radix(int i) { return ct_radix(F_, K_, i); }
     static constexpr int L(int i) {
         int l = M;

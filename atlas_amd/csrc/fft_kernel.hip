@@ -237,10 +237,171 @@ __device__ __forceinline__ void gather_modes_to_lds(const FourierParams& p, long
     }
 }
 
+// workgroup barrier that orders LDS accesses only: global loads requested before it stay in flight (__syncthreads() would
+// drain them: its workgroup-scope fence waits for vmcnt(0))
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ void wave_lds_fence() {
+    // producer and consumer lanes are in this wavefront: LDS executes a wavefront's instructions in order, only the
+    // compiler must not move accesses across this point
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- [R0,16,16] rows of the LDS-heavy classes (M >= 3840: two workgroups of four wavefronts per CU, 256 registers):
+// the whole row in one function, so that every table value is requested a phase (or more) before its use and the ones
+// used twice are kept.  Same arithmetic, in the same order, as row_phase_ct (the host emulation and the planner run that).
+//   before the gather completes : stage-0 twiddle w0, c2r factors P and chirp C of this worker's stage-0 butterfly, the
+//                                 level-1 twiddle wm (one entry serves the DIF and the DIT stage of the level)
+//   after phase 0               : the filter spectrum of the worker's first middle butterfly (used in phase 2)
+//   before phase 3              : the chirp of the outputs (phase 4); wm and w0 are kept
+// Per-wavefront trace of the previous form (profiles/r03_fft_trace.txt): gather 4.1 us, phase 0 4.0 us, phase 2 1.7 - 4.5 us
+// of a 16 us workgroup whose vector-ALU work is 3.8 us per wavefront.
+template <class S>
+constexpr bool ct3_fast_path() {
+    return S::NS == 3 && S::wave_local_middle() && S::radix(1) == 16 && S::radix(2) == 16 && S::M / S::radix(0) == 256 &&
+           S::NT == 256 && S::WPS == 2;
+}
+
+template <class S, bool F32, class Stamp>
+__device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTablesCt& r, const fft::RowOut& io,
+                                        long long lat_local, int f, cplx* work, int t, Stamp&& stamp) {
+    constexpr int M    = S::M;
+    constexpr int R0   = S::radix(0);
+    constexpr int NT   = S::NT;
+    constexpr int NZ   = (R0 + 1) / 2;
+    constexpr int NMID = M / 16;                      // butterflies of a middle stage
+    constexpr int NBM  = (NMID + NT - 1) / NT;        // rounds of the middle stages (2 for M > 4096: first wavefront only)
+    const int h        = r.h;
+    const int pt       = fft::PAD(t);   // t < 256: PAD(t + 256 q) = PAD(t) + 256 q (the swizzle stays inside blocks of 256)
+    static_assert(NT == 256, "stage-0 butterfly b == worker t");
+#if defined(AA_FFT_ABLATE)
+    if (!(p.abl & 32))   // dev: bit 5 leaves the gather out altogether (results wrong): what the phase costs
+#endif
+    gather_modes_to_lds<F32>(p, lat_local, f, io.mmax, work, t, NT);
+    // ---- table values of phases 0, 1, 3 and 4
+    const cplx w0 = r.tw[t];
+    const cplx wm = r.tw[(t & 15) * (M / 256)];
+    cplx P[NZ], C[NZ];
+#pragma unroll
+    for (int q = 0; q < NZ; ++q) {   // the tables are padded to NZ * 256 entries (fft_plan.cpp): no clamp
+        P[q] = r.pre[(t + q * 256) * AA_ABL(r, 1)];
+        C[q] = r.chirp[(t + q * 256) * AA_ABL(r, 1)];
+    }
+    AA_SCHED_FENCE();
+    __syncthreads();
+    stamp(2);
+    // ---- phase 0: c2r pre-processing + chirp + DIF stage 0 (one block of M, stride 256), inputs from the staging area
+    {
+        const cplx* raw = work;
+        cplx x[R0];
+#pragma unroll
+        for (int q = 0; q < NZ; ++q) {
+            const int k  = t + q * 256;
+            const int kc = k < h ? k : h - 1;
+            const cplx a = fft::ct_raw_mode(raw, io.mmax, kc, h);
+            const cplx c = fft::cconj(fft::ct_raw_mode(raw, io.mmax, h - kc, h));
+            const cplx z = fft::cmul(fft::c2r_pre(a, c, P[q]), C[q]);
+            x[q]         = k < h ? z : cplx{0., 0.};
+        }
+#pragma unroll
+        for (int q = NZ; q < R0; ++q) x[q] = cplx{0., 0.};
+        fft::bfly<R0>(x, -1);
+        cplx w1 = w0;
+        w1.im   = -w1.im;
+        fft::twiddle_apply<R0>(x, w1);
+        lds_barrier();   // the staging area aliases the work array: everybody has read it
+#pragma unroll
+        for (int q = 0; q < R0; ++q) work[pt + q * 256] = x[q];
+    }
+    // filter spectrum of the first middle butterfly: in flight during phase 1
+    cplx flt[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) flt[q] = r.bhat_t[(q * NMID + t) * AA_ABL(r, 2)];
+    AA_SCHED_FENCE();
+    lds_barrier();
+    stamp(3);
+    // ---- phase 1: DIF level 1 (blocks of 256 = 16 consecutive workers, radix 16, stride 16)
+#pragma unroll
+    for (int ib = 0; ib < NBM; ++ib) {
+        const int b = t + ib * NT;
+        if (b < NMID) {
+            fft::dif_butterfly_w<16>(work, (b >> 4) * 256 + (b & 15), 16, wm, -1);
+        }
+    }
+    wave_lds_fence();
+    stamp(4);
+    // ---- phase 2: last DIF stage * filter spectrum * first DIT stage (16 contiguous elements, no twiddles)
+#pragma unroll
+    for (int ib = 0; ib < NBM; ++ib) {
+        const int b = t + ib * NT;
+        if (b < NMID) {
+            if (ib > 0) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) flt[q] = r.bhat_t[(q * NMID + b) * AA_ABL(r, 2)];
+                AA_SCHED_FENCE();
+            }
+            cplx x[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) x[q] = work[fft::PAD(b * 16 + q)];
+            fft::bfly<16>(x, -1);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) x[q] = fft::cmul(x[q], flt[q]);
+            fft::bfly<16>(x, +1);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) work[fft::PAD(b * 16 + q)] = x[q];
+        }
+    }
+    wave_lds_fence();
+    stamp(5);
+    // chirp of the outputs again (kept from phase 0 it costs 4 NZ registers through the two widest phases: spills)
+#pragma unroll
+    for (int q = 0; q < NZ; ++q) {
+        C[q] = r.chirp[(t + q * 256) * AA_ABL(r, 3)];
+    }
+    AA_SCHED_FENCE();
+    // ---- phase 3: DIT level 1
+#pragma unroll
+    for (int ib = 0; ib < NBM; ++ib) {
+        const int b = t + ib * NT;
+        if (b < NMID) {
+            fft::dit_butterfly_w<16>(work, (b >> 4) * 256 + (b & 15), 16, wm, +1);
+        }
+    }
+    lds_barrier();
+    stamp(6);
+    // ---- phase 4: DIT stage 0 + chirp + store (outputs q >= NZ are padding: their butterfly arithmetic is dead)
+    {
+        cplx x[R0];
+#pragma unroll
+        for (int q = 0; q < R0; ++q) x[q] = work[pt + q * 256];
+        fft::twiddle_apply<R0>(x, w0);
+        fft::bfly<R0>(x, +1);
+#pragma unroll
+        for (int q = 0; q < NZ; ++q) {
+            x[q]    = fft::cmul(x[q], C[q]);
+            x[q].re = x[q].re * io.scale;  // 1/cos(lat) for the wind fields, exactly 1 otherwise
+            x[q].im = x[q].im * io.scale;
+        }
+        fft::with_store_flavour(io, [&](auto f32c, auto alc) {
+#pragma unroll
+            for (int q = 0; q < NZ; ++q) {
+                const int k = t + q * 256;
+                if (k < h) {
+                    fft::store_pair_t<decltype(f32c)::value, decltype(alc)::value>(io, (int64_t)k * AA_ABL(r, 4), x[q]);
+                }
+            }
+        });
+    }
+    stamp(7);
+}
+
 // One workgroup of S::NT workers per (row, field).  Every mode of the row is fetched from the Fourier intermediate once,
 // into an LDS staging area that aliases the work array (phase 0 reads it completely before writing its results).
 template <class S, bool F32>
-__global__ void __launch_bounds__(S::NT, 3) fft_rows_ct_kernel(FourierParams p) {
+__global__ void __launch_bounds__(S::NT, S::WPS) fft_rows_ct_kernel(FourierParams p) {
     extern __shared__ double lds_raw[];
     cplx* work = reinterpret_cast<cplx*>(lds_raw);
     int row, f;
@@ -275,8 +436,32 @@ __global__ void __launch_bounds__(S::NT, 3) fft_rows_ct_kernel(FourierParams p) 
     if (prof) {
         tprev = clock64();
     }
+#if defined(AA_FFT_TRACE)
+    // poor man's thread trace: every wavefront records where it runs and the shader clock at its phase boundaries
+    unsigned long long* trc = nullptr;
+    if (p.trace) {
+        const unsigned long long slot = ((unsigned long long)blockIdx.x * (nt / 64) + (tid >> 6)) * 8;
+        if (slot + 8 <= p.trace_cap && (tid & 63) == 0) {
+            trc = p.trace + slot;
+            const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+            const unsigned xcc  = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+            trc[0] = ((unsigned long long)xcc << 32) | hwid;
+            trc[1] = __builtin_amdgcn_s_memtime();
+        }
+    }
+#define AA_TRACE_STAMP(k) do { if (trc) trc[(k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AA_TRACE_STAMP(k) ((void)0)
+#endif
+#if !defined(AA_FFT_NO_CT3)
+    if constexpr (ct3_fast_path<S>()) {
+        row_ct3<S, F32>(p, r, io, (long long)(row - p.lat0), f, work, tid, [&](int k) { (void)k; AA_TRACE_STAMP(k); });
+        return;
+    }
+#endif
     gather_modes_to_lds<F32>(p, (long long)(row - p.lat0), f, io.mmax, work, tid, nt);
     __syncthreads();
+    AA_TRACE_STAMP(2);
     if (prof) {
         const unsigned long long tn = clock64();
         atomicAdd(&p.prof[30], tn - tprev);
@@ -298,6 +483,9 @@ __global__ void __launch_bounds__(S::NT, 3) fft_rows_ct_kernel(FourierParams p) 
             else {
                 __syncthreads();
             }
+        }
+        if constexpr (ph < 5) {
+            AA_TRACE_STAMP(3 + ph);
         }
         if (prof) {
             const unsigned long long tn = clock64();

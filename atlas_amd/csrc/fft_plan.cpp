@@ -274,6 +274,17 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, const PlanOptions
         for (int k = 0; k < h; ++k) {
             ps.table.push_back(unit_root(k, n));
         }
+        // specialised Bluestein rows: the stage-0 butterfly b reads the entries b + q * (M / R0), q < ceil(R0 / 2), some of
+        // them beyond h (zero padding of the convolution: the values are not used).  Padding `pre` and `chirp` to that extent
+        // (with copies of entry h - 1) lets the kernel address them without a clamp: one base register + immediates.
+        int table_pad = 0;
+        if (p.method == FFT_BLUESTEIN && p.ct_k >= 0) {
+            const int R0 = p.shape.radix[0];
+            table_pad    = std::max(0, (R0 + 1) / 2 * (M / R0) - h);
+        }
+        for (int k = 0; k < table_pad; ++k) {
+            ps.table.push_back(unit_root(h - 1, n));
+        }
         if (p.method == FFT_HYBRID) {
             const int A = p.hyb_A, Kp = (A + 1) / 2;
             p.hyb_Mt    = (Kp + 15) / 16;
@@ -305,6 +316,9 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, const PlanOptions
                 const int64_t q = ((int64_t)k * k) % (2 * (int64_t)h);
                 chirp[k]        = unit_root(q, 2 * (int64_t)h);
                 ps.table.push_back(chirp[k]);
+            }
+            for (int k = 0; k < table_pad; ++k) {
+                ps.table.push_back(chirp[h - 1]);
             }
             // filter b[d] = conj(c[|d|]) wrapped into M; spectrum via the kernel's own forward DIF (padded layout),
             // stored in position order and scaled by 1/M

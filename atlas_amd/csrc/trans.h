@@ -119,6 +119,9 @@ public:
     // dev profiling: per-phase shader-clock totals of the FFT kernel (thread 0 of every workgroup)
     void enable_phase_profile(bool on);
     void read_phase_profile(unsigned long long out[64]);
+    // dev builds (-DAA_FFT_TRACE): out == nullptr allocates and zeroes a trace buffer of `words` 64-bit words (0 frees it);
+    // otherwise copies the first `words` words out (layout: device_structs.h, FourierParams::trace)
+    void fft_trace(unsigned long long words, unsigned long long* out);
 
 private:
     void upload();
@@ -190,6 +193,8 @@ private:
     size_t all_cap_     = 0;
     double* d_vd_       = nullptr;  // host-API staging of vor ++ div
     unsigned long long* d_prof_ = nullptr;
+    unsigned long long* d_trace_ = nullptr;
+    unsigned long long trace_cap_ = 0;
     size_t vd_cap_      = 0;
     void ensure(double*& ptr, size_t& cap, size_t n);
     // host-pointer pipeline (pinned staging)

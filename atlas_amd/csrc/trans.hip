@@ -179,6 +179,7 @@ void Trans::release() noexcept {
     fr(d_win_n_);
     fr(d_win_off_);
     fr(d_prof_);
+    fr(d_trace_);
     fr(d_vd_);
     for (auto& e : events_) {
         (void)hipEventDestroy(e);
@@ -587,6 +588,8 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
     p.scale_uv_fields = std::min(2 * nb_vordiv, nb_fields);
     p.coslatinv       = d_coslatinv_;
     p.prof            = d_prof_;
+    p.trace           = d_trace_;
+    p.trace_cap       = trace_cap_;
     p.abl             = std::getenv("ATLAS_AMD_FFT_ABLATE") ? atoi(std::getenv("ATLAS_AMD_FFT_ABLATE")) : 0;
     TraceRange trace(geo_.regular ? "Inverse Fourier Transform (mi355x, RegularGrid)"      // TransLocal.cc:1107
                                   : "Inverse Fourier Transform (mi355x, ReducedGrid)");    // TransLocal.cc:1159
@@ -914,6 +917,26 @@ void Trans::enable_phase_profile(bool on) {
     else if (d_prof_) {
         HIP_CHECK(hipFree(d_prof_));
         d_prof_ = nullptr;
+    }
+}
+
+void Trans::fft_trace(unsigned long long words, unsigned long long* out) {
+    synchronize();
+    if (!out) {   // (re)allocate and zero
+        if (d_trace_) {
+            HIP_CHECK(hipFree(d_trace_));
+            d_trace_ = nullptr;
+        }
+        trace_cap_ = words;
+        if (words) {
+            HIP_CHECK(hipMalloc((void**)&d_trace_, words * sizeof(unsigned long long)));
+            HIP_CHECK(hipMemset(d_trace_, 0, words * sizeof(unsigned long long)));
+        }
+        return;
+    }
+    const unsigned long long n = words < trace_cap_ ? words : trace_cap_;
+    if (n) {
+        HIP_CHECK(hipMemcpy(out, d_trace_, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     }
 }
 

@@ -282,6 +282,10 @@ int atlas_amd__Trans__set_profile(atlas_amd_Trans* t, int on);
 /* dev profiling of the FFT kernel: if out != NULL read the 64 per-phase shader-clock accumulators (slots 0..31
  * Bluestein rows, 32..63 direct rows), then enable (and zero) or disable the accumulation */
 int atlas_amd__Trans__fft_phase_profile(atlas_amd_Trans* t, int enable, unsigned long long out[64]);
+/* dev builds of the library (-DAA_FFT_TRACE) only: per-wavefront trace of the specialised Fourier kernel (hardware id and
+ * shader clock at the phase boundaries, 8 words per wavefront).  out == NULL: allocate and zero `words` words (0 frees);
+ * else copy the first `words` words out.  A normal build accepts the call and records nothing. */
+int atlas_amd__Trans__fft_trace(atlas_amd_Trans* t, unsigned long long words, unsigned long long* out);
 
 /* host-only helpers exposed for CPU tests of the host logic (no GPU needed) */
 int atlas_amd__fourier_truncation(int truncation, int nx, int nxmax, int ndgl, double lat_rad, int fullgrid);

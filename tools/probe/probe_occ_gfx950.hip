@@ -17,9 +17,9 @@ __global__ void spin(long long clocks, double* out) {
 int main() {
     double* out;
     CK(hipMalloc(&out, 64));
-    const int sizes[] = {16384, 20480, 27136, 32768, 36864, 40960, 41984, 49152, 53248, 54016};
+    const int sizes[] = {16384, 32768, 36864, 40960, 53248, 54016, 61440, 65536, 73728, 80896, 81920, 98304};
     for (int lds : sizes) {
-        for (int nthr : {256, 512}) {
+        for (int nthr : {192, 256, 320, 512}) {
             CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&spin), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             int occ = -1;
             CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, spin, nthr, lds));
