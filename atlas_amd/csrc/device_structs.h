@@ -59,6 +59,7 @@ struct FourierParams {
     const int* rows;                  // rows handled by this launch (size class)
     int nrows;
     unsigned nvirt;                   // virtual blocks (row, field slots) of the launch, set by the launcher
+    int jobs;                         // tools/experiments/fft_kernel_p.hip only (field groups a workgroup walks through); 1
     int T;
     int RP;
     int nf;

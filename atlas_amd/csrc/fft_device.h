@@ -1,0 +1,109 @@
+// Device-side helpers shared by the Fourier kernels (fft_kernel.hip, fft_kernel_p.hip): block -> job maps, the reader of the
+// Fourier intermediate, LDS-only barriers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_structs.h"
+
+namespace atlas_amd {
+namespace trans {
+
+using fft::cplx;
+
+constexpr int FFT_MAX_NTHR = 512;  // 2 waves per SIMD -> 256 VGPRs: radix-16 butterflies stay in registers
+constexpr int FGROUP   = 8;  // fields whose modes share one 128-byte line of F
+
+// Block -> (row, field).  Eight consecutive fields of one row share every 128-byte line of F, and hardware places
+// block b on XCD b % 8, so blocks {b, b+8, ..., b+56} (same XCD, dispatched back to back) are given the same
+// (row, field group): the line is then fetched into that XCD's L2 once.  Speed heuristic only.
+__device__ __forceinline__ bool fft_block_to_job(const FourierParams& p, int b, int& row, int& f) {
+    const int x   = b & 7;
+    const int q   = b >> 3;
+    const int j   = q & 7;
+    const int u   = (q >> 3) * 8 + x;
+    const int ngr = (p.f_end - p.f_begin + FGROUP - 1) / FGROUP;
+    const int ri  = u / ngr;
+    const int fg  = u - ri * ngr;
+    if (ri >= p.nrows) {
+        return false;
+    }
+    f = p.f_begin + fg * FGROUP + j;
+    if (f >= p.f_end) {
+        return false;
+    }
+    row = p.rows[ri];
+    return true;
+}
+
+// Input modes of one (row, field).  The Fourier intermediate may be split by zonal wavenumber over `nparts`
+// producers (multi-GPU m-sharding: wavenumber m belongs to part m % nparts, local index m / nparts):
+//   X[m] = *(cplx*)(base[m % nparts] + (lat_local * cnt[m % nparts] + m / nparts) * RP + 2*field)
+// nparts == 1 is the single-device layout F[(lat*(T+1) + m)*RP + r].
+// STORAGE: 0 = double intermediate, 1 = float (fp32 variant), 2 = decided at run time by p.f32 (generic kernel)
+template <int STORAGE>
+struct ModeReaderT {
+    const FourierParams& p;
+    long long lat_local;
+    int f2;
+    // address of mode m (fp64 storage: a double*; fp32 storage: element index in floats, see operator())
+    __device__ __forceinline__ const double* locate(int m, long long& o) const {
+        const double* base = p.part_base[0];
+        int cnt            = p.part_cnt[0];
+        int ml             = m;
+        if (p.nparts > 1) {
+            ml             = m / p.nparts;
+            const int part = m - ml * p.nparts;
+#pragma unroll
+            for (int i = 1; i < fft::MAX_PARTS; ++i) {  // select chain: keeps the kernel arguments in SGPRs
+                if (part == i) {
+                    base = p.part_base[i];
+                    cnt  = p.part_cnt[i];
+                }
+            }
+        }
+#if defined(AA_FFT_ABLATE)
+        if (p.abl & 1) ml = 0;
+#endif
+        o = (lat_local * cnt + ml) * p.RP + f2;
+        return base;
+    }
+    __device__ __forceinline__ const double* address(int m) const {   // fp64 storage only
+        long long o;
+        const double* base = locate(m, o);
+        return base + o;
+    }
+    __device__ __forceinline__ cplx operator()(int m) const {
+        long long o;
+        const double* base = locate(m, o);
+        if (STORAGE == 1 || (STORAGE == 2 && p.f32)) {  // fp32 intermediate: same element indexing, float storage
+            const fft::fpair v = *reinterpret_cast<const fft::fpair*>(reinterpret_cast<const float*>(base) + o);
+            return cplx{(double)v.x, (double)v.y};
+        }
+        return *reinterpret_cast<const cplx*>(base + o);
+    }
+};
+using ModeReader = ModeReaderT<2>;
+
+
+// workgroup barrier that orders LDS accesses only: global loads requested before it stay in flight (__syncthreads() would
+// drain them: its workgroup-scope fence waits for vmcnt(0))
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ void wave_lds_fence() {
+    // producer and consumer lanes are in this wavefront: LDS executes a wavefront's instructions in order, only the
+    // compiler must not move accesses across this point
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// the [R0,16,16] rows of the LDS-heavy classes (see fft_kernel.hip: row_ct3)
+template <class S>
+constexpr bool ct3_fast_path() {
+    return S::NS == 3 && S::wave_local_middle() && S::radix(1) == 16 && S::radix(2) == 16 && S::M / S::radix(0) == 256 &&
+           S::NT == 256 && S::WPS == 2;
+}
+
+}  // namespace trans
+}  // namespace atlas_amd

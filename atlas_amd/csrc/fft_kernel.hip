@@ -8,85 +8,10 @@
 #include <hip/hip_runtime.h>
 
 #include "device_structs.h"
+#include "fft_device.h"
 
 namespace atlas_amd {
 namespace trans {
-
-using fft::cplx;
-
-constexpr int FFT_MAX_NTHR = 512;  // 2 waves per SIMD -> 256 VGPRs: radix-16 butterflies stay in registers
-constexpr int FGROUP   = 8;  // fields whose modes share one 128-byte line of F
-
-// Block -> (row, field).  Eight consecutive fields of one row share every 128-byte line of F, and hardware places
-// block b on XCD b % 8, so blocks {b, b+8, ..., b+56} (same XCD, dispatched back to back) are given the same
-// (row, field group): the line is then fetched into that XCD's L2 once.  Speed heuristic only.
-__device__ __forceinline__ bool fft_block_to_job(const FourierParams& p, int b, int& row, int& f) {
-    const int x   = b & 7;
-    const int q   = b >> 3;
-    const int j   = q & 7;
-    const int u   = (q >> 3) * 8 + x;
-    const int ngr = (p.f_end - p.f_begin + FGROUP - 1) / FGROUP;
-    const int ri  = u / ngr;
-    const int fg  = u - ri * ngr;
-    if (ri >= p.nrows) {
-        return false;
-    }
-    f = p.f_begin + fg * FGROUP + j;
-    if (f >= p.f_end) {
-        return false;
-    }
-    row = p.rows[ri];
-    return true;
-}
-
-// Input modes of one (row, field).  The Fourier intermediate may be split by zonal wavenumber over `nparts`
-// producers (multi-GPU m-sharding: wavenumber m belongs to part m % nparts, local index m / nparts):
-//   X[m] = *(cplx*)(base[m % nparts] + (lat_local * cnt[m % nparts] + m / nparts) * RP + 2*field)
-// nparts == 1 is the single-device layout F[(lat*(T+1) + m)*RP + r].
-// STORAGE: 0 = double intermediate, 1 = float (fp32 variant), 2 = decided at run time by p.f32 (generic kernel)
-template <int STORAGE>
-struct ModeReaderT {
-    const FourierParams& p;
-    long long lat_local;
-    int f2;
-    // address of mode m (fp64 storage: a double*; fp32 storage: element index in floats, see operator())
-    __device__ __forceinline__ const double* locate(int m, long long& o) const {
-        const double* base = p.part_base[0];
-        int cnt            = p.part_cnt[0];
-        int ml             = m;
-        if (p.nparts > 1) {
-            ml             = m / p.nparts;
-            const int part = m - ml * p.nparts;
-#pragma unroll
-            for (int i = 1; i < fft::MAX_PARTS; ++i) {  // select chain: keeps the kernel arguments in SGPRs
-                if (part == i) {
-                    base = p.part_base[i];
-                    cnt  = p.part_cnt[i];
-                }
-            }
-        }
-#if defined(AA_FFT_ABLATE)
-        if (p.abl & 1) ml = 0;
-#endif
-        o = (lat_local * cnt + ml) * p.RP + f2;
-        return base;
-    }
-    __device__ __forceinline__ const double* address(int m) const {   // fp64 storage only
-        long long o;
-        const double* base = locate(m, o);
-        return base + o;
-    }
-    __device__ __forceinline__ cplx operator()(int m) const {
-        long long o;
-        const double* base = locate(m, o);
-        if (STORAGE == 1 || (STORAGE == 2 && p.f32)) {  // fp32 intermediate: same element indexing, float storage
-            const fft::fpair v = *reinterpret_cast<const fft::fpair*>(reinterpret_cast<const float*>(base) + o);
-            return cplx{(double)v.x, (double)v.y};
-        }
-        return *reinterpret_cast<const cplx*>(base + o);
-    }
-};
-using ModeReader = ModeReaderT<2>;
 
 __global__ void __launch_bounds__(FFT_MAX_NTHR) fft_rows_kernel(FourierParams p) {
     extern __shared__ double lds_raw[];
@@ -237,19 +162,6 @@ __device__ __forceinline__ void gather_modes_to_lds(const FourierParams& p, long
     }
 }
 
-// workgroup barrier that orders LDS accesses only: global loads requested before it stay in flight (__syncthreads() would
-// drain them: its workgroup-scope fence waits for vmcnt(0))
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-__device__ __forceinline__ void wave_lds_fence() {
-    // producer and consumer lanes are in this wavefront: LDS executes a wavefront's instructions in order, only the
-    // compiler must not move accesses across this point
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // ---- [R0,16,16] rows of the LDS-heavy classes (M >= 3840: two workgroups of four wavefronts per CU, 256 registers):
 // the whole row in one function, so that every table value is requested a phase (or more) before its use and the ones
 // used twice are kept.  Same arithmetic, in the same order, as row_phase_ct (the host emulation and the planner run that).
@@ -259,12 +171,6 @@ __device__ __forceinline__ void wave_lds_fence() {
 //   before phase 3              : the chirp of the outputs (phase 4); wm and w0 are kept
 // Per-wavefront trace of the previous form (profiles/r03_fft_trace.txt): gather 4.1 us, phase 0 4.0 us, phase 2 1.7 - 4.5 us
 // of a 16 us workgroup whose vector-ALU work is 3.8 us per wavefront.
-template <class S>
-constexpr bool ct3_fast_path() {
-    return S::NS == 3 && S::wave_local_middle() && S::radix(1) == 16 && S::radix(2) == 16 && S::M / S::radix(0) == 256 &&
-           S::NT == 256 && S::WPS == 2;
-}
-
 template <class S, bool F32, class Stamp>
 __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTablesCt& r, const fft::RowOut& io,
                                         long long lat_local, int f, cplx* work, int t, Stamp&& stamp) {
@@ -400,8 +306,9 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
 
 // One workgroup of S::NT workers per (row, field).  Every mode of the row is fetched from the Fourier intermediate once,
 // into an LDS staging area that aliases the work array (phase 0 reads it completely before writing its results).
-template <class S, bool F32>
-__global__ void __launch_bounds__(S::NT, S::WPS) fft_rows_ct_kernel(FourierParams p) {
+// FAST: the row_ct3 form (256 registers, two wavefronts per SIMD) where the shape has it
+template <class S, bool F32, bool FAST>
+__global__ void __launch_bounds__(S::NT, (FAST ? S::WPS : 3)) fft_rows_ct_kernel(FourierParams p) {
     extern __shared__ double lds_raw[];
     cplx* work = reinterpret_cast<cplx*>(lds_raw);
     int row, f;
@@ -454,7 +361,7 @@ __global__ void __launch_bounds__(S::NT, S::WPS) fft_rows_ct_kernel(FourierParam
 #define AA_TRACE_STAMP(k) ((void)0)
 #endif
 #if !defined(AA_FFT_NO_CT3)
-    if constexpr (ct3_fast_path<S>()) {
+    if constexpr (FAST && ct3_fast_path<S>()) {
         row_ct3<S, F32>(p, r, io, (long long)(row - p.lat0), f, work, tid, [&](int k) { (void)k; AA_TRACE_STAMP(k); });
         return;
     }
@@ -625,16 +532,13 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR, 4) fft_rows_hyb_kernel(FourierPa
 }
 
 hipError_t launch_fourier_hyb(const FourierParams& p, int lds_bytes, int nthreads, hipStream_t stream) {
-    static int max_set[2] = {0, 0};
-    const int v = p.f32 ? 1 : 0;
-    if (lds_bytes > max_set[v]) {
+    {
         hipError_t e = hipFuncSetAttribute(
             p.f32 ? reinterpret_cast<const void*>(&fft_rows_hyb_kernel<true>) : reinterpret_cast<const void*>(&fft_rows_hyb_kernel<false>),
             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) {
             return e;
         }
-        max_set[v] = lds_bytes;
     }
     const int ngr         = (p.f_end - p.f_begin + FGROUP - 1) / FGROUP;
     const long long units = (long long)p.nrows * ngr;
@@ -648,20 +552,18 @@ hipError_t launch_fourier_hyb(const FourierParams& p, int lds_bytes, int nthread
     return hipGetLastError();
 }
 
-template <class S, bool F32>
+template <class S, bool F32, bool FAST>
 static hipError_t launch_ct_t(FourierParams p, int lds_bytes, unsigned nblk, hipStream_t stream) {
-    static int max_set = 0;
-    if (lds_bytes > max_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_ct_kernel<S, F32>),
+    {   // set on every launch (cheap): a per-process cache would be wrong for a second device and racy between host threads
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_ct_kernel<S, F32, FAST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) {
             return e;
         }
-        max_set = lds_bytes;
     }
     if (const char* e = std::getenv("ATLAS_AMD_FFT_LDS_PAD")) {  // dev tool: occupancy sensitivity (more LDS per workgroup)
         lds_bytes += atoi(e);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_ct_kernel<S, F32>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_ct_kernel<S, F32, FAST>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     }
     const unsigned grid = nblk;
@@ -669,18 +571,39 @@ static hipError_t launch_ct_t(FourierParams p, int lds_bytes, unsigned nblk, hip
     static const bool debug = std::getenv("ATLAS_AMD_FFT_DEBUG") != nullptr;
     if (debug) {
         int per_cu = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fft_rows_ct_kernel<S, F32>, S::NT, lds_bytes);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fft_rows_ct_kernel<S, F32, FAST>, S::NT, lds_bytes);
         hipFuncAttributes fa{};
-        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&fft_rows_ct_kernel<S, F32>));
+        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&fft_rows_ct_kernel<S, F32, FAST>));
         std::fprintf(stderr, "[atlas_amd] fft ct M=%d threads=%d lds=%d rows*fields=%u regs=%d scratch=%zu -> %d workgroups/CU\n",
                      S::M, S::NT, lds_bytes, nblk, fa.numRegs, (size_t)fa.localSizeBytes, per_cu);
     }
-    hipLaunchKernelGGL((fft_rows_ct_kernel<S, F32>), dim3(grid), dim3(S::NT), lds_bytes, stream, p);
+    hipLaunchKernelGGL((fft_rows_ct_kernel<S, F32, FAST>), dim3(grid), dim3(S::NT), lds_bytes, stream, p);
     return hipGetLastError();
+}
+// dev switch ATLAS_AMD_FFT_FAST_M=<M>,<M>,...: only these lengths take the row_ct3 form (A/B runs); unset: every shape that has it
+static bool ct3_enabled_for(int M) {
+    static const char* e = std::getenv("ATLAS_AMD_FFT_FAST_M");
+    if (!e) {
+        return true;
+    }
+    for (const char* c = e; *c;) {
+        if (atoi(c) == M) {
+            return true;
+        }
+        while (*c && *c != ',') ++c;
+        if (*c == ',') ++c;
+    }
+    return false;
 }
 template <class S>
 static hipError_t launch_ct(const FourierParams& p, int lds_bytes, unsigned nblk, hipStream_t stream) {
-    return p.f32 ? launch_ct_t<S, true>(p, lds_bytes, nblk, stream) : launch_ct_t<S, false>(p, lds_bytes, nblk, stream);
+    if constexpr (ct3_fast_path<S>()) {
+        if (ct3_enabled_for(S::M)) {
+            return p.f32 ? launch_ct_t<S, true, true>(p, lds_bytes, nblk, stream)
+                         : launch_ct_t<S, false, true>(p, lds_bytes, nblk, stream);
+        }
+    }
+    return p.f32 ? launch_ct_t<S, true, false>(p, lds_bytes, nblk, stream) : launch_ct_t<S, false, false>(p, lds_bytes, nblk, stream);
 }
 
 hipError_t launch_fourier_ct(const FourierParams& p, int ctf, int ctk, int lds_bytes, int nthreads,
@@ -695,14 +618,12 @@ hipError_t launch_fourier_ct(const FourierParams& p, int ctf, int ctk, int lds_b
 
 template <class S, bool F32>
 static hipError_t launch_dct_t(const FourierParams& p, int lds_bytes, int nthreads, unsigned nblk, hipStream_t stream) {
-    static int max_set = 0;
-    if (lds_bytes > max_set) {
+    {   // set on every launch (cheap): a per-process cache would be wrong for a second device and racy between host threads
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_dct_kernel<S, F32>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) {
             return e;
         }
-        max_set = lds_bytes;
     }
     hipLaunchKernelGGL((fft_rows_dct_kernel<S, F32>), dim3(nblk), dim3(nthreads), lds_bytes, stream, p);
     return hipGetLastError();
@@ -723,14 +644,12 @@ hipError_t launch_fourier_dct(const FourierParams& p, int ctf, int ctk, int lds_
 }
 
 hipError_t launch_fourier(const FourierParams& p, int lds_bytes, int nthreads, hipStream_t stream) {
-    static int max_set = 0;
-    if (lds_bytes > max_set) {
+    {   // set on every launch (cheap): a per-process cache would be wrong for a second device and racy between host threads
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) {
             return e;
         }
-        max_set = lds_bytes;
     }
     const int ngr         = (p.f_end - p.f_begin + FGROUP - 1) / FGROUP;
     const long long units = (long long)p.nrows * ngr;

@@ -588,6 +588,7 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
     p.scale_uv_fields = std::min(2 * nb_vordiv, nb_fields);
     p.coslatinv       = d_coslatinv_;
     p.prof            = d_prof_;
+    p.jobs            = 1;
     p.trace           = d_trace_;
     p.trace_cap       = trace_cap_;
     p.abl             = std::getenv("ATLAS_AMD_FFT_ABLATE") ? atoi(std::getenv("ATLAS_AMD_FFT_ABLATE")) : 0;
