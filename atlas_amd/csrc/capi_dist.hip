@@ -1,6 +1,7 @@
 // extern "C" layer of include/atlas_amd.h: communicators, distributed inverse transform, halo exchange between ranks.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -20,7 +21,14 @@ struct atlas_amd_CommHub {
     std::shared_ptr<atlas_amd::parallel::LocalHub> hub;
 };
 struct atlas_amd_Comm {
-    std::unique_ptr<atlas_amd::parallel::Comm> impl;
+    // shared: a DistributedTrans made for this communicator co-owns it, so deleting the handle while a Trans still uses it
+    // cannot leave a dangling reference (the communicator then lives until that Trans is deleted or switches)
+    std::shared_ptr<atlas_amd::parallel::Comm> impl;
+    unsigned long long id = next_id();   // serial number: handles are compared by it, not by address
+    static unsigned long long next_id() {
+        static std::atomic<unsigned long long> counter{0};
+        return ++counter;
+    }
 };
 
 #define DX_TRY try {
@@ -147,10 +155,15 @@ static atlas_amd::trans::DistributedTrans& dist_of(atlas_amd_Trans* t, atlas_amd
     if (!t || !c || !c->impl) {
         throw std::invalid_argument("invtrans_distributed: null Trans / Comm");
     }
-    if (!t->dist || t->dist_comm != c) {
+    if (!t->dist || t->dist_comm != c || t->dist_comm_id != c->id) {
         t->dist.reset();
-        t->dist.reset(new atlas_amd::trans::DistributedTrans(*t->impl, *c->impl));
-        t->dist_comm = c;
+        // the deleter keeps the communicator alive as long as the DistributedTrans that refers to it
+        std::shared_ptr<atlas_amd::parallel::Comm> keep = c->impl;
+        t->dist = std::shared_ptr<atlas_amd::trans::DistributedTrans>(
+            new atlas_amd::trans::DistributedTrans(*t->impl, *keep),
+            [keep](atlas_amd::trans::DistributedTrans* d) { delete d; });
+        t->dist_comm    = c;
+        t->dist_comm_id = c->id;
     }
     return *t->dist;
 }
@@ -193,7 +206,7 @@ int atlas_amd__Trans__set_max_message_bytes(atlas_amd_Trans* t, atlas_amd_Comm* 
     if (bytes < 8) {
         throw std::invalid_argument("set_max_message_bytes: at least 8");
     }
-    dist_of(t, c).max_message_elems = bytes / 8;
+    dist_of(t, c).set_max_message_elems(bytes / 8);
     DX_CATCH
 }
 int atlas_amd__transpose_messages(int truncation, int RP, int nparts, int part, const int bands[], long long max_message_elems,
@@ -213,6 +226,32 @@ int atlas_amd__transpose_messages(int truncation, int RP, int nparts, int part, 
         send_end[i]   = msgs[i].send_end;
         recv_begin[i] = msgs[i].recv_begin;
         recv_end[i]   = msgs[i].recv_end;
+    }
+    DX_CATCH
+}
+
+int atlas_amd__packed_transpose_messages(int nlats, const int row_mmax[], int cols, int nparts, int part, const int bands[],
+                                         long long max_message_elems, int capacity, int* peer, long long* send_begin,
+                                         long long* send_end, long long* recv_begin, long long* recv_end, int* count,
+                                         long long totals[2]) {
+    DX_TRY
+    if (!row_mmax || !bands || !count || nparts < 1 || nlats < 0) {
+        throw std::invalid_argument("packed_transpose_messages: bad arguments");
+    }
+    std::vector<int> b(bands, bands + nparts + 1), mm(row_mmax, row_mmax + nlats);
+    const auto plan = atlas_amd::trans::make_packed_transpose_plan(mm, cols, b, nparts, part);
+    const auto msgs = atlas_amd::trans::packed_transpose_messages(plan, b, nparts, part, max_message_elems);
+    *count          = (int)msgs.size();
+    for (int i = 0; i < (int)msgs.size() && i < capacity; ++i) {
+        peer[i]       = msgs[i].peer;
+        send_begin[i] = msgs[i].send_begin;
+        send_end[i]   = msgs[i].send_end;
+        recv_begin[i] = msgs[i].recv_begin;
+        recv_end[i]   = msgs[i].recv_end;
+    }
+    if (totals) {
+        totals[0] = plan.send_total;
+        totals[1] = plan.out_total;
     }
     DX_CATCH
 }

@@ -48,6 +48,8 @@ using LegendreParamsF32 = LegendreParamsT<float>;   // fp32 variant (BASELINE co
 struct FourierParams {
     const double* part_base[fft::MAX_PARTS];  // Fourier intermediate pieces, one per m-owner (see fft_core.h: RowIO)
     int part_cnt[fft::MAX_PARTS];
+    const long long* part_rowoff[fft::MAX_PARTS];  // packed form: per piece, offset (doubles) of every local row; else unused
+    int packed_cols;                               // packed form: doubles per (row, wavenumber) = 2 * nb_fields; 0: classic layout
     int nparts;
     int lat0;                         // first row of the local latitude band
     double* gp;                       // gp[f*npts + (rowoff[lat]-rowoff[lat0]) + i], npts = points of the local band

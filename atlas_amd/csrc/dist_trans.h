@@ -43,6 +43,28 @@ struct TransposeMsg {
 std::vector<TransposeMsg> transpose_messages(const TransposePlan& plan, const std::vector<int>& bands, int RP, int nparts,
                                              int part, int64_t max_message_elems);
 
+// ---- packed transposition [r3]: only what the Fourier stage reads travels.  Row `lat` keeps the wavenumbers m <= mmax(lat)
+// (its Fourier truncation); rank p owns kept(p, lat) = |{m <= mmax(lat) : m % P == p}| of them, each with `cols` = 2 * nb_fields
+// live columns (no pitch padding).  Rank p packs its intermediate row by row,
+//     S_p[rowoff_p[lat] + ml * cols + c] = F_p[(lat * cnt_p + ml) * RP + c],   ml < kept(p, lat), c < cols,
+// the rows of band q are one contiguous run of S_p and go to rank q, which receives the P runs back to back into R; the
+// Fourier kernels read wavenumber m of local row r at  R[out_offset[m % P] + rowoff_{m % P}[band_q + r] - rowoff_{m % P}[band_q]
+// + (m / P) * cols + 2 f].  At TL1279 / O1280 / 137 fields: 5.07 GB over all ranks instead of 7.55 GB (slabs of allocated rows).
+struct PackedTransposePlan {
+    int cols = 0;                                  // doubles per (row, wavenumber): 2 * nb_fields
+    std::vector<std::vector<int64_t>> rowoff;      // [nparts][nlats + 1] prefix sums of kept(p, lat) * cols (doubles)
+    std::vector<int64_t> out_offsets;              // [nparts] where rank p's run starts in this rank's R
+    int64_t out_total  = 0;                        // doubles in R
+    int64_t send_total = 0;                        // doubles in this rank's S (= rowoff[part][nlats])
+};
+// row_mmax[lat]: highest kept wavenumber of the row (-1: none), all rows of the grid
+PackedTransposePlan make_packed_transpose_plan(const std::vector<int>& row_mmax, int cols, const std::vector<int>& bands,
+                                               int nparts, int part);
+// messages of rank `part`, cut by rows into pieces of at most max_message_elems doubles (>= 1); the cut depends on global
+// quantities only: both ends of a pair cut alike and list the pieces in the same order.  send_* index S, recv_* index R.
+std::vector<TransposeMsg> packed_transpose_messages(const PackedTransposePlan& plan, const std::vector<int>& bands, int nparts,
+                                                    int part, int64_t max_message_elems);
+
 class DistributedTrans {
 public:
     DistributedTrans(Trans& trans, parallel::Comm& comm);
@@ -61,17 +83,23 @@ public:
     void invtrans_many_halo(int ntransforms, int nb_fields, const double* const* sp_dev, double* const* gp_dev,
                             parallel::HaloExchange& hx, double* const* field_dev);
     hipStream_t comm_stream() const { return comm_stream_; }
-    int64_t max_message_elems = int64_t(1) << 26;   // 512 MiB of doubles
+    // largest message of the transposition in doubles (default 512 MiB).  MUST be the same on every rank (both ends of a
+    // pair cut their slabs alike); takes effect at the next transform (the message list is rebuilt).
+    void set_max_message_elems(int64_t elems);
+    int64_t max_message_elems() const { return max_message_elems_; }
+    const PackedTransposePlan& packed_plan() const { return pplan_; }
 
 private:
     struct Slot {
-        double* F = nullptr;
-        double* R = nullptr;
+        double* F = nullptr;   // this rank's intermediate (all rows, its wavenumbers; Legendre kernel layout)
+        double* S = nullptr;   // packed copy that is sent
+        double* R = nullptr;   // received runs, one per source rank
         hipEvent_t legendre_done, exchange_done, fourier_done;
         bool used = false;
     };
     void ensure(int nb_fields);
     void legendre(int nb_fields, const double* sp_dev, Slot& s);
+    void poison(Slot& s);
     void exchange(Slot& s);
     void fourier(int nb_fields, Slot& s, double* gp_dev);
     void halo(int nb_fields, Slot& s, const double* gp_dev, parallel::HaloExchange& hx, double* field_dev);
@@ -79,9 +107,15 @@ private:
     Trans& trans_;
     parallel::Comm& comm_;
     hipStream_t comm_stream_ = nullptr;
-    int nf_cap_ = 0, RP_ = 0;
-    TransposePlan plan_;
+    int nf_cap_ = 0, nf_plan_ = 0, RP_ = 0;
+    int64_t max_message_elems_ = int64_t(1) << 26;
+    int64_t msgs_limit_        = 0;     // the limit msgs_ was built with
+    bool poison_               = false; // ATLAS_AMD_DIST_POISON=1 (tests): F, S, R are filled with NaN before every transform
+    PackedTransposePlan pplan_;
     std::vector<TransposeMsg> msgs_;
+    long long* d_rowoff_src_ = nullptr;   // [nlats + 1]: rowoff of this rank as a source (pack kernel)
+    long long* d_rowoff_dst_ = nullptr;   // [nparts][rows of my band]: row offsets inside each received run (Fourier kernels)
+    int* d_kept_             = nullptr;   // [nlats]: kept(part, lat)
     Slot slot_[2];
 };
 

@@ -2,6 +2,7 @@
 #include "dist_trans.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <sstream>
 #include <stdexcept>
 
@@ -42,6 +43,9 @@ TransposePlan make_transpose_plan(int T, int RP, const std::vector<int>& bands, 
 
 std::vector<TransposeMsg> transpose_messages(const TransposePlan& plan, const std::vector<int>& bands, int RP, int nparts,
                                              int part, int64_t max_message_elems) {
+    if (max_message_elems < 1) {
+        throw std::invalid_argument("transpose_messages: max_message_elems must be at least 1");
+    }
     const int64_t biggest = (int64_t)*std::max_element(plan.rows.begin(), plan.rows.end()) *
                             *std::max_element(plan.cnt.begin(), plan.cnt.end()) * RP;
     int64_t K = std::max<int64_t>(1, (biggest + max_message_elems - 1) / max_message_elems);
@@ -69,12 +73,99 @@ std::vector<TransposeMsg> transpose_messages(const TransposePlan& plan, const st
     return msgs;
 }
 
+PackedTransposePlan make_packed_transpose_plan(const std::vector<int>& row_mmax, int cols, const std::vector<int>& bands,
+                                               int nparts, int part) {
+    const int nlats = (int)row_mmax.size();
+    if ((int)bands.size() != nparts + 1 || part < 0 || part >= nparts || cols <= 0 || bands[0] != 0 || bands[nparts] != nlats) {
+        throw std::invalid_argument("make_packed_transpose_plan: bands / part / cols");
+    }
+    PackedTransposePlan pl;
+    pl.cols = cols;
+    pl.rowoff.assign(nparts, std::vector<int64_t>(nlats + 1, 0));
+    for (int p = 0; p < nparts; ++p) {
+        for (int lat = 0; lat < nlats; ++lat) {
+            const int mm     = row_mmax[lat];
+            const int kept   = mm >= p ? (mm - p) / nparts + 1 : 0;   // |{m in [0, mmax] : m % nparts == p}|
+            pl.rowoff[p][lat + 1] = pl.rowoff[p][lat] + (int64_t)kept * cols;
+        }
+    }
+    pl.out_offsets.resize(nparts);
+    int64_t off = 0;
+    for (int p = 0; p < nparts; ++p) {
+        pl.out_offsets[p] = off;
+        off += pl.rowoff[p][bands[part + 1]] - pl.rowoff[p][bands[part]];
+    }
+    pl.out_total  = off;
+    pl.send_total = pl.rowoff[part][nlats];
+    return pl;
+}
+
+std::vector<TransposeMsg> packed_transpose_messages(const PackedTransposePlan& pl, const std::vector<int>& bands, int nparts,
+                                                    int part, int64_t max_message_elems) {
+    if (max_message_elems < 1) {
+        throw std::invalid_argument("packed_transpose_messages: max_message_elems must be at least 1");
+    }
+    // K pieces per pair, the same for every pair: from the largest run of any (source, destination) -- global quantities
+    int64_t biggest = 0;
+    int minrows     = 0;
+    for (int q = 0; q < nparts; ++q) {
+        const int rows = bands[q + 1] - bands[q];
+        if (rows > 0 && (minrows == 0 || rows < minrows)) {
+            minrows = rows;
+        }
+        for (int p = 0; p < nparts; ++p) {
+            biggest = std::max(biggest, pl.rowoff[p][bands[q + 1]] - pl.rowoff[p][bands[q]]);
+        }
+    }
+    int64_t K = std::max<int64_t>(1, (biggest + max_message_elems - 1) / max_message_elems);
+    K         = std::max<int64_t>(1, std::min<int64_t>(K, std::max(minrows, 1)));
+    std::vector<TransposeMsg> msgs;
+    const int myrows = bands[part + 1] - bands[part];
+    for (int64_t k = 0; k < K; ++k) {
+        for (int peer = 0; peer < nparts; ++peer) {
+            const int prow = bands[peer + 1] - bands[peer];
+            const int s0 = (int)(prow * k / K), s1 = (int)(prow * (k + 1) / K);       // rows of the peer's band I send
+            const int r0 = (int)(myrows * k / K), r1 = (int)(myrows * (k + 1) / K);   // rows of my band I receive
+            TransposeMsg m;
+            m.peer       = peer;
+            m.send_begin = pl.rowoff[part][bands[peer] + s0];
+            m.send_end   = pl.rowoff[part][bands[peer] + s1];
+            m.recv_begin = pl.out_offsets[peer] + pl.rowoff[peer][bands[part] + r0] - pl.rowoff[peer][bands[part]];
+            m.recv_end   = pl.out_offsets[peer] + pl.rowoff[peer][bands[part] + r1] - pl.rowoff[peer][bands[part]];
+            msgs.push_back(m);
+        }
+    }
+    return msgs;
+}
+
+// S[rowoff[lat] + ml * cols + c] = F[(lat * cnt + ml) * RP + c]: one workgroup per row, 16-byte pieces (cols, RP and the
+// row offsets are even)
+__global__ void __launch_bounds__(256) pack_rows_kernel(const double* __restrict__ F, double* __restrict__ S,
+                                                        const long long* __restrict__ rowoff, const int* __restrict__ kept,
+                                                        int cnt, int RP, int cols) {
+    const int lat   = blockIdx.x;
+    const int k     = kept[lat];
+    const int c2    = cols >> 1;
+    const int total = k * c2;
+    const double2* src = reinterpret_cast<const double2*>(F + (long long)lat * cnt * RP);
+    double2* dst       = reinterpret_cast<double2*>(S + rowoff[lat]);
+    const int rp2      = RP >> 1;
+    for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < total; e += blockDim.x * gridDim.y) {
+        const int ml = e / c2;
+        const int c  = e - ml * c2;
+        dst[e]       = src[(long long)ml * rp2 + c];
+    }
+}
+
 DistributedTrans::DistributedTrans(Trans& trans, parallel::Comm& comm) : trans_(trans), comm_(comm) {
     if (trans.nparts() != comm.size() || trans.part() != comm.rank()) {
         throw std::invalid_argument("DistributedTrans: the Trans must be made with (nparts, part) = (comm size, comm rank)");
     }
     if (trans.nparts() > 1 && trans.fourier_parts() != trans.nparts()) {
         throw std::invalid_argument("DistributedTrans: the Trans must be sharded by wavenumber (shard = m)");
+    }
+    if (const char* e = std::getenv("ATLAS_AMD_DIST_POISON")) {
+        poison_ = atoi(e) != 0;
     }
     HIP_CHECK(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));
     for (Slot& s : slot_) {
@@ -94,39 +185,100 @@ DistributedTrans::~DistributedTrans() {
         if (s.R) {
             (void)hipFree(s.R);
         }
+        if (s.S) {
+            (void)hipFree(s.S);
+        }
         (void)hipEventDestroy(s.legendre_done);
         (void)hipEventDestroy(s.exchange_done);
         (void)hipEventDestroy(s.fourier_done);
     }
     (void)hipStreamDestroy(comm_stream_);
+    (void)hipFree(d_rowoff_src_);
+    (void)hipFree(d_rowoff_dst_);
+    (void)hipFree(d_kept_);
+}
+
+void DistributedTrans::set_max_message_elems(int64_t elems) {
+    if (elems < 1) {
+        throw std::invalid_argument("DistributedTrans: the message limit must be at least one element");
+    }
+    max_message_elems_ = elems;   // ensure() rebuilds the message list when it differs from the one in use
 }
 
 void DistributedTrans::ensure(int nb_fields) {
-    if (nb_fields <= nf_cap_ && RP_ == trans_.fourier_row_pitch(nb_fields)) {
+    const bool same_plan = nb_fields == nf_plan_;
+    if (same_plan && msgs_limit_ == max_message_elems_) {
         return;
     }
     HIP_CHECK(hipStreamSynchronize(comm_stream_));
     trans_.synchronize();
-    RP_   = trans_.fourier_row_pitch(nb_fields);
-    plan_ = make_transpose_plan(trans_.truncation(), RP_, trans_.bands(), trans_.nparts(), trans_.part());
-    msgs_ = transpose_messages(plan_, trans_.bands(), RP_, trans_.nparts(), trans_.part(), max_message_elems);
-    for (Slot& s : slot_) {
-        if (s.F) {
-            HIP_CHECK(hipFree(s.F));
-            s.F = nullptr;
+    if (!same_plan) {
+        const TransGeometry& geo = trans_.geometry();
+        std::vector<int> row_mmax(geo.nlats);
+        for (int j = 0; j < geo.nlats; ++j) {
+            const int jleg = j < geo.nlatsNH ? j : geo.nlats - 1 - j;
+            row_mmax[j]    = std::min(geo.mmax_leg[jleg], geo.T);
         }
-        if (s.R) {
-            HIP_CHECK(hipFree(s.R));
-            s.R = nullptr;
+        RP_    = trans_.fourier_row_pitch(nb_fields);
+        pplan_ = make_packed_transpose_plan(row_mmax, 2 * nb_fields, trans_.bands(), trans_.nparts(), trans_.part());
+        // device copies of the offsets: source side (pack kernel), destination side (Fourier kernels)
+        const int P = trans_.nparts(), part = trans_.part();
+        const int b0 = trans_.bands()[part], b1 = trans_.bands()[part + 1];
+        std::vector<long long> src(pplan_.rowoff[part].begin(), pplan_.rowoff[part].end());
+        std::vector<int> kept(geo.nlats);
+        for (int j = 0; j < geo.nlats; ++j) {
+            kept[j] = (int)((src[j + 1] - src[j]) / pplan_.cols);
         }
-        HIP_CHECK(hipMalloc((void**)&s.F, std::max<size_t>(trans_.fourier_doubles(nb_fields), 1) * sizeof(double)));
-        HIP_CHECK(hipMalloc((void**)&s.R, std::max<int64_t>(plan_.out_total, 1) * sizeof(double)));
-        s.used = false;
+        std::vector<long long> dst((size_t)P * std::max(b1 - b0, 1), 0);
+        for (int p = 0; p < P; ++p) {
+            for (int r = 0; r < b1 - b0; ++r) {
+                dst[(size_t)p * (b1 - b0) + r] = pplan_.rowoff[p][b0 + r] - pplan_.rowoff[p][b0];
+            }
+        }
+        (void)hipFree(d_rowoff_src_);
+        (void)hipFree(d_rowoff_dst_);
+        (void)hipFree(d_kept_);
+        d_rowoff_src_ = nullptr, d_rowoff_dst_ = nullptr, d_kept_ = nullptr;
+        HIP_CHECK(hipMalloc((void**)&d_rowoff_src_, src.size() * sizeof(long long)));
+        HIP_CHECK(hipMalloc((void**)&d_rowoff_dst_, dst.size() * sizeof(long long)));
+        HIP_CHECK(hipMalloc((void**)&d_kept_, kept.size() * sizeof(int)));
+        HIP_CHECK(hipMemcpy(d_rowoff_src_, src.data(), src.size() * sizeof(long long), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(d_rowoff_dst_, dst.data(), dst.size() * sizeof(long long), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(d_kept_, kept.data(), kept.size() * sizeof(int), hipMemcpyHostToDevice));
+        for (Slot& s : slot_) {
+            for (double** ptr : {&s.F, &s.S, &s.R}) {
+                if (*ptr) {
+                    HIP_CHECK(hipFree(*ptr));
+                    *ptr = nullptr;
+                }
+            }
+            HIP_CHECK(hipMalloc((void**)&s.F, std::max<size_t>(trans_.fourier_doubles(nb_fields), 1) * sizeof(double)));
+            HIP_CHECK(hipMalloc((void**)&s.S, std::max<int64_t>(pplan_.send_total, 1) * sizeof(double)));
+            HIP_CHECK(hipMalloc((void**)&s.R, std::max<int64_t>(pplan_.out_total, 1) * sizeof(double)));
+            s.used = false;
+        }
+        nf_cap_  = nb_fields;
+        nf_plan_ = nb_fields;
     }
-    nf_cap_ = nb_fields;
+    msgs_       = packed_transpose_messages(pplan_, trans_.bands(), trans_.nparts(), trans_.part(), max_message_elems_);
+    msgs_limit_ = max_message_elems_;
+}
+
+// tests (ATLAS_AMD_DIST_POISON=1): every byte of the three buffers is NaN before the transform writes them, so a read of a
+// slot nobody wrote -- or an uninitialised byte on the wire -- shows up in the result
+void DistributedTrans::poison(Slot& s) {
+    HIP_CHECK(hipMemsetAsync(s.F, 0xFF, std::max<size_t>(trans_.fourier_doubles(nf_cap_), 1) * sizeof(double), trans_.stream()));
+    HIP_CHECK(hipMemsetAsync(s.S, 0xFF, std::max<int64_t>(pplan_.send_total, 1) * sizeof(double), trans_.stream()));
+    HIP_CHECK(hipMemsetAsync(s.R, 0xFF, std::max<int64_t>(pplan_.out_total, 1) * sizeof(double), trans_.stream()));
 }
 
 void DistributedTrans::legendre(int nb_fields, const double* sp_dev, Slot& s) {
+    if (poison_) {
+        if (s.used) {
+            HIP_CHECK(hipStreamWaitEvent(trans_.stream(), s.exchange_done, 0));   // S of this slot may still be on the wire
+        }
+        poison(s);
+    }
     trans_.legendre_device(trans_.truncation(), nb_fields, sp_dev, s.F);
     HIP_CHECK(hipEventRecord(s.legendre_done, trans_.stream()));
 }
@@ -136,10 +288,17 @@ void DistributedTrans::exchange(Slot& s) {
     if (s.used) {
         HIP_CHECK(hipStreamWaitEvent(comm_stream_, s.fourier_done, 0));   // R of this slot is still being read
     }
+    // pack: the kept wavenumbers and live columns of every row, contiguous per destination band
+    if (pplan_.send_total > 0) {
+        const int nlats = trans_.geometry().nlats;
+        hipLaunchKernelGGL(pack_rows_kernel, dim3(nlats, 4), dim3(256), 0, comm_stream_, s.F, s.S, d_rowoff_src_, d_kept_,
+                           trans_.owned_wavenumbers(), RP_, pplan_.cols);
+        HIP_CHECK(hipGetLastError());
+    }
     std::vector<parallel::Msg> sends, recvs;
     for (const TransposeMsg& m : msgs_) {
         if (m.send_end > m.send_begin) {
-            sends.push_back(parallel::Msg{m.peer, s.F + m.send_begin, size_t(m.send_end - m.send_begin) * sizeof(double)});
+            sends.push_back(parallel::Msg{m.peer, s.S + m.send_begin, size_t(m.send_end - m.send_begin) * sizeof(double)});
         }
         if (m.recv_end > m.recv_begin) {
             recvs.push_back(parallel::Msg{m.peer, s.R + m.recv_begin, size_t(m.recv_end - m.recv_begin) * sizeof(double)});
@@ -151,12 +310,15 @@ void DistributedTrans::exchange(Slot& s) {
 
 void DistributedTrans::fourier(int nb_fields, Slot& s, double* gp_dev) {
     HIP_CHECK(hipStreamWaitEvent(trans_.stream(), s.exchange_done, 0));
-    const int P = trans_.nparts();
+    const int P    = trans_.nparts();
+    const int rows = trans_.band_end() - trans_.band_begin();
     std::vector<const double*> base(P);
+    std::vector<const long long*> rowoff(P);
     for (int p = 0; p < P; ++p) {
-        base[p] = s.R + plan_.out_offsets[p];
+        base[p]   = s.R + pplan_.out_offsets[p];
+        rowoff[p] = d_rowoff_dst_ + (size_t)p * rows;
     }
-    trans_.fourier_device(nb_fields, 0, base.data(), plan_.cnt.data(), gp_dev);
+    trans_.fourier_device_packed(nb_fields, 0, base.data(), rowoff.data(), pplan_.cols, gp_dev);
     HIP_CHECK(hipEventRecord(s.fourier_done, trans_.stream()));
     s.used = true;
 }

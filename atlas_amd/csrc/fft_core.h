@@ -1301,7 +1301,7 @@ inline void hyb_dense_host(const RowTablesHyb& r, cplx* work) {
     }
 }
 
-#if defined(__HIPCC__)
+#if defined(__HIPCC__) && defined(ATLAS_AMD_EXPERIMENTS)
 typedef double aa_d4 __attribute__((ext_vector_type(4)));
 // dense stage on the matrix cores.  Output tile (mt, ct) = rows j = 16 mt .. +15, groups g = 16 ct .. +15, numbered
 // ct * Mt + mt and dealt to the wavefronts round robin, HYB_UPW per wavefront and round.  A round covers whole column

@@ -39,6 +39,8 @@ __device__ __forceinline__ bool fft_block_to_job(const FourierParams& p, int b, 
 // producers (multi-GPU m-sharding: wavenumber m belongs to part m % nparts, local index m / nparts):
 //   X[m] = *(cplx*)(base[m % nparts] + (lat_local * cnt[m % nparts] + m / nparts) * RP + 2*field)
 // nparts == 1 is the single-device layout F[(lat*(T+1) + m)*RP + r].
+// Packed form (p.packed_cols != 0, distributed transform [r3]): X[m] = *(cplx*)(base[m % nparts] + rowoff[m % nparts][lat_local]
+//   + (m / nparts) * packed_cols + 2*field) -- only the kept wavenumbers of a row and the live columns are stored.
 // STORAGE: 0 = double intermediate, 1 = float (fp32 variant), 2 = decided at run time by p.f32 (generic kernel)
 template <int STORAGE>
 struct ModeReaderT {
@@ -64,6 +66,20 @@ struct ModeReaderT {
 #if defined(AA_FFT_ABLATE)
         if (p.abl & 1) ml = 0;
 #endif
+        if (p.packed_cols) {   // packed runs of the distributed transform (dist_trans.h): per-row offsets, no pitch padding
+            const long long* ro = p.part_rowoff[0];
+            if (p.nparts > 1) {
+                const int part = m - ml * p.nparts;
+#pragma unroll
+                for (int i = 1; i < fft::MAX_PARTS; ++i) {
+                    if (part == i) {
+                        ro = p.part_rowoff[i];
+                    }
+                }
+            }
+            o = ro[lat_local] + (long long)ml * p.packed_cols + f2;
+            return base;
+        }
         o = (lat_local * cnt + ml) * p.RP + f2;
         return base;
     }

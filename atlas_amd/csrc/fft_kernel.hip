@@ -465,92 +465,13 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR, 3) fft_rows_dct_kernel(FourierPa
     });
 }
 
-// ---- hybrid rows (fft_core.h: "HYBRID rows"): dense radix-A stage on the matrix cores + radix-{2..16} stages of B -----
-template <bool F32>
-__global__ void __launch_bounds__(FFT_MAX_NTHR, 4) fft_rows_hyb_kernel(FourierParams p) {
-    extern __shared__ double lds_raw[];
-    cplx* work = reinterpret_cast<cplx*>(lds_raw);
-    int row, f;
-    if (!fft_block_to_job(p, blockIdx.x, row, f)) {
-        return;
-    }
-    const fft::FftRowPlan* pl = p.plans + p.row_plan[row];
-    const long long goff      = (long long)f * p.npts + (p.rowoff[row] - p.rowoff[p.lat0]);
-    const int tid             = threadIdx.x;
-    const int nt              = blockDim.x;
-    const double scale        = (f < p.scale_uv_fields) ? p.coslatinv[row] : 1.0;
-    const int mmax            = p.row_mmax[row];
-    fft::RowTablesHyb r;
-    r.n     = pl->n;
-    r.h     = pl->h;
-    r.A     = pl->hyb_A;
-    r.B     = pl->hyb_B;
-    r.Kp    = (pl->hyb_A + 1) / 2;
-    r.Mt    = pl->hyb_Mt;
-    r.Ks    = pl->hyb_Ks;
-    r.shape = &pl->shape;
-    r.tw    = p.table + pl->off_tw;
-    r.pre   = p.table + pl->off_pre;
-    r.cs    = p.table + pl->off_cs;
-    cplx* raw = work + fft::padded_size(r.h);
-    fft::RowOut io;
-    io.mmax      = mmax < r.h ? mmax : r.h;
-    io.y         = F32 ? reinterpret_cast<double*>(reinterpret_cast<float*>(p.gp) + goff) : p.gp + goff;
-    io.aligned16 = ((goff & 1) == 0);
-    io.f32       = F32 ? 1 : 0;
-    io.scale     = scale;
-    unsigned long long tprev = 0;
-    const bool prof = p.prof != nullptr && tid == 0;
-    auto stamp = [&](int slot) {
-        if (prof) {
-            const unsigned long long tn = clock64();
-            if (slot >= 0) {
-                atomicAdd(&p.prof[32 + slot], tn - tprev);
-            }
-            tprev = tn;
-        }
-    };
-    stamp(-1);
-    gather_modes_to_lds<F32>(p, (long long)(row - p.lat0), f, io.mmax, raw, tid, nt);
-    fft::HybFoldWork fw;
-    fft::hyb_fold_prefetch(r, tid, nt, fw);   // table values of the fold: in flight next to the gather
-    __syncthreads();
-    stamp(0);
-    fft::hyb_fold_split(r, io, raw, work, tid, nt, fw);
-    __syncthreads();
-    stamp(1);
-    fft::hyb_dense_device(r, work, tid, nt);
-    __syncthreads();
-    stamp(2);
-    for (int i = pl->shape.nstages - 2; i >= 0; --i) {
-        fft::hyb_native_phase(i, r, io, work, tid, nt);
-        if (i) {
-            __syncthreads();
-        }
-        stamp(i ? 3 : 4);
-    }
+#if defined(ATLAS_AMD_EXPERIMENTS)
+#include "../../tools/experiments/fft_hybrid_rows.inc"
+#else
+hipError_t launch_fourier_hyb(const FourierParams&, int, int, hipStream_t) {
+    return hipErrorNotSupported;   // hybrid rows are planned only in experiment builds (fft_plan.cpp)
 }
-
-hipError_t launch_fourier_hyb(const FourierParams& p, int lds_bytes, int nthreads, hipStream_t stream) {
-    {
-        hipError_t e = hipFuncSetAttribute(
-            p.f32 ? reinterpret_cast<const void*>(&fft_rows_hyb_kernel<true>) : reinterpret_cast<const void*>(&fft_rows_hyb_kernel<false>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) {
-            return e;
-        }
-    }
-    const int ngr         = (p.f_end - p.f_begin + FGROUP - 1) / FGROUP;
-    const long long units = (long long)p.nrows * ngr;
-    const unsigned nblk   = (unsigned)((units + 7) / 8 * 64);
-    if (p.f32) {
-        hipLaunchKernelGGL((fft_rows_hyb_kernel<true>), dim3(nblk), dim3(nthreads), lds_bytes, stream, p);
-    }
-    else {
-        hipLaunchKernelGGL((fft_rows_hyb_kernel<false>), dim3(nblk), dim3(nthreads), lds_bytes, stream, p);
-    }
-    return hipGetLastError();
-}
+#endif
 
 template <class S, bool F32, bool FAST>
 static hipError_t launch_ct_t(FourierParams p, int lds_bytes, unsigned nblk, hipStream_t stream) {

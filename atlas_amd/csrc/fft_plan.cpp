@@ -176,7 +176,13 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, bool specialised_
     PlanOptions opt;
     opt.specialised_shapes = specialised_shapes;
     if (const char* e = std::getenv("ATLAS_AMD_FFT_HYBRID")) {
+#if defined(ATLAS_AMD_EXPERIMENTS)
         opt.hybrid = atoi(e) != 0;
+#else
+        if (atoi(e) != 0) {   // the dense-stage kernel lives in tools/experiments: not in this build
+            throw std::runtime_error("ATLAS_AMD_FFT_HYBRID=1 needs a library built with -DATLAS_AMD_EXPERIMENTS (make -C atlas_amd/csrc experiments)");
+        }
+#endif
     }
     return make_fft_plans(row_lengths, opt);
 }

@@ -234,11 +234,9 @@ void RegionalTrans::dft(int trc_in, int nb_fields, int nb_vordiv, const double* 
     if (lds > 160 * 1024) {
         throw std::runtime_error("RegionalTrans: truncation too large for the direct Fourier kernel");
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    {   // on every launch (cheap): a per-process flag is wrong for a second device and racy between host threads
         RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&regional_dft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      160 * 1024));
-        attr_set = true;
     }
     hipLaunchKernelGGL(regional_dft_kernel, dim3(nlat(), nb_fields), dim3(256), lds, inner_->stream(), F, d_rowsel_, d_table_, gp_dev,
                        T_, T_ + 1, inner_->fourier_row_pitch(nb_fields), nlon_, nlat(), d_scale_, 2 * nb_vordiv);

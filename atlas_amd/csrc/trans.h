@@ -90,6 +90,9 @@ public:
     void fourier_device(int nb_fields, int nb_vordiv, const double* fourier_dev, double* gp_dev);
     void fourier_device(int nb_fields, int nb_vordiv, const double* const* part_base, const int* part_cnt,
                         double* gp_dev);
+    // packed pieces (dist_trans.h: PackedTransposePlan): part_rowoff_dev[i][r] = offset in doubles of local row r inside piece i
+    void fourier_device_packed(int nb_fields, int nb_vordiv, const double* const* part_base,
+                               const long long* const* part_rowoff_dev, int cols, double* gp_dev);
     size_t fourier_doubles(int nb_fields) const;  // local Fourier intermediate: nlats * owned m * RP
     int fourier_row_pitch(int nb_fields) const;   // RP = 16*ceil(2*nb_fields/16)
     double* fourier_buffer(int nb_fields);        // scratch intermediate owned by the object (grown on demand)
@@ -129,7 +132,8 @@ private:
     void timed_begin(int kind, hipStream_t s = nullptr);
     void legendre_chunks(int trc_in, int nb_fields, const double* sp_dev, double* fourier_dev, int chunk0, int nrun);
     void fourier_fields(int nb_fields, int nb_vordiv, const double* const* part_base, const int* part_cnt,
-                        double* gp_dev, int f_begin, int f_end, hipStream_t stream, bool f32 = false);
+                        double* gp_dev, int f_begin, int f_end, hipStream_t stream, bool f32 = false,
+                        const long long* const* part_rowoff_dev = nullptr, int packed_cols = 0);
     void timed_end();
 
     TransGeometry geo_;

@@ -543,16 +543,27 @@ void Trans::fourier_device(int nb_fields, int nb_vordiv, const double* const* pa
     fourier_fields(nb_fields, nb_vordiv, part_base, part_cnt, gp_dev, 0, nb_fields, stream_);
 }
 
+void Trans::fourier_device_packed(int nb_fields, int nb_vordiv, const double* const* part_base,
+                                  const long long* const* part_rowoff_dev, int cols, double* gp_dev) {
+    if (!part_rowoff_dev || cols != 2 * nb_fields) {
+        throw std::invalid_argument("fourier_device_packed: row offsets / cols == 2 * nb_fields");
+    }
+    fourier_fields(nb_fields, nb_vordiv, part_base, nullptr, gp_dev, 0, nb_fields, stream_, false, part_rowoff_dev, cols);
+}
+
 void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* part_base, const int* part_cnt,
-                           double* gp_dev, int f_begin, int f_end, hipStream_t stream, bool f32) {
+                           double* gp_dev, int f_begin, int f_end, hipStream_t stream, bool f32,
+                           const long long* const* part_rowoff_dev, int packed_cols) {
     if (nb_fields <= 0 || f_end <= f_begin) {
         return;
     }
     FourierParams p;
     for (int i = 0; i < fft::MAX_PARTS; ++i) {
-        p.part_base[i] = i < fourier_parts() ? part_base[i] : nullptr;
-        p.part_cnt[i]  = i < fourier_parts() ? part_cnt[i] : 0;
+        p.part_base[i]   = i < fourier_parts() ? part_base[i] : nullptr;
+        p.part_cnt[i]    = (i < fourier_parts() && part_cnt) ? part_cnt[i] : 0;
+        p.part_rowoff[i] = (i < fourier_parts() && part_rowoff_dev) ? part_rowoff_dev[i] : nullptr;
     }
+    p.packed_cols = part_rowoff_dev ? packed_cols : 0;
     p.nparts          = fourier_parts();
     p.lat0            = band_begin();
     p.gp              = gp_dev;

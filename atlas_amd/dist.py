@@ -38,6 +38,30 @@ _transpose_messages = _sig("atlas_amd__transpose_messages", c_int, c_int, c_int,
                            c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p)
 
 
+_packed_transpose_messages = _sig("atlas_amd__packed_transpose_messages", c_int, c_int, c_void_p, c_int, c_int, c_int,
+                                  c_void_p, C.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p)
+
+
+def packed_transpose_messages(row_mmax, cols, bands, nparts, part, max_message_elems=1 << 26):
+    """the messages of the library's distributed transform (csrc/dist_trans.hip: packed runs) for rank `part`:
+    ([(peer, send_begin, send_end, recv_begin, recv_end)] in doubles, (doubles sent, doubles received))"""
+    mm = np.ascontiguousarray(row_mmax, dtype=np.int32)
+    b = np.ascontiguousarray(bands, dtype=np.int32)
+    cap = 64 * int(nparts) + 64
+    while True:
+        peer = np.zeros(cap, dtype=np.int32)
+        arr = [np.zeros(cap, dtype=np.int64) for _ in range(4)]
+        n = c_int(0)
+        tot = np.zeros(2, dtype=np.int64)
+        _lib.check(_packed_transpose_messages(len(mm), mm.ctypes.data, int(cols), int(nparts), int(part), b.ctypes.data,
+                                              int(max_message_elems), cap, peer.ctypes.data, *[a.ctypes.data for a in arr],
+                                              C.byref(n), tot.ctypes.data))
+        if n.value <= cap:
+            return [(int(peer[i]),) + tuple(int(a[i]) for a in arr) for i in range(n.value)], (int(tot[0]), int(tot[1]))
+        cap = n.value
+
+
 def transpose_messages(T, RP, bands, nparts, part, max_message_elems=1 << 26):
     """the library's message list of the transposition for rank `part` (csrc/dist_trans.hip):
     [(peer, send_begin, send_end, recv_begin, recv_end)] in doubles"""

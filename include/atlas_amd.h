@@ -373,9 +373,20 @@ int atlas_amd__Trans__invtrans_distributed_many(atlas_amd_Trans* t, atlas_amd_Co
 int atlas_amd__Trans__invtrans_distributed_many_halo(atlas_amd_Trans* t, atlas_amd_Comm* c, int ntransforms, int nb_fields,
                                                      const double* const* sp_dev, double* const* gp_dev,
                                                      atlas_amd_HaloExchange* hx, double* const* field_dev);
+/* largest message of the transposition (default 512 MiB).  MUST be set to the same value on every rank -- both ends of a
+ * pair cut their runs alike; takes effect at the next transform. */
 int atlas_amd__Trans__set_max_message_bytes(atlas_amd_Trans* t, atlas_amd_Comm* comm, long long bytes);
-/* the messages of the transposition for rank `part` (test hook): offsets in doubles into the rank's intermediate and
- * into its receive buffer */
+/* [r3] the messages the distributed transform sends (test hook, host only): rank `part` packs, for every latitude row, the
+ * wavenumbers m <= row_mmax[row] it owns (m % nparts == part) with `cols` = 2 * nb_fields doubles each -- no dead
+ * wavenumbers above the row's Fourier truncation, no pitch padding -- and the rows of band q, one contiguous run, go to
+ * rank q.  Offsets in doubles into the rank's packed send buffer / its receive buffer; totals = {doubles sent (all
+ * destinations, itself included), doubles received}. */
+int atlas_amd__packed_transpose_messages(int nlats, const int row_mmax[], int cols, int nparts, int part, const int bands[],
+                                         long long max_message_elems, int capacity, int* peer, long long* send_begin,
+                                         long long* send_end, long long* recv_begin, long long* recv_end, int* count,
+                                         long long totals[2]);
+/* the slab form of the transposition (rows x owned wavenumbers x RP, what atlas_amd/dist_torch.py sends over
+ * torch.distributed; test hook): offsets in doubles into the rank's intermediate and into its receive buffer */
 int atlas_amd__transpose_messages(int truncation, int RP, int nparts, int part, const int bands[], long long max_message_elems,
                                   int capacity, int* peer, long long* send_begin, long long* send_end, long long* recv_begin,
                                   long long* recv_end, int* count);

@@ -306,3 +306,105 @@ def test_library_transpose_messages_equal_the_python_plan(nparts, maxmsg):
         for _, _, _, rb, re in got:
             cover[rb:re] += 1
         assert (cover == 1).all()
+
+
+def _row_mmax(gridname, T):
+    """Fourier truncation of every row through the library's host-only geometry probe"""
+    import ctypes as C
+    import atlas_amd
+    from atlas_amd import _lib
+    g = atlas_amd.Grid(gridname)
+    nlat0 = np.zeros(T + 1, dtype=np.int32)
+    mm = np.zeros(g.ny(), dtype=np.int32)
+    probe = _lib._sig("atlas_amd__trans_geometry_probe", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+    _lib.check(probe(g._h, T, 0, nlat0.ctypes.data, mm.ctypes.data))
+    return g, np.minimum(mm, T)
+
+
+def _packed_plan_py(row_mmax, cols, bands, nparts, part, maxmsg):
+    """Python formulation of csrc/dist_trans.hip: make_packed_transpose_plan + packed_transpose_messages"""
+    nl = len(row_mmax)
+    rowoff = np.zeros((nparts, nl + 1), dtype=np.int64)
+    for p in range(nparts):
+        kept = np.where(row_mmax >= p, (row_mmax - p) // nparts + 1, 0)
+        rowoff[p, 1:] = np.cumsum(kept * cols)
+    out_off, off = [], 0
+    for p in range(nparts):
+        out_off.append(off)
+        off += int(rowoff[p, bands[part + 1]] - rowoff[p, bands[part]])
+    biggest = max(int(rowoff[p, bands[q + 1]] - rowoff[p, bands[q]]) for p in range(nparts) for q in range(nparts))
+    rows = [int(bands[q + 1] - bands[q]) for q in range(nparts)]
+    K = max(1, -(-biggest // maxmsg))
+    K = max(1, min(K, max(min([r for r in rows if r > 0], default=1), 1)))
+    msgs = []
+    for k in range(K):
+        for peer in range(nparts):
+            s0, s1 = rows[peer] * k // K, rows[peer] * (k + 1) // K
+            r0, r1 = rows[part] * k // K, rows[part] * (k + 1) // K
+            msgs.append((peer, int(rowoff[part, bands[peer] + s0]), int(rowoff[part, bands[peer] + s1]),
+                         out_off[peer] + int(rowoff[peer, bands[part] + r0] - rowoff[peer, bands[part]]),
+                         out_off[peer] + int(rowoff[peer, bands[part] + r1] - rowoff[peer, bands[part]])))
+    return msgs, int(rowoff[part, nl]), off, rowoff, out_off
+
+
+@pytest.mark.parametrize("nparts,maxmsg", [(1, 1 << 26), (2, 1 << 26), (3, 500), (8, 1 << 26), (8, 300), (5, 64)])
+def test_packed_transposition_messages(nparts, maxmsg):
+    """[r3] the messages the library's distributed transform really sends: per row only the wavenumbers up to the row's
+    Fourier truncation, 2 * nf columns each.  Library list == Python formulation; every double of the send buffer leaves
+    exactly once, every double of the receive buffer is written exactly once; the two ends of every pair agree on the
+    piece sizes in the same order; the address the Fourier kernels compute (fft_device.h: ModeReaderT, packed form) lands,
+    for every kept (row, m), on the element the owner packed."""
+    from atlas_amd.dist import packed_transpose_messages
+    g, mm = _row_mmax("O32", 31)
+    cols = 2 * 5
+    bands = np.asarray(_bands(np.asarray(g.nx()), nparts), dtype=np.int32)
+    per_rank = []
+    for part in range(nparts):
+        want, stot, rtot, rowoff, out_off = _packed_plan_py(mm, cols, bands, nparts, part, maxmsg)
+        got, (gs, gr) = packed_transpose_messages(mm, cols, bands, nparts, part, maxmsg)
+        assert got == want and (gs, gr) == (stot, rtot)
+        send = np.zeros(stot, dtype=np.int32)
+        recv = np.zeros(rtot, dtype=np.int32)
+        for _, sb, se, rb, re in got:
+            send[sb:se] += 1
+            recv[rb:re] += 1
+        assert (send == 1).all() and (recv == 1).all()
+        per_rank.append((got, rowoff, out_off))
+    for a in range(nparts):
+        for b in range(nparts):
+            sa = [se - sb for peer, sb, se, _, _ in per_rank[a][0] if peer == b]
+            rb_ = [re - rb for peer, _, _, rb, re in per_rank[b][0] if peer == a]
+            assert sa == rb_
+    # reader addresses: rank q, local row r, wavenumber m -> piece p = m % P, offset inside R
+    for q in range(nparts):
+        _, rowoff, out_off = per_rank[q]
+        seen = set()
+        for r in range(int(bands[q + 1] - bands[q])):
+            lat = int(bands[q]) + r
+            for m in range(int(mm[lat]) + 1):
+                p, ml = m % nparts, m // nparts
+                o = out_off[p] + int(rowoff[p, lat] - rowoff[p, bands[q]]) + ml * cols
+                assert o + cols <= out_off[p] + int(rowoff[p, bands[q + 1]] - rowoff[p, bands[q]])
+                seen.add(o)
+        assert len(seen) * cols == sum(int(rowoff[p, bands[q + 1]] - rowoff[p, bands[q]]) for p in range(nparts))
+
+
+def test_packed_transposition_volume_at_operational_resolution():
+    """TL1279 -> O1280, 137 fields: the kept part of the Fourier intermediate -- 2 312 346 (row, wavenumber) pairs x 274
+    doubles -- is 5.07 GB (7.55 GB as allocated slabs of 288-column rows); a device sends (P - 1) / P of its share to the
+    other devices"""
+    from atlas_amd.dist import packed_transpose_messages
+    g, mm = _row_mmax("O1280", 1279)
+    nf = 137
+    kept_total = int((mm.astype(np.int64) + 1).sum()) * 2 * nf * 8
+    assert kept_total == 2312346 * 274 * 8
+    nx = np.asarray(g.nx())
+    for P in (2, 4, 8):
+        bands = np.asarray(_bands(nx, P), dtype=np.int32)
+        off_device = 0
+        for part in range(P):
+            msgs, (stot, rtot) = packed_transpose_messages(mm, 2 * nf, bands, P, part)
+            off_device += sum(se - sb for peer, sb, se, _, _ in msgs if peer != part) * 8
+        slab_total = 7.55e9
+        assert abs(off_device - kept_total * (P - 1) / P) < 0.02 * kept_total      # the wavenumbers are dealt round robin
+        assert off_device < 0.68 * slab_total * (P - 1) / P

@@ -76,6 +76,47 @@ def test_native_distributed_transform_equals_single_device(gridname, T, nf, npar
             assert np.array_equal(got.reshape(nf, -1), ref[:, sl])
 
 
+@pytest.mark.parametrize("gridname,T,nf,nparts,maxmsg", [("O64", 63, 3, 2, None), ("O64", 47, 5, 3, 8192), ("O160", 159, 9, 8, 1 << 15)])
+def test_transposition_reads_no_uninitialised_bytes(gridname, T, nf, nparts, maxmsg, monkeypatch):
+    """[r3] the transposition ships per row only the kept wavenumbers and the live columns (dist_trans.h: packed runs).
+    With ATLAS_AMD_DIST_POISON=1 the library fills the intermediate, the packed send buffer and the receive buffer with NaN
+    before every transform: anything the Legendre stage did not write that reached the wire or the Fourier stage would show
+    up in the grid points, which must still equal the single-device transform bit for bit."""
+    monkeypatch.setenv("ATLAS_AMD_DIST_POISON", "1")
+    g = atlas_amd.Grid(gridname)
+    sps = [torch.from_numpy(red_spectra(T, nf, seed=s)).cuda() for s in (5, 6, 7)]
+    tr = atlas_amd.Trans(g, T)
+    refs = []
+    for sp in sps:
+        gp = torch.zeros(nf * g.size(), dtype=torch.float64, device="cuda")
+        tr.invtrans(nf, sp, gp)
+        tr.synchronize()
+        refs.append(gp.cpu().numpy().reshape(nf, -1))
+    off = np.concatenate([[0], np.cumsum(g.nx())])
+
+    def rank(comm):
+        d = DistributedTrans(g, T, comm=comm, mode="alltoall")
+        if maxmsg:
+            d.set_max_message_bytes(maxmsg)
+        n = d.trans.nb_gridpoints()
+        gps = [torch.full((nf * n,), float("nan"), dtype=torch.float64, device="cuda") for _ in sps]
+        d.invtrans_many(nf, sps, gps)
+        d.trans.synchronize()
+        # a limit set after the first transform takes effect (the message list is rebuilt), identically on every rank
+        d.set_max_message_bytes(4096)
+        again = torch.full((nf * n,), float("nan"), dtype=torch.float64, device="cuda")
+        d.invtrans(nf, sps[1], again)
+        d.trans.synchronize()
+        return d.bands[comm.rank()], d.bands[comm.rank() + 1], [x.cpu().numpy() for x in gps], again.cpu().numpy()
+
+    for b0, b1, many, again in run_ranks(nparts, rank):
+        sl = slice(off[b0], off[b1])
+        for got, ref in zip(many, refs):
+            assert np.isfinite(got).all()
+            assert np.array_equal(got.reshape(nf, -1), ref[:, sl])
+        assert np.array_equal(again.reshape(nf, -1), refs[1][:, sl])
+
+
 @pytest.mark.parametrize("gridname,nparts,halo", [("O16", 2, 1), ("O32", 3, 2), ("F16", 4, 1)])
 def test_native_halo_exchange_between_ranks(gridname, nparts, halo):
     g = atlas_amd.Grid(gridname)

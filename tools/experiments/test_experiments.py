@@ -1,0 +1,52 @@
+"""GPU parity tests of the experiments that are NOT in the product library (tools/experiments/*.inc).
+Build the experiments library and point the loader at it:
+    make -C atlas_amd/csrc experiments
+    ATLAS_AMD_LIB=atlas_amd/lib/dev/libatlas_amd_exp.so python -m pytest tools/experiments/test_experiments.py -q
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import atlas_amd  # noqa: E402
+import oracle  # noqa: E402
+import test_gpu_trans as product_tests  # noqa: E402
+from helpers import compute_rms, red_spectra  # noqa: E402
+from test_gpu_trans import run_device  # noqa: E402
+
+pytestmark = pytest.mark.skipif("exp" not in os.environ.get("ATLAS_AMD_LIB", ""),
+                                reason="needs ATLAS_AMD_LIB=.../libatlas_amd_exp.so (make -C atlas_amd/csrc experiments)")
+
+
+def test_hybrid_fourier_rows_equal_the_bluestein_rows(monkeypatch):
+    """the dense-stage ("hybrid", opt-in) Fourier kernel -- radix-A DFT on the fp64 matrix cores + radix-{2..9} stages --
+    against the Bluestein kernels on every row of O320 / TL319 and against the oracle on sampled rows"""
+    g = atlas_amd.Grid("O320")
+    T, nf = 319, 9
+    sp = red_spectra(T, nf, seed=81)
+    monkeypatch.setenv("ATLAS_AMD_FFT_HYBRID", "0")
+    a = run_device(atlas_amd.Trans(g, T), nf, sp)
+    monkeypatch.setenv("ATLAS_AMD_FFT_HYBRID", "1")
+    b = run_device(atlas_amd.Trans(g, T), nf, sp)
+    assert compute_rms(b, a) < 1e-14 and not np.array_equal(a, b)      # different arithmetic, same transform
+    rows = [40, 63, 200, 319, 500]
+    op = oracle.OraclePlan(T, g.nx(), g.y(), with_tables=False)
+    off = np.concatenate([[0], np.cumsum(g.nx())])
+    for r, ref in zip(rows, op.invtrans_rows(nf, sp, rows, use_fft=True)):
+        assert compute_rms(b.reshape(nf, -1)[:, off[r]:off[r + 1]], ref) < 1e-13, r
+
+
+
+@pytest.mark.parametrize("case", ["scalar_O160_nf40", "vordiv_F64", "sharded_O160_nf44", "band_O160_nf42", "scalar_O64_nf137"])
+def test_legendre_experiment_kernels_are_bitwise_equal(case, monkeypatch):
+    """"split" (role-split) and "dma" (both operands by LDS-DMA) against "classic" / "lean": the product test with two more
+    kernel names"""
+    monkeypatch.setattr(product_tests, "LEG_KERNELS", ("classic", "lean", "split", "dma"))
+    product_tests.test_legendre_kernel_variants_are_bitwise_equal.__wrapped__(case, monkeypatch) \
+        if hasattr(product_tests.test_legendre_kernel_variants_are_bitwise_equal, "__wrapped__") \
+        else product_tests.test_legendre_kernel_variants_are_bitwise_equal(case, monkeypatch)
