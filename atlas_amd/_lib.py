@@ -157,6 +157,7 @@ Trans_legendre_flops = _sig("atlas_amd__Trans__legendre_flops", C.c_double, c_vo
 Trans_legendre_table_bytes = _sig("atlas_amd__Trans__legendre_table_bytes", C.c_int64, c_void_p)
 Trans_mirror_rows = _sig("atlas_amd__Trans__mirror_rows", C.c_int, c_void_p, c_void_p)
 mirror_bands = _sig("atlas_amd__mirror_bands", C.c_int, c_void_p, C.c_int, c_void_p)
+latitude_bands = _sig("atlas_amd__latitude_bands", C.c_int, c_void_p, C.c_int, C.c_int, c_void_p)
 trans_geometry_probe = _sig("atlas_amd__trans_geometry_probe", C.c_int, c_void_p, C.c_int, C.c_int, c_void_p, c_void_p)
 Trans_legendre_table_download = _sig("atlas_amd__Trans__legendre_table_download", C.c_int, c_void_p, c_void_p,
                                      C.c_size_t)

@@ -795,6 +795,15 @@ int atlas_amd__mirror_bands(const atlas_amd_Grid* grid, int nparts, int bands_ou
     std::memcpy(bands_out, b.data(), sizeof(int) * b.size());
     AA_CATCH_INT
 }
+int atlas_amd__latitude_bands(const atlas_amd_Grid* grid, int truncation, int nparts, int bands_out[]) {
+    AA_TRY
+    if (!grid || !bands_out || nparts < 1) {
+        throw std::invalid_argument("latitude_bands: bad arguments");
+    }
+    const std::vector<int> b = trans::latitude_bands(trans::make_geometry(grid->g, truncation), nparts);
+    std::memcpy(bands_out, b.data(), sizeof(int) * b.size());
+    AA_CATCH_INT
+}
 int atlas_amd__trans_geometry_probe(const atlas_amd_Grid* grid, int truncation, int caps_rows, int nlat0_out[],
                                     int row_mmax_out[]) {
     AA_TRY

@@ -700,6 +700,48 @@ AA_HD void row_phase(int ph, int t, int nt, const RowTables& r, const Reader& rd
 }
 
 
+// ---- odd {3,5}-smooth row lengths (classic reduced Gaussian grids): complex DIT of length n on the Hermitian extension
+//      Z[k] = X[k] (k <= mmax), conj(X[n - k]) (n - k <= mmax), 0 otherwise; y[j] = Re z[j].  Phases: load | DIT stages | store
+AA_HD int row_num_phases_odd(const RowTables& r) {
+    return 1 + r.shape->nstages + 1;
+}
+template <class Reader>
+AA_HD void row_phase_odd(int ph, int t, int nt, const RowTables& r, const Reader& rd, const RowOut& io, cplx* work) {
+    const int n  = r.n;
+    const int ns = r.shape->nstages;
+    if (ph == 0) {
+        for (int k = t; k < n; k += nt) {
+            cplx z = cplx{0., 0.};
+            if (k <= io.mmax) {
+                z = rd(k);
+                if (k == 0) {
+                    z.im = 0.;   // conventions of row_mode(): the imaginary part of the mean is dropped
+                }
+            }
+            else if (n - k <= io.mmax) {
+                z = cconj(rd(n - k));
+            }
+            work[PAD(pos_of_freq(*r.shape, k))] = z;
+        }
+        return;
+    }
+    ph -= 1;
+    if (ph < ns) {
+        const int i = ns - 1 - ph;
+        dit_stage_any(r.shape->radix[i], work, n, stage_L(*r.shape, i), r.shape->lsh[i], r.tw, +1, t, nt);
+        return;
+    }
+    for (int j = t; j < n; j += nt) {
+        const double v = work[PAD(j)].re * io.scale;
+        if (io.f32) {
+            reinterpret_cast<float*>(io.y)[j] = (float)v;
+        }
+        else {
+            io.y[j] = v;
+        }
+    }
+}
+
 // ======================================================================================================
 // Compile-time specialised Bluestein rows: M = F * 2^K (F in {1,3,5}).  Same stage primitives as above, but the
 // stage list is a template parameter so every stride / shift folds to a constant, the load + c2r pre-processing +

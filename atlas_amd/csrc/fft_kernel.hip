@@ -55,6 +55,28 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR) fft_rows_kernel(FourierParams p)
         return;
     }
 
+    if (method == fft::FFT_ODD) {
+        // odd {3,5}-smooth length (classic reduced Gaussian grids): complex DIT of length n, real part stored
+        fft::RowTables ro;
+        ro.n      = n;
+        ro.h      = n;
+        ro.method = method;
+        ro.shape  = &pl->shape;
+        ro.tw     = p.table + pl->off_tw;
+        ro.pre = ro.chirp = ro.bhat = nullptr;
+        fft::RowOut io;
+        io.mmax      = mmax < (n - 1) / 2 ? mmax : (n - 1) / 2;
+        io.y         = y;
+        io.aligned16 = 0;
+        io.scale     = scale;
+        io.f32       = p.f32;
+        const int nph = fft::row_num_phases_odd(ro);
+        for (int ph = 0; ph < nph; ++ph) {
+            fft::row_phase_odd(ph, tid, FFT_NTHR, ro, rd, io, work);
+            __syncthreads();
+        }
+        return;
+    }
     fft::RowTables r;
     r.n      = n;
     r.h      = h;

@@ -210,6 +210,17 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, const PlanOptions
         FftRowPlan p{};
         p.n    = n;
         p.ct_k = -1;
+        if (n % 2 != 0 && n >= 9 && is_smooth235(n)) {
+            // odd {3,5}-smooth length: a complex transform of length n itself (no half-length trick for odd n)
+            p.method      = FFT_ODD;
+            p.h           = n;   // complex points of the transform
+            p.shape       = make_shape(n);
+            p.lds_complex = padded_size(n);
+            p.off_tw      = twiddles(n);
+            p.off_pre     = p.off_tw;
+            ps.plans.push_back(p);
+            continue;
+        }
         if (n % 2 != 0) {
             p.method      = FFT_DFT;
             p.h           = 0;
@@ -365,6 +376,24 @@ static void row_phase_ct_host(int ph, int t, int nt, const RowTablesCt& r, const
 void host_execute_row(const FftPlanSet& ps, int plan, const cplx* X, int mmax, double* y, int nthreads,
                       bool use_specialised) {
     const FftRowPlan& p = ps.plans.at(plan);
+    if (p.method == FFT_ODD) {
+        RowTables r;
+        r.n = p.n, r.h = p.h, r.method = p.method;
+        r.shape = &p.shape;
+        r.tw    = ps.table.data() + p.off_tw;
+        r.pre = r.chirp = r.bhat = nullptr;
+        RowOut io;
+        io.mmax = std::min(mmax, (p.n - 1) / 2), io.y = y, io.aligned16 = 0, io.scale = 1.0;
+        std::vector<cplx> work(padded_size(p.n));
+        auto rd = [&](int m) { return X[m]; };
+        const int nph = row_num_phases_odd(r);
+        for (int ph = 0; ph < nph; ++ph) {
+            for (int t = 0; t < nthreads; ++t) {
+                row_phase_odd(ph, t, nthreads, r, rd, io, work.data());
+            }
+        }
+        return;
+    }
     if (p.method == FFT_DFT) {
         const cplx* w = ps.table.data() + p.off_pre;
         const int n   = p.n;

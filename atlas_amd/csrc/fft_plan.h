@@ -5,6 +5,8 @@
 //
 // Method per row length n (h = n/2):
 //   DIRECT    n even, h is {2,3,5}-smooth : half-length complex FFT (c2r pre-processing + in-place DIT)
+//   ODD       n odd and {3,5}-smooth (rows of the classic reduced Gaussian grids: 25, 45, 75, ... 3645): complex mixed-radix
+//             DIT of length n on the Hermitian extension of the kept modes, real part stored  [r3]
 //   HYBRID    n even, h = A*B, B smooth, A = product of the primes > 5 of h, 7 <= A <= HYB_MAX_A :
 //                                          half-length complex FFT whose radix-A stage is a dense DFT on the matrix
 //                                          cores (fft_core.h: "HYBRID rows"), no Bluestein
@@ -19,7 +21,7 @@
 namespace atlas_amd {
 namespace fft {
 
-enum FftMethod : int { FFT_DIRECT = 0, FFT_BLUESTEIN = 1, FFT_DFT = 2, FFT_HYBRID = 3 };
+enum FftMethod : int { FFT_DIRECT = 0, FFT_BLUESTEIN = 1, FFT_DFT = 2, FFT_HYBRID = 3, FFT_ODD = 4 };
 
 struct FftRowPlan {
     int n;              // row length (number of longitudes of the global row)

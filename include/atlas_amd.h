@@ -252,6 +252,9 @@ int atlas_amd__Trans__legendre_cache_export(const atlas_amd_Trans* t, void* buff
 int atlas_amd__Trans__mirror_rows(const atlas_amd_Trans* t, int out[2]);
 /* the row boundaries shard=mirror uses for nparts parts (nparts+1 values over rows 0 .. ny/2; host only) */
 int atlas_amd__mirror_bands(const atlas_amd_Grid* grid, int nparts, int bands_out[]);
+/* the latitude bands of the distributed transform for nparts ranks (nparts+1 row boundaries; Atlas BandsDistribution rule:
+ * a row belongs to the part of its first point) -- what atlas_amd__Trans__bands returns, without a device (host only) */
+int atlas_amd__latitude_bands(const atlas_amd_Grid* grid, int truncation, int nparts, int bands_out[]);
 /* host-only test hook: nlat0[T+1] and the Fourier truncation of every row, for the grid (caps_rows = 0) or for its two
  * polar caps of caps_rows latitudes each taken as a grid inside the full one (2*caps_rows rows) */
 int atlas_amd__trans_geometry_probe(const atlas_amd_Grid* grid, int truncation, int caps_rows, int nlat0_out[],

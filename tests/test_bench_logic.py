@@ -121,3 +121,26 @@ def test_eight_ranks_auto_is_the_all_to_all_decomposition(tmp_path):
     assert out["n_gpus"] == 8 and out["config"]["parallelism"].startswith("m-sharded")
     assert out["multi_gpu_crosscheck"]["bitwise_equal_on_all_ranks"] is True
     assert "8 transform(s) per step" in out["config"]["workload"]
+
+
+@pytest.mark.parametrize("ngpus", [2, 8])
+def test_bench_dry_run_checks_the_message_plan_without_a_device(ngpus):
+    """`bench.py --gpus N --dry-run`: the library's host code builds bands and messages of all N ranks
+    at the headline resolution; the plan must cover both buffers exactly once, the two ends of every pair must agree, and
+    the totals must be the kept part of the intermediate"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ngpus), "--dry-run", "--xgmi-gbs", "40"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["dry_run"] and d["n_gpus"] == ngpus and d["problems"] == []
+    assert all(d["plan_checks"].values())
+    assert d["kept_intermediate_bytes"] == 2312346 * 274 * 8
+    assert sum(d["latitude_bands_rows"]) == 2560 and sum(d["band_points"]) == 6599680
+    lo, hi = d["bytes_leaving_a_gpu_per_transform"]["min"], d["bytes_leaving_a_gpu_per_transform"]["max"]
+    share = d["kept_intermediate_bytes"] / ngpus * (ngpus - 1) / ngpus
+    assert 0.8 * share < lo <= hi < 1.2 * share
+    assert d["expected_exchange_ms_per_transform"]["assumed_link_GBs"] == 40

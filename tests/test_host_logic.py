@@ -354,3 +354,32 @@ def test_rectangular_domain_crop_of_a_global_grid():
         g.crop_to_domain(0.3, 0.4, -10., 10.)                  # no point of a row inside
     with pytest.raises(_lib.AtlasAmdError):
         g.crop_to_domain(10., 0., -10., 10.)
+
+
+@pytest.mark.parametrize("N", [1280, 320, 80])
+def test_fft_phase_code_on_every_row_length_of_the_classic_reduced_grid(N):
+    """[r3] every distinct row length of N<N> -- all {2,3,5}-smooth, 19 of them ODD at N = 1280 (25 ... 3645: complex DIT of
+    length n on the Hermitian extension, fft_core.h: row_phase_odd) -- through the host run of the kernel's phase code with
+    the row's own Fourier truncation, against pocketfft"""
+    g = atlas_amd.Grid(f"N{N}")
+    T = N - 1
+    rng = np.random.default_rng(N + 7)
+    nx, y = np.asarray(g.nx()), g.y()
+    worst, odd = 0.0, 0
+    for n in sorted(set(nx[:N].tolist())):
+        j = int(np.argmax(nx == n))
+        nc = n // 2 + 1
+        mmax = _lib.fourier_truncation(T, n, g.nxmax(), 2 * N, math.radians(y[j]), 0)
+        assert 0 <= mmax <= min(T, (n - 1) // 2)
+        x = rng.standard_normal(nc) + 1j * rng.standard_normal(nc)
+        x[mmax + 1:] = 0
+        out = np.zeros(n)
+        _lib.check(_lib.fft_host_row(n, np.ascontiguousarray(x).ctypes.data, mmax, out.ctypes.data))
+        xx = x.copy()
+        xx[0] = xx[0].real
+        if n % 2 == 0:
+            xx[-1] = xx[-1].real
+        worst = max(worst, compute_rms(out, np.fft.irfft(xx, n) * n))
+        odd += n % 2
+    assert worst < 2e-15, worst
+    assert odd == {1280: 19, 320: 13, 80: 4}[N]

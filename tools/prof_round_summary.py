@@ -72,6 +72,13 @@ for st, cs in stage.items():
         wr = cs["WRITE_SIZE"] * 1e3 / ntr
         traffic[st] = rd + wr
         detail[st] = {"read_bytes(2xFETCH_SIZE)": rd, "write_bytes(WRITE_SIZE)": wr}
+# vector-ALU wave-instructions per transform (SQ_INSTS_VALU of the "sq" pass): the issue floor of a stage that is bound by
+# its own instruction stream, not by memory (bench.py: roofline.valu_issue_floor_ms)
+valu = {}
+for st, cs in stage.items():
+    n = stage_launch.get(("legendre_kernel", "SQ_INSTS_VALU"), 0) or ntr
+    if "SQ_INSTS_VALU" in cs:
+        valu[st] = cs["SQ_INSTS_VALU"] / n
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 try:
     import bench
@@ -79,6 +86,7 @@ try:
 except Exception:  # noqa: BLE001
     digest = None
 out = {"traffic_bytes_per_launch": traffic, "detail": detail, "transforms_profiled": ntr,
+       "valu_wave_instructions_per_transform": valu,
        "kernel_source_sha256": digest,
        "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes over bench.py --steps 2 --warmup 1; "
                "FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B); fourier_stage = sum over the row-class "
