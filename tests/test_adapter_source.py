@@ -36,11 +36,18 @@ def _methods(text, pattern):
     return found
 
 
+ADAPTER_FILES = ("TransMI355X.h", "TransMI355X.cc", "VorDivToUVMI355X.cc", "LegendreCacheCreatorMI355X.cc", "HaloExchangeMI355X.h")
+
+
+def _adapter(name):
+    return open(os.path.join(ROOT, "adapter", name)).read()
+
+
 def test_every_atlas_amd_symbol_of_the_adapter_exists():
-    src = open(os.path.join(ROOT, "adapter", "TransMI355X.cc")).read()
+    src = "\n".join(_adapter(f) for f in ADAPTER_FILES)
     header = open(os.path.join(ROOT, "include", "atlas_amd.h")).read()
     used = set(re.findall(r"\b(atlas_amd__[A-Za-z_0-9]+)\s*\(", src))
-    assert len(used) >= 10
+    assert len(used) >= 25
     for sym in used:
         assert re.search(r"\b" + sym + r"\s*\(", header), f"{sym} not declared in include/atlas_amd.h"
         assert hasattr(_lib.lib, sym), f"{sym} not exported by libatlas_amd.so"
@@ -52,9 +59,83 @@ def test_adapter_overrides_every_pure_virtual_of_TransImpl():
     ref = ref[ref.index("class TransImpl"):]
     pure = _methods(ref, r"virtual\s+[^;{}()]*?\b([A-Za-z_0-9]+)\s*\(([^;{}]*?)\)\s*const\s*=\s*0\s*;")
     assert len(pure) >= 28, len(pure)
-    src = open(os.path.join(ROOT, "adapter", "TransMI355X.cc")).read()
-    cls = src[src.index("class TransMI355X"):src.index("TransMI355X::TransMI355X(")]
+    src = _adapter("TransMI355X.cc")
+    hdr = _adapter("TransMI355X.h")
+    cls = hdr[hdr.index("class TransMI355X"):]
     mine = _methods(cls, r"\b([A-Za-z_0-9]+)\s*\(([^;{}]*?)\)\s*const\s*override")
     missing = sorted(m for m in pure if m not in mine)
     assert not missing, missing
     assert re.search(r'TransBuilderGrid<TransMI355X>\s+builder\("mi355x",\s*"mi355x"\)', src)
+
+
+REF_TRANS = "/root/reference/src/atlas/trans"
+needs_ref = pytest.mark.skipif(not os.path.exists(REF), reason="the reference checkout is only present in the build container")
+
+
+@needs_ref
+def test_adapter_registers_vordivtouv_and_overrides_its_interface():
+    """VorDivToUVImpl (VorDivToUV.h:36-62): truncation() and execute(nb_coeff, nb_fields, vor, div, U, V, config); the builder
+    template needs constructors (FunctionSpace, config) and (int, config) (VorDivToUV.h:96-104)"""
+    ref = open(os.path.join(REF_TRANS, "VorDivToUV.h")).read()
+    ref = ref[ref.index("class VorDivToUVImpl"):ref.index("class VorDivToUVFactory")]
+    pure = _methods(ref, r"virtual\s+[^;{}()]*?\b([A-Za-z_0-9]+)\s*\(([^;{}]*?)\)\s*const\s*=\s*0\s*;")
+    assert {m[0] for m in pure} == {"truncation", "execute"}
+    src = _adapter("VorDivToUVMI355X.cc")
+    mine = _methods(src, r"\b([A-Za-z_0-9]+)\s*\(([^;{}]*?)\)\s*const\s*override")
+    assert not sorted(m for m in pure if m not in mine)
+    assert re.search(r'VorDivToUVBuilder<VorDivToUVMI355X>\s+builder\("mi355x"\)', src)
+    assert re.search(r"VorDivToUVMI355X\(const FunctionSpace&", src) and re.search(r"VorDivToUVMI355X\(int truncation", src)
+
+
+@needs_ref
+def test_adapter_registers_legendre_cache_creator_and_overrides_its_interface():
+    """LegendreCacheCreatorImpl (LegendreCacheCreator.h:30-44): supported, uid, create(path), create(), estimate; the
+    builder constructs T(grid, truncation, config) (LegendreCacheCreator.h:98-105)"""
+    ref = open(os.path.join(REF_TRANS, "LegendreCacheCreator.h")).read()
+    ref = ref[ref.index("class LegendreCacheCreatorImpl"):ref.index("class LegendreCacheCreator :")]
+    pure = _methods(ref, r"virtual\s+[^;{}()]*?\b([A-Za-z_0-9]+)\s*\(([^;{}]*?)\)\s*const\s*=\s*0\s*;")
+    assert {m[0] for m in pure} == {"supported", "uid", "create", "estimate"} and len(pure) == 5
+    src = _adapter("LegendreCacheCreatorMI355X.cc")
+    mine = _methods(src, r"\b([A-Za-z_0-9]+)\s*\(([^;{}]*?)\)\s*const\s*override")
+    assert not sorted(m for m in pure if m not in mine)
+    assert re.search(r'LegendreCacheCreatorBuilder<LegendreCacheCreatorMI355X>\s+builder\("mi355x"\)', src)
+    assert re.search(r"LegendreCacheCreatorMI355X\(const Grid& grid, int truncation, const eckit::Configuration&", src)
+    # create() hands out what the Trans exported, as LegendreCacheCreatorLocal.cc:153-158; the Trans honours both keys
+    trans = _adapter("TransMI355X.cc")
+    assert "export_legendre_" in src and 'getBool("export_legendre"' in trans and 'getString("write_legendre"' in trans
+
+
+@needs_ref
+def test_adapter_halo_exchange_has_the_public_surface_of_parallel_HaloExchange():
+    """HaloExchange.h:37-58: constructors, name(), four setup overloads, execute / execute_adjoint templates"""
+    ref = open("/root/reference/src/atlas/parallel/HaloExchange.h").read()
+    ref = ref[ref.index("class HaloExchange"):ref.index("private:  // methods")]
+    src = _adapter("HaloExchangeMI355X.h")
+    mine = src[src.index("class HaloExchangeMI355X"):src.index("private:")]
+
+    def setups(text):
+        out = set()
+        for m in re.finditer(r"void\s+setup\(([^)]*)\)", text):
+            out.add(_norm_params(m.group(1)))
+        return out
+    assert len(setups(ref)) == 4 and setups(ref) == setups(mine)
+    for name in ("execute", "execute_adjoint"):
+        pat = r"template\s*<typename DATA_TYPE, int RANK, typename ParallelDim = array::FirstDim>\s*void\s+" + name + \
+              r"\(array::Array& field, bool on_device = false\) const"
+        assert re.search(pat, ref) and re.search(pat, mine), name
+    assert re.search(r"const std::string& name\(\) const", mine)
+    assert re.search(r"HaloExchangeMI355X\(const std::string& name\)", mine) and re.search(r"HaloExchangeMI355X\(\)", mine)
+    # the two collectives and the point-to-point calls of the reference are the adapter's as well
+    for call in ("allToAll(", "allToAllv(", "iReceive(", "iSend(", "wait("):
+        assert call in src, call
+
+
+def test_adapter_trans_selects_the_target_as_translocal_does():
+    """a non-global RegularGrid goes to the no_nest class (RegionalTrans), an unstructured grid to the point-wise
+    one, other non-global grids are refused; library objects are held by owning pointers"""
+    src = _adapter("TransMI355X.cc")
+    hdr = _adapter("TransMI355X.h")
+    assert "atlas_amd__RegionalTrans__new(" in src and "atlas_amd__RegionalTrans__new_unstructured(" in src
+    assert "domain().global()" in src and "throw_NotImplemented" in src
+    assert "std::unique_ptr<atlas_amd_Trans" in hdr and "std::unique_ptr<atlas_amd_Grid" in hdr
+    assert "make_device_view<double, 1>" in src and "deviceAllocated()" in src      # device-resident fields stay on the device
