@@ -442,18 +442,25 @@ atlas_amd_RegionalTrans* atlas_amd__RegionalTrans__new_unstructured(int npts, co
 void atlas_amd__RegionalTrans__delete(atlas_amd_RegionalTrans* t) {
     delete t;
 }
+static void need(const atlas_amd_RegionalTrans* t) {
+    if (!t || !t->impl) {
+        throw std::invalid_argument("RegionalTrans: null handle");
+    }
+}
 int64_t atlas_amd__RegionalTrans__nb_gridpoints(const atlas_amd_RegionalTrans* t) {
-    return t->impl->nb_gridpoints();
+    return t && t->impl ? t->impl->nb_gridpoints() : -1;
 }
 int atlas_amd__RegionalTrans__invtrans_scalar(atlas_amd_RegionalTrans* t, int nb_fields, const double scalar_spectra[],
                                               double gp_fields[]) {
     AA_TRY
+    need(t);
     t->impl->invtrans(nb_fields, scalar_spectra, gp_fields);
     AA_CATCH_INT
 }
 int atlas_amd__RegionalTrans__invtrans_scalar_device(atlas_amd_RegionalTrans* t, int nb_fields, const double* sp_dev,
                                                      double* gp_dev) {
     AA_TRY
+    need(t);
     t->impl->invtrans_scalar_device(nb_fields, sp_dev, gp_dev);
     AA_CATCH_INT
 }
@@ -461,16 +468,18 @@ int atlas_amd__RegionalTrans__invtrans_vordiv(atlas_amd_RegionalTrans* t, int nb
                                               int nb_vordiv_fields, const double vorticity_spectra[],
                                               const double divergence_spectra[], double gp_fields[]) {
     AA_TRY
+    need(t);
     t->impl->invtrans(nb_scalar_fields, scalar_spectra, nb_vordiv_fields, vorticity_spectra, divergence_spectra, gp_fields);
     AA_CATCH_INT
 }
 int atlas_amd__RegionalTrans__synchronize(atlas_amd_RegionalTrans* t) {
     AA_TRY
+    need(t);
     t->impl->synchronize();
     AA_CATCH_INT
 }
 void* atlas_amd__RegionalTrans__stream(const atlas_amd_RegionalTrans* t) {
-    return (void*)t->impl->stream();
+    return t && t->impl ? (void*)t->impl->stream() : nullptr;
 }
 
 int atlas_amd__Grid__crop_to_domain(const atlas_amd_Grid* grid, double west, double east, double south, double north,

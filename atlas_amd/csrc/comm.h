@@ -19,6 +19,7 @@
 #include <cstddef>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <vector>
 
 namespace atlas_amd {
@@ -66,7 +67,10 @@ public:
 
 private:
     friend class LocalComm;
-    void rendezvous();   // all ranks arrive
+    void rendezvous();   // all ranks arrive (throws on every rank once one of them has failed)
+    void fail(const std::string& what);
+    bool failed_ = false;
+    std::string failure_;
     int n_;
     std::mutex m_;
     std::condition_variable cv_;

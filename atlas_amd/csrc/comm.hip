@@ -41,6 +41,11 @@ void Comm::release_helper_stream() {
 
 void Comm::all_to_allv(const int* send, const int* sendcounts, int* recv, const int* recvcounts) {
     const int n        = size();
+    for (int p = 0; p < n; ++p) {   // before anything is allocated or summed
+        if (sendcounts[p] < 0 || recvcounts[p] < 0) {
+            throw std::invalid_argument("Comm::all_to_allv: negative count");
+        }
+    }
     const size_t nsend = std::accumulate(sendcounts, sendcounts + n, (size_t)0);
     const size_t nrecv = std::accumulate(recvcounts, recvcounts + n, (size_t)0);
     int *ds = nullptr, *dr = nullptr;
@@ -115,11 +120,22 @@ const RcclApi& rccl() {
             a.where = "process image";
         }
         else {
+            // a copy that is mapped but not in the global namespace (torch loads its bundled RCCL RTLD_LOCAL): take THAT one
+            // -- RTLD_NOLOAD finds it by soname without mapping anything -- before a second RCCL enters the process
+            for (const char* name : {"librccl.so.1", "librccl.so"}) {
+                h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+                if (h) {
+                    a.where = std::string(name) + " (already mapped)";
+                    break;
+                }
+            }
             for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                if (h) {
+                    break;
+                }
                 h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
                 if (h) {
                     a.where = name;
-                    break;
                 }
             }
         }
@@ -273,6 +289,9 @@ LocalHub::~LocalHub() {
 }
 void LocalHub::rendezvous() {
     std::unique_lock<std::mutex> lk(m_);
+    if (failed_) {
+        throw std::runtime_error("Comm::exchange: another rank of this hub failed: " + failure_);
+    }
     const long long g = gen_;
     if (++arrived_ == n_) {
         arrived_ = 0;
@@ -280,8 +299,21 @@ void LocalHub::rendezvous() {
         cv_.notify_all();
     }
     else {
-        cv_.wait(lk, [&] { return gen_ != g; });
+        cv_.wait(lk, [&] { return gen_ != g || failed_; });
+        if (failed_) {
+            throw std::runtime_error("Comm::exchange: another rank of this hub failed: " + failure_);
+        }
     }
+}
+// a rank that throws between two meeting points would leave the others waiting for ever: it marks the hub failed first,
+// every waiter (and every later arrival) then throws as well
+void LocalHub::fail(const std::string& what) {
+    std::lock_guard<std::mutex> lk(m_);
+    if (!failed_) {
+        failed_  = true;
+        failure_ = what;
+    }
+    cv_.notify_all();
 }
 
 class LocalComm : public Comm {
@@ -297,6 +329,17 @@ public:
     const char* kind() const override { return "local"; }
 
     void exchange(const std::vector<Msg>& sends, const std::vector<Msg>& recvs, hipStream_t stream) override {
+        try {
+            exchange_impl(sends, recvs, stream);
+        }
+        catch (const std::exception& e) {
+            hub_->fail(e.what());   // releases the ranks that wait at a meeting point (a failing test fails, it does not hang)
+            throw;
+        }
+    }
+
+private:
+    void exchange_impl(const std::vector<Msg>& sends, const std::vector<Msg>& recvs, hipStream_t stream) {
         LocalHub& h = *hub_;
         const int n = h.size();
         // 1. my send buffers are complete once the work already in my stream has run
@@ -351,7 +394,6 @@ public:
         h.rendezvous();
     }
 
-private:
     bool waited_done(int p) const { return std::find(done_marks_.begin(), done_marks_.end(), p) != done_marks_.end(); }
     void mark_done(int p) { done_marks_.push_back(p); }
     std::shared_ptr<LocalHub> hub_;

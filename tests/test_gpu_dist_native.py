@@ -214,3 +214,31 @@ def test_config_C3_TL639_O640_137_levels_on_four_ranks():
 
     for same, halo_ok in run_ranks(nparts, rank):
         assert same and halo_ok
+
+
+def test_a_failing_rank_releases_the_others_instead_of_hanging():
+    """a rank of the in-process communicator that throws between two meeting points (here: a receive whose size
+    does not match the peer's send) marks the hub failed; the rank that waits at the meeting point throws too."""
+    import ctypes as C
+    from atlas_amd import _lib
+    exchange = _lib._sig("atlas_amd__Comm__exchange", C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+    bufs = [torch.zeros(64, dtype=torch.float64, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    errors = [None, None]
+
+    def rank(comm):
+        r = comm.rank()
+        peer = (C.c_int * 1)(1 - r)
+        ptr = (C.c_void_p * 1)(bufs[r].data_ptr())
+        nbytes = (C.c_size_t * 1)(16 if r == 0 else 32)       # rank 0 sends 16 bytes, rank 1 expects 32
+        if r == 0:
+            rc = exchange(comm._h, 1, peer, ptr, nbytes, 0, None, None, None, None)
+        else:
+            rc = exchange(comm._h, 0, None, None, None, 1, peer, ptr, nbytes, None)
+        errors[r] = _lib.last_error().decode() if rc != 0 else None
+        return rc
+
+    rcs = run_ranks(2, rank)
+    assert all(rc != 0 for rc in rcs), rcs
+    assert any("matching send" in (e or "") for e in errors) and any("another rank" in (e or "") or "matching" in (e or "") for e in errors)
