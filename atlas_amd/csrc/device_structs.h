@@ -25,6 +25,8 @@ struct LegendreParamsT {
     const Real* sp;              // spectra, layout of TransLocal.cc:970-987 with truncation trc_in
     Real* F;                     // Fourier intermediate F[(lat*(T+1)+m)*RP + r]
     const LegendreItemDev* items;  // launch-ordered work items
+    const LegendreItemDev* items2; // the same paired: two consecutive tiles of one m per item (legendre_kernel_lean2), or null
+    int nitems2;
     const int* nlat0;              // [T+1]
     const Real* zero;            // a 0.0 in device memory (target of the spectra loads of padding columns)
     int T;

@@ -624,6 +624,7 @@ static hipError_t launch_lean(LegendreParams p, int nitems, int nchunks, int chu
     return hipGetLastError();
 }
 
+
 #if defined(ATLAS_AMD_EXPERIMENTS)
 #include "../../tools/experiments/legendre_kernel_experiments.inc"
 #endif
@@ -694,7 +695,7 @@ hipError_t launch_legendre(const LegendreParams& p, int nitems, int chunk0, int 
     if (rtw == 3 && nrg == 2) {
         // the 96-column workgroup (every field count whose 16-column tiles come in sixes, e.g. 137 levels) has two more
         // implementations of the same arithmetic: "lean" (default) and, in experiment builds only, "split" and "dma"
-        // (tools/experiments/legendre_kernel_experiments.inc); ATLAS_AMD_LEG_KERNEL=classic selects the generic template
+        // and "lean2" (tools/experiments/legendre_kernel_experiments.inc); ATLAS_AMD_LEG_KERNEL=classic selects the generic template
         const char* e       = std::getenv("ATLAS_AMD_LEG_KERNEL");
         const std::string k = e ? e : "lean";
         if (nrun <= 0) {
@@ -705,6 +706,9 @@ hipError_t launch_legendre(const LegendreParams& p, int nitems, int chunk0, int 
             return launch_lean(p, nitems, nchunks, chunk0, nrun, stream);
         }
 #if defined(ATLAS_AMD_EXPERIMENTS)
+        if (k == "lean2" && p.items2 && p.nitems2 > 0) {
+            return launch_lean2(p, nchunks, chunk0, nrun, stream);
+        }
         if (k == "split") {
             return launch_v2<8, 4>(p, nitems, nchunks, chunk0, nrun, stream);
         }
@@ -712,7 +716,7 @@ hipError_t launch_legendre(const LegendreParams& p, int nitems, int chunk0, int 
             return launch_dma(p, nitems, nchunks, chunk0, nrun, stream);
         }
 #else
-        if (k == "split" || k == "dma") {
+        if (k == "split" || k == "dma" || k == "lean2") {
             return hipErrorNotSupported;   // tools/experiments: needs a library built with -DATLAS_AMD_EXPERIMENTS
         }
 #endif

@@ -159,6 +159,8 @@ private:
     // device state
     double* d_P_         = nullptr;
     void* d_items_       = nullptr;
+    void* d_items2_      = nullptr;  // paired work list (two consecutive tiles of one m per item)
+    int nitems2_         = 0;
     int* d_nlat0_        = nullptr;
     double* d_zero_      = nullptr;  // zeros: load target of padding columns in the Legendre kernel
     float* d_P32_        = nullptr;  // fp32 variant: table, zero target and Fourier intermediate in float (lazily)

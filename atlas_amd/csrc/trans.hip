@@ -155,6 +155,7 @@ void Trans::release() noexcept {
     };
     fr(d_P_);
     fr(d_items_);
+    fr(d_items2_);
     fr(d_nlat0_);
     fr(d_zero_);
     fr(d_P32_);
@@ -328,6 +329,41 @@ void Trans::upload() {
             items[i]               = LegendreItemDev{it.m, it.tile, it.nrows, it.kpad, (long long)it.p_off};
         }
         d_items_ = dev_upload(items.data(), items.size());
+#if defined(ATLAS_AMD_EXPERIMENTS)
+        // paired list (legendre_kernel_lean2): the launch order interleaves eight per-XCD lists (item i belongs to list i % 8);
+        // inside a list the tiles of one m follow each other, and so do their blocks in the table
+        std::vector<std::vector<LegendreItemDev>> lists(8);
+        for (size_t i = 0; i < items.size(); ++i) {
+            if (items[i].m >= 0) {
+                lists[i % 8].push_back(items[i]);
+            }
+        }
+        std::vector<std::vector<LegendreItemDev>> pairs(8);
+        size_t maxlen = 0;
+        for (int x = 0; x < 8; ++x) {
+            for (size_t i = 0; i < lists[x].size(); ++i) {
+                LegendreItemDev a = lists[x][i];
+                if (i + 1 < lists[x].size()) {
+                    const LegendreItemDev& b = lists[x][i + 1];
+                    if (b.m == a.m && b.tile == a.tile + 1 && a.nrows == LEG_BN_DEV &&
+                        b.p_off == a.p_off + 2ll * a.kpad * LEG_BN_DEV) {
+                        a.nrows += b.nrows;
+                        ++i;
+                    }
+                }
+                pairs[x].push_back(a);
+            }
+            maxlen = std::max(maxlen, pairs[x].size());
+        }
+        std::vector<LegendreItemDev> items2;
+        for (size_t q = 0; q < maxlen; ++q) {
+            for (int x = 0; x < 8; ++x) {
+                items2.push_back(q < pairs[x].size() ? pairs[x][q] : LegendreItemDev{-1, 0, 0, 0, 0});
+            }
+        }
+        nitems2_  = (int)items2.size();
+        d_items2_ = items2.empty() ? nullptr : dev_upload(items2.data(), items2.size());
+#endif
     }
     d_nlat0_ = dev_upload(geo_.nlat0.data(), geo_.nlat0.size());
     {
@@ -519,6 +555,8 @@ void Trans::legendre_chunks(int trc_in, int nb_fields, const double* sp_dev, dou
     p.sp     = sp_dev;
     p.F      = fourier_dev;
     p.items  = (const LegendreItemDev*)d_items_;
+    p.items2 = (const LegendreItemDev*)d_items2_;
+    p.nitems2 = nitems2_;
     p.nlat0  = d_nlat0_;
     p.zero   = d_zero_;
     p.T      = geo_.T;
@@ -762,6 +800,8 @@ void Trans::invtrans_scalar_device_f32(int nb_fields, const float* sp_dev, float
     p.sp        = sp_dev;
     p.F         = d_fourier32_;
     p.items     = (const LegendreItemDev*)d_items_;
+    p.items2    = nullptr;
+    p.nitems2   = 0;
     p.nlat0     = d_nlat0_;
     p.zero      = d_zero32_;
     p.T         = geo_.T;

@@ -509,7 +509,7 @@ LEG_KERNELS = ("classic", "lean")
 def test_legendre_kernel_variants_are_bitwise_equal(case, monkeypatch):
     """The 96-column workgroup of the Legendre stage (field counts whose 16-column tiles come in sixes: nf 33..48, 81..96,
     129..144, ...) has two implementations of the same arithmetic in the same order: the generic template ("classic") and
-    the default without vector-ALU work in its stage loop ("lean").  (Two more that lost -- "split", "dma" -- live in
+    the default without vector-ALU work in its stage loop ("lean").  (Three more that lost -- "split", "dma", "lean2" -- live in
     tools/experiments and are compared the same way by tools/experiments/test_experiments.py on an experiments build.)
     ATLAS_AMD_LEG_KERNEL is read at every launch; every entry point that reaches the stage must give identical bits."""
     outs = {}

@@ -44,9 +44,9 @@ def test_hybrid_fourier_rows_equal_the_bluestein_rows(monkeypatch):
 
 @pytest.mark.parametrize("case", ["scalar_O160_nf40", "vordiv_F64", "sharded_O160_nf44", "band_O160_nf42", "scalar_O64_nf137"])
 def test_legendre_experiment_kernels_are_bitwise_equal(case, monkeypatch):
-    """"split" (role-split) and "dma" (both operands by LDS-DMA) against "classic" / "lean": the product test with two more
+    """"lean2" (pairs of latitude tiles), "split" (role-split) and "dma" (both operands by LDS-DMA) against "classic" / "lean": the product test with two more
     kernel names"""
-    monkeypatch.setattr(product_tests, "LEG_KERNELS", ("classic", "lean", "split", "dma"))
+    monkeypatch.setattr(product_tests, "LEG_KERNELS", ("classic", "lean", "lean2", "split", "dma"))
     product_tests.test_legendre_kernel_variants_are_bitwise_equal.__wrapped__(case, monkeypatch) \
         if hasattr(product_tests.test_legendre_kernel_variants_are_bitwise_equal, "__wrapped__") \
         else product_tests.test_legendre_kernel_variants_are_bitwise_equal(case, monkeypatch)
