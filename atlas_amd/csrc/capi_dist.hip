@@ -183,6 +183,29 @@ int atlas_amd__Trans__invtrans_distributed_many(atlas_amd_Trans* t, atlas_amd_Co
     dist_of(t, c).invtrans_many(ntransforms, nb_fields, sp_dev, gp_dev);
     DX_CATCH
 }
+int atlas_amd__Trans__invtrans_distributed_sharded(atlas_amd_Trans* t, atlas_amd_Comm* c, int ntransforms, int nb_fields,
+                                                   const double* const* sp_shard_dev, double* const* gp_dev) {
+    DX_TRY
+    if (ntransforms > 0 && (!sp_shard_dev || !gp_dev)) {
+        throw std::invalid_argument("invtrans_distributed_sharded: null arrays");
+    }
+    dist_of(t, c).invtrans_many_sharded(ntransforms, nb_fields, sp_shard_dev, gp_dev);
+    DX_CATCH
+}
+int atlas_amd__Trans__spectral_shard(const atlas_amd_Trans* t, long long moff_out[], long long* size_per_field) {
+    DX_TRY
+    if (!t || !t->impl || !size_per_field) {
+        throw std::invalid_argument("spectral_shard: null argument");
+    }
+    std::vector<long long> moff;
+    *size_per_field = t->impl->spectral_shard_offsets(moff);
+    if (moff_out) {
+        for (int m = 0; m <= t->impl->truncation(); ++m) {
+            moff_out[m] = moff[m];
+        }
+    }
+    DX_CATCH
+}
 int atlas_amd__Trans__invtrans_distributed_many_halo(atlas_amd_Trans* t, atlas_amd_Comm* c, int ntransforms, int nb_fields,
                                                      const double* const* sp_dev, double* const* gp_dev,
                                                      atlas_amd_HaloExchange* hx, double* const* field_dev) {

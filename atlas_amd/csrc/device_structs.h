@@ -23,6 +23,8 @@ template <class Real>
 struct LegendreParamsT {
     const Real* P;               // tile-blocked Legendre table
     const Real* sp;              // spectra, layout of TransLocal.cc:970-987 with truncation trc_in
+    const long long* sp_moff;    // null: `sp` is the full array (block of wavenumber m at the reference's offset); else [T+2]: `sp`
+                                 // holds only this rank's wavenumbers back to back, block m at sp_moff[m] * nf doubles [r3]
     Real* F;                     // Fourier intermediate F[(lat*(T+1)+m)*RP + r]
     const LegendreItemDev* items;  // launch-ordered work items
     const LegendreItemDev* items2; // the same paired: two consecutive tiles of one m per item (legendre_kernel_lean2), or null

@@ -76,6 +76,9 @@ public:
     // Trans stream.
     void invtrans(int nb_fields, const double* sp_dev, double* gp_dev);
     void invtrans_many(int ntransforms, int nb_fields, const double* const* sp_dev, double* const* gp_dev);
+    // [r3] sharded input: every sp_dev[i] holds only this rank's wavenumbers (Trans::legendre_device_sharded; SURVEY 8(e):
+    // the spectra are scattered by m) -- 1/P of the replicated array per rank
+    void invtrans_many_sharded(int ntransforms, int nb_fields, const double* const* sp_shard_dev, double* const* gp_dev);
     // invtrans_many + per transform, on the communication stream (i.e. beside the Legendre stage of the transforms that
     // follow): its grid points transposed into the owned part of a StructuredColumns field [size_halo][nb_fields] whose
     // partition is this rank's latitude band, then that field's halo exchange between the ranks (HaloExchange.h:191-219).
@@ -99,6 +102,7 @@ private:
     };
     void ensure(int nb_fields);
     void legendre(int nb_fields, const double* sp_dev, Slot& s);
+    bool sharded_input_ = false;   // set for the duration of invtrans_many_sharded
     void poison(Slot& s);
     void exchange(Slot& s);
     void fourier(int nb_fields, Slot& s, double* gp_dev);

@@ -279,7 +279,12 @@ void DistributedTrans::legendre(int nb_fields, const double* sp_dev, Slot& s) {
         }
         poison(s);
     }
-    trans_.legendre_device(trans_.truncation(), nb_fields, sp_dev, s.F);
+    if (sharded_input_) {
+        trans_.legendre_device_sharded(nb_fields, sp_dev, s.F);
+    }
+    else {
+        trans_.legendre_device(trans_.truncation(), nb_fields, sp_dev, s.F);
+    }
     HIP_CHECK(hipEventRecord(s.legendre_done, trans_.stream()));
 }
 
@@ -345,6 +350,19 @@ void DistributedTrans::invtrans_many(int ntransforms, int nb_fields, const doubl
         }
     }
     fourier(nb_fields, slot_[(ntransforms - 1) & 1], gp_dev[ntransforms - 1]);
+}
+
+void DistributedTrans::invtrans_many_sharded(int ntransforms, int nb_fields, const double* const* sp_shard_dev,
+                                             double* const* gp_dev) {
+    sharded_input_ = true;
+    try {
+        invtrans_many(ntransforms, nb_fields, sp_shard_dev, gp_dev);
+    }
+    catch (...) {
+        sharded_input_ = false;
+        throw;
+    }
+    sharded_input_ = false;
 }
 
 hipError_t launch_gp_to_field(const double* gp, double* field, long long npts, int nf, hipStream_t stream);

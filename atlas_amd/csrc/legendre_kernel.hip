@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
     const int ntop1 = TL - 1 + ((TL - m) & 1);
     const int nmax  = trc < TL ? trc : TL;  // highest n present in the input spectra
     const bool m_ok = m < trc;              // TransLocal.cc:982  (jm < truncation)
-    const long long ioff = (long long)(2 * trc + 3 - m) * m / 2 * nf * 2;
+    const long long ioff = p.sp_moff ? p.sp_moff[m] * nf : (long long)(2 * trc + 3 - m) * m / 2 * nf * 2;
     const Real* __restrict__ sp = p.sp + ioff;
     const Real* __restrict__ Pb = p.P + it.p_off;
     const int nstage = it.kpad / KB;
@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(512, 4) legendre_kernel_lean(LegendreParams p)
     const int ntop1 = TL - 1 + ((TL - m) & 1);
     const int nmax  = trc < TL ? trc : TL;
     const bool m_ok = m < trc;
-    const long long ioff = (long long)(2 * trc + 3 - m) * m / 2 * nf * 2;
+    const long long ioff = p.sp_moff ? p.sp_moff[m] * nf : (long long)(2 * trc + 3 - m) * m / 2 * nf * 2;
     const double* __restrict__ sp = p.sp + ioff;
     const double* __restrict__ Pb = p.P + it.p_off;
     const int nstage = it.kpad / KB;

@@ -87,6 +87,11 @@ public:
     void invtrans_uv_device(int trc_in, int nb_fields, int nb_vordiv, const double* sp_dev, double* gp_dev);
     // the two stages separately (multi-GPU driver, stage-level parity tests)
     void legendre_device(int trc_in, int nb_fields, const double* sp_dev, double* fourier_dev);
+    // [r3] the same from a spectral array that holds only this object's wavenumbers (m % nparts == part), their blocks in
+    // the reference's inner layout back to back in increasing m (spectral_shard_offsets): SURVEY 8(e) scatters the input by m
+    void legendre_device_sharded(int nb_fields, const double* sp_shard_dev, double* fourier_dev);
+    // offset of wavenumber m's block in that array, in doubles per field (-1: not owned), and the array's size per field
+    long long spectral_shard_offsets(std::vector<long long>& moff) const;
     void fourier_device(int nb_fields, int nb_vordiv, const double* fourier_dev, double* gp_dev);
     void fourier_device(int nb_fields, int nb_vordiv, const double* const* part_base, const int* part_cnt,
                         double* gp_dev);
@@ -130,7 +135,8 @@ private:
     void upload();
     void collect_timings();
     void timed_begin(int kind, hipStream_t s = nullptr);
-    void legendre_chunks(int trc_in, int nb_fields, const double* sp_dev, double* fourier_dev, int chunk0, int nrun);
+    void legendre_chunks(int trc_in, int nb_fields, const double* sp_dev, double* fourier_dev, int chunk0, int nrun,
+                         bool sharded_input = false);
     void fourier_fields(int nb_fields, int nb_vordiv, const double* const* part_base, const int* part_cnt,
                         double* gp_dev, int f_begin, int f_end, hipStream_t stream, bool f32 = false,
                         const long long* const* part_rowoff_dev = nullptr, int packed_cols = 0);
@@ -162,6 +168,7 @@ private:
     void* d_items2_      = nullptr;  // paired work list (two consecutive tiles of one m per item)
     int nitems2_         = 0;
     int* d_nlat0_        = nullptr;
+    long long* d_sp_moff_ = nullptr;   // block offsets of the owned wavenumbers in a sharded spectral array (lazily)
     double* d_zero_      = nullptr;  // zeros: load target of padding columns in the Legendre kernel
     float* d_P32_        = nullptr;  // fp32 variant: table, zero target and Fourier intermediate in float (lazily)
     float* d_zero32_     = nullptr;

@@ -156,6 +156,7 @@ void Trans::release() noexcept {
     fr(d_P_);
     fr(d_items_);
     fr(d_items2_);
+    fr(d_sp_moff_);
     fr(d_nlat0_);
     fr(d_zero_);
     fr(d_P32_);
@@ -542,8 +543,31 @@ void Trans::legendre_device(int trc_in, int nb_fields, const double* sp_dev, dou
     legendre_chunks(trc_in, nb_fields, sp_dev, fourier_dev, 0, 0);
 }
 
+long long Trans::spectral_shard_offsets(std::vector<long long>& moff) const {
+    const int T = geo_.T, P = cfg_.by_band ? 1 : cfg_.nparts, part = cfg_.by_band ? 0 : cfg_.part;
+    moff.assign(T + 2, -1);
+    long long off = 0;
+    for (int m = part; m <= T; m += P) {
+        moff[m] = off;
+        off += 2ll * (T + 1 - m);   // (n = m .. T) x (re, im), per field
+    }
+    return off;
+}
+
+void Trans::legendre_device_sharded(int nb_fields, const double* sp_shard_dev, double* fourier_dev) {
+    if (!d_sp_moff_) {
+        std::vector<long long> moff;
+        spectral_shard_offsets(moff);
+        for (long long& v : moff) {
+            v = v < 0 ? 0 : v;   // never read for wavenumbers this object does not own
+        }
+        d_sp_moff_ = dev_upload(moff.data(), moff.size());
+    }
+    legendre_chunks(geo_.T, nb_fields, sp_shard_dev, fourier_dev, 0, 0, true);
+}
+
 void Trans::legendre_chunks(int trc_in, int nb_fields, const double* sp_dev, double* fourier_dev, int chunk0,
-                            int nrun) {
+                            int nrun, bool sharded_input) {
     if (nb_fields <= 0) {
         return;
     }
@@ -553,6 +577,7 @@ void Trans::legendre_chunks(int trc_in, int nb_fields, const double* sp_dev, dou
     LegendreParams p;
     p.P      = d_P_;
     p.sp     = sp_dev;
+    p.sp_moff = sharded_input ? d_sp_moff_ : nullptr;
     p.F      = fourier_dev;
     p.items  = (const LegendreItemDev*)d_items_;
     p.items2 = (const LegendreItemDev*)d_items2_;
@@ -802,6 +827,7 @@ void Trans::invtrans_scalar_device_f32(int nb_fields, const float* sp_dev, float
     p.items     = (const LegendreItemDev*)d_items_;
     p.items2    = nullptr;
     p.nitems2   = 0;
+    p.sp_moff   = nullptr;
     p.nlat0     = d_nlat0_;
     p.zero      = d_zero32_;
     p.T         = geo_.T;

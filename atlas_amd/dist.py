@@ -33,6 +33,9 @@ Trans_invtrans_distributed_many_halo = _sig("atlas_amd__Trans__invtrans_distribu
                                            c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p)
 Trans_invtrans_distributed_many = _sig("atlas_amd__Trans__invtrans_distributed_many", c_int, c_void_p, c_void_p, c_int,
                                        c_int, c_void_p, c_void_p)
+Trans_invtrans_distributed_sharded = _sig("atlas_amd__Trans__invtrans_distributed_sharded", c_int, c_void_p, c_void_p, c_int,
+                                          c_int, c_void_p, c_void_p)
+Trans_spectral_shard = _sig("atlas_amd__Trans__spectral_shard", c_int, c_void_p, c_void_p, c_void_p)
 Trans_set_max_message_bytes = _sig("atlas_amd__Trans__set_max_message_bytes", c_int, c_void_p, c_void_p, C.c_longlong)
 _transpose_messages = _sig("atlas_amd__transpose_messages", c_int, c_int, c_int, c_int, c_int, c_void_p, C.c_longlong,
                            c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p)
@@ -109,6 +112,37 @@ class DistributedTrans:
                            shard={"band": "band", "mirror": "mirror", "alltoall": "m"}[mode], tables="device")
         self.T = truncation
         self.bands = self.trans.bands() if mode != "mirror" else None
+
+    def spectral_shard(self):
+        """layout of this rank's share of the spectra for invtrans_sharded: (moff[T+1] in doubles per field, -1 where the
+        wavenumber belongs to another rank; doubles per field of the whole shard)"""
+        T = self.trans.truncation()
+        moff = np.zeros(T + 1, dtype=np.int64)
+        size = C.c_longlong(0)
+        _lib.check(Trans_spectral_shard(self.trans._h, moff.ctypes.data, C.byref(size)))
+        return moff, int(size.value)
+
+    def shard_spectra(self, nf, sp_full):
+        """host helper: this rank's wavenumbers out of a replicated spectral array (numpy, layout of invtrans)"""
+        T = self.trans.truncation()
+        moff, size = self.spectral_shard()
+        out = np.empty(size * nf, dtype=np.float64)
+        full = np.asarray(sp_full).reshape(-1)
+        for m in range(T + 1):
+            if moff[m] >= 0:
+                src = (2 * T + 3 - m) * m // 2 * 2 * nf
+                n = 2 * (T + 1 - m) * nf
+                out[moff[m] * nf:moff[m] * nf + n] = full[src:src + n]
+        return out
+
+    def invtrans_many_sharded(self, nf, sp_shards, gps):
+        """as invtrans_many with every sp_shards[i] holding only this rank's wavenumbers (device tensors)"""
+        n = len(sp_shards)
+        a = (C.c_void_p * n)(*[s.data_ptr() for s in sp_shards])
+        b = (C.c_void_p * n)(*[g.data_ptr() for g in gps])
+        with _lib.torch_stream_order(self.trans.stream()):
+            _lib.check(Trans_invtrans_distributed_sharded(self.trans._h, self.comm._h, n, int(nf), a, b))
+        return gps
 
     def set_max_message_bytes(self, nbytes):
         _lib.check(Trans_set_max_message_bytes(self.trans._h, self.comm._h, int(nbytes)))

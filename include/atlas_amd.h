@@ -366,6 +366,14 @@ int atlas_amd__Trans__invtrans_distributed(atlas_amd_Trans* t, atlas_amd_Comm* c
                                            double* gp_dev);
 int atlas_amd__Trans__invtrans_distributed_many(atlas_amd_Trans* t, atlas_amd_Comm* comm, int ntransforms, int nb_fields,
                                                 const double* const* sp_dev, double* const* gp_dev);
+/* [r3] the same with the input scattered by zonal wavenumber: sp_shard_dev[i] holds only the wavenumbers this rank
+ * owns (m % P == p), the block of every such m in the inner layout of atlas__Trans__invtrans_scalar -- (n = m..T) x (re, im) x
+ * nb_fields -- back to back in increasing m: 1/P of the replicated array.  atlas_amd__Trans__spectral_shard gives the layout:
+ * moff_out[m] (T+1 entries, may be NULL) = offset of m's block in doubles PER FIELD (multiply by nb_fields), -1 if m is not
+ * owned; *size_per_field = doubles per field of the whole shard. */
+int atlas_amd__Trans__invtrans_distributed_sharded(atlas_amd_Trans* t, atlas_amd_Comm* comm, int ntransforms, int nb_fields,
+                                                   const double* const* sp_shard_dev, double* const* gp_dev);
+int atlas_amd__Trans__spectral_shard(const atlas_amd_Trans* t, long long moff_out[], long long* size_per_field);
 /* invtrans_distributed_many + per transform, on the library's communication stream -- i.e. beside the Legendre stage of
  * the transforms that follow: the band's grid points transposed into the owned part of field_dev[i], a StructuredColumns
  * field [size_halo][nb_fields] of doubles on the partition that owns this rank's latitude band (the row_bands distribution

@@ -117,6 +117,43 @@ def test_transposition_reads_no_uninitialised_bytes(gridname, T, nf, nparts, max
         assert np.array_equal(again.reshape(nf, -1), refs[1][:, sl])
 
 
+@pytest.mark.parametrize("gridname,T,nf,nparts", [("O64", 63, 5, 2), ("O160", 159, 41, 3), ("F32", 31, 3, 8)])
+def test_distributed_transform_from_spectra_scattered_by_wavenumber(gridname, T, nf, nparts):
+    """[r3] SURVEY 8(e) scatters the input by m: every rank passes only the blocks of its own wavenumbers
+    (atlas_amd__Trans__invtrans_distributed_sharded, layout from __spectral_shard); the bands must equal the single-device
+    transform bit for bit, as with the replicated input"""
+    g = atlas_amd.Grid(gridname)
+    sps = [red_spectra(T, nf, seed=s) for s in (31, 32)]
+    tr = atlas_amd.Trans(g, T)
+    refs = []
+    for sp in sps:
+        gp = torch.zeros(nf * g.size(), dtype=torch.float64, device="cuda")
+        tr.invtrans(nf, torch.from_numpy(sp).cuda(), gp)
+        tr.synchronize()
+        refs.append(gp.cpu().numpy().reshape(nf, -1))
+    off = np.concatenate([[0], np.cumsum(g.nx())])
+    total = (T + 1) * (T + 2) * nf
+
+    def rank(comm):
+        d = DistributedTrans(g, T, comm=comm, mode="alltoall")
+        moff, size = d.spectral_shard()
+        owned = [m for m in range(T + 1) if moff[m] >= 0]
+        assert owned == list(range(comm.rank(), T + 1, nparts)) and size == sum(2 * (T + 1 - m) for m in owned)
+        shards = [torch.from_numpy(d.shard_spectra(nf, sp)).cuda() for sp in sps]
+        assert all(s.numel() == size * nf for s in shards)
+        n = d.trans.nb_gridpoints()
+        gps = [torch.full((nf * n,), float("nan"), dtype=torch.float64, device="cuda") for _ in sps]
+        d.invtrans_many_sharded(nf, shards, gps)
+        d.trans.synchronize()
+        return d.bands[comm.rank()], d.bands[comm.rank() + 1], size * nf, [x.cpu().numpy() for x in gps]
+
+    res = run_ranks(nparts, rank)
+    assert sum(r[2] for r in res) == total            # the shards are a partition of the replicated array
+    for b0, b1, _, many in res:
+        for got, ref in zip(many, refs):
+            assert np.array_equal(got.reshape(nf, -1), ref[:, off[b0]:off[b1]])
+
+
 @pytest.mark.parametrize("gridname,nparts,halo", [("O16", 2, 1), ("O32", 3, 2), ("F16", 4, 1)])
 def test_native_halo_exchange_between_ranks(gridname, nparts, halo):
     g = atlas_amd.Grid(gridname)
