@@ -47,7 +47,8 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X spec, dense fp64 matrix = 1024 SIMDs x 3
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-KERNEL_SOURCES = ("legendre_kernel.hip", "fft_kernel.hip", "fft_device.h", "fft_core.h", "fft_plan.cpp", "trans.hip", "trans_plan.cpp")
+KERNEL_SOURCES = ("legendre_kernel.hip", "fft_kernel.hip", "fft_device.h", "fft_core.h", "fft_plan.cpp", "trans.hip", "trans_plan.cpp",
+                  "Makefile")   # the Makefile carries per-file code-generation flags
 
 
 def kernel_source_digest():
