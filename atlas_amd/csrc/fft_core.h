@@ -81,6 +81,9 @@ AA_HD int padded_size(int M) {
 #endif
 
 constexpr int MAX_STAGES = 12;
+#ifndef AA_FFT_KEEP_192
+#define AA_FFT_KEEP_192 0
+#endif
 
 struct FftShape {           // stage list of an M-point transform
     int M;
@@ -793,7 +796,11 @@ struct CtShape {
 #if defined(AA_FFT_KEEP_5WAVE)
     static constexpr int NT = NT0;
 #else
-    static constexpr int NT = (NT0 == 320 || NT0 == 384) ? 256 : NT0;
+    // M = 3072 = [12,16,16] (192 middle butterflies, 48 KiB: three workgroups per CU either way): 256 workers as well -- stage 0
+    // and the last stage have 256 butterflies, one per worker, the fourth wavefront sits out the middle stages: 0.77 -> 0.70 ms
+    // for the class.  Not for M = 2560 / 2304 (40 / 36 KiB: four workgroups of three wavefronts fit, only three of four):
+    // 0.31 -> 0.33 ms (tools/r03_classes.sh).
+    static constexpr int NT = (NT0 == 320 || NT0 == 384 || (M == 3072 && !AA_FFT_KEEP_192)) ? 256 : NT0;
 #endif
     // wavefronts per SIMD the kernel is compiled for: the LDS footprint M * 16 allows two workgroups per CU above
     // 53 KiB (two wavefronts per SIMD at most: 256 registers), three below

@@ -234,7 +234,33 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, const PlanOptions
         }
         const int h = n / 2;
         p.h         = h;
-        if (is_smooth235(h)) {
+        // a {2,3,5}-smooth h that is NOT a length of the specialised family would take the run-time-shaped direct kernel,
+        // which costs 1.4 - 1.6 x a compile-time-shaped Bluestein row of the same length (profiles/r02_fft_rowlen_probe.txt):
+        // such rows go through Bluestein as well when a specialised Bluestein instance exists for them [r3] (O1280: 156 rows,
+        // 3.3 % of the points, 0.57 -> 0.37 ms; the classic N grids: nearly every row).  ATLAS_AMD_FFT_SMOOTH_DIRECT=1: old rule.
+        bool smooth_direct = is_smooth235(h);
+        if (smooth_direct && specialised_shapes) {
+            bool family = false;
+            for (int f : {1, 3, 5, 9, 15}) {
+                if (h % f == 0) {
+                    const int k = ilog2_exact(h / f);
+                    family      = family || (k >= 0 && ct_supported(f, k));
+                }
+            }
+            static const bool old_rule = std::getenv("ATLAS_AMD_FFT_SMOOTH_DIRECT") && atoi(std::getenv("ATLAS_AMD_FFT_SMOOTH_DIRECT")) != 0;
+            if (!family && !old_rule) {
+                const int Mb = next_bluestein_length(2 * h - 1);
+                for (int f : {1, 3, 5, 9, 15}) {
+                    if (Mb % f == 0) {
+                        const int k = ilog2_exact(Mb / f);
+                        if (k >= 0 && ct_supported(f, k)) {
+                            smooth_direct = false;   // falls through to the Bluestein branch below
+                        }
+                    }
+                }
+            }
+        }
+        if (smooth_direct) {
             p.method = FFT_DIRECT;
             // h itself a length of the specialised family?  (regular grids: every row)
             if (specialised_shapes) {
