@@ -49,11 +49,34 @@ struct LegendreParamsT {
 using LegendreParams    = LegendreParamsT<double>;
 using LegendreParamsF32 = LegendreParamsT<float>;   // fp32 variant (BASELINE config C5)
 
+// Everything a workgroup of the specialised Bluestein kernels needs to know about its row, in ONE 64-byte record read with one
+// scalar load: the kernels used to walk rows[] -> row_plan[] -> plans[] (+ rowoff[], row_mmax[], coslatinv[]), three dependent
+// L2 round trips (~2 us) before the first mode could be requested (per-wavefront trace, profiles/r03_fft_trace.txt) [r3]
+struct alignas(64) FftRowDesc {
+    int row;                 // latitude row (global index)
+    int mmax;                // highest kept wavenumber, already clamped to h
+    int h, n;                // half length, length
+    long long goff_rel;      // rowoff[row] - rowoff[lat0]: offset of the row inside a field of the local band
+    double coslatinv;        // 1 / cos(lat)
+    long long off_tw, off_pre, off_chirp, off_bhat_t;   // into FourierParams::table
+};
+
+struct FourierParts {
+    const double* base[fft::MAX_PARTS];
+    const long long* rowoff[fft::MAX_PARTS];
+    int cnt[fft::MAX_PARTS];
+};
+
 struct FourierParams {
-    const double* part_base[fft::MAX_PARTS];  // Fourier intermediate pieces, one per m-owner (see fft_core.h: RowIO)
-    int part_cnt[fft::MAX_PARTS];
-    const long long* part_rowoff[fft::MAX_PARTS];  // packed form: per piece, offset (doubles) of every local row; else unused
+    const FftRowDesc* desc;                   // [nrows] of this launch (specialised Bluestein classes), else null
+    // Fourier intermediate pieces, one per m-owner (see fft_core.h: RowIO).  Piece 0 travels in the kernel arguments; with more
+    // than one piece the kernels read FourierParts from device memory (as kernel arguments the 16 x 3 entries sat in scalar
+    // registers for the whole kernel and pushed ~200 scalar spill moves per wavefront into the vector ALU) [r3]
+    const double* part_base0;
+    const long long* part_rowoff0;                 // packed form: offset (doubles) of every local row inside the piece; else unused
+    int part_cnt0;
     int packed_cols;                               // packed form: doubles per (row, wavenumber) = 2 * nb_fields; 0: classic layout
+    const FourierParts* parts;                     // [nparts > 1] all pieces
     int nparts;
     int lat0;                         // first row of the local latitude band
     double* gp;                       // gp[f*npts + (rowoff[lat]-rowoff[lat0]) + i], npts = points of the local band
@@ -66,6 +89,9 @@ struct FourierParams {
     int nrows;
     unsigned nvirt;                   // virtual blocks (row, field slots) of the launch, set by the launcher
     int jobs;                         // tools/experiments/fft_kernel_p.hip only (field groups a workgroup walks through); 1
+    int pf_dist;                      // L2 prefetch of the modes of the job 8 * pf_dist further on (same XCD); 0: off
+    int pf_sectors;                   // requests per 128-byte line of that prefetch (1, 2 or 4)
+    int row_affinity;                 // FftRowDesc kernels: a row's field groups all on one XCD (fft_device.h: fft_unit_to_job)
     int T;
     int RP;
     int nf;

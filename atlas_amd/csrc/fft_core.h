@@ -554,11 +554,21 @@ AA_HD void store_pair_t(const RowOut& io, int64_t k, cplx z) {
         }
     }
     else if (ALIGNED) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(AA_FFT_PLAIN_STORE)
+        typedef double d2_t __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(d2_t{z.re, z.im}, reinterpret_cast<d2_t*>(io.y + 2 * k));
+#else
         *reinterpret_cast<cplx*>(io.y + 2 * k) = z;
+#endif
     }
     else {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(AA_FFT_PLAIN_STORE)
+        __builtin_nontemporal_store(z.re, io.y + 2 * k);
+        __builtin_nontemporal_store(z.im, io.y + 2 * k + 1);
+#else
         io.y[2 * k]     = z.re;
         io.y[2 * k + 1] = z.im;
+#endif
     }
 }
 // calls fn(std::integral_constant<bool, f32>, std::integral_constant<bool, aligned>) for the row's flavour

@@ -16,6 +16,44 @@ constexpr int FGROUP   = 8;  // fields whose modes share one 128-byte line of F
 // Block -> (row, field).  Eight consecutive fields of one row share every 128-byte line of F, and hardware places
 // block b on XCD b % 8, so blocks {b, b+8, ..., b+56} (same XCD, dispatched back to back) are given the same
 // (row, field group): the line is then fetched into that XCD's L2 once.  Speed heuristic only.
+// the same map for the kernels that read FftRowDesc, in two steps: workgroup -> (XCD x, sequence number idx on that XCD, field
+// j of the group), then (x, idx) -> (row index ri of the launch's list, field group fg).
+// p.row_affinity: the rows in full sets of 8 stay on ONE XCD each (row 8 k + x on XCD x), so that a row's tables (chirp, c2r
+// factors, filter spectrum: 130 - 200 KB) are fetched into one L2 instead of all eight; the last nrows % 8 rows are dealt
+// out by field group as before (balance).
+__device__ __forceinline__ bool fft_unit_to_job(const FourierParams& p, int ngr, int x, int idx, int& ri, int& fg) {
+    if (p.row_affinity) {
+        const int nfull = p.nrows & ~7;
+        const int main_ = (nfull >> 3) * ngr;
+        if (idx < main_) {
+            const int k = idx / ngr;
+            ri          = 8 * k + x;
+            fg          = idx - k * ngr;
+            return true;
+        }
+        const int u = (idx - main_) * 8 + x;
+        const int k = u / ngr;
+        ri          = nfull + k;
+        fg          = u - k * ngr;
+        return ri < p.nrows;
+    }
+    const int u = idx * 8 + x;
+    ri          = u / ngr;
+    fg          = u - ri * ngr;
+    return ri < p.nrows;
+}
+__device__ __forceinline__ bool fft_block_to_job_index(const FourierParams& p, int b, int& ri, int& f) {
+    const int x   = b & 7;
+    const int q   = b >> 3;
+    const int j   = q & 7;
+    const int ngr = (p.f_end - p.f_begin + FGROUP - 1) / FGROUP;
+    int fg;
+    if (!fft_unit_to_job(p, ngr, x, q >> 3, ri, fg)) {
+        return false;
+    }
+    f = p.f_begin + fg * FGROUP + j;
+    return f < p.f_end;
+}
 __device__ __forceinline__ bool fft_block_to_job(const FourierParams& p, int b, int& row, int& f) {
     const int x   = b & 7;
     const int q   = b >> 3;
@@ -47,36 +85,34 @@ struct ModeReaderT {
     const FourierParams& p;
     long long lat_local;
     int f2;
+    // pointers into the Fourier intermediate are GLOBAL pointers, and typed so: one that comes out of the piece table would
+    // otherwise be a generic pointer and every mode a flat load (LDS and vector-memory counters both)
+    typedef const __attribute__((address_space(1))) double* gdouble_ptr;
+    typedef const __attribute__((address_space(1))) long long* glong_ptr;
     // address of mode m (fp64 storage: a double*; fp32 storage: element index in floats, see operator())
-    __device__ __forceinline__ const double* locate(int m, long long& o) const {
-        const double* base = p.part_base[0];
-        int cnt            = p.part_cnt[0];
-        int ml             = m;
-        if (p.nparts > 1) {
+    __device__ __forceinline__ gdouble_ptr locate(int m, long long& o) const {
+        gdouble_ptr base = (gdouble_ptr)(uintptr_t)p.part_base0;
+        glong_ptr ro     = (glong_ptr)(uintptr_t)p.part_rowoff0;
+        int cnt          = p.part_cnt0;
+        int ml           = m;
+        if (p.nparts > 1) {   // the piece of wavenumber m: a (cached) table lookup per lane
             ml             = m / p.nparts;
             const int part = m - ml * p.nparts;
-#pragma unroll
-            for (int i = 1; i < fft::MAX_PARTS; ++i) {  // select chain: keeps the kernel arguments in SGPRs
-                if (part == i) {
-                    base = p.part_base[i];
-                    cnt  = p.part_cnt[i];
-                }
-            }
+            const FourierParts* tb = p.parts;
+            uintptr_t b    = (uintptr_t)tb->base[part];
+            uintptr_t r    = (uintptr_t)tb->rowoff[part];
+            int c          = tb->cnt[part];
+            // values, not "a load from one of two addresses": left alone, the compiler turns the choice between a kernel
+            // argument and a table entry into a load through a generic pointer (the argument copied to scratch), per mode
+            asm volatile("" : "+v"(b), "+v"(r), "+v"(c));
+            base = (gdouble_ptr)b;
+            ro   = (glong_ptr)r;
+            cnt  = c;
         }
 #if defined(AA_FFT_ABLATE)
         if (p.abl & 1) ml = 0;
 #endif
         if (p.packed_cols) {   // packed runs of the distributed transform (dist_trans.h): per-row offsets, no pitch padding
-            const long long* ro = p.part_rowoff[0];
-            if (p.nparts > 1) {
-                const int part = m - ml * p.nparts;
-#pragma unroll
-                for (int i = 1; i < fft::MAX_PARTS; ++i) {
-                    if (part == i) {
-                        ro = p.part_rowoff[i];
-                    }
-                }
-            }
             o = ro[lat_local] + (long long)ml * p.packed_cols + f2;
             return base;
         }
@@ -85,17 +121,21 @@ struct ModeReaderT {
     }
     __device__ __forceinline__ const double* address(int m) const {   // fp64 storage only
         long long o;
-        const double* base = locate(m, o);
-        return base + o;
+        gdouble_ptr base = locate(m, o);
+        return (const double*)(base + o);
     }
     __device__ __forceinline__ cplx operator()(int m) const {
         long long o;
-        const double* base = locate(m, o);
+        gdouble_ptr base = locate(m, o);
         if (STORAGE == 1 || (STORAGE == 2 && p.f32)) {  // fp32 intermediate: same element indexing, float storage
-            const fft::fpair v = *reinterpret_cast<const fft::fpair*>(reinterpret_cast<const float*>(base) + o);
+            typedef float f2_t __attribute__((ext_vector_type(2)));
+            typedef const __attribute__((address_space(1))) float* gfloat_ptr;
+            const f2_t v = *(const __attribute__((address_space(1))) f2_t*)((gfloat_ptr)base + o);
             return cplx{(double)v.x, (double)v.y};
         }
-        return *reinterpret_cast<const cplx*>(base + o);
+        typedef double d2_t __attribute__((ext_vector_type(2)));
+        const d2_t v = *(const __attribute__((address_space(1))) d2_t*)(base + o);
+        return cplx{v.x, v.y};
     }
 };
 using ModeReader = ModeReaderT<2>;

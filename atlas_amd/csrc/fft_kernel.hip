@@ -193,9 +193,27 @@ __device__ __forceinline__ void gather_modes_to_lds(const FourierParams& p, long
 //   before phase 3              : the chirp of the outputs (phase 4); wm and w0 are kept
 // Per-wavefront trace of the previous form (profiles/r03_fft_trace.txt): gather 4.1 us, phase 0 4.0 us, phase 2 1.7 - 4.5 us
 // of a 16 us workgroup whose vector-ALU work is 3.8 us per wavefront.
+// What a workgroup requests for a LATER workgroup of its XCD: the 128-byte lines (8 fields x one wavenumber) that job will
+// gather, so that they come from L2 instead of HBM.  The 8 workgroups of a field group share the lines of the target group.
+struct PrefetchJob {
+    long long lat_local;   // row of the target job, -1: none
+    int mmax;
+    int f0;                // first field of the target group
+    int j, nj;             // this workgroup's share: j of nj
+};
+
+// -DAA_FFT_TRACE_PH0 (with -DAA_FFT_TRACE): the stamps 3..7 sit INSIDE phase 0 instead of at the phase ends:
+//   3 staging reads returned | 4 butterfly + twiddles issued | 5 past the barrier | 6 results written, filter requested | 7 past the barrier
+#if defined(AA_FFT_TRACE_PH0)
+#define AA_STAMP_N(k) ((void)0)
+#define AA_STAMP_0(k) stamp(k)
+#else
+#define AA_STAMP_N(k) stamp(k)
+#define AA_STAMP_0(k) ((void)0)
+#endif
 template <class S, bool F32, class Stamp>
 __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTablesCt& r, const fft::RowOut& io,
-                                        long long lat_local, int f, cplx* work, int t, Stamp&& stamp) {
+                                        long long lat_local, int f, cplx* work, int t, const PrefetchJob& pfj, Stamp&& stamp) {
     constexpr int M    = S::M;
     constexpr int R0   = S::radix(0);
     constexpr int NT   = S::NT;
@@ -221,6 +239,25 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
     AA_SCHED_FENCE();
     __syncthreads();
     stamp(2);
+    // ---- L2 prefetch for a later job: plain loads whose result nobody reads.  Inline assembly, so that no wait is generated for
+    // them; they are older than the filter-spectrum requests below, whose wait (phase 2) therefore covers them (vector memory
+    // loads return in order), and `pf` is pinned until then.
+    unsigned pf = 0;
+    if (!F32 && pfj.lat_local >= 0) {
+        const ModeReaderT<0> rd{p, pfj.lat_local, 2 * pfj.f0};
+        const int L   = pfj.mmax + 1;
+        const int cnt = (L + pfj.nj - 1) / pfj.nj;
+        const int m0  = pfj.j * cnt;
+        const int m1  = (m0 + cnt < L) ? m0 + cnt : L;
+        const int S_  = p.pf_sectors;
+        const int tot = (m1 - m0) * S_;
+        for (int i = t; i < tot; i += NT) {
+            const int m      = m0 + i / S_;
+            const int sub    = i - (i / S_) * S_;
+            const double* a  = rd.address(m) + sub * (16 / S_);
+            asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(a) : "memory");
+        }
+    }
     // ---- phase 0: c2r pre-processing + chirp + DIF stage 0 (one block of M, stride 256), inputs from the staging area
     {
         const cplx* raw = work;
@@ -234,13 +271,23 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
             const cplx z = fft::cmul(fft::c2r_pre(a, c, P[q]), C[q]);
             x[q]         = k < h ? z : cplx{0., 0.};
         }
+#if defined(AA_FFT_TRACE_PH0)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        AA_STAMP_0(3);
 #pragma unroll
         for (int q = NZ; q < R0; ++q) x[q] = cplx{0., 0.};
         fft::bfly<R0>(x, -1);
         cplx w1 = w0;
         w1.im   = -w1.im;
         fft::twiddle_apply<R0>(x, w1);
+#if defined(AA_FFT_TRACE_PH0)
+#pragma unroll
+        for (int q = 0; q < R0; ++q) asm volatile("" : "+v"(x[q].re), "+v"(x[q].im));   // the arithmetic stays above the stamp
+#endif
+        AA_STAMP_0(4);
         lds_barrier();   // the staging area aliases the work array: everybody has read it
+        AA_STAMP_0(5);
 #pragma unroll
         for (int q = 0; q < R0; ++q) work[pt + q * 256] = x[q];
     }
@@ -249,8 +296,10 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
 #pragma unroll
     for (int q = 0; q < 16; ++q) flt[q] = r.bhat_t[(q * NMID + t) * AA_ABL(r, 2)];
     AA_SCHED_FENCE();
+    AA_STAMP_0(6);
     lds_barrier();
-    stamp(3);
+    AA_STAMP_0(7);
+    AA_STAMP_N(3);
     // ---- phase 1: DIF level 1 (blocks of 256 = 16 consecutive workers, radix 16, stride 16)
 #pragma unroll
     for (int ib = 0; ib < NBM; ++ib) {
@@ -260,7 +309,7 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
         }
     }
     wave_lds_fence();
-    stamp(4);
+    AA_STAMP_N(4);
     // ---- phase 2: last DIF stage * filter spectrum * first DIT stage (16 contiguous elements, no twiddles)
 #pragma unroll
     for (int ib = 0; ib < NBM; ++ib) {
@@ -283,7 +332,8 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
         }
     }
     wave_lds_fence();
-    stamp(5);
+    AA_STAMP_N(5);
+    asm volatile("" ::"v"(pf));   // the prefetch requests have returned (see above): their register is free from here
     // chirp of the outputs again (kept from phase 0 it costs 4 NZ registers through the two widest phases: spills)
 #pragma unroll
     for (int q = 0; q < NZ; ++q) {
@@ -299,7 +349,7 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
         }
     }
     lds_barrier();
-    stamp(6);
+    AA_STAMP_N(6);
     // ---- phase 4: DIT stage 0 + chirp + store (outputs q >= NZ are padding: their butterfly arithmetic is dead)
     {
         cplx x[R0];
@@ -323,7 +373,7 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
             }
         });
     }
-    stamp(7);
+    AA_STAMP_N(7);
 }
 
 // One workgroup of S::NT workers per (row, field).  Every mode of the row is fetched from the Fourier intermediate once,
@@ -333,30 +383,30 @@ template <class S, bool F32, bool FAST>
 __global__ void __launch_bounds__(S::NT, (FAST ? S::WPS : 3)) fft_rows_ct_kernel(FourierParams p) {
     extern __shared__ double lds_raw[];
     cplx* work = reinterpret_cast<cplx*>(lds_raw);
-    int row, f;
-    if (!fft_block_to_job(p, blockIdx.x, row, f)) {
+    int ri, f;
+    if (!fft_block_to_job_index(p, blockIdx.x, ri, f)) {
         return;
     }
     const int tid      = threadIdx.x;
     constexpr int nt   = S::NT;
     constexpr int NPH  = fft::row_num_phases_ct<S>();
     const bool prof    = p.prof != nullptr && tid == 0;
-    const fft::FftRowPlan* pl = p.plans + p.row_plan[row];
-    const long long goff      = (long long)f * p.npts + (p.rowoff[row] - p.rowoff[p.lat0]);
-    const double scale        = (f < p.scale_uv_fields) ? p.coslatinv[row] : 1.0;
-    const int mmax            = p.row_mmax[row];
+    const FftRowDesc d = p.desc[ri];   // one 64-byte scalar load: everything about the row
+    const int row             = d.row;
+    const long long goff      = (long long)f * p.npts + d.goff_rel;
+    const double scale        = (f < p.scale_uv_fields) ? d.coslatinv : 1.0;
     fft::RowTablesCt r;
 #if defined(AA_FFT_ABLATE)
     r.abl    = p.abl;
 #endif
-    r.n      = pl->n;
-    r.h      = pl->h;
-    r.tw     = p.table + pl->off_tw;
-    r.pre    = p.table + pl->off_pre;
-    r.chirp  = p.table + pl->off_chirp;
-    r.bhat_t = p.table + pl->off_bhat_t;
+    r.n      = d.n;
+    r.h      = d.h;
+    r.tw     = p.table + d.off_tw;
+    r.pre    = p.table + d.off_pre;
+    r.chirp  = p.table + d.off_chirp;
+    r.bhat_t = p.table + d.off_bhat_t;
     fft::RowOut io;
-    io.mmax      = mmax < r.h ? mmax : r.h;
+    io.mmax      = d.mmax;
     io.y         = F32 ? reinterpret_cast<double*>(reinterpret_cast<float*>(p.gp) + goff) : p.gp + goff;
     io.aligned16 = ((goff & 1) == 0);
     io.f32       = F32 ? 1 : 0;
@@ -384,7 +434,21 @@ __global__ void __launch_bounds__(S::NT, (FAST ? S::WPS : 3)) fft_rows_ct_kernel
 #endif
 #if !defined(AA_FFT_NO_CT3)
     if constexpr (FAST && ct3_fast_path<S>()) {
-        row_ct3<S, F32>(p, r, io, (long long)(row - p.lat0), f, work, tid, [&](int k) { (void)k; AA_TRACE_STAMP(k); });
+        PrefetchJob pfj{-1, 0, 0, 0, 1};
+        if (p.pf_dist > 0) {
+            const int ngr = (p.f_end - p.f_begin + FGROUP - 1) / FGROUP;
+            const int fg  = (f - p.f_begin) / FGROUP;
+            int ri2, fg2;
+            if (fft_unit_to_job(p, ngr, blockIdx.x & 7, (blockIdx.x >> 6) + p.pf_dist, ri2, fg2)) {
+                const int left = p.f_end - p.f_begin - fg * FGROUP;
+                pfj.lat_local  = p.desc[ri2].row - p.lat0;
+                pfj.mmax       = p.desc[ri2].mmax;
+                pfj.f0         = p.f_begin + fg2 * FGROUP;
+                pfj.j          = (f - p.f_begin) - fg * FGROUP;
+                pfj.nj         = left < FGROUP ? left : FGROUP;
+            }
+        }
+        row_ct3<S, F32>(p, r, io, (long long)(row - p.lat0), f, work, tid, pfj, [&](int k) { (void)k; AA_TRACE_STAMP(k); });
         return;
     }
 #endif

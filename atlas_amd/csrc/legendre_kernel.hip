@@ -31,6 +31,13 @@
 
 #include "device_structs.h"
 
+// the Fourier intermediate is written once and read once, by another kernel, after everything else of this launch
+#if !defined(AA_LEG_PLAIN_STORE)
+#define AA_LEG_STORE(ptr, v) __builtin_nontemporal_store((v), (ptr))
+#else
+#define AA_LEG_STORE(ptr, v) (*(ptr) = (v))
+#endif
+
 namespace atlas_amd {
 namespace trans {
 
@@ -294,10 +301,10 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
                         as = 0;
                     }
                     if (st_n) {
-                        fn[r] = sy + as;
+                        AA_LEG_STORE(fn + r, (Real)(sy + as));
                     }
                     if (st_s) {
-                        fs[r] = sy - as;  // for an equator row the southern value wins (TransLocal.cc:1056-1068 runs last)
+                        AA_LEG_STORE(fs + r, (Real)(sy - as));  // for an equator row the southern value wins (TransLocal.cc:1056-1068 runs last)
                     }
                 }
             }
@@ -594,10 +601,10 @@ __global__ void __launch_bounds__(512, 4) legendre_kernel_lean(LegendreParams p)
                         as = 0;
                     }
                     if (st_n) {
-                        fn[r] = sy + as;
+                        AA_LEG_STORE(fn + r, sy + as);
                     }
                     if (st_s) {
-                        fs[r] = sy - as;
+                        AA_LEG_STORE(fs + r, sy - as);
                     }
                 }
             }

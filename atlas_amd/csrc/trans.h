@@ -50,6 +50,7 @@ struct StageTimings {
     int legendre_calls = 0, fourier_calls = 0;
 };
 
+struct FourierParts;
 class Trans {
 public:
     Trans(const grid::StructuredGrid& grid, int truncation, const TransConfig& cfg = TransConfig());
@@ -188,6 +189,7 @@ private:
         bool hybrid = false;  // dense-stage rows (fft_rows_hyb_kernel)
         int nrows;
         int* d_rows;
+        void* d_desc = nullptr;   // FftRowDesc[nrows] for the specialised Bluestein kernels
     };
     std::vector<SizeClass> classes_;
     double* d_fourier_  = nullptr;
@@ -207,6 +209,9 @@ private:
     double* d_vd_       = nullptr;  // host-API staging of vor ++ div
     unsigned long long* d_prof_ = nullptr;
     unsigned long long* d_trace_ = nullptr;
+    std::vector<std::pair<std::vector<unsigned char>, void*>> parts_cache_;   // piece tables (device_structs.h: FourierParts)
+    size_t parts_evict_ = 0;                                                  // on the device, by content
+    const FourierParts* device_parts(const FourierParts& hp);
     unsigned long long trace_cap_ = 0;
     size_t vd_cap_      = 0;
     void ensure(double*& ptr, size_t& cap, size_t n);

@@ -170,8 +170,13 @@ void Trans::release() noexcept {
     fr(d_coslatinv_);
     for (auto& c : classes_) {
         fr(c.d_rows);
+        fr(c.d_desc);
     }
     classes_.clear();
+    for (auto& e : parts_cache_) {
+        fr(e.second);
+    }
+    parts_cache_.clear();
     fr(d_fourier_);
     fr(d_sp_);
     fr(d_gp_);
@@ -485,6 +490,25 @@ void Trans::upload() {
             return na > nb || (na == nb && a < b);
         });
         c.d_rows = dev_upload(it->second.data(), it->second.size());
+        if (it->first.first == 1) {   // specialised Bluestein rows: one flat record per row (device_structs.h: FftRowDesc)
+            std::vector<FftRowDesc> desc(it->second.size());
+            for (size_t i = 0; i < desc.size(); ++i) {
+                const int j               = it->second[i];
+                const fft::FftRowPlan& pl = fftplans_.plans[row_plan[j]];
+                FftRowDesc& d             = desc[i];
+                d.row        = j;
+                d.mmax       = std::min(row_mmax[j], pl.h);
+                d.h          = pl.h;
+                d.n          = pl.n;
+                d.goff_rel   = (long long)(geo_.rowoff[j] - geo_.rowoff[band_begin()]);
+                d.coslatinv  = coslatinv[j];
+                d.off_tw     = pl.off_tw;
+                d.off_pre    = pl.off_pre;
+                d.off_chirp  = pl.off_chirp;
+                d.off_bhat_t = pl.off_bhat_t;
+            }
+            c.d_desc = dev_upload(desc.data(), desc.size());
+        }
         classes_.push_back(c);
     }
 }
@@ -614,6 +638,30 @@ void Trans::fourier_device_packed(int nb_fields, int nb_vordiv, const double* co
     fourier_fields(nb_fields, nb_vordiv, part_base, nullptr, gp_dev, 0, nb_fields, stream_, false, part_rowoff_dev, cols);
 }
 
+// device copy of a piece table: the callers alternate between a few buffer sets (dist_trans.h slots), so a handful of tables
+// is kept by content; one that may still be read by kernels in flight is never overwritten without a device synchronisation
+const FourierParts* Trans::device_parts(const FourierParts& hp) {
+    const unsigned char* bytes = reinterpret_cast<const unsigned char*>(&hp);
+    for (auto& e : parts_cache_) {
+        if (std::memcmp(e.first.data(), bytes, sizeof(hp)) == 0) {
+            return static_cast<const FourierParts*>(e.second);
+        }
+    }
+    void* d = nullptr;
+    if (parts_cache_.size() < 8) {
+        HIP_CHECK(hipMalloc(&d, sizeof(FourierParts)));
+        parts_cache_.emplace_back(std::vector<unsigned char>(bytes, bytes + sizeof(hp)), d);
+    }
+    else {
+        HIP_CHECK(hipDeviceSynchronize());
+        auto& e = parts_cache_[parts_evict_++ % parts_cache_.size()];
+        e.first.assign(bytes, bytes + sizeof(hp));
+        d = e.second;
+    }
+    HIP_CHECK(hipMemcpy(d, &hp, sizeof(hp), hipMemcpyHostToDevice));
+    return static_cast<const FourierParts*>(d);
+}
+
 void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* part_base, const int* part_cnt,
                            double* gp_dev, int f_begin, int f_end, hipStream_t stream, bool f32,
                            const long long* const* part_rowoff_dev, int packed_cols) {
@@ -621,11 +669,17 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
         return;
     }
     FourierParams p;
+    FourierParts hp;
+    std::memset(&hp, 0, sizeof(hp));   // compared by content: no indeterminate padding
     for (int i = 0; i < fft::MAX_PARTS; ++i) {
-        p.part_base[i]   = i < fourier_parts() ? part_base[i] : nullptr;
-        p.part_cnt[i]    = (i < fourier_parts() && part_cnt) ? part_cnt[i] : 0;
-        p.part_rowoff[i] = (i < fourier_parts() && part_rowoff_dev) ? part_rowoff_dev[i] : nullptr;
+        hp.base[i]   = i < fourier_parts() ? part_base[i] : nullptr;
+        hp.cnt[i]    = (i < fourier_parts() && part_cnt) ? part_cnt[i] : 0;
+        hp.rowoff[i] = (i < fourier_parts() && part_rowoff_dev) ? part_rowoff_dev[i] : nullptr;
     }
+    p.part_base0   = hp.base[0];
+    p.part_cnt0    = hp.cnt[0];
+    p.part_rowoff0 = hp.rowoff[0];
+    p.parts        = fourier_parts() > 1 ? device_parts(hp) : nullptr;
     p.packed_cols = part_rowoff_dev ? packed_cols : 0;
     p.nparts          = fourier_parts();
     p.lat0            = band_begin();
@@ -663,6 +717,18 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
     p.coslatinv       = d_coslatinv_;
     p.prof            = d_prof_;
     p.jobs            = 1;
+    p.pf_dist         = 2;   // 16 jobs of the XCD ahead (profiles/r03_fft_experiments.txt, 12.)
+    p.pf_sectors      = 1;
+    p.row_affinity    = 1;
+    if (const char* e = std::getenv("ATLAS_AMD_FFT_ROW_AFFINITY")) {
+        p.row_affinity = atoi(e);
+    }
+    if (const char* e = std::getenv("ATLAS_AMD_FFT_PREFETCH")) {   // "distance[,requests per line]"
+        p.pf_dist = atoi(e);
+        if (const char* c = strchr(e, ',')) {
+            p.pf_sectors = std::max(1, std::min(4, atoi(c + 1)));
+        }
+    }
     p.trace           = d_trace_;
     p.trace_cap       = trace_cap_;
     p.abl             = std::getenv("ATLAS_AMD_FFT_ABLATE") ? atoi(std::getenv("ATLAS_AMD_FFT_ABLATE")) : 0;
@@ -695,6 +761,7 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
     for (const SizeClass& c : classes_) {
         p.rows  = c.d_rows;
         p.nrows = c.nrows;
+        p.desc  = (const FftRowDesc*)c.d_desc;
         if (only_m && c.lds_bytes != fft::padded_size(only_m) * 16) {  // dev tool (tools/fft_phase_prof.py): one class
             continue;
         }

@@ -1,0 +1,10 @@
+#!/bin/bash
+# Dev tool (GPU box): product build against several dev builds, alternating: tools/r03_ab3.sh "base prev" [repeats]
+REP=${2:-2}
+for rep in $(seq $REP); do for v in product $1; do
+  if [ $v = product ]; then unset ATLAS_AMD_LIB; else export ATLAS_AMD_LIB=$PWD/atlas_amd/lib/dev/libatlas_amd_$v.so; fi
+  python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('rep $rep $v', 'ms/step', round(d['ms_per_step'],3), [round(k['avg_ms'],3) for k in d.get('roofline_kernels',[])])"
+done; done
