@@ -171,7 +171,7 @@ __device__ __forceinline__ void gather_modes_to_lds(const FourierParams& p, long
             }
         }
         else {
-            if ((m0 + (tid & ~63)) <= mmax) {   // wave-uniform: this wavefront has at least one live lane
+            if (m <= mmax) {   // lanes past the last mode request nothing (their LDS slots belong to the caller: row_ct3 zeroes them)
                 const double* src = rd.address(mc);
                 cplx* dst         = raw + m0 + (tid & ~63);   // wave-uniform
                 __builtin_amdgcn_global_load_lds(
@@ -202,14 +202,19 @@ struct PrefetchJob {
     int j, nj;             // this workgroup's share: j of nj
 };
 
-// -DAA_FFT_TRACE_PH0 (with -DAA_FFT_TRACE): the stamps 3..7 sit INSIDE phase 0 instead of at the phase ends:
-//   3 staging reads returned | 4 butterfly + twiddles issued | 5 past the barrier | 6 results written, filter requested | 7 past the barrier
+// -DAA_FFT_TRACE_PH0 (with -DAA_FFT_TRACE): 16 words per wavefront and the stamps 3..12 INSIDE phase 0:
+//   3 prefetch requested | 4 staging reads issued | 5 returned | 6 c2r + chirp | 7 butterfly | 8 twiddles | 9 past the barrier |
+//   10 results written | 11 filter requested | 12 past the barrier | 13 phase 1 | 14 phase 2 | 15 end
 #if defined(AA_FFT_TRACE_PH0)
+#define AA_FFT_TRACE_WORDS 16
 #define AA_STAMP_N(k) ((void)0)
-#define AA_STAMP_0(k) stamp(k)
+#define AA_STAMP_0(k) do { asm volatile("" ::: "memory"); stamp(k); asm volatile("" ::: "memory"); } while (0)
+#define AA_PIN(x, n) do { _Pragma("unroll") for (int q_ = 0; q_ < (n); ++q_) asm volatile("" : "+v"((x)[q_].re), "+v"((x)[q_].im)); } while (0)
 #else
+#define AA_FFT_TRACE_WORDS 8
 #define AA_STAMP_N(k) stamp(k)
 #define AA_STAMP_0(k) ((void)0)
+#define AA_PIN(x, n) ((void)0)
 #endif
 template <class S, bool F32, class Stamp>
 __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTablesCt& r, const fft::RowOut& io,
@@ -227,6 +232,11 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
     if (!(p.abl & 32))   // dev: bit 5 leaves the gather out altogether (results wrong): what the phase costs
 #endif
     gather_modes_to_lds<F32>(p, lat_local, f, io.mmax, work, t, NT);
+    // the staging slots above the last kept mode, up to the last one phase 0 reads: zeros, so that phase 0 reads X[k] and X[h-k]
+    // without masks (the exec-masked reads were 1.1 us of a 13 us workgroup, profiles/r03_fft_trace.txt)
+    for (int m = io.mmax + 1 + t; m < NZ * 256; m += NT) {
+        work[m] = cplx{0., 0.};
+    }
     // ---- table values of phases 0, 1, 3 and 4
     const cplx w0 = r.tw[t];
     const cplx wm = r.tw[(t & 15) * (M / 256)];
@@ -258,47 +268,78 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
             asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(a) : "memory");
         }
     }
+    AA_STAMP_0(3);
     // ---- phase 0: c2r pre-processing + chirp + DIF stage 0 (one block of M, stride 256), inputs from the staging area
     {
         const cplx* raw = work;
         cplx x[R0];
+#if defined(AA_FFT_TRACE_PH0)
+        cplx av[NZ], cv[NZ];
 #pragma unroll
         for (int q = 0; q < NZ; ++q) {
-            const int k  = t + q * 256;
-            const int kc = k < h ? k : h - 1;
-            const cplx a = fft::ct_raw_mode(raw, io.mmax, kc, h);
-            const cplx c = fft::cconj(fft::ct_raw_mode(raw, io.mmax, h - kc, h));
-            const cplx z = fft::cmul(fft::c2r_pre(a, c, P[q]), C[q]);
-            x[q]         = k < h ? z : cplx{0., 0.};
+            const int k = t + q * 256;
+            const int j = h - k;
+            av[q]       = raw[k];
+            cv[q]       = raw[j < 0 ? 0 : j];
         }
-#if defined(AA_FFT_TRACE_PH0)
+        AA_STAMP_0(4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        AA_PIN(av, NZ);
+        AA_PIN(cv, NZ);
+        AA_STAMP_0(5);
+#pragma unroll
+        for (int q = 0; q < NZ; ++q) {
+            if (q == 0 && t == 0) {
+                av[q].im = 0.;
+                cv[q].im = 0.;
+            }
+            x[q] = fft::cmul(fft::c2r_pre(av[q], fft::cconj(cv[q]), P[q]), C[q]);
+        }
+        AA_PIN(x, NZ);
+        AA_STAMP_0(6);
+#else
+#pragma unroll
+        for (int q = 0; q < NZ; ++q) {
+            // X[k] and X[h-k] straight from the staging area: modes above mmax are zeros there, k >= h (padding of the
+            // convolution) reads a slot that exists and is multiplied by the zero chirp of the table padding
+            const int k = t + q * 256;
+            const int j = h - k;
+            cplx a      = raw[k];
+            cplx v      = raw[j < 0 ? 0 : j];
+            if (q == 0 && t == 0) {   // k = 0: Im X[0] and Im X[h] do not enter (conventions of row_mode())
+                a.im = 0.;
+                v.im = 0.;
+            }
+            x[q] = fft::cmul(fft::c2r_pre(a, fft::cconj(v), P[q]), C[q]);
+        }
 #endif
-        AA_STAMP_0(3);
 #pragma unroll
         for (int q = NZ; q < R0; ++q) x[q] = cplx{0., 0.};
         fft::bfly<R0>(x, -1);
+        AA_PIN(x, R0);
+        AA_STAMP_0(7);
         cplx w1 = w0;
         w1.im   = -w1.im;
         fft::twiddle_apply<R0>(x, w1);
-#if defined(AA_FFT_TRACE_PH0)
-#pragma unroll
-        for (int q = 0; q < R0; ++q) asm volatile("" : "+v"(x[q].re), "+v"(x[q].im));   // the arithmetic stays above the stamp
-#endif
-        AA_STAMP_0(4);
+        AA_PIN(x, R0);
+        AA_STAMP_0(8);
         lds_barrier();   // the staging area aliases the work array: everybody has read it
-        AA_STAMP_0(5);
+        AA_STAMP_0(9);
 #pragma unroll
         for (int q = 0; q < R0; ++q) work[pt + q * 256] = x[q];
+#if defined(AA_FFT_TRACE_PH0)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        AA_STAMP_0(10);
     }
     // filter spectrum of the first middle butterfly: in flight during phase 1
     cplx flt[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) flt[q] = r.bhat_t[(q * NMID + t) * AA_ABL(r, 2)];
     AA_SCHED_FENCE();
-    AA_STAMP_0(6);
+    AA_STAMP_0(11);
     lds_barrier();
-    AA_STAMP_0(7);
+    AA_STAMP_0(12);
     AA_STAMP_N(3);
     // ---- phase 1: DIF level 1 (blocks of 256 = 16 consecutive workers, radix 16, stride 16)
 #pragma unroll
@@ -310,6 +351,7 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
     }
     wave_lds_fence();
     AA_STAMP_N(4);
+    AA_STAMP_0(13);
     // ---- phase 2: last DIF stage * filter spectrum * first DIT stage (16 contiguous elements, no twiddles)
 #pragma unroll
     for (int ib = 0; ib < NBM; ++ib) {
@@ -333,6 +375,7 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
     }
     wave_lds_fence();
     AA_STAMP_N(5);
+    AA_STAMP_0(14);
     asm volatile("" ::"v"(pf));   // the prefetch requests have returned (see above): their register is free from here
     // chirp of the outputs again (kept from phase 0 it costs 4 NZ registers through the two widest phases: spills)
 #pragma unroll
@@ -374,6 +417,7 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
         });
     }
     AA_STAMP_N(7);
+    AA_STAMP_0(15);
 }
 
 // One workgroup of S::NT workers per (row, field).  Every mode of the row is fetched from the Fourier intermediate once,
@@ -419,8 +463,8 @@ __global__ void __launch_bounds__(S::NT, (FAST ? S::WPS : 3)) fft_rows_ct_kernel
     // poor man's thread trace: every wavefront records where it runs and the shader clock at its phase boundaries
     unsigned long long* trc = nullptr;
     if (p.trace) {
-        const unsigned long long slot = ((unsigned long long)blockIdx.x * (nt / 64) + (tid >> 6)) * 8;
-        if (slot + 8 <= p.trace_cap && (tid & 63) == 0) {
+        const unsigned long long slot = ((unsigned long long)blockIdx.x * (nt / 64) + (tid >> 6)) * AA_FFT_TRACE_WORDS;
+        if (slot + AA_FFT_TRACE_WORDS <= p.trace_cap && (tid & 63) == 0) {
             trc = p.trace + slot;
             const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
             const unsigned xcc  = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID

@@ -319,7 +319,8 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, const PlanOptions
         }
         // specialised Bluestein rows: the stage-0 butterfly b reads the entries b + q * (M / R0), q < ceil(R0 / 2), some of
         // them beyond h (zero padding of the convolution: the values are not used).  Padding `pre` and `chirp` to that extent
-        // (with copies of entry h - 1) lets the kernel address them without a clamp: one base register + immediates.
+        // (`pre`: copies of entry h - 1, `chirp`: zeros) lets the kernel address them without a clamp: one base register +
+        // immediates -- and, the chirp of a padding element being zero, phase 0 needs no select for k >= h (row_ct3).
         int table_pad = 0;
         if (p.method == FFT_BLUESTEIN && p.ct_k >= 0) {
             const int R0 = p.shape.radix[0];
@@ -361,7 +362,7 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, const PlanOptions
                 ps.table.push_back(chirp[k]);
             }
             for (int k = 0; k < table_pad; ++k) {
-                ps.table.push_back(chirp[h - 1]);
+                ps.table.push_back(cplx{0., 0.});   // a zero chirp: the padding elements of phase 0 come out as zeros unmasked
             }
             // filter b[d] = conj(c[|d|]) wrapped into M; spectrum via the kernel's own forward DIF (padded layout),
             // stored in position order and scaled by 1/M

@@ -24,7 +24,8 @@ tm = tr.timings()
 buf = np.zeros(WORDS, dtype=np.uint64)
 _lib.check(_lib.Trans_fft_trace(tr._h, WORDS, buf.ctypes.data_as(C.c_void_p)))
 print("fourier ms", tm["fourier_ms"], "ONLY_M", os.environ.get("ATLAS_AMD_FFT_ONLY_M"))
-rec = buf.reshape(-1, 8)
+W = int(os.environ.get('FFT_TRACE_WORDS', '8'))   # 16 for a -DAA_FFT_TRACE_PH0 build
+rec = buf.reshape(-1, W)
 rec = rec[rec[:, 1] != 0]
 if os.environ.get("FFT_TRACE_SAVE"):
     np.savez_compressed(os.environ["FFT_TRACE_SAVE"], rec=rec, fourier_ms=tm["fourier_ms"])
@@ -49,7 +50,7 @@ print("kernel span in s_memtime ticks:", span, " (ticks per ms: %.0f)" % (span /
 tick_ns = tm["fourier_ms"] * 1e6 / span
 life = end - t[:, 0]
 print("wave lifetime: mean %.1f us  p10 %.1f  p50 %.1f  p90 %.1f" % tuple(x * tick_ns / 1e3 for x in (life.mean(), np.percentile(life, 10), np.percentile(life, 50), np.percentile(life, 90))))
-names = ["gather+barrier", "phase0", "phase1", "phase2", "phase3", "phase4"]
+names = ["gather+barrier", "phase0", "phase1", "phase2", "phase3", "phase4"] if W == 8 else ["gather+barrier", "prefetch issue", "staging reads issue", "reads return", "c2r+chirp", "butterfly", "twiddles", "barrier", "write", "filter request", "barrier", "phase1", "phase2", "phase3+4"]
 nph = int(nvalid.max()) - 1
 for k in range(nph):
     ok = nvalid > k + 1

@@ -22,10 +22,10 @@ for path in sys.argv[1:]:
     end = t[:, nst - 1]; start = t[:, 0]
     life = (end - start) * tick
     print("  wave life us: mean %.2f p10 %.2f p50 %.2f p90 %.2f" % (life.mean(), *np.percentile(life, [10, 50, 90])))
-    names = ["gather", "ph0", "ph1", "ph2", "ph3", "ph4"]
+    names = ["gather", "ph0", "ph1", "ph2", "ph3", "ph4"] if t.shape[1] == 7 else ["gather", "pf issue", "rd issue", "rd return", "c2r+chirp", "bfly", "twiddle", "barrier", "write", "flt req", "barrier", "ph1", "ph2", "ph3+4"]
     for k in range(nst - 1):
         dd = (t[:, k + 1] - t[:, k]) * tick
-        print("   %-7s mean %6.2f p10 %6.2f p50 %6.2f p90 %6.2f us" % (names[k] if k < 6 else str(k), dd.mean(), *np.percentile(dd, [10, 50, 90])))
+        print("   %-7s mean %6.2f p10 %6.2f p50 %6.2f p90 %6.2f us" % (names[k] if k < len(names) else str(k), dd.mean(), *np.percentile(dd, [10, 50, 90])))
     print("  avg live waves per CU: %.2f" % ((end - start).sum() / sum(spans)))
     cnt = collections.Counter(); simdh = collections.Counter()
     for c in cus[::8]:
