@@ -82,6 +82,7 @@ struct FourierParams {
     double* gp;                       // gp[f*npts + (rowoff[lat]-rowoff[lat0]) + i], npts = points of the local band
     const fft::FftRowPlan* plans;     // device copy of the plan structs
     const fft::cplx* table;           // device copy of all FFT tables
+    const fft::cplxf* table_f32;      // the same rounded to float (fp32 variant: the direct rows run in fp32 arithmetic), or null
     const int* row_plan;              // [nlats] plan index of each row
     const int* row_mmax;              // [nlats] highest kept wavenumber of each row (-1: none)
     const long long* rowoff;          // [nlats+1]

@@ -32,30 +32,44 @@
 namespace atlas_amd {
 namespace fft {
 
-struct alignas(16) cplx {
-    double re, im;
+// complex number of reals R.  The row kernels are written for `cplx` (double); the arithmetic below it (butterflies, twiddles,
+// one DIT stage, the direct rows) is templated on the complex type so that the fp32 variant of the transform can run its
+// direct rows in fp32 ARITHMETIC as well [r3]: hipcc turns the (re, im) pairs of `cplxf` into packed v_pk_{add,mul,fma}_f32
+// (2/3 of the instructions of the fp64 form), LDS and registers per element halve.
+template <class R>
+struct alignas(2 * sizeof(R)) cplx_t {
+    R re, im;
+    using real = R;
 };
+using cplx  = cplx_t<double>;
+using cplxf = cplx_t<float>;
 
-AA_HD cplx cmul(cplx a, cplx b) {
-    return cplx{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+template <class C>
+AA_HD C cmul(C a, C b) {
+    return C{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
 }
-AA_HD cplx cadd(cplx a, cplx b) {
-    return cplx{a.re + b.re, a.im + b.im};
+template <class C>
+AA_HD C cadd(C a, C b) {
+    return C{a.re + b.re, a.im + b.im};
 }
-AA_HD cplx csub(cplx a, cplx b) {
-    return cplx{a.re - b.re, a.im - b.im};
+template <class C>
+AA_HD C csub(C a, C b) {
+    return C{a.re - b.re, a.im - b.im};
 }
-AA_HD cplx cconj(cplx a) {
-    return cplx{a.re, -a.im};
+template <class C>
+AA_HD C cconj(C a) {
+    return C{a.re, -a.im};
 }
 // multiply by +i (dir=+1) or -i (dir=-1)
-AA_HD cplx cmuli(cplx a, int dir) {
-    return dir > 0 ? cplx{-a.im, a.re} : cplx{a.im, -a.re};
+template <class C>
+AA_HD C cmuli(C a, int dir) {
+    return dir > 0 ? C{-a.im, a.re} : C{a.im, -a.re};
 }
 // multiply by (c + i*dir*s)
-AA_HD cplx cmulw(cplx a, double c, double s, int dir) {
-    const double sd = dir > 0 ? s : -s;
-    return cplx{a.re * c - a.im * sd, a.re * sd + a.im * c};
+template <class C>
+AA_HD C cmulw(C a, typename C::real c, typename C::real s, int dir) {
+    const typename C::real sd = dir > 0 ? s : -s;
+    return C{a.re * c - a.im * sd, a.re * sd + a.im * c};
 }
 
 #ifndef AA_FFT_LDS_SWIZZLE
@@ -93,51 +107,59 @@ struct FftShape {           // stage list of an M-point transform
 };
 
 // ---- radix butterflies: y_q = sum_p x_p exp(dir 2 pi i p q / r) ------------------------------------------------
-AA_HD void bfly2(cplx* x) {
-    cplx a = x[0], b = x[1];
-    x[0]   = cadd(a, b);
-    x[1]   = csub(a, b);
+template <class C>
+AA_HD void bfly2(C* x) {
+    C a = x[0], b = x[1];
+    x[0] = cadd(a, b);
+    x[1] = csub(a, b);
 }
-AA_HD void bfly4(cplx* x, int dir) {
-    cplx a = cadd(x[0], x[2]), b = csub(x[0], x[2]);
-    cplx c = cadd(x[1], x[3]), d = cmuli(csub(x[1], x[3]), dir);
-    x[0]   = cadd(a, c);
-    x[1]   = cadd(b, d);
-    x[2]   = csub(a, c);
-    x[3]   = csub(b, d);
+template <class C>
+AA_HD void bfly4(C* x, int dir) {
+    C a = cadd(x[0], x[2]), b = csub(x[0], x[2]);
+    C c = cadd(x[1], x[3]), d = cmuli(csub(x[1], x[3]), dir);
+    x[0] = cadd(a, c);
+    x[1] = cadd(b, d);
+    x[2] = csub(a, c);
+    x[3] = csub(b, d);
 }
-AA_HD void bfly3(cplx* x, int dir) {
-    const double s = 0.86602540378443864676372317075294 * dir;  // sin(2pi/3)
-    cplx t1 = cadd(x[1], x[2]);
-    cplx t2 = cplx{x[0].re - 0.5 * t1.re, x[0].im - 0.5 * t1.im};
-    cplx t3 = csub(x[1], x[2]);
-    cplx t4 = cplx{-s * t3.im, s * t3.re};  // i*s*t3
-    x[0]    = cadd(x[0], t1);
-    x[1]    = cadd(t2, t4);
-    x[2]    = csub(t2, t4);
+template <class C>
+AA_HD void bfly3(C* x, int dir) {
+    using R   = typename C::real;
+    const R s = (R)0.86602540378443864676372317075294 * dir;  // sin(2pi/3)
+    const R h = (R)0.5;
+    C t1 = cadd(x[1], x[2]);
+    C t2 = C{x[0].re - h * t1.re, x[0].im - h * t1.im};
+    C t3 = csub(x[1], x[2]);
+    C t4 = C{-s * t3.im, s * t3.re};  // i*s*t3
+    x[0] = cadd(x[0], t1);
+    x[1] = cadd(t2, t4);
+    x[2] = csub(t2, t4);
 }
-AA_HD void bfly5(cplx* x, int dir) {
-    const double c1 = 0.30901699437494742410229341718282;        // cos(2pi/5)
-    const double c2 = -0.80901699437494742410229341718282;       // cos(4pi/5)
-    const double s1 = 0.95105651629515357211643933337938 * dir;  // sin(2pi/5)
-    const double s2 = 0.58778525229247312916870595463907 * dir;  // sin(4pi/5)
-    cplx a1 = cadd(x[1], x[4]), b1 = csub(x[1], x[4]);
-    cplx a2 = cadd(x[2], x[3]), b2 = csub(x[2], x[3]);
-    cplx x0 = x[0];
-    x[0]    = cplx{x0.re + a1.re + a2.re, x0.im + a1.im + a2.im};
-    cplx m1 = cplx{x0.re + c1 * a1.re + c2 * a2.re, x0.im + c1 * a1.im + c2 * a2.im};
-    cplx m2 = cplx{x0.re + c2 * a1.re + c1 * a2.re, x0.im + c2 * a1.im + c1 * a2.im};
-    cplx n1 = cplx{-(s1 * b1.im + s2 * b2.im), s1 * b1.re + s2 * b2.re};
-    cplx n2 = cplx{-(s2 * b1.im - s1 * b2.im), s2 * b1.re - s1 * b2.re};
-    x[1]    = cadd(m1, n1);
-    x[4]    = csub(m1, n1);
-    x[2]    = cadd(m2, n2);
-    x[3]    = csub(m2, n2);
+template <class C>
+AA_HD void bfly5(C* x, int dir) {
+    using R    = typename C::real;
+    const R c1 = (R)0.30901699437494742410229341718282;        // cos(2pi/5)
+    const R c2 = (R)-0.80901699437494742410229341718282;       // cos(4pi/5)
+    const R s1 = (R)0.95105651629515357211643933337938 * dir;  // sin(2pi/5)
+    const R s2 = (R)0.58778525229247312916870595463907 * dir;  // sin(4pi/5)
+    C a1 = cadd(x[1], x[4]), b1 = csub(x[1], x[4]);
+    C a2 = cadd(x[2], x[3]), b2 = csub(x[2], x[3]);
+    C x0 = x[0];
+    x[0] = C{x0.re + a1.re + a2.re, x0.im + a1.im + a2.im};
+    C m1 = C{x0.re + c1 * a1.re + c2 * a2.re, x0.im + c1 * a1.im + c2 * a2.im};
+    C m2 = C{x0.re + c2 * a1.re + c1 * a2.re, x0.im + c2 * a1.im + c1 * a2.im};
+    C n1 = C{-(s1 * b1.im + s2 * b2.im), s1 * b1.re + s2 * b2.re};
+    C n2 = C{-(s2 * b1.im - s1 * b2.im), s2 * b1.re - s1 * b2.re};
+    x[1] = cadd(m1, n1);
+    x[4] = csub(m1, n1);
+    x[2] = cadd(m2, n2);
+    x[3] = csub(m2, n2);
 }
 // radix 8 = 2 x 4:  p = 4 p1 + p0, q = 2 q1 + q0:  w8^{pq} = w2^{p1 q0} w4^{p0 q1} w8^{p0 q0}
-AA_HD void bfly8(cplx* x, int dir) {
+template <class C>
+AA_HD void bfly8(C* x, int dir) {
     const double r = 0.70710678118654752440084436210485;
-    cplx t0[4], t1[4];
+    C t0[4], t1[4];
 #pragma unroll
     for (int p0 = 0; p0 < 4; ++p0) {
         t0[p0] = cadd(x[p0], x[4 + p0]);
@@ -155,14 +177,15 @@ AA_HD void bfly8(cplx* x, int dir) {
     }
 }
 // radix 16 = 4 x 4:  p = 4 p1 + p0, q = 4 q1 + q0:  w16^{pq} = w4^{p1 q0} w4^{p0 q1} w16^{p0 q0}
-AA_HD void bfly16(cplx* x, int dir) {
+template <class C>
+AA_HD void bfly16(C* x, int dir) {
     const double c1 = 0.92387953251128675612818318939679;  // cos(pi/8)
     const double s1 = 0.38268343236508977172845998403040;  // sin(pi/8)
     const double r  = 0.70710678118654752440084436210485;
-    cplx t[4][4];  // t[p0][q0]
+    C t[4][4];  // t[p0][q0]
 #pragma unroll
     for (int p0 = 0; p0 < 4; ++p0) {
-        cplx u[4] = {x[p0], x[4 + p0], x[8 + p0], x[12 + p0]};
+        C u[4] = {x[p0], x[4 + p0], x[8 + p0], x[12 + p0]};
         bfly4(u, dir);
 #pragma unroll
         for (int q0 = 0; q0 < 4; ++q0) t[p0][q0] = u[q0];
@@ -179,21 +202,22 @@ AA_HD void bfly16(cplx* x, int dir) {
     t[3][3] = cmulw(t[3][3], -c1, -s1, dir);
 #pragma unroll
     for (int q0 = 0; q0 < 4; ++q0) {
-        cplx u[4] = {t[0][q0], t[1][q0], t[2][q0], t[3][q0]};
+        C u[4] = {t[0][q0], t[1][q0], t[2][q0], t[3][q0]};
         bfly4(u, dir);
 #pragma unroll
         for (int q1 = 0; q1 < 4; ++q1) x[4 * q1 + q0] = u[q1];
     }
 }
 // radix 9 = 3 x 3:  p = 3 p1 + p0, q = 3 q1 + q0:  w9^{pq} = w3^{p1 q0} w9^{p0 q0} w3^{p0 q1}
-AA_HD void bfly9(cplx* x, int dir) {
+template <class C>
+AA_HD void bfly9(C* x, int dir) {
     const double c1 = 0.76604444311897803520239265055542, s1 = 0.64278760968653932632264340990726;   // 40 deg
     const double c2 = 0.17364817766693034885171662676931, s2 = 0.98480775301220805936674302458952;   // 80 deg
     const double c4 = -0.93969262078590838405410927732473, s4 = 0.34202014332566873304409961468226;  // 160 deg
-    cplx t[3][3];  // t[p0][q0]
+    C t[3][3];  // t[p0][q0]
 #pragma unroll
     for (int p0 = 0; p0 < 3; ++p0) {
-        cplx u[3] = {x[p0], x[3 + p0], x[6 + p0]};
+        C u[3] = {x[p0], x[3 + p0], x[6 + p0]};
         bfly3(u, dir);
 #pragma unroll
         for (int q0 = 0; q0 < 3; ++q0) t[p0][q0] = u[q0];
@@ -204,7 +228,7 @@ AA_HD void bfly9(cplx* x, int dir) {
     t[2][2] = cmulw(t[2][2], c4, s4, dir);
 #pragma unroll
     for (int q0 = 0; q0 < 3; ++q0) {
-        cplx u[3] = {t[0][q0], t[1][q0], t[2][q0]};
+        C u[3] = {t[0][q0], t[1][q0], t[2][q0]};
         bfly3(u, dir);
 #pragma unroll
         for (int q1 = 0; q1 < 3; ++q1) x[3 * q1 + q0] = u[q1];
@@ -212,30 +236,31 @@ AA_HD void bfly9(cplx* x, int dir) {
 }
 // exp(dir * 2 pi i k / 360), k in [0,360): the index is a compile-time constant after unrolling, so the entries
 // become literal operands
-AA_HD cplx cmul_root360(cplx a, int k, int dir) {
+template <class C>
+AA_HD C cmul_root360(C a, int k, int dir) {
     constexpr double tab[360][2] = {
 #include "fft_roots360.inc"
     };
     if (k == 0) return a;
     if (k == 90) return cmuli(a, dir);
-    if (k == 180) return cplx{-a.re, -a.im};
+    if (k == 180) return C{-a.re, -a.im};
     if (k == 270) return cmuli(a, -dir);
     return cmulw(a, tab[k][0], tab[k][1], dir);
 }
 
-template <int R>
-AA_HD void bfly(cplx* x, int dir);
+template <int R, class C>
+AA_HD void bfly(C* x, int dir);
 
 // composite radix R = R1 * R2 (R a divisor of 360), Cooley-Tukey inside registers:
 // p = R2 p1 + p0, q = R1 q1 + q0:  w_R^{pq} = w_R1^{p1 q0} w_R^{p0 q0} w_R2^{p0 q1}
-template <int R1, int R2>
-AA_HD void bfly_comp(cplx* x, int dir) {
+template <int R1, int R2, class C>
+AA_HD void bfly_comp(C* x, int dir) {
     constexpr int R = R1 * R2;
     static_assert(360 % R == 0, "root table covers divisors of 360");
-    cplx t[R2][R1];
+    C t[R2][R1];
 #pragma unroll
     for (int p0 = 0; p0 < R2; ++p0) {
-        cplx u[R1];
+        C u[R1];
 #pragma unroll
         for (int p1 = 0; p1 < R1; ++p1) u[p1] = x[R2 * p1 + p0];
         bfly<R1>(u, dir);
@@ -244,7 +269,7 @@ AA_HD void bfly_comp(cplx* x, int dir) {
     }
 #pragma unroll
     for (int q0 = 0; q0 < R1; ++q0) {
-        cplx u[R2];
+        C u[R2];
 #pragma unroll
         for (int p0 = 0; p0 < R2; ++p0) u[p0] = t[p0][q0];
         bfly<R2>(u, dir);
@@ -253,8 +278,8 @@ AA_HD void bfly_comp(cplx* x, int dir) {
     }
 }
 
-template <int R>
-AA_HD void bfly(cplx* x, int dir) {
+template <int R, class C>
+AA_HD void bfly(C* x, int dir) {
     if constexpr (R == 2) bfly2(x);
     else if constexpr (R == 3) bfly3(x, dir);
     else if constexpr (R == 4) bfly4(x, dir);
@@ -273,9 +298,9 @@ AA_HD void bfly(cplx* x, int dir) {
 }
 
 // powers w^1 .. w^(R-1) by halving products (depth <= log2 R roundings)
-template <int R>
-AA_HD void twiddle_powers(cplx w1, cplx* w) {
-    w[0] = cplx{1., 0.};
+template <int R, class C>
+AA_HD void twiddle_powers(C w1, C* w) {
+    w[0] = C{1, 0};
     w[1] = w1;
 #pragma unroll
     for (int q = 2; q < R; ++q) {
@@ -285,22 +310,22 @@ AA_HD void twiddle_powers(cplx w1, cplx* w) {
 
 // x[q] *= w1^q, q = 1..R-1, with few live twiddles: q = STEP*j + i walks w1^i * (w1^STEP)^j (chains of at most
 // R/STEP products); radix-16/20/24 stages would otherwise hold R twiddles (4 VGPRs each) next to R data elements
-template <int R>
-AA_HD void twiddle_apply(cplx* x, cplx w1) {
+template <int R, class C>
+AA_HD void twiddle_apply(C* x, C w1) {
     if constexpr (R <= 5) {
-        cplx w[R];
+        C w[R];
         twiddle_powers<R>(w1, w);
 #pragma unroll
         for (int q = 1; q < R; ++q) x[q] = cmul(x[q], w[q]);
     }
     else {
         constexpr int STEP = 4;
-        cplx wi[STEP];
+        C wi[STEP];
         twiddle_powers<STEP>(w1, wi);
-        const cplx ws = cmul(wi[2], wi[2]);
+        const C ws = cmul(wi[2], wi[2]);
 #pragma unroll
         for (int i = 0; i < STEP; ++i) {
-            cplx t = wi[i];
+            C t = wi[i];
 #pragma unroll
             for (int q = i; q < R; q += STEP) {
                 if (q > 0) x[q] = cmul(x[q], t);
@@ -351,8 +376,8 @@ AA_HD void dif_stage(cplx* d, int M, int L, int lsh, const cplx* __restrict__ tw
     }
 }
 // ---- one DIT stage (inverse of the DIF stage with the same L, R): twiddle first, then butterfly --------------
-template <int R>
-AA_HD void dit_stage(cplx* d, int M, int L, int lsh, const cplx* __restrict__ tw, int dir, int t, int nt) {
+template <int R, class C>
+AA_HD void dit_stage(C* d, int M, int L, int lsh, const C* __restrict__ tw, int dir, int t, int nt) {
     const int Ls  = L / R;
     const int tws = M / L;
     const int nb  = M / R;
@@ -360,14 +385,14 @@ AA_HD void dit_stage(cplx* d, int M, int L, int lsh, const cplx* __restrict__ tw
         int blk, j;
         split_index(b, Ls, lsh, blk, j);
         const int base = blk * L + j;
-        cplx x[R];
+        C x[R];
         x[0] = d[PAD(base)];
         if (Ls == 1) {
 #pragma unroll
             for (int q = 1; q < R; ++q) x[q] = d[PAD(base + q)];
         }
         else {
-            cplx w1 = tw[j * tws];
+            C w1 = tw[j * tws];
             if (dir < 0) w1.im = -w1.im;
 #pragma unroll
             for (int q = 1; q < R; ++q) x[q] = d[PAD(base + q * Ls)];
@@ -393,9 +418,9 @@ AA_HD void dif_butterfly_w(cplx* d, int base, int Ls, cplx w1, int dir) {
 #pragma unroll
     for (int q = 1; q < R; ++q) d[PAD(base + q * Ls)] = x[q];
 }
-template <int R>
-AA_HD void dit_butterfly_w(cplx* d, int base, int Ls, cplx w1, int dir) {
-    cplx x[R];
+template <int R, class C>
+AA_HD void dit_butterfly_w(C* d, int base, int Ls, C w1, int dir) {
+    C x[R];
     x[0] = d[PAD(base)];
     if (dir < 0) w1.im = -w1.im;
 #pragma unroll
@@ -488,10 +513,11 @@ AA_HD int pos_of_freq(const FftShape& s, int k) {
 // ---- c2r pre-processing: half-spectrum X[0..h] of a length n=2h real signal -> Z[0..h) such that
 //      z = IDFT_h(Z) (unnormalised, sign +) gives y[2j] = Re z[j], y[2j+1] = Im z[j].
 //      wn = exp(+2 pi i k / n).  A = X[k], B = conj(X[h-k]).
-AA_HD cplx c2r_pre(cplx A, cplx B, cplx wn) {
-    cplx s = cadd(A, B);
-    cplx d = cmul(csub(A, B), wn);
-    return cplx{s.re - d.im, s.im + d.re};  // s + i*d
+template <class C>
+AA_HD C c2r_pre(C A, C B, C wn) {
+    C s = cadd(A, B);
+    C d = cmul(csub(A, B), wn);
+    return C{s.re - d.im, s.im + d.re};  // s + i*d
 }
 
 // ---- one row (one latitude x one field) of the c2r transform, expressed as barrier-separated phases ----------
@@ -541,12 +567,17 @@ AA_HD void store_pair(const RowOut& io, int64_t k, cplx z) {
 }
 
 // the same with the two (uniform) decisions taken by the caller, outside its element loop
-template <bool F32, bool ALIGNED>
-AA_HD void store_pair_t(const RowOut& io, int64_t k, cplx z) {
+template <bool F32, bool ALIGNED, class C>
+AA_HD void store_pair_t(const RowOut& io, int64_t k, C z) {
     if (F32) {
         float* yf = reinterpret_cast<float*>(io.y);
         if (ALIGNED) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(AA_FFT_PLAIN_STORE)
+            typedef float f2_t __attribute__((ext_vector_type(2)));
+            __builtin_nontemporal_store(f2_t{(float)z.re, (float)z.im}, reinterpret_cast<f2_t*>(yf + 2 * k));
+#else
             *reinterpret_cast<fpair*>(yf + 2 * k) = fpair{(float)z.re, (float)z.im};
+#endif
         }
         else {
             yf[2 * k]     = (float)z.re;
@@ -556,18 +587,18 @@ AA_HD void store_pair_t(const RowOut& io, int64_t k, cplx z) {
     else if (ALIGNED) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(AA_FFT_PLAIN_STORE)
         typedef double d2_t __attribute__((ext_vector_type(2)));
-        __builtin_nontemporal_store(d2_t{z.re, z.im}, reinterpret_cast<d2_t*>(io.y + 2 * k));
+        __builtin_nontemporal_store(d2_t{(double)z.re, (double)z.im}, reinterpret_cast<d2_t*>(io.y + 2 * k));
 #else
-        *reinterpret_cast<cplx*>(io.y + 2 * k) = z;
+        *reinterpret_cast<cplx*>(io.y + 2 * k) = cplx{(double)z.re, (double)z.im};
 #endif
     }
     else {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(AA_FFT_PLAIN_STORE)
-        __builtin_nontemporal_store(z.re, io.y + 2 * k);
-        __builtin_nontemporal_store(z.im, io.y + 2 * k + 1);
+        __builtin_nontemporal_store((double)z.re, io.y + 2 * k);
+        __builtin_nontemporal_store((double)z.im, io.y + 2 * k + 1);
 #else
-        io.y[2 * k]     = z.re;
-        io.y[2 * k + 1] = z.im;
+        io.y[2 * k]     = (double)z.re;
+        io.y[2 * k + 1] = (double)z.im;
 #endif
     }
 }
@@ -614,13 +645,14 @@ AA_HD cplx row_mode(const Reader& rd, int mmax, int m, int h) {
 AA_HD int row_mode_index(int mmax, int m) {
     return m > mmax ? (mmax < 0 ? 0 : mmax) : m;
 }
-AA_HD cplx row_mode_mask(cplx v, int mmax, int m, int h) {
+template <class C>
+AA_HD C row_mode_mask(C v, int mmax, int m, int h) {
     if (m > mmax || mmax < 0) {
-        v.re = 0.;
-        v.im = 0.;
+        v.re = 0;
+        v.im = 0;
     }
     if (m == 0 || m == h) {
-        v.im = 0.;
+        v.im = 0;
     }
     return v;
 }
@@ -846,14 +878,16 @@ struct CtShape {
 #define AA_ABL(r, bit) 1
 #endif
 
-struct RowTablesCt {
+template <class C>
+struct RowTablesCtT {
     int abl = 0;
     int n, h;
-    const cplx* tw;       // [M]
-    const cplx* pre;      // [h]
-    const cplx* chirp;    // [h]
-    const cplx* bhat_t;   // [R_last][M / R_last]  filter spectrum, transposed for the fused middle stage
+    const C* tw;       // [M]
+    const C* pre;      // [h]
+    const C* chirp;    // [h]
+    const C* bhat_t;   // [R_last][M / R_last]  filter spectrum, transposed for the fused middle stage
 };
+using RowTablesCt = RowTablesCtT<cplx>;
 
 template <class S, int I, class Fn>
 AA_HD void ct_stage_dispatch(int i, Fn&& fn) {
@@ -874,10 +908,11 @@ AA_HD constexpr int row_num_phases_ct() {
 
 // ---- the row's kept modes are fetched ONCE per row into an LDS staging area `raw` before phase 0, which needs every
 //      mode twice (X[k] and X[h-k]).  Device: fft_kernel.hip (LDS-DMA gather); host emulation: plain copy.
-AA_HD cplx ct_raw_mode(const cplx* raw, int mmax, int m, int h) {
-    cplx v = m <= mmax ? raw[m] : cplx{0., 0.};
+template <class C>
+AA_HD C ct_raw_mode(const C* raw, int mmax, int m, int h) {
+    C v = m <= mmax ? raw[m] : C{0, 0};
     if (m == 0 || m == h) {
-        v.im = 0.;   // conventions of row_mode()
+        v.im = 0;   // conventions of row_mode()
     }
     return v;
 }
@@ -1094,9 +1129,10 @@ AA_HD int dct_first_butterfly(int bp) {
     return b;
 }
 
-template <class S0, class Reader>
-AA_HD void row_phase_dct(int ph, int t, int nt, const RowTablesCt& r, const Reader& rd, const RowOut& io,
-                         cplx* work) {
+template <class S0, class Reader, class C>
+AA_HD void row_phase_dct(int ph, int t, int nt, const RowTablesCtT<C>& r, const Reader& rd, const RowOut& io,
+                         C* work) {
+    using Real        = typename C::real;
     using S           = CtShapeRev<S0>;
     constexpr int M   = S::M;
     constexpr int NS  = S::NS;
@@ -1108,23 +1144,25 @@ AA_HD void row_phase_dct(int ph, int t, int nt, const RowTablesCt& r, const Read
     if (ph == 0) {
         constexpr int NB = RL >= 16 ? 2 : (RL % 4 == 0 ? 4 : (RL % 5 == 0 ? 5 : (RL % 3 == 0 ? 3 : (RL % 2 == 0 ? 2 : 1))));
         for (int bp = t; bp < nbl; bp += nt) {
-            cplx x[RL];
+            C x[RL];
 #pragma unroll
             for (int q0 = 0; q0 < RL; q0 += NB) {
-                cplx A[NB], B[NB], P[NB];
+                C A[NB], B[NB], P[NB];
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
                     const int k = bp + (q0 + i) * nbl;
-                    A[i]        = rd(row_mode_index(io.mmax, k));
-                    B[i]        = rd(row_mode_index(io.mmax, h - k));
+                    const cplx a0 = rd(row_mode_index(io.mmax, k));       // (a float -> double -> float round trip of the fp32
+                    const cplx b0 = rd(row_mode_index(io.mmax, h - k));   //  form is folded away by the compiler)
+                    A[i]          = C{(Real)a0.re, (Real)a0.im};
+                    B[i]          = C{(Real)b0.re, (Real)b0.im};
                     P[i]        = r.pre[k];
                 }
                 AA_SCHED_FENCE();
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
                     const int k  = bp + (q0 + i) * nbl;
-                    const cplx a = row_mode_mask(A[i], io.mmax, k, h);
-                    const cplx c = cconj(row_mode_mask(B[i], io.mmax, h - k, h));
+                    const C a = row_mode_mask(A[i], io.mmax, k, h);
+                    const C c = cconj(row_mode_mask(B[i], io.mmax, h - k, h));
                     x[q0 + i]    = c2r_pre(a, c, P[i]);
                 }
             }
@@ -1147,8 +1185,8 @@ AA_HD void row_phase_dct(int ph, int t, int nt, const RowTablesCt& r, const Read
     }
     // ---- DIT stage 0 + store
     for (int b = t; b < Ls0; b += nt) {
-        const cplx w1 = r.tw[b];
-        cplx x[R0];
+        const C w1 = r.tw[b];
+        C x[R0];
 #pragma unroll
         for (int q = 0; q < R0; ++q) x[q] = work[PAD(b + q * Ls0)];
         twiddle_apply<R0>(x, w1);
@@ -1157,7 +1195,7 @@ AA_HD void row_phase_dct(int ph, int t, int nt, const RowTablesCt& r, const Read
 #pragma unroll
             for (int q = 0; q < R0; ++q) {
                 store_pair_t<decltype(f32c)::value, decltype(alc)::value>(
-                    io, b + q * Ls0, cplx{x[q].re * io.scale, x[q].im * io.scale});
+                    io, b + q * Ls0, C{x[q].re * (Real)io.scale, x[q].im * (Real)io.scale});
             }
         });
     }

@@ -112,11 +112,13 @@ struct ModeReaderT {
 #if defined(AA_FFT_ABLATE)
         if (p.abl & 1) ml = 0;
 #endif
+        // wavenumber x record length as a 24-bit product (one full-rate instruction; the host checks (T + 1) * RP < 2^31,
+        // trans.hip: fourier_fields): the 64-bit form cost the direct rows more integer multiplies than butterfly arithmetic
         if (p.packed_cols) {   // packed runs of the distributed transform (dist_trans.h): per-row offsets, no pitch padding
-            o = ro[lat_local] + (long long)ml * p.packed_cols + f2;
+            o = ro[lat_local] + (long long)__umul24((unsigned)ml, (unsigned)p.packed_cols) + f2;
             return base;
         }
-        o = (lat_local * cnt + ml) * p.RP + f2;
+        o = (lat_local * cnt) * p.RP + f2 + (long long)__umul24((unsigned)ml, (unsigned)p.RP);
         return base;
     }
     __device__ __forceinline__ const double* address(int m) const {   // fp64 storage only

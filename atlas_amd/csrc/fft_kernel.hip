@@ -6,6 +6,7 @@
 // (src/atlas/trans/local/TransLocal.cc:1101-1136, 1155-1196) and the FFTW / pocketfft c2r they call
 // (src/atlas/linalg/fft/FFTW.cc:38-61).  Output layout gp[f*npts + rowoff(lat) + lon] as TransLocal.cc:1132,1187.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "device_structs.h"
 #include "fft_device.h"
@@ -154,9 +155,10 @@ __device__ __forceinline__ void for_each_phase(Fn&& fn) {
 // lane straight from the Fourier intermediate into LDS (no staging registers; destination = wave-uniform base + 16 * lane,
 // so lane l of wave w handles m = sweep * nt + 64 w + l; lanes beyond mmax re-read mode mmax into slots nobody reads).
 // fp32 intermediate: through registers (the 8-byte element has no DMA width).
-template <bool F32>
+template <bool F32, class C>
 __device__ __forceinline__ void gather_modes_to_lds(const FourierParams& p, long long lat_local, int f, int mmax,
-                                                    cplx* raw, int tid, int nt) {
+                                                    C* raw, int tid, int nt) {
+    static_assert(F32 || sizeof(C) == 16, "the LDS-DMA gather moves 16-byte elements");
     const ModeReaderT<(F32 ? 1 : 0)> rd{p, lat_local, 2 * f};
     if (mmax < 0) {
         return;
@@ -165,9 +167,9 @@ __device__ __forceinline__ void gather_modes_to_lds(const FourierParams& p, long
         const int m  = m0 + tid;
         const int mc = m <= mmax ? m : mmax;
         if constexpr (F32) {
-            const cplx v = rd(mc);
+            const cplx v = rd(mc);   // (float -> double; back to float for C = cplxf: folded away)
             if (m <= mmax) {
-                raw[m] = v;
+                raw[m] = C{(typename C::real)v.re, (typename C::real)v.im};
             }
         }
         else {
@@ -532,11 +534,48 @@ __global__ void __launch_bounds__(S::NT, (FAST ? S::WPS : 3)) fft_rows_ct_kernel
     });
 }
 
-// ---- compile-time specialised direct rows (fft_core.h: row_phase_dct): regular grids, smooth rows of reduced grids
-template <class S, bool F32>
-__global__ void __launch_bounds__(FFT_MAX_NTHR, 3) fft_rows_dct_kernel(FourierParams p) {
+// workers of a direct row: one butterfly per worker in every stage (max over the stages of M / radix, whole wavefronts)
+template <class S>
+constexpr int dct_workers() {
+    int w = 64;
+    for (int i = 0; i < S::NS; ++i) {
+        const int nb = (S::M / S::radix(i) + 63) / 64 * 64;
+        w            = nb > w ? nb : w;
+    }
+    return w;
+}
+
+// compile-time loops over the middle DIT stages I = 1 .. NS-2 of a reversed shape (up / down)
+template <class SR, int I, class Fn>
+__device__ __forceinline__ void dct_for_each_mid(Fn&& fn) {
+    if constexpr (I <= SR::NS - 2) {
+        fn(std::integral_constant<int, I>{});
+        dct_for_each_mid<SR, I + 1>(fn);
+    }
+}
+template <class SR, int I, class Fn>
+__device__ __forceinline__ void dct_for_each_mid_down(Fn&& fn) {
+    if constexpr (I >= 1) {
+        fn(std::integral_constant<int, I>{});
+        dct_for_each_mid_down<SR, I - 1>(fn);
+    }
+}
+
+// ---- compile-time specialised direct rows (fft_core.h: row_phase_dct): regular grids, smooth rows of reduced grids.
+// F32A: the fp32 variant in fp32 ARITHMETIC (float tables, 8-byte LDS elements; the (re, im) pairs compile to packed
+// v_pk_{add,mul,fma}_f32); F32 && !F32A: float storage around fp64 arithmetic
+// wavefronts per SIMD a direct-row kernel is compiled for: 3 (168 registers), 2 where the first butterfly is too wide for that
+// (radix >= 15 in fp64 -- such rows are >= 60 KB of LDS: two workgroups per CU anyway -- or >= 20 in fp32: 30 - 310 spilled registers)
+template <class S, bool F32A>
+constexpr int dct_waves_per_simd() {
+    return S::radix(0) >= (F32A ? 20 : 15) ? 2 : 3;
+}
+
+template <class S, bool F32, bool F32A>
+__global__ void __launch_bounds__(FFT_MAX_NTHR, (dct_waves_per_simd<S, F32A>())) fft_rows_dct_kernel(FourierParams p) {
+    using C = std::conditional_t<F32A, fft::cplxf, cplx>;
     extern __shared__ double lds_raw[];
-    cplx* work = reinterpret_cast<cplx*>(lds_raw);
+    C* work = reinterpret_cast<C*>(lds_raw);
     int row, f;
     if (!fft_block_to_job(p, blockIdx.x, row, f)) {
         return;
@@ -547,15 +586,20 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR, 3) fft_rows_dct_kernel(FourierPa
     const int nt              = blockDim.x;
     const double scale        = (f < p.scale_uv_fields) ? p.coslatinv[row] : 1.0;
     const int mmax            = p.row_mmax[row];
-    const ModeReaderT<(F32 ? 1 : 0)> rd{p, (long long)(row - p.lat0), 2 * f};
-    fft::RowTablesCt r;
+    fft::RowTablesCtT<C> r;
 #if defined(AA_FFT_ABLATE)
     r.abl    = p.abl;
 #endif
-    r.n      = pl->n;
-    r.h      = pl->h;
-    r.tw     = p.table + pl->off_tw;
-    r.pre    = p.table + pl->off_pre;
+    r.n = pl->n;
+    r.h = pl->h;
+    if constexpr (F32A) {
+        r.tw  = p.table_f32 + pl->off_tw;
+        r.pre = p.table_f32 + pl->off_pre;
+    }
+    else {
+        r.tw  = p.table + pl->off_tw;
+        r.pre = p.table + pl->off_pre;
+    }
     r.chirp  = nullptr;
     r.bhat_t = nullptr;
     fft::RowOut io;
@@ -564,35 +608,118 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR, 3) fft_rows_dct_kernel(FourierPa
     io.aligned16 = ((goff & 1) == 0);
     io.f32       = F32 ? 1 : 0;
     io.scale     = scale;
-    constexpr int NPH = fft::row_num_phases_dct<S>();
     unsigned long long tprev = 0;
     const bool prof = p.prof != nullptr && tid == 0;
     if (prof) {
         tprev = clock64();
     }
-    // compile-time recursion over the phases: `#pragma unroll` gives up on the largest shapes ("unrolled size is too
-    // large") and would leave a run-time loop around a switch
-    for_each_phase_n<NPH, 0>([&](auto phc) {
-        constexpr int ph = decltype(phc)::value;
-        fft::row_phase_dct<S>(ph, tid, nt, r, rd, io, work);
-        if constexpr (ph < NPH - 1) {
-            if constexpr (false) {
-                // producer and consumer lanes of the next phase are in this wavefront: LDS executes a wavefront's
-                // instructions in order, only the compiler must not move accesses across this point
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // Phase 0 from an LDS staging area (as the Bluestein rows): every kept mode is fetched once (the row_phase_dct form reads
+    // X[k] and X[h-k] from the intermediate, every mode twice, in RL / NB dependent batches: 8 - 10 round trips to L2 / HBM per
+    // row); the c2r factors are requested before the gather is waited for.  The staging area aliases the work array: all
+    // butterflies of phase 0 are in registers before the first result is written (M / RL <= workers).
+    using SR           = fft::CtShapeRev<S>;
+    constexpr int RL   = SR::radix(SR::NS - 1);
+    constexpr int nbl  = S::M / RL;
+    // (the launcher starts dct_workers<S>() workers: launch_dct_t; a shape with a stage of more butterflies than a workgroup
+    // has workers -- M = 8192 = [16,16,16,2] -- takes the phase loop of row_phase_dct below)
+    if constexpr (dct_workers<S>() <= FFT_MAX_NTHR) {
+        gather_modes_to_lds<F32>(p, (long long)(row - p.lat0), f, io.mmax, work, tid, nt);
+        const bool act = tid < nbl;
+        const int bp   = act ? tid : 0;
+        // c2r factors of this worker's butterfly: all of them before the gather is waited for where the registers allow it
+        // (RL complex values next to the RL inputs: 168 registers hold 10 fp64 / 20 fp32 pairs of them), else in batches in phase 0
+        constexpr bool PRELOAD = RL * sizeof(C) <= 160;
+        constexpr int NB = PRELOAD ? RL : (RL % 4 == 0 ? 4 : (RL % 5 == 0 ? 5 : (RL % 3 == 0 ? 3 : (RL % 2 == 0 ? 2 : 1))));
+        C P[PRELOAD ? RL : NB], x[RL];
+        if constexpr (PRELOAD) {
+#pragma unroll
+            for (int q = 0; q < RL; ++q) P[q] = r.pre[bp + q * nbl];
+        }
+        // the twiddles of the later stages as well (one butterfly per worker and stage): the stages then start from LDS alone
+        constexpr int NMIDS = SR::NS > 2 ? SR::NS - 2 : 0;
+        C wmid[NMIDS > 0 ? NMIDS : 1];
+        int mbase[NMIDS > 0 ? NMIDS : 1];
+        dct_for_each_mid<SR, 1>([&](auto ic) {
+            constexpr int I  = decltype(ic)::value;
+            constexpr int R  = SR::radix(I);
+            constexpr int L  = SR::L(I);
+            const int b      = tid < SR::M / R ? tid : 0;
+            int blk, j;
+            fft::split_index(b, L / R, SR::lsh(I), blk, j);
+            mbase[I - 1] = blk * L + j;
+            wmid[I - 1]  = r.tw[j * (SR::M / L)];
+        });
+        constexpr int R0   = SR::radix(0);
+        constexpr int Ls0  = SR::M / R0;
+        const C wlast      = r.tw[tid < Ls0 ? tid : 0];
+        AA_SCHED_FENCE();
+        __syncthreads();
+        const int h = r.h;
+#pragma unroll
+        for (int q0 = 0; q0 < RL; q0 += NB) {
+            if constexpr (!PRELOAD) {
+#pragma unroll
+                for (int i = 0; i < NB; ++i) P[i] = r.pre[bp + (q0 + i) * nbl];
+                AA_SCHED_FENCE();
             }
-            else {
-                __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int k = bp + (q0 + i) * nbl;
+                const C a   = fft::ct_raw_mode(work, io.mmax, k, h);
+                const C c   = fft::cconj(fft::ct_raw_mode(work, io.mmax, h - k, h));
+                x[q0 + i]   = fft::c2r_pre(a, c, P[PRELOAD ? q0 + i : i]);
             }
         }
+        fft::bfly<RL>(x, +1);
+        lds_barrier();   // everybody has read the staging area
+        if (act) {
+            const int b = fft::dct_first_butterfly<S>(bp);
+#pragma unroll
+            for (int q = 0; q < RL; ++q) work[fft::PAD(b * RL + q)] = x[q];
+        }
+        __syncthreads();
         if (prof) {
             const unsigned long long tn = clock64();
-            atomicAdd(&p.prof[32 + ph], tn - tprev);
+            atomicAdd(&p.prof[32], tn - tprev);
             tprev = tn;
         }
-    });
+        // ---- DIT stages NS-2 .. 1 (row_phase_dct: dit_stage; here one butterfly per worker, twiddle already in a register)
+        dct_for_each_mid_down<SR, SR::NS - 2>([&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            constexpr int R = SR::radix(I);
+            if (tid < SR::M / R) {
+                fft::dit_butterfly_w<R>(work, mbase[I - 1], SR::L(I) / R, wmid[I - 1], +1);
+            }
+            __syncthreads();
+        });
+        // ---- DIT stage 0 + store
+        if (tid < Ls0) {
+            C y[R0];
+#pragma unroll
+            for (int q = 0; q < R0; ++q) y[q] = work[fft::PAD(tid + q * Ls0)];
+            fft::twiddle_apply<R0>(y, wlast);
+            fft::bfly<R0>(y, +1);
+            using Real = typename C::real;
+            fft::with_store_flavour(io, [&](auto f32c, auto alc) {
+#pragma unroll
+                for (int q = 0; q < R0; ++q) {
+                    fft::store_pair_t<decltype(f32c)::value, decltype(alc)::value>(
+                        io, tid + q * Ls0, C{y[q].re * (Real)io.scale, y[q].im * (Real)io.scale});
+                }
+            });
+        }
+    }
+    else {
+        const ModeReaderT<(F32 ? 1 : 0)> rd{p, (long long)(row - p.lat0), 2 * f};
+        constexpr int NPH = fft::row_num_phases_dct<S>();
+        for_each_phase_n<NPH, 0>([&](auto phc) {
+            constexpr int ph = decltype(phc)::value;
+            fft::row_phase_dct<S>(ph, tid, nt, r, rd, io, work);
+            if constexpr (ph < NPH - 1) {
+                __syncthreads();
+            }
+        });
+    }
 }
 
 #if defined(ATLAS_AMD_EXPERIMENTS)
@@ -667,22 +794,30 @@ hipError_t launch_fourier_ct(const FourierParams& p, int ctf, int ctk, int lds_b
     return hipErrorInvalidValue;
 }
 
-template <class S, bool F32>
+template <class S, bool F32, bool F32A>
 static hipError_t launch_dct_t(const FourierParams& p, int lds_bytes, int nthreads, unsigned nblk, hipStream_t stream) {
+    if (F32A) {
+        lds_bytes /= 2;   // 8-byte elements
+    }
+    lds_bytes += 256;     // staging of phase 0: modes 0..mmax, mmax <= M (one element more than the work array)
     {   // set on every launch (cheap): a per-process cache would be wrong for a second device and racy between host threads
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_dct_kernel<S, F32>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_dct_kernel<S, F32, F32A>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) {
             return e;
         }
     }
-    hipLaunchKernelGGL((fft_rows_dct_kernel<S, F32>), dim3(nblk), dim3(nthreads), lds_bytes, stream, p);
+    const int workers = dct_workers<S>() <= FFT_MAX_NTHR ? dct_workers<S>() : nthreads;
+    hipLaunchKernelGGL((fft_rows_dct_kernel<S, F32, F32A>), dim3(nblk), dim3(workers), lds_bytes, stream, p);
     return hipGetLastError();
 }
 template <class S>
 static hipError_t launch_dct(const FourierParams& p, int lds_bytes, int nthreads, unsigned nblk, hipStream_t stream) {
-    return p.f32 ? launch_dct_t<S, true>(p, lds_bytes, nthreads, nblk, stream)
-                 : launch_dct_t<S, false>(p, lds_bytes, nthreads, nblk, stream);
+    if (p.f32) {
+        return p.table_f32 ? launch_dct_t<S, true, true>(p, lds_bytes, nthreads, nblk, stream)
+                           : launch_dct_t<S, true, false>(p, lds_bytes, nthreads, nblk, stream);
+    }
+    return launch_dct_t<S, false, false>(p, lds_bytes, nthreads, nblk, stream);
 }
 
 hipError_t launch_fourier_dct(const FourierParams& p, int ctf, int ctk, int lds_bytes, int nthreads,

@@ -177,6 +177,7 @@ private:
     size_t fourier32_cap_ = 0;
     void* d_fftplans_    = nullptr;
     void* d_ffttable_    = nullptr;
+    void* d_ffttable_f32_ = nullptr;   // float copy, uploaded by the first fp32 call
     int* d_row_plan_     = nullptr;
     int* d_row_mmax_     = nullptr;
     long long* d_rowoff_ = nullptr;

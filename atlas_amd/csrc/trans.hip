@@ -164,6 +164,7 @@ void Trans::release() noexcept {
     fr(d_fourier32_);
     fr(d_fftplans_);
     fr(d_ffttable_);
+    fr(d_ffttable_f32_);
     fr(d_row_plan_);
     fr(d_row_mmax_);
     fr(d_rowoff_);
@@ -703,6 +704,18 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
     }
     p.plans           = (const fft::FftRowPlan*)d_fftplans_;
     p.table           = (const fft::cplx*)d_ffttable_;
+    if ((long long)(geo_.T + 1) * fourier_row_pitch(nb_fields) >= (1LL << 31) || fourier_row_pitch(nb_fields) >= (1 << 24) ||
+        geo_.T + 1 >= (1 << 24)) {   // fft_device.h: ModeReaderT forms wavenumber x record length as a 24-bit product
+        throw std::invalid_argument("invtrans: (truncation + 1) x 2 nb_fields exceeds the 31-bit record offset of the Fourier stage");
+    }
+    if (f32 && !d_ffttable_f32_ && !std::getenv("ATLAS_AMD_FFT_F32_ARITH_OFF")) {
+        std::vector<fft::cplxf> tf(fftplans_.table.size());
+        for (size_t i = 0; i < tf.size(); ++i) {
+            tf[i] = fft::cplxf{(float)fftplans_.table[i].re, (float)fftplans_.table[i].im};
+        }
+        d_ffttable_f32_ = dev_upload(tf.data(), tf.size());
+    }
+    p.table_f32       = (f32 && !std::getenv("ATLAS_AMD_FFT_F32_ARITH_OFF")) ? (const fft::cplxf*)d_ffttable_f32_ : nullptr;
     p.row_plan        = d_row_plan_;
     p.row_mmax        = d_row_mmax_;
     p.rowoff          = d_rowoff_;
