@@ -348,8 +348,8 @@ AA_HD void split_index(int b, int Ls, int lsh, int& blk, int& j) {
 }
 
 // ---- one DIF stage: blocks of length L, radix R; twiddle table of M entries, w_L^j = tw[j * M/L] ---------------
-template <int R>
-AA_HD void dif_stage(cplx* d, int M, int L, int lsh, const cplx* __restrict__ tw, int dir, int t, int nt) {
+template <int R, class C>
+AA_HD void dif_stage(C* d, int M, int L, int lsh, const C* __restrict__ tw, int dir, int t, int nt) {
     const int Ls  = L / R;
     const int tws = M / L;
     const int nb  = M / R;
@@ -357,7 +357,7 @@ AA_HD void dif_stage(cplx* d, int M, int L, int lsh, const cplx* __restrict__ tw
         int blk, j;
         split_index(b, Ls, lsh, blk, j);
         const int base = blk * L + j;
-        cplx x[R];
+        C x[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) x[q] = d[PAD(base + q * Ls)];
         bfly<R>(x, dir);
@@ -367,7 +367,7 @@ AA_HD void dif_stage(cplx* d, int M, int L, int lsh, const cplx* __restrict__ tw
             for (int q = 1; q < R; ++q) d[PAD(base + q)] = x[q];
         }
         else {
-            cplx w1 = tw[j * tws];
+            C w1 = tw[j * tws];
             if (dir < 0) w1.im = -w1.im;
             twiddle_apply<R>(x, w1);
 #pragma unroll
@@ -406,9 +406,9 @@ AA_HD void dit_stage(C* d, int M, int L, int lsh, const C* __restrict__ tw, int 
 
 // the same two stages for one butterfly with the stage twiddle w1 = tw[j * tws] supplied by the caller (the specialised
 // device path loads it once per row and keeps it: the DIF and the DIT stage of one level use the same entry)
-template <int R>
-AA_HD void dif_butterfly_w(cplx* d, int base, int Ls, cplx w1, int dir) {
-    cplx x[R];
+template <int R, class C>
+AA_HD void dif_butterfly_w(C* d, int base, int Ls, C w1, int dir) {
+    C x[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) x[q] = d[PAD(base + q * Ls)];
     bfly<R>(x, dir);
@@ -921,25 +921,25 @@ AA_HD C ct_raw_mode(const C* raw, int mmax, int m, int h) {
 // registers.  M >= 2h-1 and M even: h <= M/2, so the inputs q >= NZ = ceil(R0/2) are zero padding for every b.  The
 // table loads are issued in batches of NB elements ahead of a scheduling fence: left alone, the compiler serialises
 // them one round trip at a time to save registers.
-template <class S>
-AA_HD void ct_phase0_compute(int b, const RowTablesCt& r, const cplx* raw, const RowOut& io, cplx* x) {
+template <class S, class C>
+AA_HD void ct_phase0_compute(int b, const RowTablesCtT<C>& r, const C* raw, const RowOut& io, C* x) {
     constexpr int M   = S::M;
     constexpr int R0  = S::radix(0);
     constexpr int Ls0 = M / R0;
     constexpr int NZ  = (R0 + 1) / 2;
     constexpr int NB  = NZ <= 5 ? NZ : (NZ % 5 == 0 ? 5 : (NZ % 4 == 0 ? 4 : (NZ % 3 == 0 ? 3 : 2)));
     const int h       = r.h;
-    cplx w1           = r.tw[b];
+    C w1              = r.tw[b];
 #pragma unroll
     for (int q0 = 0; q0 < NZ; q0 += NB) {
-        cplx P[NB], C[NB];
+        C P[NB], Ch[NB];
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             if (q0 + i < NZ) {
                 const int k  = b + (q0 + i) * Ls0;
                 const int kc = k < h ? k : h - 1;
                 P[i]         = r.pre[kc * AA_ABL(r, 1)];
-                C[i]         = r.chirp[kc * AA_ABL(r, 1)];
+                Ch[i]        = r.chirp[kc * AA_ABL(r, 1)];
             }
         }
         AA_SCHED_FENCE();
@@ -948,15 +948,15 @@ AA_HD void ct_phase0_compute(int b, const RowTablesCt& r, const cplx* raw, const
             if (q0 + i < NZ) {
                 const int k  = b + (q0 + i) * Ls0;
                 const int kc = k < h ? k : h - 1;
-                const cplx a = ct_raw_mode(raw, io.mmax, kc, h);
-                const cplx c = cconj(ct_raw_mode(raw, io.mmax, h - kc, h));
-                const cplx z = cmul(c2r_pre(a, c, P[i]), C[i]);
-                x[q0 + i]    = k < h ? z : cplx{0., 0.};
+                const C a = ct_raw_mode(raw, io.mmax, kc, h);
+                const C c = cconj(ct_raw_mode(raw, io.mmax, h - kc, h));
+                const C z = cmul(c2r_pre(a, c, P[i]), Ch[i]);
+                x[q0 + i] = k < h ? z : C{0, 0};
             }
         }
     }
 #pragma unroll
-    for (int q = NZ; q < R0; ++q) x[q] = cplx{0., 0.};
+    for (int q = NZ; q < R0; ++q) x[q] = C{0, 0};
     bfly<R0>(x, -1);
     w1.im = -w1.im;
     twiddle_apply<R0>(x, w1);
@@ -964,9 +964,10 @@ AA_HD void ct_phase0_compute(int b, const RowTablesCt& r, const cplx* raw, const
 
 // RAW_ALIASES_WORK: the staging area lives inside `work` (device: LDS is the scarce resource), so every worker
 // finishes reading it before anybody writes stage-0 results; needs nt == S::NT.
-template <class S, bool RAW_ALIASES_WORK>
-AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCt& r, const cplx* raw, const RowOut& io,
-                        cplx* work) {
+template <class S, bool RAW_ALIASES_WORK, class C>
+AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCtT<C>& r, const C* raw, const RowOut& io,
+                        C* work) {
+    using Real        = typename C::real;
     constexpr int M   = S::M;
     constexpr int NS  = S::NS;
     constexpr int R0  = S::radix(0);
@@ -977,7 +978,7 @@ AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCt& r, const cplx*
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (RAW_ALIASES_WORK) {
             constexpr int NBUT = (Ls0 + S::NT - 1) / S::NT;
-            cplx x[NBUT][R0];
+            C x[NBUT][R0];
 #pragma unroll
             for (int ib = 0; ib < NBUT; ++ib) {
                 const int b = t + ib * S::NT;
@@ -998,7 +999,7 @@ AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCt& r, const cplx*
         }
 #endif
         for (int b = t; b < Ls0; b += nt) {
-            cplx x[R0];
+            C x[R0];
             ct_phase0_compute<S>(b, r, raw, io, x);
 #pragma unroll
             for (int q = 0; q < R0; ++q) work[PAD(b + q * Ls0)] = x[q];
@@ -1017,11 +1018,11 @@ AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCt& r, const cplx*
     if (ph == NS - 1) {  // ---- fused middle: last DIF stage * filter * first DIT stage (L = RL, no twiddles)
         constexpr int nb = M / RL;
         for (int b = t; b < nb; b += nt) {
-            cplx f[RL];  // filter spectrum: all loads in flight before the LDS reads (see phase 0)
+            C f[RL];  // filter spectrum: all loads in flight before the LDS reads (see phase 0)
 #pragma unroll
             for (int q = 0; q < RL; ++q) f[q] = r.bhat_t[(q * nb + b) * AA_ABL(r, 2)];
             AA_SCHED_FENCE();
-            cplx x[RL];
+            C x[RL];
 #pragma unroll
             for (int q = 0; q < RL; ++q) x[q] = work[PAD(b * RL + q)];
             bfly<RL>(x, -1);
@@ -1046,15 +1047,15 @@ AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCt& r, const cplx*
     // ---- fused: DIT stage 0 + chirp + store (outputs q >= NZ are padding: their butterfly arithmetic is dead)
     constexpr int NZ = (R0 + 1) / 2;
     for (int b = t; b < Ls0; b += nt) {
-        cplx w1 = r.tw[b];
-        cplx c[NZ];
+        C w1 = r.tw[b];
+        C c[NZ];
 #pragma unroll
         for (int q = 0; q < NZ; ++q) {
             const int k = b + q * Ls0;
             c[q]        = r.chirp[(k < h ? k : h - 1) * AA_ABL(r, 3)];
         }
         AA_SCHED_FENCE();
-        cplx x[R0];
+        C x[R0];
 #pragma unroll
         for (int q = 0; q < R0; ++q) x[q] = work[PAD(b + q * Ls0)];
         twiddle_apply<R0>(x, w1);
@@ -1062,8 +1063,8 @@ AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCt& r, const cplx*
 #pragma unroll
         for (int q = 0; q < NZ; ++q) {
             x[q]    = cmul(x[q], c[q]);
-            x[q].re = x[q].re * io.scale;  // 1/cos(lat) for the wind fields, exactly 1 otherwise
-            x[q].im = x[q].im * io.scale;
+            x[q].re = x[q].re * (Real)io.scale;  // 1/cos(lat) for the wind fields, exactly 1 otherwise
+            x[q].im = x[q].im * (Real)io.scale;
         }
         with_store_flavour(io, [&](auto f32c, auto alc) {
 #pragma unroll

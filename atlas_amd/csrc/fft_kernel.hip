@@ -11,6 +11,17 @@
 #include "device_structs.h"
 #include "fft_device.h"
 
+// the fp32 variant's specialised rows in fp32 ARITHMETIC (float tables, 8-byte LDS elements, packed v_pk_*_f32); a dev build with
+// -DAA_FFT_F32_FP64_ARITH keeps float storage around fp64 arithmetic (rounds 1 - 2)
+#ifndef AA_FFT_F32_FAST_WPS
+#define AA_FFT_F32_FAST_WPS 2   // wavefronts per SIMD the fp32 row_ct3 kernels are compiled for (3: 13 - 37 spilled registers, C4f32 5.62 vs 5.44 ms)
+#endif
+#if defined(AA_FFT_F32_FP64_ARITH)
+#define AA_FFT_F32_ARITH 0
+#else
+#define AA_FFT_F32_ARITH 1
+#endif
+
 namespace atlas_amd {
 namespace trans {
 
@@ -163,14 +174,32 @@ __device__ __forceinline__ void gather_modes_to_lds(const FourierParams& p, long
     if (mmax < 0) {
         return;
     }
+    if constexpr (F32) {
+        // through registers, 8 sweeps of requests in flight before the first LDS store (left as one sweep per iteration the
+        // loop is a chain of dependent round trips: request, wait, store, next request)
+        constexpr int U = 8;
+        for (int m0 = 0; m0 <= mmax; m0 += U * nt) {
+            cplx v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int m = m0 + u * nt + tid;
+                v[u]        = rd(m <= mmax ? m : mmax);   // (float -> double; back to float for C = cplxf: folded away)
+            }
+            AA_SCHED_FENCE();
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int m = m0 + u * nt + tid;
+                if (m <= mmax) {
+                    raw[m] = C{(typename C::real)v[u].re, (typename C::real)v[u].im};
+                }
+            }
+        }
+        return;
+    }
     for (int m0 = 0; m0 <= mmax; m0 += nt) {
         const int m  = m0 + tid;
         const int mc = m <= mmax ? m : mmax;
         if constexpr (F32) {
-            const cplx v = rd(mc);   // (float -> double; back to float for C = cplxf: folded away)
-            if (m <= mmax) {
-                raw[m] = C{(typename C::real)v.re, (typename C::real)v.im};
-            }
         }
         else {
             if (m <= mmax) {   // lanes past the last mode request nothing (their LDS slots belong to the caller: row_ct3 zeroes them)
@@ -218,9 +247,10 @@ struct PrefetchJob {
 #define AA_STAMP_0(k) ((void)0)
 #define AA_PIN(x, n) ((void)0)
 #endif
-template <class S, bool F32, class Stamp>
-__device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTablesCt& r, const fft::RowOut& io,
-                                        long long lat_local, int f, cplx* work, int t, const PrefetchJob& pfj, Stamp&& stamp) {
+template <class S, bool F32, class C, class Stamp>
+__device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTablesCtT<C>& r, const fft::RowOut& io,
+                                        long long lat_local, int f, C* work, int t, const PrefetchJob& pfj, Stamp&& stamp) {
+    using Real         = typename C::real;
     constexpr int M    = S::M;
     constexpr int R0   = S::radix(0);
     constexpr int NT   = S::NT;
@@ -237,16 +267,16 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
     // the staging slots above the last kept mode, up to the last one phase 0 reads: zeros, so that phase 0 reads X[k] and X[h-k]
     // without masks (the exec-masked reads were 1.1 us of a 13 us workgroup, profiles/r03_fft_trace.txt)
     for (int m = io.mmax + 1 + t; m < NZ * 256; m += NT) {
-        work[m] = cplx{0., 0.};
+        work[m] = C{0, 0};
     }
     // ---- table values of phases 0, 1, 3 and 4
-    const cplx w0 = r.tw[t];
-    const cplx wm = r.tw[(t & 15) * (M / 256)];
-    cplx P[NZ], C[NZ];
+    const C w0 = r.tw[t];
+    const C wm = r.tw[(t & 15) * (M / 256)];
+    C P[NZ], Ch[NZ];
 #pragma unroll
     for (int q = 0; q < NZ; ++q) {   // the tables are padded to NZ * 256 entries (fft_plan.cpp): no clamp
         P[q] = r.pre[(t + q * 256) * AA_ABL(r, 1)];
-        C[q] = r.chirp[(t + q * 256) * AA_ABL(r, 1)];
+        Ch[q] = r.chirp[(t + q * 256) * AA_ABL(r, 1)];
     }
     AA_SCHED_FENCE();
     __syncthreads();
@@ -273,10 +303,10 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
     AA_STAMP_0(3);
     // ---- phase 0: c2r pre-processing + chirp + DIF stage 0 (one block of M, stride 256), inputs from the staging area
     {
-        const cplx* raw = work;
-        cplx x[R0];
+        const C* raw = work;
+        C x[R0];
 #if defined(AA_FFT_TRACE_PH0)
-        cplx av[NZ], cv[NZ];
+        C av[NZ], cv[NZ];
 #pragma unroll
         for (int q = 0; q < NZ; ++q) {
             const int k = t + q * 256;
@@ -295,7 +325,7 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
                 av[q].im = 0.;
                 cv[q].im = 0.;
             }
-            x[q] = fft::cmul(fft::c2r_pre(av[q], fft::cconj(cv[q]), P[q]), C[q]);
+            x[q] = fft::cmul(fft::c2r_pre(av[q], fft::cconj(cv[q]), P[q]), Ch[q]);
         }
         AA_PIN(x, NZ);
         AA_STAMP_0(6);
@@ -306,21 +336,21 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
             // convolution) reads a slot that exists and is multiplied by the zero chirp of the table padding
             const int k = t + q * 256;
             const int j = h - k;
-            cplx a      = raw[k];
-            cplx v      = raw[j < 0 ? 0 : j];
+            C a      = raw[k];
+            C v      = raw[j < 0 ? 0 : j];
             if (q == 0 && t == 0) {   // k = 0: Im X[0] and Im X[h] do not enter (conventions of row_mode())
                 a.im = 0.;
                 v.im = 0.;
             }
-            x[q] = fft::cmul(fft::c2r_pre(a, fft::cconj(v), P[q]), C[q]);
+            x[q] = fft::cmul(fft::c2r_pre(a, fft::cconj(v), P[q]), Ch[q]);
         }
 #endif
 #pragma unroll
-        for (int q = NZ; q < R0; ++q) x[q] = cplx{0., 0.};
+        for (int q = NZ; q < R0; ++q) x[q] = C{0, 0};
         fft::bfly<R0>(x, -1);
         AA_PIN(x, R0);
         AA_STAMP_0(7);
-        cplx w1 = w0;
+        C w1 = w0;
         w1.im   = -w1.im;
         fft::twiddle_apply<R0>(x, w1);
         AA_PIN(x, R0);
@@ -335,7 +365,7 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
         AA_STAMP_0(10);
     }
     // filter spectrum of the first middle butterfly: in flight during phase 1
-    cplx flt[16];
+    C flt[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) flt[q] = r.bhat_t[(q * NMID + t) * AA_ABL(r, 2)];
     AA_SCHED_FENCE();
@@ -364,7 +394,7 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
                 for (int q = 0; q < 16; ++q) flt[q] = r.bhat_t[(q * NMID + b) * AA_ABL(r, 2)];
                 AA_SCHED_FENCE();
             }
-            cplx x[16];
+            C x[16];
 #pragma unroll
             for (int q = 0; q < 16; ++q) x[q] = work[fft::PAD(b * 16 + q)];
             fft::bfly<16>(x, -1);
@@ -382,7 +412,7 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
     // chirp of the outputs again (kept from phase 0 it costs 4 NZ registers through the two widest phases: spills)
 #pragma unroll
     for (int q = 0; q < NZ; ++q) {
-        C[q] = r.chirp[(t + q * 256) * AA_ABL(r, 3)];
+        Ch[q] = r.chirp[(t + q * 256) * AA_ABL(r, 3)];
     }
     AA_SCHED_FENCE();
     // ---- phase 3: DIT level 1
@@ -397,16 +427,16 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
     AA_STAMP_N(6);
     // ---- phase 4: DIT stage 0 + chirp + store (outputs q >= NZ are padding: their butterfly arithmetic is dead)
     {
-        cplx x[R0];
+        C x[R0];
 #pragma unroll
         for (int q = 0; q < R0; ++q) x[q] = work[pt + q * 256];
         fft::twiddle_apply<R0>(x, w0);
         fft::bfly<R0>(x, +1);
 #pragma unroll
         for (int q = 0; q < NZ; ++q) {
-            x[q]    = fft::cmul(x[q], C[q]);
-            x[q].re = x[q].re * io.scale;  // 1/cos(lat) for the wind fields, exactly 1 otherwise
-            x[q].im = x[q].im * io.scale;
+            x[q]    = fft::cmul(x[q], Ch[q]);
+            x[q].re = x[q].re * (Real)io.scale;  // 1/cos(lat) for the wind fields, exactly 1 otherwise
+            x[q].im = x[q].im * (Real)io.scale;
         }
         fft::with_store_flavour(io, [&](auto f32c, auto alc) {
 #pragma unroll
@@ -426,9 +456,12 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
 // into an LDS staging area that aliases the work array (phase 0 reads it completely before writing its results).
 // FAST: the row_ct3 form (256 registers, two wavefronts per SIMD) where the shape has it
 template <class S, bool F32, bool FAST>
-__global__ void __launch_bounds__(S::NT, (FAST ? S::WPS : 3)) fft_rows_ct_kernel(FourierParams p) {
+__global__ void __launch_bounds__(S::NT, (FAST ? ((F32 && AA_FFT_F32_ARITH) ? AA_FFT_F32_FAST_WPS : S::WPS) : 3)) fft_rows_ct_kernel(FourierParams p) {
+    // the fp32 variant runs in fp32 arithmetic: float tables, 8-byte LDS elements, packed v_pk_*_f32 (-DAA_FFT_F32_FP64_ARITH:
+    // float storage around fp64 arithmetic, the form of rounds 1 - 2)
+    using C = std::conditional_t<(F32 && AA_FFT_F32_ARITH), fft::cplxf, cplx>;
     extern __shared__ double lds_raw[];
-    cplx* work = reinterpret_cast<cplx*>(lds_raw);
+    C* work = reinterpret_cast<C*>(lds_raw);
     int ri, f;
     if (!fft_block_to_job_index(p, blockIdx.x, ri, f)) {
         return;
@@ -441,16 +474,23 @@ __global__ void __launch_bounds__(S::NT, (FAST ? S::WPS : 3)) fft_rows_ct_kernel
     const int row             = d.row;
     const long long goff      = (long long)f * p.npts + d.goff_rel;
     const double scale        = (f < p.scale_uv_fields) ? d.coslatinv : 1.0;
-    fft::RowTablesCt r;
+    fft::RowTablesCtT<C> r;
 #if defined(AA_FFT_ABLATE)
     r.abl    = p.abl;
 #endif
     r.n      = d.n;
     r.h      = d.h;
-    r.tw     = p.table + d.off_tw;
-    r.pre    = p.table + d.off_pre;
-    r.chirp  = p.table + d.off_chirp;
-    r.bhat_t = p.table + d.off_bhat_t;
+    const C* table;
+    if constexpr (std::is_same<C, cplx>::value) {
+        table = p.table;
+    }
+    else {
+        table = p.table_f32;
+    }
+    r.tw     = table + d.off_tw;
+    r.pre    = table + d.off_pre;
+    r.chirp  = table + d.off_chirp;
+    r.bhat_t = table + d.off_bhat_t;
     fft::RowOut io;
     io.mmax      = d.mmax;
     io.y         = F32 ? reinterpret_cast<double*>(reinterpret_cast<float*>(p.gp) + goff) : p.gp + goff;
@@ -739,6 +779,15 @@ static hipError_t launch_ct_t(FourierParams p, int lds_bytes, unsigned nblk, hip
             return e;
         }
     }
+    if (F32 && AA_FFT_F32_ARITH) {
+        lds_bytes /= 2;   // 8-byte elements
+        if (!p.table_f32) {
+            return hipErrorInvalidValue;
+        }
+    }
+    if (!p.desc) {
+        return hipErrorInvalidValue;
+    }
     if (const char* e = std::getenv("ATLAS_AMD_FFT_LDS_PAD")) {  // dev tool: occupancy sensitivity (more LDS per workgroup)
         lds_bytes += atoi(e);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_ct_kernel<S, F32, FAST>),
@@ -814,8 +863,10 @@ static hipError_t launch_dct_t(const FourierParams& p, int lds_bytes, int nthrea
 template <class S>
 static hipError_t launch_dct(const FourierParams& p, int lds_bytes, int nthreads, unsigned nblk, hipStream_t stream) {
     if (p.f32) {
-        return p.table_f32 ? launch_dct_t<S, true, true>(p, lds_bytes, nthreads, nblk, stream)
-                           : launch_dct_t<S, true, false>(p, lds_bytes, nthreads, nblk, stream);
+        if (!AA_FFT_F32_ARITH) {
+            return launch_dct_t<S, true, false>(p, lds_bytes, nthreads, nblk, stream);
+        }
+        return p.table_f32 ? launch_dct_t<S, true, (AA_FFT_F32_ARITH != 0)>(p, lds_bytes, nthreads, nblk, stream) : hipErrorInvalidValue;
     }
     return launch_dct_t<S, false, false>(p, lds_bytes, nthreads, nblk, stream);
 }

@@ -708,14 +708,14 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
         geo_.T + 1 >= (1 << 24)) {   // fft_device.h: ModeReaderT forms wavenumber x record length as a 24-bit product
         throw std::invalid_argument("invtrans: (truncation + 1) x 2 nb_fields exceeds the 31-bit record offset of the Fourier stage");
     }
-    if (f32 && !d_ffttable_f32_ && !std::getenv("ATLAS_AMD_FFT_F32_ARITH_OFF")) {
+    if (f32 && !d_ffttable_f32_) {   // float copy of the tables: the fp32 variant's specialised rows run in fp32 arithmetic
         std::vector<fft::cplxf> tf(fftplans_.table.size());
         for (size_t i = 0; i < tf.size(); ++i) {
             tf[i] = fft::cplxf{(float)fftplans_.table[i].re, (float)fftplans_.table[i].im};
         }
         d_ffttable_f32_ = dev_upload(tf.data(), tf.size());
     }
-    p.table_f32       = (f32 && !std::getenv("ATLAS_AMD_FFT_F32_ARITH_OFF")) ? (const fft::cplxf*)d_ffttable_f32_ : nullptr;
+    p.table_f32       = f32 ? (const fft::cplxf*)d_ffttable_f32_ : nullptr;
     p.row_plan        = d_row_plan_;
     p.row_mmax        = d_row_mmax_;
     p.rowoff          = d_rowoff_;

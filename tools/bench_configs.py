@@ -10,6 +10,7 @@ Template: the reference's own benchmark driver, src/sandbox/benchmark_trans/atla
   C4batch   TL1279 -> O1280, 1370 fields in ONE invtrans    (configs[3]: "10 fields" x 137 levels; single device)
   C5        TL1279 -> F1280 ("N1280 full"), 137 levels, fp32 (configs[4]);  C5f64: the same grid in fp64
   C5n       TL1279 -> N1280 (classic reduced Gaussian), fp32
+  C4f32     TL1279 -> O1280, 137 levels, fp32 (the headline grid in the precision of C5; not a BASELINE configuration)
 """
 import argparse
 import json
@@ -30,6 +31,7 @@ CONFIGS = {
     "C5": ("F1280", 1279, 137, True, 10, 3),
     "C5f64": ("F1280", 1279, 137, False, 10, 3),
     "C5n": ("N1280", 1279, 137, True, 10, 3),
+    "C4f32": ("O1280", 1279, 137, True, 10, 3),
 }
 
 
