@@ -9,6 +9,7 @@
 #include <type_traits>
 
 #include "device_structs.h"
+#include "dyn_lds.h"
 #include "fft_device.h"
 
 // the fp32 variant's specialised rows in fp32 ARITHMETIC (float tables, 8-byte LDS elements, packed v_pk_*_f32); a dev build with
@@ -772,12 +773,8 @@ hipError_t launch_fourier_hyb(const FourierParams&, int, int, hipStream_t) {
 
 template <class S, bool F32, bool FAST>
 static hipError_t launch_ct_t(FourierParams p, int lds_bytes, unsigned nblk, hipStream_t stream) {
-    {   // set on every launch (cheap): a per-process cache would be wrong for a second device and racy between host threads
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_ct_kernel<S, F32, FAST>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) {
-            return e;
-        }
+    if (hipError_t e = ensure_dynamic_lds<&fft_rows_ct_kernel<S, F32, FAST>>(lds_bytes); e != hipSuccess) {   // dyn_lds.h
+        return e;
     }
     if (F32 && AA_FFT_F32_ARITH) {
         lds_bytes /= 2;   // 8-byte elements
@@ -790,8 +787,7 @@ static hipError_t launch_ct_t(FourierParams p, int lds_bytes, unsigned nblk, hip
     }
     if (const char* e = std::getenv("ATLAS_AMD_FFT_LDS_PAD")) {  // dev tool: occupancy sensitivity (more LDS per workgroup)
         lds_bytes += atoi(e);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_ct_kernel<S, F32, FAST>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        (void)ensure_dynamic_lds<&fft_rows_ct_kernel<S, F32, FAST>>(lds_bytes);
     }
     const unsigned grid = nblk;
     p.nvirt             = nblk;
@@ -849,12 +845,8 @@ static hipError_t launch_dct_t(const FourierParams& p, int lds_bytes, int nthrea
         lds_bytes /= 2;   // 8-byte elements
     }
     lds_bytes += 256;     // staging of phase 0: modes 0..mmax, mmax <= M (one element more than the work array)
-    {   // set on every launch (cheap): a per-process cache would be wrong for a second device and racy between host threads
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_dct_kernel<S, F32, F32A>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) {
-            return e;
-        }
+    if (hipError_t e = ensure_dynamic_lds<&fft_rows_dct_kernel<S, F32, F32A>>(lds_bytes); e != hipSuccess) {   // dyn_lds.h
+        return e;
     }
     const int workers = dct_workers<S>() <= FFT_MAX_NTHR ? dct_workers<S>() : nthreads;
     hipLaunchKernelGGL((fft_rows_dct_kernel<S, F32, F32A>), dim3(nblk), dim3(workers), lds_bytes, stream, p);
@@ -881,12 +873,8 @@ hipError_t launch_fourier_dct(const FourierParams& p, int ctf, int ctk, int lds_
 }
 
 hipError_t launch_fourier(const FourierParams& p, int lds_bytes, int nthreads, hipStream_t stream) {
-    {   // set on every launch (cheap): a per-process cache would be wrong for a second device and racy between host threads
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) {
-            return e;
-        }
+    if (hipError_t e = ensure_dynamic_lds<&fft_rows_kernel>(lds_bytes); e != hipSuccess) {   // dyn_lds.h
+        return e;
     }
     const int ngr         = (p.f_end - p.f_begin + FGROUP - 1) / FGROUP;
     const long long units = (long long)p.nrows * ngr;

@@ -30,6 +30,7 @@
 #include <string>
 
 #include "device_structs.h"
+#include "dyn_lds.h"
 
 // the Fourier intermediate is written once and read once, by another kernel, after everything else of this launch
 #if !defined(AA_LEG_PLAIN_STORE)
@@ -614,12 +615,8 @@ __global__ void __launch_bounds__(512, 4) legendre_kernel_lean(LegendreParams p)
 
 static hipError_t launch_lean(LegendreParams p, int nitems, int nchunks, int chunk0, int nrun, hipStream_t stream) {
     using L = LegLds<3, 2, double>;
-    {   // on every launch (cheap): a per-process flag is wrong for a second device and racy between host threads
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&legendre_kernel_lean),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES);
-        if (e != hipSuccess) {
-            return e;
-        }
+    if (hipError_t e = ensure_dynamic_lds<&legendre_kernel_lean>(L::BYTES); e != hipSuccess) {   // dyn_lds.h
+        return e;
     }
     p.nitems        = nitems;
     p.nchunks       = nchunks;
@@ -639,12 +636,8 @@ static hipError_t launch_lean(LegendreParams p, int nitems, int nchunks, int chu
 template <int RTW, int NRG, class Real>
 static hipError_t launch_cfg(LegendreParamsT<Real> p, int nitems, int nchunks, int chunk0, int nrun, hipStream_t stream) {
     using L = LegLds<RTW, NRG, Real>;
-    {   // on every launch (cheap): a per-process flag is wrong for a second device and racy between host threads
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&legendre_kernel<RTW, NRG, Real>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES);
-        if (e != hipSuccess) {
-            return e;
-        }
+    if (hipError_t e = ensure_dynamic_lds<&legendre_kernel<RTW, NRG, Real>>(L::BYTES); e != hipSuccess) {   // dyn_lds.h
+        return e;
     }
     p.nitems        = nitems;
     p.nchunks       = nchunks;
