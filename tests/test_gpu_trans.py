@@ -190,6 +190,83 @@ def test_regular_lonlat_grid_with_poles_and_equator():
     assert compute_rms(gp, ref) < TOL
 
 
+DIRECT_SHAPES = [(f, k) for f, ks in ((1, range(8, 14)), (3, range(7, 12)), (5, range(6, 11)), (9, (8, 9)), (15, (8,))) for k in ks]
+
+
+@pytest.mark.parametrize("f,k", DIRECT_SHAPES)
+def test_every_direct_row_shape_fp64_and_fp32(f, k):
+    """One regular grid per specialised direct-row shape (h = n/2 = F * 2^K itself a length of the family, fft_core.h:
+    ct_supported): the staged form of the direct rows (modes gathered once into LDS, twiddles requested up front, one butterfly
+    per worker and stage; M = 8192 = [16,16,16,2] keeps the phase loop), its 256-register instances (first radix >= 15) and
+    the fp32-arithmetic instances of the fp32 variant.  Oracle: the fp64 CPU restatement; fp32: 2e-6 rel-RMS against the
+    fp64 device result of the float-rounded spectra."""
+    M, T, nf = f << k, 21, 3
+    lat = np.array([70.0, 25.0, -25.0, -70.0])
+    g = atlas_amd.StructuredGrid(nx=np.full(4, 2 * M), y=lat)
+    tr = atlas_amd.Trans(g, T)
+    sp = red_spectra(T, nf, seed=300 + M % 97)
+    gp = run_device(tr, nf, sp)
+    ref = oracle.OraclePlan(T, g.nx(), g.y()).invtrans(nf, sp, use_fft=True)
+    assert compute_rms(gp, ref) < TOL
+    sp32 = sp.astype(np.float32)
+    ref32 = run_device(tr, nf, sp32.astype(np.float64))
+    gp32 = torch.full((nf * g.size(),), float("nan"), dtype=torch.float32, device="cuda")
+    tr.invtrans(nf, torch.from_numpy(sp32).cuda(), gp32)
+    tr.synchronize()
+    assert compute_rms(gp32.cpu().numpy().astype(np.float64), ref32) < 2e-6
+
+
+def _largest_prime_at_most(n):
+    while True:
+        if n > 1 and all(n % d for d in range(2, int(n ** 0.5) + 1)):
+            return n
+        n -= 1
+
+
+@pytest.mark.parametrize("f,k", DIRECT_SHAPES)
+def test_every_bluestein_row_shape_fp64_and_fp32(f, k):
+    """One grid per specialised Bluestein shape M = F * 2^K: rows whose half length h is the largest prime with 2h - 1 <= M (and a
+    second, smaller prime half length of the same class), full truncation up to the row's Nyquist limit for the short shapes.
+    Covers the plain and the row_ct3 (M >= 3840) kernels, the zero-filled staging / zero chirp padding, and the fp32-arithmetic
+    instances of both (the BASELINE-sized fp32 tests only reach M <= 768 through Bluestein)."""
+    M = f << k
+    h1 = _largest_prime_at_most((M + 1) // 2)
+    h2 = _largest_prime_at_most(h1 - 1)
+    nx = np.array([2 * h1, 2 * h2, 2 * h2, 2 * h1])
+    lat = np.array([70.0, 25.0, -25.0, -70.0])
+    T, nf = min(191, h2 - 1), 9                     # nine fields: a full field group and a one-field group
+    g = atlas_amd.StructuredGrid(nx=nx, y=lat)
+    tr = atlas_amd.Trans(g, T)
+    sp = red_spectra(T, nf, seed=500 + M % 89)
+    gp = run_device(tr, nf, sp)
+    ref = oracle.OraclePlan(T, g.nx(), g.y()).invtrans(nf, sp, use_fft=True)
+    assert compute_rms(gp, ref) < TOL
+    sp32 = sp.astype(np.float32)
+    ref32 = run_device(tr, nf, sp32.astype(np.float64))
+    gp32 = torch.full((nf * g.size(),), float("nan"), dtype=torch.float32, device="cuda")
+    tr.invtrans(nf, torch.from_numpy(sp32).cuda(), gp32)
+    tr.synchronize()
+    assert bool(torch.isfinite(gp32).all())
+    assert compute_rms(gp32.cpu().numpy().astype(np.float64), ref32) < 2e-6
+
+
+def test_fourier_scheduling_switches_do_not_change_results(monkeypatch):
+    """L2 prefetch of a later job's modes, row -> XCD affinity and the number of class streams only move work around:
+    bit-identical grid points with them off (fft_kernel.hip: PrefetchJob, fft_device.h: fft_unit_to_job)."""
+    g, tr = get_trans("O320", 319)
+    nf = 19                                   # three field groups, the last one with three fields
+    sp = red_spectra(319, nf, seed=77)
+    ref = run_device(tr, nf, sp)
+    for env in ({"ATLAS_AMD_FFT_PREFETCH": "0"}, {"ATLAS_AMD_FFT_ROW_AFFINITY": "0"}, {"ATLAS_AMD_FFT_PREFETCH": "7"},
+                {"ATLAS_AMD_FFT_STREAMS": "1"}, {"ATLAS_AMD_FFT_PREFETCH": "0", "ATLAS_AMD_FFT_ROW_AFFINITY": "0"}):
+        for k2, v in env.items():
+            monkeypatch.setenv(k2, v)
+        got = run_device(tr, nf, sp)
+        for k2 in env:
+            monkeypatch.delenv(k2)
+        assert np.array_equal(got, ref), env
+
+
 def test_not_implemented_like_translocal():
     g, tr = get_trans("O32", 31)
     with pytest.raises(NotImplementedError):
