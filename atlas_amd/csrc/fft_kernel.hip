@@ -456,8 +456,13 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
 // One workgroup of S::NT workers per (row, field).  Every mode of the row is fetched from the Fourier intermediate once,
 // into an LDS staging area that aliases the work array (phase 0 reads it completely before writing its results).
 // FAST: the row_ct3 form (256 registers, two wavefronts per SIMD) where the shape has it
+#if defined(AA_COEX)
+#define AA_FFT_VGPR_CAP __attribute__((amdgpu_num_vgpr(120)))   // dev build: room for a Legendre workgroup (2 x 136 registers per SIMD)
+#else
+#define AA_FFT_VGPR_CAP
+#endif
 template <class S, bool F32, bool FAST>
-__global__ void __launch_bounds__(S::NT, (FAST ? ((F32 && AA_FFT_F32_ARITH) ? AA_FFT_F32_FAST_WPS : S::WPS) : 3)) fft_rows_ct_kernel(FourierParams p) {
+__global__ void AA_FFT_VGPR_CAP __launch_bounds__(S::NT, (FAST ? ((F32 && AA_FFT_F32_ARITH) ? AA_FFT_F32_FAST_WPS : S::WPS) : 3)) fft_rows_ct_kernel(FourierParams p) {
     // the fp32 variant runs in fp32 arithmetic: float tables, 8-byte LDS elements, packed v_pk_*_f32 (-DAA_FFT_F32_FP64_ARITH:
     // float storage around fp64 arithmetic, the form of rounds 1 - 2)
     using C = std::conditional_t<(F32 && AA_FFT_F32_ARITH), fft::cplxf, cplx>;

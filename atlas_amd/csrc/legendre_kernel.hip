@@ -329,7 +329,16 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
 //     address arithmetic: every LDS offset is an immediate);
 //   * columns beyond the last field load the last field instead of a zero word (their products land in the padding
 //     columns of F), which removes the per-lane pointer/step pairs.
-__global__ void __launch_bounds__(512, 4) legendre_kernel_lean(LegendreParams p) {
+// -DAA_COEX (dev build, tools/r03_coex.sh): 136 registers per wavefront, so that a CU takes ONE workgroup of this kernel (two need
+// 4 x 136 registers per SIMD) and keeps 240 registers per SIMD and 112 KiB of LDS for a workgroup of the Fourier stage of another
+// transform -- the co-residency experiment of DESIGN 3.4
+#if defined(AA_COEX)
+#define AA_LEAN_WPS 3
+#else
+#define AA_LEAN_WPS 4
+#endif
+__global__ void __launch_bounds__(512, AA_LEAN_WPS) legendre_kernel_lean(LegendreParams p) {
+
     using L  = LegLds<3, 2, double>;
     using RT = RealTraits<double>;
     using acc_t = typename RT::acc_t;
@@ -611,6 +620,9 @@ __global__ void __launch_bounds__(512, 4) legendre_kernel_lean(LegendreParams p)
             }
         }
     }
+#if defined(AA_COEX)
+    asm volatile("" ::: "v135");   // register count 136 (see above)
+#endif
 }
 
 static hipError_t launch_lean(LegendreParams p, int nitems, int nchunks, int chunk0, int nrun, hipStream_t stream) {
