@@ -10,7 +10,7 @@ O=$R/gpurun_out/round
 rm -rf $O; mkdir -p $O
 ( time python bench.py ) > $O/bench_default.json 2> $O/bench_default.err
 cd /tmp
-BENCH="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+BENCH="python $R/bench.py --no-cpu-baseline"   # the default run (10 steps, 3 warm-up steps) without the CPU leg
 rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- $BENCH > $O/stats.log 2>&1
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" \
             "sq SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU"; do
