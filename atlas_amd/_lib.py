@@ -181,6 +181,7 @@ LegendreCacheCreator_supported = _sig("atlas_amd__LegendreCacheCreator__supporte
 fft_host_row = _sig("atlas_amd__fft_host_row", C.c_int, C.c_int, c_void_p, C.c_int, c_void_p)
 fft_host_row_generic = _sig("atlas_amd__fft_host_row_generic", C.c_int, C.c_int, c_void_p, C.c_int, c_void_p)
 fft_host_row_hybrid = _sig("atlas_amd__fft_host_row_hybrid", C.c_int, C.c_int, c_void_p, C.c_int, c_void_p)
+fft_host_row_coarse = _sig("atlas_amd__fft_host_row_coarse", C.c_int, C.c_int, c_void_p, C.c_int, c_void_p)
 
 
 def check(rc):

@@ -970,6 +970,17 @@ int atlas_amd__fft_host_row_hybrid(int n, const double* modes, int mmax, double*
     fft::host_execute_row(ps, 0, reinterpret_cast<const fft::cplx*>(modes), mmax, out);
     AA_CATCH_INT
 }
+int atlas_amd__fft_host_row_coarse(int n, const double* modes, int mmax, double* out) {
+    AA_TRY
+    if (n < 1 || !modes || !out) {
+        throw std::invalid_argument("fft_host_row_coarse: n >= 1 and non-null arrays are required");
+    }
+    fft::PlanOptions po;
+    po.coarse_classes = true;
+    fft::FftPlanSet ps = fft::make_fft_plans({n}, po);
+    fft::host_execute_row(ps, 0, reinterpret_cast<const fft::cplx*>(modes), mmax, out);
+    AA_CATCH_INT
+}
 int atlas_amd__fft_host_row_generic(int n, const double* modes, int mmax, double* out) {
     AA_TRY
     if (n < 1 || !modes || !out) {

@@ -87,6 +87,15 @@ int next_bluestein_length(int n) {
     return best;
 }
 
+int coarse_bluestein_length(int n) {
+    for (int m : {256, 512, 1024, 2048}) {
+        if (m >= n) {
+            return m;
+        }
+    }
+    return 0;
+}
+
 FftShape make_shape(int M, int max_pow2_radix) {
     if (!is_smooth235(M)) {
         throw std::invalid_argument("make_shape: M is not {2,3,5}-smooth");
@@ -239,6 +248,10 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, const PlanOptions
         // such rows go through Bluestein as well when a specialised Bluestein instance exists for them [r3] (O1280: 156 rows,
         // 3.3 % of the points, 0.57 -> 0.37 ms; the classic N grids: nearly every row).  ATLAS_AMD_FFT_SMOOTH_DIRECT=1: old rule.
         bool smooth_direct = is_smooth235(h);
+        const int Mcoarse  = (opt.coarse_classes && specialised_shapes) ? coarse_bluestein_length(2 * h - 1) : 0;
+        if (Mcoarse > 0) {
+            smooth_direct = false;   // one of the few coarse Bluestein classes (PlanOptions::coarse_classes)
+        }
         if (smooth_direct && specialised_shapes) {
             bool family = false;
             for (int f : {1, 3, 5, 9, 15}) {
@@ -276,7 +289,7 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, const PlanOptions
             }
             p.shape = p.ct_k >= 0 ? make_ct_shape(p.ct_f, p.ct_k) : make_shape(h);
         }
-        else if (opt.hybrid && h >= opt.hybrid_min_h && hybrid_dense_radix(h) <= std::min(opt.hybrid_max_a, HYB_MAX_A)) {
+        else if (Mcoarse == 0 && opt.hybrid && h >= opt.hybrid_min_h && hybrid_dense_radix(h) <= std::min(opt.hybrid_max_a, HYB_MAX_A)) {
             p.method = FFT_HYBRID;
             p.hyb_A  = hybrid_dense_radix(h);
             p.hyb_B  = h / p.hyb_A;
@@ -295,7 +308,7 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, const PlanOptions
         }
         else {
             p.method     = FFT_BLUESTEIN;
-            const int Mb = next_bluestein_length(2 * h - 1);
+            const int Mb = Mcoarse > 0 ? Mcoarse : next_bluestein_length(2 * h - 1);
             // M = F * 2^K with a specialised instance?
             if (specialised_shapes) {
                 for (int f : {1, 3, 5, 9, 15}) {

@@ -46,7 +46,14 @@ struct PlanOptions {
     int hybrid_max_a        = HYB_MAX_A;
     int hybrid_min_h        = 64;
     int max_mode            = 1 << 30;  // highest wavenumber any row can carry (sizes the staging area of HYBRID rows)
+    // Small reduced grids are launch-bound: TL159 -> O160 / 60 fields spends 0.15 of its 0.21 ms in 19 row-class launches of a
+    // few microseconds of work each.  With `coarse_classes` every even row takes a Bluestein row of one of a few lengths
+    // (256, 512, 1024, 2048: any M >= 2h - 1 is a valid convolution length) -- up to 4 x the butterflies of the tight length,
+    // a handful of launches.  Set by Trans for reduced grids of at most 704 points per row (a property of the GLOBAL grid, so
+    // that every decomposition of one grid plans its rows alike); ATLAS_AMD_FFT_COARSE=0/1 overrides.
+    bool coarse_classes     = false;
 };
+int coarse_bluestein_length(int n);   // smallest of 256, 512, 1024, 2048 that is >= n (0: none)
 
 struct FftPlanSet {
     std::vector<FftRowPlan> plans;   // one per distinct n

@@ -147,6 +147,7 @@ private:
     TransConfig cfg_;
     LegendreWork work_;
     fft::FftPlanSet fftplans_;
+    bool fft_coarse_ = false;   // coarse row classes (fft_plan.h: PlanOptions::coarse_classes): small reduced grid, one class stream
     std::vector<int> bands_;
     int m_cnt_          = 0;
     bool profile_       = false;

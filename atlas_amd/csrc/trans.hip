@@ -124,6 +124,17 @@ Trans::Trans(const grid::StructuredGrid& grid, int truncation, const TransConfig
         if (const char* e = std::getenv("ATLAS_AMD_FFT_HYB_MAXA")) {    // largest dense radix
             po.hybrid_max_a = atoi(e);
         }
+        {
+            // small reduced grids: a few coarse row classes instead of one per tight Bluestein length (fft_plan.h)
+            std::vector<int> distinct(lengths);
+            std::sort(distinct.begin(), distinct.end());
+            distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+            po.coarse_classes = !geo_.regular && geo_.nxmax <= 704 && distinct.size() >= 24;
+            if (const char* e = std::getenv("ATLAS_AMD_FFT_COARSE")) {
+                po.coarse_classes = atoi(e) != 0;
+            }
+            fft_coarse_ = po.coarse_classes;
+        }
         fftplans_ = fft::make_fft_plans(lengths, po);
     }
     // upload() allocates the table and every plan buffer and can throw (cache size, row length, out of memory): the
@@ -755,7 +766,9 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
     // descending row length): 9.3 ms on one stream, 8.9 / 8.6 / 8.0 / 8.3 / 8.6 ms on 2 / 3 / 4 / 5 / 6-8 streams; 150 random
     // orders and stream assignments found nothing below the round robin over four (profiles/r02_fft_streams.txt).
     // ATLAS_AMD_FFT_STREAMS overrides.  All streams fork from and join the caller's stream through events.
-    const int nstreams_env = std::getenv("ATLAS_AMD_FFT_STREAMS") ? atoi(std::getenv("ATLAS_AMD_FFT_STREAMS")) : 4;
+    // Small reduced grids (coarse row classes: three or four launches of tens of microseconds): one stream -- forking and joining
+    // side streams costs more than the tails (TL159 -> O160, 60 fields: stage 0.133 / 0.110 / 0.100 ms on 4 / 2 / 1 streams).
+    const int nstreams_env = std::getenv("ATLAS_AMD_FFT_STREAMS") ? atoi(std::getenv("ATLAS_AMD_FFT_STREAMS")) : (fft_coarse_ ? 1 : 4);
     const int nstreams = std::max(1, std::min(nstreams_env, 8));
     while ((int)side_streams_.size() < nstreams - 1) {
         hipStream_t st;

@@ -310,6 +310,9 @@ int atlas_amd__fft_host_row_generic(int n, const double* modes, int mmax, double
 /* same with the dense-stage ("hybrid") plan where the row length admits one: h = n/2 = A*B, A the product of the prime
  * factors > 5 of h (A <= 257), B {2,3,5}-smooth; other lengths take their usual plan */
 int atlas_amd__fft_host_row_hybrid(int n, const double* modes, int mmax, double* out);
+/* same with the coarse row classes Trans plans for small reduced grids (Bluestein rows of length 256 / 512 / 1024 / 2048 for
+ * every even n whose 2 (n/2) - 1 fits; csrc/fft_plan.h: PlanOptions::coarse_classes) */
+int atlas_amd__fft_host_row_coarse(int n, const double* modes, int mmax, double* out);
 
 /* atlas::trans::LegendreCacheCreator, type "local" (src/atlas/trans/LegendreCacheCreator.h:30-111,
  * local/LegendreCacheCreatorLocal.cc:66-165): uid = "local-T<T>-GaussianN<N>|L-ny<ny>|S-ny<ny>|grid-<md5>-OPT<md5>" (expected

@@ -209,6 +209,26 @@ def test_fft_phase_code_on_every_row_length_of_the_octahedral_grid(N):
     assert worst < 2e-15, worst
 
 
+def test_fft_phase_code_with_the_coarse_row_classes_of_small_reduced_grids():
+    """every distinct row length of O160 and O32 (what Trans plans with PlanOptions::coarse_classes: Bluestein rows of length
+    256 / 512 / 1024 for every even n, whatever the tight length would be -- smooth or not) through the host run of the
+    kernel's phase code against pocketfft, full and truncated spectra"""
+    rng = np.random.default_rng(160)
+    worst = 0.0
+    for n in sorted(set(range(20, 20 + 4 * 160, 4)) | {20, 24, 32, 128, 130, 256, 258, 512, 514, 1024, 1026, 2050}):
+        nc = n // 2 + 1
+        for mmax in (nc - 1, max(0, n // 5)):
+            x = rng.standard_normal(nc) + 1j * rng.standard_normal(nc)
+            x[mmax + 1:] = 0
+            out = np.zeros(n)
+            _lib.check(_lib.fft_host_row_coarse(n, np.ascontiguousarray(x).ctypes.data, mmax, out.ctypes.data))
+            xx = x.copy()
+            xx[0] = xx[0].real
+            xx[-1] = xx[-1].real
+            worst = max(worst, compute_rms(out, np.fft.irfft(xx, n) * n))
+    assert worst < 2e-15, worst
+
+
 HYBRID_LENGTHS = [28, 44, 52, 68, 76, 132, 140, 148, 244, 260, 404, 1004, 2 * 514, 4 * 61 * 10, 4 * 7 * 183, 4 * 1285,
                   2 * 2 * 3 * 7 * 61, 4 * 1283]   # the last two: no dense-stage plan (A > 257), usual plan
 
