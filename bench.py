@@ -217,6 +217,45 @@ def dry_run(args):
         raise SystemExit(1)
 
 
+class Watchdog:
+    """N > 1 only: a multi-rank run that hangs (a collective one rank never enters, an RCCL group whose two ends disagree)
+    would sit until the caller's time limit with nothing on stdout.  Every phase of the run re-arms a timer; if a phase does not
+    finish in `limit_s` seconds the rank says which one on stderr, rank 0 prints a JSON line with "error" (value null:
+    unmeasured, never a number) and the process exits with status 3.  BENCH_WATCHDOG_S overrides (0: off)."""
+
+    def __init__(self, rank, world, enabled, limit_s=None):
+        self.rank, self.world = rank, world
+        self.limit_s = float(os.environ.get("BENCH_WATCHDOG_S", "900" if limit_s is None else str(limit_s)))
+        self.enabled = bool(enabled) and self.limit_s > 0
+        self.timer, self.name = None, None
+
+    def _expired(self, name):
+        sys.stderr.write(f"[bench] rank {self.rank}: watchdog: phase '{name}' did not finish in {self.limit_s:.0f} s\n")
+        sys.stderr.flush()
+        if self.rank == 0:
+            sys.stdout.write(json.dumps({
+                "metric": "inverse SH transforms/sec (TL1279, O1280, 137 lev)", "value": None, "unit": "transforms/s",
+                "n_gpus": self.world, "error": f"watchdog: phase '{name}' did not finish in {self.limit_s:.0f} s on rank 0 "
+                                               f"(multi-rank run hung; see stderr of the other ranks)"}) + "\n")
+            sys.stdout.flush()
+        os._exit(3)
+
+    def phase(self, name):
+        if not self.enabled:
+            return
+        import threading
+        self.done()
+        self.name = name
+        self.timer = threading.Timer(self.limit_s, self._expired, args=(name,))
+        self.timer.daemon = True
+        self.timer.start()
+
+    def done(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -268,6 +307,8 @@ def main():
     g = atlas_amd.Grid(GRID)
 
     use_dist = world > 1 or args.force_dist
+    wd = Watchdog(rank, world, enabled=world > 1)
+    wd.phase("set-up (process group, tables, communicator)")
     crosscheck = None
     if not use_dist:
         tr = atlas_amd.Trans(g, TRUNC, profile=True)
@@ -342,6 +383,7 @@ def main():
             return out
 
         if dtr.mode == "alltoall":
+            wd.phase("cross-check of the transposed decomposition against the band decomposition")
             crosscheck = crosscheck_against_bands(dtr, DistributedTrans)
             if not crosscheck["bitwise_equal_on_all_ranks"] and impl == "native":
                 from atlas_amd.dist_torch import DistributedTrans
@@ -362,9 +404,11 @@ def main():
             dist.barrier()
             sync()
 
+    wd.phase("warm-up steps")
     for _ in range(args.warmup):
         step()
     barrier()
+    wd.phase("timed steps")
     tr.timings(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -376,6 +420,7 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=DEVICE)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    wd.phase("after the timed region (alternative decomposition, report)")
     tm = tr.timings()
     transforms = args.steps * world
     ms_per_step = dt / args.steps * 1e3
@@ -528,6 +573,7 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    wd.done()
     if rank == 0:
         # the JSON line is the LAST thing on stdout: RCCL prints its version banner through C stdio, which would
         # otherwise be flushed after Python's line at exit

@@ -144,3 +144,31 @@ def test_bench_dry_run_checks_the_message_plan_without_a_device(ngpus):
     share = d["kept_intermediate_bytes"] / ngpus * (ngpus - 1) / ngpus
     assert 0.8 * share < lo <= hi < 1.2 * share
     assert d["expected_exchange_ms_per_transform"]["assumed_link_GBs"] == 40
+
+
+def _watchdog_worker(outdir):
+    sys.path.insert(0, ROOT)
+    import time
+    import bench
+    os.environ["BENCH_WATCHDOG_S"] = "0.5"
+    sys.stdout = open(os.path.join(outdir, "wd_stdout.txt"), "w")
+    wd = bench.Watchdog(rank=0, world=2, enabled=True)
+    wd.phase("a phase that finishes")
+    wd.phase("a phase that hangs")
+    time.sleep(30)
+
+
+def test_watchdog_reports_the_hung_phase_of_a_multi_rank_run(tmp_path):
+    """bench.py, N > 1: a phase that does not finish ends the process with status 3 and a JSON line whose value is null"""
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_watchdog_worker, args=(str(tmp_path),))
+    p.start()
+    p.join(20)
+    assert p.exitcode == 3
+    out = json.loads(open(tmp_path / "wd_stdout.txt").read().strip().splitlines()[-1])
+    assert out["value"] is None and out["n_gpus"] == 2 and "a phase that hangs" in out["error"]
+    import bench
+    wd = bench.Watchdog(rank=0, world=1, enabled=False)     # single GPU: never armed
+    wd.phase("x")
+    assert wd.timer is None
+    wd.done()
