@@ -337,12 +337,17 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
 #else
 #define AA_LEAN_WPS 4
 #endif
-__global__ void __launch_bounds__(512, AA_LEAN_WPS) legendre_kernel_lean(LegendreParams p) {
-
-    using L  = LegLds<3, 2, double>;
-    using RT = RealTraits<double>;
+// The body is written once for both scalar types [r3]: Real = double is the kernel described above; Real = float (BASELINE config C5 and the
+// other fp32 calls) is the same kernel with 4-byte elements -- 8-byte table loads, 4-byte spectra loads and fragment reads,
+// v_mfma_f32_16x16x4_f32 -- and the summation order of legendre_kernel<3, 2, float> (bit-identical results).
+template <class Real>
+__device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p) {
+    using L  = LegLds<3, 2, Real>;
+    using RT = RealTraits<Real>;
     using acc_t = typename RT::acc_t;
     constexpr int RTW = 3, NTHR = 512;
+    constexpr int EB   = (int)sizeof(Real);   // element bytes
+    constexpr bool F64 = EB == 8;
     // dynamic LDS: L::BYTES, addressed from absolute offset 0 by the inline asm below.  The kernel must not have static LDS
     // (it would be placed at offset 0 and alias the staging buffers): the extern array is the only declaration.
     extern __shared__ double lean_lds[];
@@ -375,8 +380,8 @@ __global__ void __launch_bounds__(512, AA_LEAN_WPS) legendre_kernel_lean(Legendr
     const int nmax  = trc < TL ? trc : TL;
     const bool m_ok = m < trc;
     const long long ioff = p.sp_moff ? p.sp_moff[m] * nf : (long long)(2 * trc + 3 - m) * m / 2 * nf * 2;
-    const double* __restrict__ sp = p.sp + ioff;
-    const double* __restrict__ Pb = p.P + it.p_off;
+    const Real* __restrict__ sp = p.sp + ioff;
+    const Real* __restrict__ Pb = p.P + it.p_off;
     const int nstage = it.kpad / KB;
     const int ntop_hi = ntop0 > ntop1 ? ntop0 : ntop1, ntop_lo = ntop0 < ntop1 ? ntop0 : ntop1;
 
@@ -388,12 +393,14 @@ __global__ void __launch_bounds__(512, AA_LEAN_WPS) legendre_kernel_lean(Legendr
 
     // ---- staging registers of one stage: one 16-byte table load and three spectra elements per thread ----
     typedef int i4_t __attribute__((ext_vector_type(4)));
+    typedef int i2_t __attribute__((ext_vector_type(2)));
+    using preg_t = std::conditional_t<F64, i4_t, i2_t>;   // two table elements
     constexpr int NSET = 3;   // register sets: the stage being written to LDS and the ones still in flight
-    i4_t preg[NSET];
-    double sreg[NSET][RTW];
+    preg_t preg[NSET];
+    Real sreg[NSET][RTW];
     // table element pair 2 tid of the stage tile [2 parities][8 k][64 latitudes]
     const int pe = 2 * tid, ppar = pe >> 9, pk = (pe & 511) >> 6, pc = pe & 63;
-    const unsigned pbo = 8u * (unsigned)((ppar * it.kpad + pk) * BN + pc);   // bytes from the stage's first table row
+    const unsigned pbo = (unsigned)EB * (unsigned)((ppar * it.kpad + pk) * BN + pc);   // bytes from the stage's first table row
     const int plds     = ppar * (KB * PSTR) + pk * PSTR + pc;
     // spectra element q = tid + 512 i of the stage tile [16 rows (parity, k)][96 columns]
     unsigned sbo[RTW];   // bytes from the stage base (lowest wavenumber row of the stage)
@@ -411,15 +418,15 @@ __global__ void __launch_bounds__(512, AA_LEAN_WPS) legendre_kernel_lean(Legendr
         const int ntop = par ? ntop1 : ntop0;
         scolo[i] = (r & 1) * nf + f;
         sn0[i]   = ntop - 2 * k;
-        sbo[i]   = 8u * (unsigned)((ntop - ntop_lo + 2 * (KB - 1 - k)) * 2 * nf + scolo[i]);
+        sbo[i]   = (unsigned)EB * (unsigned)((ntop - ntop_lo + 2 * (KB - 1 - k)) * 2 * nf + scolo[i]);
         slds[i]  = L::P_ELEM + row * L::SSTR + col;
     }
     // stages whose 16 rows are all inside [m, nmax]
     const int s_ff = ntop_hi > nmax ? (ntop_hi - nmax + 2 * KB - 1) / (2 * KB) : 0;
     const int s_lf = m_ok ? (ntop_lo - 2 * (KB - 1) - m >= 0 ? (ntop_lo - 2 * (KB - 1) - m) / (2 * KB) : -1) : -1;
     // scalar bases of the next stage to be requested (stages are requested in order)
-    const double* pbase = Pb;
-    const double* sbase = sp + (long long)(ntop_lo - 2 * (KB - 1) - m) * 2 * nf;
+    const Real* pbase = Pb;
+    const Real* sbase = sp + (long long)(ntop_lo - 2 * (KB - 1) - m) * 2 * nf;
     const long long sstride = (long long)4 * KB * nf;   // 2 KB wavenumbers down
 
     unsigned szero[NSET] = {0, 0, 0};   // bit i: element i of the staged stage is outside [m, nmax]
@@ -427,11 +434,21 @@ __global__ void __launch_bounds__(512, AA_LEAN_WPS) legendre_kernel_lean(Legendr
     // stage t travels through register set t % 3 into LDS buffer t & 1; it is requested three stages before it is used
     auto load_stage = [&](int s, auto setc) {   // must be called for s = 0, 1, 2, ... in order
         constexpr int SET = decltype(setc)::value;
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(preg[SET]) : "v"(pbo), "s"(pbase) : "memory");
+        if constexpr (F64) {
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(preg[SET]) : "v"(pbo), "s"(pbase) : "memory");
+        }
+        else {
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(preg[SET]) : "v"(pbo), "s"(pbase) : "memory");
+        }
         if (s >= s_ff && s <= s_lf) {
 #pragma unroll
             for (int i = 0; i < RTW; ++i) {
-                asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(sreg[SET][i]) : "v"(sbo[i]), "s"(sbase) : "memory");
+                if constexpr (F64) {
+                    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(sreg[SET][i]) : "v"(sbo[i]), "s"(sbase) : "memory");
+                }
+                else {
+                    asm volatile("global_load_dword %0, %1, %2" : "=v"(sreg[SET][i]) : "v"(sbo[i]), "s"(sbase) : "memory");
+                }
             }
             sedge[SET] = false;
         }
@@ -442,8 +459,13 @@ __global__ void __launch_bounds__(512, AA_LEAN_WPS) legendre_kernel_lean(Legendr
                 const int n  = sn0[i] - 2 * KB * s;
                 const int nc = n < m ? m : (n > nmax ? nmax : n);
                 // one load in every case; outside the spectra of this m read the table
-                const double* src = m_ok ? sp + (long long)(nc - m) * 2 * nf + scolo[i] : p.P;
-                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(sreg[SET][i]) : "v"(src) : "memory");
+                const Real* src = m_ok ? sp + (long long)(nc - m) * 2 * nf + scolo[i] : p.P;
+                if constexpr (F64) {
+                    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(sreg[SET][i]) : "v"(src) : "memory");
+                }
+                else {
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(sreg[SET][i]) : "v"(src) : "memory");
+                }
                 z |= (unsigned)(!m_ok || nc != n) << i;
             }
             szero[SET] = z;
@@ -452,11 +474,11 @@ __global__ void __launch_bounds__(512, AA_LEAN_WPS) legendre_kernel_lean(Legendr
         pbase += KB * BN;
         sbase -= sstride;
     };
-    const unsigned plds_b = 8u * (unsigned)plds;
+    const unsigned plds_b = (unsigned)EB * (unsigned)plds;
     unsigned slds_b[RTW];
 #pragma unroll
     for (int i = 0; i < RTW; ++i) {
-        slds_b[i] = 8u * (unsigned)slds[i];
+        slds_b[i] = (unsigned)EB * (unsigned)slds[i];
     }
     constexpr int LPS = 1 + RTW;   // loads per stage and thread
     auto store_stage = [&](auto bufc, auto setc, int younger_in_flight) {
@@ -474,24 +496,39 @@ __global__ void __launch_bounds__(512, AA_LEAN_WPS) legendre_kernel_lean(Legendr
         }
         // stores as asm volatile as well: they stay behind the wait, and their offsets are immediates
         {
-            const i4_t pv     = preg[SET];
+            const preg_t pv   = preg[SET];
             const unsigned la = plds_b;
-            asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(la), "v"(pv), "n"(buf * L::STAGE * 8) : "memory");
+            if constexpr (F64) {
+                asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(la), "v"(pv), "n"(buf * L::STAGE * EB) : "memory");
+            }
+            else {
+                asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(la), "v"(pv), "n"(buf * L::STAGE * EB) : "memory");
+            }
         }
         if (sedge[SET]) {   // uniform; both arms are asm volatile so that this stays a branch (as selects it is 15 VALU per stage)
 #pragma unroll
             for (int i = 0; i < RTW; ++i) {
-                const double v    = ((szero[SET] >> i) & 1) ? 0. : sreg[SET][i];
+                const Real v      = ((szero[SET] >> i) & 1) ? (Real)0 : sreg[SET][i];
                 const unsigned la = slds_b[i];
-                asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(la), "v"(v), "n"(buf * L::STAGE * 8) : "memory");
+                if constexpr (F64) {
+                    asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(la), "v"(v), "n"(buf * L::STAGE * EB) : "memory");
+                }
+                else {
+                    asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(la), "v"(v), "n"(buf * L::STAGE * EB) : "memory");
+                }
             }
         }
         else {
 #pragma unroll
             for (int i = 0; i < RTW; ++i) {
-                const double v    = sreg[SET][i];
+                const Real v      = sreg[SET][i];
                 const unsigned la = slds_b[i];
-                asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(la), "v"(v), "n"(buf * L::STAGE * 8) : "memory");
+                if constexpr (F64) {
+                    asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(la), "v"(v), "n"(buf * L::STAGE * EB) : "memory");
+                }
+                else {
+                    asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(la), "v"(v), "n"(buf * L::STAGE * EB) : "memory");
+                }
             }
         }
         AA_WAIT_LGKMCNT0();   // the compiler does not see these stores: they must have landed before the barrier
@@ -513,23 +550,36 @@ __global__ void __launch_bounds__(512, AA_LEAN_WPS) legendre_kernel_lean(Legendr
 
     // four steps (parity, 4 wavenumbers) of one A and three B fragments and three MFMAs; the fragments of step t + 1
     // are requested before the MFMAs of step t
-    const unsigned a_b = 8u * (unsigned)a_off, b_b = 8u * (unsigned)b_off;
+    const unsigned a_b = (unsigned)EB * (unsigned)a_off, b_b = (unsigned)EB * (unsigned)b_off;
     auto mma_steps = [&](auto bufc) {
         constexpr int buf = decltype(bufc)::value;
         constexpr int NKS = KB / 4;
-        double a[2], b[2][RTW];
+        Real a[2], b[2][RTW];
         // fragment reads as asm with immediate offsets (the compiler pairs them into ds_read2 and pays a VALU add per pair
         // for the base); their completion is counted by hand: 1 + RTW reads per step, one step in flight
         auto fetch = [&](int t, int slot) {
             const int par = t / NKS, ks = t % NKS;
             const unsigned ab = a_b, bb = b_b;
-            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a[slot]) : "v"(ab), "n"((buf * L::STAGE + (par * KB + ks * 4) * PSTR) * 8) : "memory");
+            if constexpr (F64) {
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a[slot]) : "v"(ab), "n"((buf * L::STAGE + (par * KB + ks * 4) * PSTR) * EB) : "memory");
+            }
+            else {
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(a[slot]) : "v"(ab), "n"((buf * L::STAGE + (par * KB + ks * 4) * PSTR) * EB) : "memory");
+            }
 #pragma unroll
             for (int j = 0; j < RTW; ++j) {
-                asm volatile("ds_read_b64 %0, %1 offset:%2"
-                             : "=v"(b[slot][j])
-                             : "v"(bb), "n"((buf * L::STAGE + (par * KB + ks * 4) * L::SSTR + j * 16) * 8)
-                             : "memory");
+                if constexpr (F64) {
+                    asm volatile("ds_read_b64 %0, %1 offset:%2"
+                                 : "=v"(b[slot][j])
+                                 : "v"(bb), "n"((buf * L::STAGE + (par * KB + ks * 4) * L::SSTR + j * 16) * EB)
+                                 : "memory");
+                }
+                else {
+                    asm volatile("ds_read_b32 %0, %1 offset:%2"
+                                 : "=v"(b[slot][j])
+                                 : "v"(bb), "n"((buf * L::STAGE + (par * KB + ks * 4) * L::SSTR + j * 16) * EB)
+                                 : "memory");
+                }
             }
         };
         fetch(0, 0);
@@ -599,13 +649,13 @@ __global__ void __launch_bounds__(512, AA_LEAN_WPS) legendre_kernel_lean(Legendr
             const int js = nlats - 1 - jn;
             const bool st_n = jn != js && jn >= p.row_begin && jn < p.row_end;
             const bool st_s = js >= p.row_begin && js < p.row_end;
-            double* fn     = p.F + ((long long)(jn - p.row_begin) * p.m_cnt + ml) * RP;
-            double* fs     = p.F + ((long long)(js - p.row_begin) * p.m_cnt + ml) * RP;
+            Real* fn       = p.F + ((long long)(jn - p.row_begin) * p.m_cnt + ml) * RP;
+            Real* fs       = p.F + ((long long)(js - p.row_begin) * p.m_cnt + ml) * RP;
 #pragma unroll
             for (int j = 0; j < RTW; ++j) {
                 const int r = r0 + (rg * RTW + j) * 16 + (lane & 15);
                 if (r < RP) {
-                    double sy = acc[0][j][g], as = acc[1][j][g];
+                    Real sy = acc[0][j][g], as = acc[1][j][g];
                     if ((m == 0 && (r & 1)) || r >= 2 * nf) {   // n_imag = 1 for m = 0; padding columns hold zeros
                         sy = 0;
                         as = 0;
@@ -625,6 +675,27 @@ __global__ void __launch_bounds__(512, AA_LEAN_WPS) legendre_kernel_lean(Legendr
 #endif
 }
 
+__global__ void __launch_bounds__(512, AA_LEAN_WPS) legendre_kernel_lean(LegendreParams p) {
+    legendre_lean_body<double>(p);
+}
+__global__ void __launch_bounds__(512, 4) legendre_kernel_lean_f32(LegendreParamsF32 p) {
+    legendre_lean_body<float>(p);
+}
+
+static hipError_t launch_lean_f32(LegendreParamsF32 p, int nitems, int nchunks, int chunk0, int nrun, hipStream_t stream) {
+    using L = LegLds<3, 2, float>;
+    if (hipError_t e = ensure_dynamic_lds<&legendre_kernel_lean_f32>(L::BYTES); e != hipSuccess) {   // dyn_lds.h
+        return e;
+    }
+    p.nitems        = nitems;
+    p.nchunks       = nchunks;
+    p.chunk0        = chunk0;
+    p.nchunks_run   = nrun;
+    p.abl           = 0;
+    const int slots = (nitems + 7) / 8;
+    hipLaunchKernelGGL(legendre_kernel_lean_f32, dim3(slots * nrun * 8), dim3(L::NTHR), L::BYTES, stream, p);
+    return hipGetLastError();
+}
 static hipError_t launch_lean(LegendreParams p, int nitems, int nchunks, int chunk0, int nrun, hipStream_t stream) {
     using L = LegLds<3, 2, double>;
     if (hipError_t e = ensure_dynamic_lds<&legendre_kernel_lean>(L::BYTES); e != hipSuccess) {   // dyn_lds.h
@@ -737,6 +808,19 @@ hipError_t launch_legendre(const LegendreParams& p, int nitems, int chunk0, int 
 }
 // fp32 variant: same work list, tiling and table layout (the table converted to float)
 hipError_t launch_legendre_f32(const LegendreParamsF32& p, int nitems, int chunk0, int nrun, hipStream_t stream) {
+    int rtw, nrg, nchunks;
+    legendre_tiling(p.nf, rtw, nrg, nchunks);
+    if (rtw == 3 && nrg == 2) {
+        // the 96-column workgroup in its "lean" form for float as well [r3]; ATLAS_AMD_LEG_KERNEL=classic: the generic template
+        const char* e = std::getenv("ATLAS_AMD_LEG_KERNEL");
+        if (!e || std::string(e) == "lean") {
+            if (nrun <= 0) {
+                chunk0 = 0;
+                nrun   = nchunks;
+            }
+            return launch_lean_f32(p, nitems, nchunks, chunk0, nrun, stream);
+        }
+    }
     return launch_legendre_t<float>(p, nitems, chunk0, nrun, stream);
 }
 

@@ -582,17 +582,28 @@ def test_classic_reduced_gaussian_grid_against_oracle():
 LEG_KERNELS = ("classic", "lean")
 
 
-@pytest.mark.parametrize("case", ["scalar_O160_nf40", "vordiv_F64", "sharded_O160_nf44", "band_O160_nf42", "scalar_O64_nf137"])
+@pytest.mark.parametrize("case", ["scalar_O160_nf40", "vordiv_F64", "sharded_O160_nf44", "band_O160_nf42", "scalar_O64_nf137",
+                                  "f32_O160_nf40", "f32_O64_nf137", "f32_F64_nf44"])
 def test_legendre_kernel_variants_are_bitwise_equal(case, monkeypatch):
     """The 96-column workgroup of the Legendre stage (field counts whose 16-column tiles come in sixes: nf 33..48, 81..96,
     129..144, ...) has two implementations of the same arithmetic in the same order: the generic template ("classic") and
-    the default without vector-ALU work in its stage loop ("lean").  (Three more that lost -- "split", "dma", "lean2" -- live in
+    the default without vector-ALU work in its stage loop ("lean"), both in fp64 and in the fp32 variant.  (Three more that lost -- "split", "dma", "lean2" -- live in
     tools/experiments and are compared the same way by tools/experiments/test_experiments.py on an experiments build.)
     ATLAS_AMD_LEG_KERNEL is read at every launch; every entry point that reaches the stage must give identical bits."""
     outs = {}
     for kernel in LEG_KERNELS:
         monkeypatch.setenv("ATLAS_AMD_LEG_KERNEL", kernel)
-        if case.startswith("scalar"):
+        if case.startswith("f32"):
+            # the fp32 variant [r3]: legendre_kernel<3, 2, float> ("classic") against the float instantiation of the lean body
+            gridname, T, nf = {"f32_O160_nf40": ("O160", 159, 40), "f32_O64_nf137": ("O64", 63, 137), "f32_F64_nf44": ("F64", 63, 44)}[case]
+            g, tr = get_trans(gridname, T)
+            sp32 = red_spectra(T, nf, seed=14).astype(np.float32)
+            gp = torch.full((nf * g.size(),), float("nan"), dtype=torch.float32, device="cuda")
+            tr.invtrans(nf, torch.from_numpy(sp32).cuda(), gp)
+            tr.synchronize()
+            outs[kernel] = gp.cpu().numpy()
+            assert np.isfinite(outs[kernel]).all()
+        elif case.startswith("scalar"):
             gridname, T, nf = ("O160", 159, 40) if "O160" in case else ("O64", 63, 137)
             g, tr = get_trans(gridname, T)
             outs[kernel] = run_device(tr, nf, red_spectra(T, nf, seed=11))
