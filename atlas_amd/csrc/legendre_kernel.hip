@@ -340,12 +340,14 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
 // The body is written once for both scalar types [r3]: Real = double is the kernel described above; Real = float (BASELINE config C5 and the
 // other fp32 calls) is the same kernel with 4-byte elements -- 8-byte table loads, 4-byte spectra loads and fragment reads,
 // v_mfma_f32_16x16x4_f32 -- and the summation order of legendre_kernel<3, 2, float> (bit-identical results).
-template <class Real>
+// RTW = 16-column tiles per wavefront (1, 2 or 3; two column groups: 32 / 64 / 96 columns per workgroup) -- whatever
+// legendre_tiling() chooses for the field count, as long as the workgroup has its two column groups.
+template <int RTW, class Real>
 __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p) {
-    using L  = LegLds<3, 2, Real>;
+    using L  = LegLds<RTW, 2, Real>;
     using RT = RealTraits<Real>;
     using acc_t = typename RT::acc_t;
-    constexpr int RTW = 3, NTHR = 512;
+    constexpr int NTHR = 512;
     constexpr int EB   = (int)sizeof(Real);   // element bytes
     constexpr bool F64 = EB == 8;
     // dynamic LDS: L::BYTES, addressed from absolute offset 0 by the inline asm below.  The kernel must not have static LDS
@@ -676,10 +678,30 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
 }
 
 __global__ void __launch_bounds__(512, AA_LEAN_WPS) legendre_kernel_lean(LegendreParams p) {
-    legendre_lean_body<double>(p);
+    legendre_lean_body<3, double>(p);
 }
 __global__ void __launch_bounds__(512, 4) legendre_kernel_lean_f32(LegendreParamsF32 p) {
-    legendre_lean_body<float>(p);
+    legendre_lean_body<3, float>(p);
+}
+// the narrower workgroups (field counts whose tiles come in fours or twos per column chunk)
+template <int RTW, class Real>
+__global__ void __launch_bounds__(512, 4) legendre_kernel_lean_n(LegendreParamsT<Real> p) {
+    legendre_lean_body<RTW, Real>(p);
+}
+template <int RTW, class Real>
+static hipError_t launch_lean_n(LegendreParamsT<Real> p, int nitems, int nchunks, int chunk0, int nrun, hipStream_t stream) {
+    using L = LegLds<RTW, 2, Real>;
+    if (hipError_t e = ensure_dynamic_lds<&legendre_kernel_lean_n<RTW, Real>>(L::BYTES); e != hipSuccess) {   // dyn_lds.h
+        return e;
+    }
+    p.nitems        = nitems;
+    p.nchunks       = nchunks;
+    p.chunk0        = chunk0;
+    p.nchunks_run   = nrun;
+    p.abl           = 0;
+    const int slots = (nitems + 7) / 8;
+    hipLaunchKernelGGL((legendre_kernel_lean_n<RTW, Real>), dim3(slots * nrun * 8), dim3(L::NTHR), L::BYTES, stream, p);
+    return hipGetLastError();
 }
 
 static hipError_t launch_lean_f32(LegendreParamsF32 p, int nitems, int nchunks, int chunk0, int nrun, hipStream_t stream) {
@@ -804,6 +826,17 @@ hipError_t launch_legendre(const LegendreParams& p, int nitems, int chunk0, int 
         }
 #endif
     }
+    if (nrg == 2 && (rtw == 1 || rtw == 2)) {
+        const char* e = std::getenv("ATLAS_AMD_LEG_KERNEL");
+        if (!e || std::string(e) == "lean") {
+            if (nrun <= 0) {
+                chunk0 = 0;
+                nrun   = nchunks;
+            }
+            return rtw == 1 ? launch_lean_n<1, double>(p, nitems, nchunks, chunk0, nrun, stream)
+                            : launch_lean_n<2, double>(p, nitems, nchunks, chunk0, nrun, stream);
+        }
+    }
     return launch_legendre_t<double>(p, nitems, chunk0, nrun, stream);
 }
 // fp32 variant: same work list, tiling and table layout (the table converted to float)
@@ -819,6 +852,17 @@ hipError_t launch_legendre_f32(const LegendreParamsF32& p, int nitems, int chunk
                 nrun   = nchunks;
             }
             return launch_lean_f32(p, nitems, nchunks, chunk0, nrun, stream);
+        }
+    }
+    if (nrg == 2 && (rtw == 1 || rtw == 2)) {
+        const char* e = std::getenv("ATLAS_AMD_LEG_KERNEL");
+        if (!e || std::string(e) == "lean") {
+            if (nrun <= 0) {
+                chunk0 = 0;
+                nrun   = nchunks;
+            }
+            return rtw == 1 ? launch_lean_n<1, float>(p, nitems, nchunks, chunk0, nrun, stream)
+                            : launch_lean_n<2, float>(p, nitems, nchunks, chunk0, nrun, stream);
         }
     }
     return launch_legendre_t<float>(p, nitems, chunk0, nrun, stream);

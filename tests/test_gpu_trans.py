@@ -583,7 +583,8 @@ LEG_KERNELS = ("classic", "lean")
 
 
 @pytest.mark.parametrize("case", ["scalar_O160_nf40", "vordiv_F64", "sharded_O160_nf44", "band_O160_nf42", "scalar_O64_nf137",
-                                  "f32_O160_nf40", "f32_O64_nf137", "f32_F64_nf44"])
+                                  "f32_O160_nf40", "f32_O64_nf137", "f32_F64_nf44",
+                                  "scalar_O160_nf60", "scalar_O64_nf25", "scalar_O64_nf10", "f32_O160_nf60", "f32_O64_nf10"])
 def test_legendre_kernel_variants_are_bitwise_equal(case, monkeypatch):
     """The 96-column workgroup of the Legendre stage (field counts whose 16-column tiles come in sixes: nf 33..48, 81..96,
     129..144, ...) has two implementations of the same arithmetic in the same order: the generic template ("classic") and
@@ -595,7 +596,8 @@ def test_legendre_kernel_variants_are_bitwise_equal(case, monkeypatch):
         monkeypatch.setenv("ATLAS_AMD_LEG_KERNEL", kernel)
         if case.startswith("f32"):
             # the fp32 variant [r3]: legendre_kernel<3, 2, float> ("classic") against the float instantiation of the lean body
-            gridname, T, nf = {"f32_O160_nf40": ("O160", 159, 40), "f32_O64_nf137": ("O64", 63, 137), "f32_F64_nf44": ("F64", 63, 44)}[case]
+            gridname, T, nf = {"f32_O160_nf40": ("O160", 159, 40), "f32_O64_nf137": ("O64", 63, 137), "f32_F64_nf44": ("F64", 63, 44),
+                               "f32_O160_nf60": ("O160", 159, 60), "f32_O64_nf10": ("O64", 63, 10)}[case]
             g, tr = get_trans(gridname, T)
             sp32 = red_spectra(T, nf, seed=14).astype(np.float32)
             gp = torch.full((nf * g.size(),), float("nan"), dtype=torch.float32, device="cuda")
@@ -604,7 +606,10 @@ def test_legendre_kernel_variants_are_bitwise_equal(case, monkeypatch):
             outs[kernel] = gp.cpu().numpy()
             assert np.isfinite(outs[kernel]).all()
         elif case.startswith("scalar"):
-            gridname, T, nf = ("O160", 159, 40) if "O160" in case else ("O64", 63, 137)
+            # nf = 60: 8 tiles in two column chunks of four (two per wavefront); 25: four tiles in one chunk; 10: two tiles (one per
+            # wavefront) -- the narrower instances of the lean body [r3]
+            gridname, T, nf = {"scalar_O160_nf40": ("O160", 159, 40), "scalar_O64_nf137": ("O64", 63, 137), "scalar_O160_nf60": ("O160", 159, 60),
+                               "scalar_O64_nf25": ("O64", 63, 25), "scalar_O64_nf10": ("O64", 63, 10)}[case]
             g, tr = get_trans(gridname, T)
             outs[kernel] = run_device(tr, nf, red_spectra(T, nf, seed=11))
         elif case == "vordiv_F64":
