@@ -38,6 +38,7 @@ def _sig(name, restype, *argtypes):
 
 
 last_error = _sig("atlas_amd__last_error", C.c_char_p)
+last_note = _sig("atlas_amd__last_note", C.c_char_p)
 version = _sig("atlas_amd__version", C.c_char_p)
 device_count = _sig("atlas_amd__device_count", C.c_int)
 stream_wait_stream = _sig("atlas_amd__stream_wait_stream", C.c_int, c_void_p, c_void_p)
@@ -153,6 +154,7 @@ Trans_legendre_device = _sig("atlas_amd__Trans__legendre_device", C.c_int, c_voi
 Trans_fourier_device = _sig("atlas_amd__Trans__fourier_device", C.c_int, c_void_p, C.c_int, C.c_int, c_void_p,
                             c_void_p, c_void_p)
 Trans_nlat0 = _sig("atlas_amd__Trans__nlat0", C.c_int, c_void_p, c_void_p)
+Trans_fft_row_classes = _sig("atlas_amd__Trans__fft_row_classes", C.c_int, c_void_p, c_void_p)
 Trans_legendre_flops = _sig("atlas_amd__Trans__legendre_flops", C.c_double, c_void_p, C.c_int)
 Trans_legendre_table_bytes = _sig("atlas_amd__Trans__legendre_table_bytes", C.c_int64, c_void_p)
 Trans_mirror_rows = _sig("atlas_amd__Trans__mirror_rows", C.c_int, c_void_p, c_void_p)

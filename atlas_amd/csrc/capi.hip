@@ -25,6 +25,7 @@ using namespace atlas_amd;
 
 
 namespace atlas_amd {
+thread_local std::string g_last_note;    // diagnostics that are not errors (e.g. accepted-and-ignored option keys)
 thread_local std::string g_last_error;
 void set_last_error(const std::string& s) {
     g_last_error = s;
@@ -83,6 +84,9 @@ hipError_t launch_vd2uv(const double* vor, const double* div, double* U, double*
 
 extern "C" {
 
+const char* atlas_amd__last_note(void) {
+    return atlas_amd::g_last_note.c_str();
+}
 const char* atlas_amd__last_error(void) {
     return atlas_amd::g_last_error.c_str();
 }
@@ -285,7 +289,36 @@ atlas_amd_Trans* atlas_amd__Trans__new_config(const atlas_amd_Grid* grid, int tr
     }
     trans::TransConfig cfg;
     bool mirror = false;
+    atlas_amd::g_last_note.clear();
+    // TransLocal's own option keys (src/atlas/option/TransOptions.cc:38-74, read at TransLocal.cc:61-110,326-335): every existing
+    // caller of trans::Trans(grid, T, option::type("local") | option::fft("FFTW") | ...) passes some of them.  They select
+    // third-party kernels or side files this implementation does not have (its FFT and GEMM are its own kernels, its tables are
+    // always precomputed): accepted, validated where the reference validates, and otherwise ignored -- with a note.
+    static const char* const ignored_keys[] = {"matrix_multiply", "precompute", "warning", "write_fft", "read_fft", "write_legendre",
+                                               "read_legendre", "export_legendre", "global", "split_y", "nproma", "flt",
+                                               "scalar_derivatives", "wind_EW_derivatives", "vorticity_divergence_fields"};
+    auto note_ignored = [](const std::string& k, const std::string& v) {
+        if (!atlas_amd::g_last_note.empty()) {
+            atlas_amd::g_last_note += "; ";
+        }
+        atlas_amd::g_last_note += "option '" + k + "=" + v + "' accepted and ignored (TransLocal key without a counterpart here)";
+    };
     for (auto& kv : parse_config(config)) {
+        bool ign = false;
+        for (const char* k : ignored_keys) {
+            ign = ign || kv.first == k;
+        }
+        if (ign) {
+            note_ignored(kv.first, kv.second);
+            continue;
+        }
+        if (kv.first == "fft") {   // TransLocal.cc:90-103: OFF | FFTW | pocketfft, anything else throws
+            if (kv.second != "OFF" && kv.second != "FFTW" && kv.second != "pocketfft") {
+                throw std::invalid_argument("FFT backend \"" + kv.second + "\" is not one of the supported : OFF, FFTW, pocketfft");
+            }
+            note_ignored(kv.first, kv.second);   // (OFF selects the reference's dense Fourier matrix: same numbers, own FFT here)
+            continue;
+        }
         if (kv.first == "profile") {
             cfg.profile = std::stoi(kv.second) != 0;
         }
@@ -864,6 +897,25 @@ int atlas_amd__Trans__nlat0(const atlas_amd_Trans* t, int out[]) {
     const auto& v = t->impl->geometry().nlat0;
     std::memcpy(out, v.data(), sizeof(int) * v.size());
     return 0;
+}
+int atlas_amd__Trans__fft_row_classes(const atlas_amd_Trans* t, int out[]) {
+    AA_TRY
+    if (!t || !t->impl || !out) {
+        throw std::invalid_argument("fft_row_classes: null argument");
+    }
+    const auto& geo = t->impl->geometry();
+    const auto& ps  = t->impl->fft_plans();
+    for (int j = 0; j < geo.nlats; ++j) {
+        const int pi = ps.plan_index(geo.regular ? geo.nxmax : geo.nx[j]);
+        if (pi < 0) {
+            throw std::logic_error("fft_row_classes: row without a plan");
+        }
+        const fft::FftRowPlan& pl = ps.plans[pi];
+        out[3 * j]     = pl.method;
+        out[3 * j + 1] = pl.shape.M;
+        out[3 * j + 2] = t->impl->fft_row_kernel(pl);
+    }
+    AA_CATCH_INT
 }
 double atlas_amd__Trans__legendre_flops(const atlas_amd_Trans* t, int nb_fields) {
     return trans::legendre_flops(t->impl->geometry(), nb_fields);

@@ -69,6 +69,9 @@ public:
     const TransGeometry& geometry() const { return geo_; }
     const LegendreWork& legendre_work() const { return work_; }
     const fft::FftPlanSet& fft_plans() const { return fftplans_; }
+    // which kernel a row with this plan is launched with: 0 run-time shaped (fft_rows_kernel), 1 specialised Bluestein
+    // (fft_rows_ct_kernel), 2 specialised direct (fft_rows_dct_kernel), 3 dense-stage experiment, 4 native mixed radix
+    int fft_row_kernel(const fft::FftRowPlan& pl) const;
     int nparts() const { return cfg_.nparts; }
     int part() const { return cfg_.part; }
     int band_begin() const { return bands_[cfg_.part]; }

@@ -525,6 +525,19 @@ void Trans::upload() {
     }
 }
 
+int Trans::fft_row_kernel(const fft::FftRowPlan& pl) const {
+    if (pl.method == fft::FFT_HYBRID) {
+        return 3;
+    }
+    if (use_ct_ && pl.ct_k >= 0 && pl.method == fft::FFT_BLUESTEIN) {
+        return 1;
+    }
+    if (use_ct_ && pl.ct_k >= 0 && pl.method == fft::FFT_DIRECT) {
+        return 2;
+    }
+    return 0;
+}
+
 int Trans::fourier_row_pitch(int nb_fields) const {
     return (2 * nb_fields + 15) / 16 * 16;
 }

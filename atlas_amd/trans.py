@@ -40,7 +40,7 @@ class Trans:
     """trans::Trans(grid, truncation, config) with option::type("local") semantics, running on an MI355X."""
 
     def __init__(self, grid, truncation, profile=False, nparts=1, part=0, legendre_cache=None, shard="m", rows=None,
-                 tables=None, domain=None):
+                 tables=None, domain=None, **options):
         if isinstance(grid, str):
             grid = StructuredGrid(name=grid)
         self.grid = grid
@@ -57,11 +57,14 @@ class Trans:
             if rows is not None:
                 raise ValueError("give rows= or domain=, not both")
             cfg += ";domain=" + ",".join(repr(float(v)) for v in domain)
+        for k, v in options.items():   # atlas option:: keys (fft="FFTW", matrix_multiply=..., warning=0, ...): passed through
+            cfg += f";{k}={int(v) if isinstance(v, bool) else v}"
         cache_ptr, cache_size = None, 0
         if legendre_cache is not None:
             self._cache = np.ascontiguousarray(np.frombuffer(legendre_cache, dtype=np.uint8))
             cache_ptr, cache_size = self._cache.ctypes.data, self._cache.size
         self._h = _lib.check_ptr(_lib.Trans_new_config(grid._h, int(truncation), cfg.encode(), cache_ptr, cache_size))
+        self.notes = _lib.last_note().decode("utf-8", "replace")   # e.g. the TransLocal option keys that were accepted and ignored
         self.nparts, self.part, self.shard = int(nparts), int(part), shard
         self.rows = rows
         self.domain = domain
@@ -290,6 +293,12 @@ class Trans:
     def nlat0(self):
         out = np.zeros(self.truncation() + 1, dtype=np.int32)
         _lib.Trans_nlat0(self._h, out.ctypes.data)
+        return out
+
+    def fft_row_classes(self):
+        """(nlats, 3) int array: FftMethod, transform length M and kernel kind of every latitude row (include/atlas_amd.h)"""
+        out = np.zeros((len(self.grid.nx()), 3), dtype=np.int32)
+        _lib.check(_lib.Trans_fft_row_classes(self._h, out.ctypes.data))
         return out
 
     def legendre_flops(self, nf):

@@ -34,6 +34,10 @@ typedef struct atlas_amd_StructuredColumns atlas_amd_StructuredColumns;
  * errors / library info
  * ------------------------------------------------------------------------------------------------------------- */
 const char* atlas_amd__last_error(void);
+/* thread-local diagnostics that are not errors, set by the last call that has any (empty otherwise): e.g. the TransLocal option
+ * keys atlas_amd__Trans__new_config accepted and ignored (fft, matrix_multiply, precompute, warning, write_fft, ...;
+ * src/atlas/option/TransOptions.cc:38-74, TransLocal.cc:61-110) */
+const char* atlas_amd__last_note(void);
 const char* atlas_amd__version(void);
 /* number of visible HIP devices (0: the transform cannot run; there is no CPU fallback) */
 int atlas_amd__device_count(void);
@@ -91,6 +95,12 @@ atlas_amd_Trans* atlas_amd__Trans__new(const atlas_amd_Grid* grid, int truncatio
  *                        regional case of TransLocal (TransLocal.cc:394-470) for domains that keep whole rows;
  *                        nb_gridpoints and the output arrays then cover these rows only
  *   type=local|mi355x    accepted for atlas option::type compatibility
+ *   fft=OFF|FFTW|pocketfft, matrix_multiply=..., precompute=..., warning=..., write_fft=..., read_fft=..., write_legendre=...,
+ *   read_legendre=..., export_legendre=..., global=..., split_y=..., nproma=..., flt=..., scalar_derivatives=..., ...
+ *                        TransLocal's own option keys (option/TransOptions.cc:38-74; read at TransLocal.cc:61-110,326-335):
+ *                        accepted and ignored -- FFT and GEMM are this library's kernels, the tables are always precomputed,
+ *                        cache files are the caller's (legendre_cache argument; adapter/TransMI355X.cc handles write_legendre)
+ *                        -- each with an entry in atlas_amd__last_note(); an fft value the reference rejects is rejected
  *   tables=host|device   where the Legendre table is computed when no cache is given: on the host (OpenMP, then
  *                        uploaded) or on the device from O(T^2) host-prepared inputs (bit-identical; default: the
  *                        environment variable ATLAS_AMD_TABLES, else device: 0.9 s against 6.7 s at TL1279)
@@ -276,6 +286,11 @@ int atlas_amd__Trans__fourier_device(atlas_amd_Trans* t, int nb_fields, int nb_v
 
 /* introspection used by tests */
 int atlas_amd__Trans__nlat0(const atlas_amd_Trans* t, int nlat0_out[] /* T+1 */);
+/* the Fourier kernel every latitude row of the grid takes: out[3 j] = method (csrc/fft_plan.h: FftMethod), out[3 j + 1] = transform
+ * length M of the row's plan (Bluestein: the convolution length; direct / native rows: n/2), out[3 j + 2] = kernel
+ * (0 run-time shaped, 1 specialised Bluestein, 2 specialised direct, 3 dense-stage experiment, 4 native mixed radix).  Parity tests
+ * take one northern and one southern row of every (method, M, kernel) that is launched (TransLocal.cc:1155-1196 treats all rows alike) */
+int atlas_amd__Trans__fft_row_classes(const atlas_amd_Trans* t, int out[] /* 3 * nlats */);
 double atlas_amd__Trans__legendre_flops(const atlas_amd_Trans* t, int nb_fields);
 int64_t atlas_amd__Trans__legendre_table_bytes(const atlas_amd_Trans* t);
 /* accumulated kernel times from HIP events on the Trans stream (profile=1):

@@ -22,6 +22,24 @@ def red_spectra(T, nf, seed=20251114, trc=None):
     return sp.reshape(-1)
 
 
+def rows_of_every_fft_class(tr, extra=()):
+    """One northern and one southern latitude row of every Fourier kernel class the transform launches -- (method, transform
+    length, kernel) as reported by the library (atlas_amd__Trans__fft_row_classes) -- plus `extra`.  Northern: the longest
+    row of the class (most kept wavenumbers), southern: the shortest, so that two different lengths of a class are compared.
+    The reference runs one code path for every row (TransLocal.cc:1155-1196); here every class is its own kernel instance."""
+    cls = tr.fft_row_classes()
+    ny = len(cls)
+    north, south = {}, {}
+    for j in range(ny):
+        key = tuple(int(v) for v in cls[j])
+        if j < ny // 2:
+            north[key] = j          # the last northern row of a class is its longest
+        else:
+            south[key] = j          # the last southern row of a class is its shortest
+    rows = sorted(set(north.values()) | set(south.values()) | set(int(r) for r in extra))
+    return rows, sorted(set(north) | set(south))
+
+
 def pos(T, m, n):
     return (2 * T + 3 - m) * m // 2 + (n - m)
 

@@ -77,6 +77,44 @@ def test_single_gpu_line_has_roofline_and_cpu_baseline(tmp_path):
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "transforms/s"
     assert "multi_gpu_crosscheck" not in out and "alt_decomposition" not in out
+    # the full-field parity block: every grid point of the CPU baseline's transform against the device result
+    # of the same spectra (here the stand-in "device" computes something else: only the bookkeeping is checked)
+    par = out["parity"]
+    assert par["fields"] == 2 and par["rows"] == 32 and par["points"] > 0 and par["tolerance_rel_rms"] == 1e-12
+    assert set(par) >= {"rel_rms", "max_abs", "ok", "against"}
+
+
+def test_gpus_n_without_a_launcher_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` the way the driver launches N = 1 (no torch.distributed.run): the script re-executes itself
+    under the launcher, rendezvous on 127.0.0.1, and rank 0 prints the one JSON line.  Stand-in transform
+    over gloo (BENCH_TEST_STANDIN=1), as everywhere in this file."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update({"BENCH_TEST_STANDIN": "1", "BENCH_TEST_GRID": "O16", "BENCH_WATCHDOG_S": "200"})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "no launcher (WORLD_SIZE unset)" in r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    for k in REQUIRED:
+        assert k in out, k
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["test_standin"] is True
+    assert out["metric"].startswith("STAND-IN")
+    assert out["config"]["parallelism"].startswith("m-sharded")
+    assert out["multi_gpu_crosscheck"]["bitwise_equal_on_all_ranks"] is True
+
+
+def test_a_launcher_with_the_wrong_rank_count_is_an_error(tmp_path):
+    import subprocess
+    env = dict(os.environ)
+    env.update({"BENCH_TEST_STANDIN": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert r.returncode != 0 and "--nproc-per-node 4" in (r.stderr + r.stdout)
 
 
 def test_two_ranks_time_the_named_decomposition_and_report_the_mirror_bands_beside_it(tmp_path):

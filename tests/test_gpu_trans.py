@@ -13,7 +13,7 @@ import pytest
 import atlas_amd
 import oracle
 from atlas_amd import _lib
-from helpers import (CLOSED_FORMS, analytic_scalar, compute_rms, red_spectra, unit_spectrum, wind_kat)
+from helpers import (CLOSED_FORMS, analytic_scalar, compute_rms, red_spectra, rows_of_every_fft_class, unit_spectrum, wind_kat)
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -267,6 +267,22 @@ def test_fourier_scheduling_switches_do_not_change_results(monkeypatch):
         assert np.array_equal(got, ref), env
 
 
+def test_translocal_option_keys_are_accepted_and_change_nothing():
+    """trans::Trans(grid, T, option::type("local") | option::fft("FFTW") | option::matrix_multiply(...) | option::warning(0)):
+    keys every existing TransLocal caller passes (TransLocal.cc:61-110,326-335) -- accepted, noted, same bits"""
+    g, tr = get_trans("O32", 31)
+    sp = red_spectra(31, 3, seed=5)
+    ref = run_device(tr, 3, sp)
+    tr2 = atlas_amd.Trans(g, 31, type="local", fft="FFTW", matrix_multiply="lapack", precompute=True, warning=0,
+                          write_fft="/tmp/unused.fft")
+    for k in ("fft=FFTW", "matrix_multiply=lapack", "precompute=1", "warning=0", "write_fft=/tmp/unused.fft"):
+        assert k in tr2.notes, tr2.notes
+    assert np.array_equal(run_device(tr2, 3, sp), ref)
+    assert atlas_amd.Trans(g, 31).notes == ""
+    with pytest.raises(_lib.AtlasAmdError, match="FFT backend"):
+        atlas_amd.Trans(g, 31, fft="FFT992")
+
+
 def test_not_implemented_like_translocal():
     g, tr = get_trans("O32", 31)
     with pytest.raises(NotImplementedError):
@@ -283,17 +299,27 @@ def trans_full():
 
 
 def test_full_size_sampled_rows_against_oracle(trans_full):
+    """TL1279 -> O1280, all 137 fields: one northern and one southern row of EVERY Fourier kernel class that is launched (the
+    library reports the class of each row), at the full mode count of the row -- the 1280-piece LDS-DMA gather, the zero-filled
+    staging above mmax, the L2 prefetch and the packed mode offsets only run at this size (Bluestein
+    M = 5120 / 4096 / 2048 / 2560 ... were never sampled) -- plus the rows of rounds 1 - 3."""
     g, tr = trans_full
     T, nf = 1279, 137
     sp = red_spectra(T, nf)
     gp = run_device(tr, nf, sp).reshape(nf, -1)
     # 1275: n = 5120, h = 2560 -> specialised direct kernel; 540 / 900 / 1100: Bluestein lengths 2304 / 3840 / 4608
     # ([9,16,16], [15,16,16], [18,16,16]); 1147: h = 2304 itself -> direct kernel of that shape
-    rows = [0, 1, 540, 639, 900, 1100, 1147, 1275, 1279, 1280, 2000, 2559]
+    rows, classes = rows_of_every_fft_class(tr, extra=[0, 1, 540, 639, 900, 1100, 1147, 1275, 1279, 1280, 2000, 2559])
+    launched_M = {c[1] for c in classes if c[2] == 1}
+    assert {256, 1024, 1280, 1536, 2048, 2560, 3072, 4096, 5120, 6144} <= launched_M, launched_M
     op = oracle.OraclePlan(T, g.nx(), g.y(), with_tables=False)
     off = np.concatenate([[0], np.cumsum(g.nx())])
+    worst = 0.0
     for r, ref in zip(rows, op.invtrans_rows(nf, sp, rows, use_fft=True)):
-        assert compute_rms(gp[:, off[r]:off[r + 1]], ref) < 1e-12, r
+        err = compute_rms(gp[:, off[r]:off[r + 1]], ref)
+        worst = max(worst, err)
+        assert err < 1e-12, (r, tuple(tr.fft_row_classes()[r]), err)
+    print(f"full size: {len(rows)} rows of {len(classes)} classes, worst rel-rms {worst:.2e}")
 
 
 def test_full_size_linearity(trans_full):
@@ -528,7 +554,7 @@ def test_config_C4_batch_of_ten_transforms_sampled_rows(trans_full):
     v, v137 = gp.view(nf, -1), gp137.view(137, -1)
     for f in (0, 136, 137, 700, 1369):                 # field f of the batch == field f % 137 of the single transform
         assert torch.equal(v[f], v137[f % 137]), f
-    rows = [3, 1279, 2100]
+    rows, _ = rows_of_every_fft_class(tr, extra=[3, 1279, 2100])     # a northern and a southern row of every kernel class
     fields = [5, 640, 1368]
     op = oracle.OraclePlan(T, g.nx(), g.y(), with_tables=False)
     off = np.concatenate([[0], np.cumsum(g.nx())])
@@ -552,7 +578,7 @@ def test_config_C5_fp32_on_F1280_137_levels_against_the_oracle():
     tr.invtrans(nf, torch.from_numpy(sp32).cuda(), gp)
     tr.synchronize()
     assert bool(torch.isfinite(gp).all())
-    rows = [0, 11, 1279, 1280, 2559]
+    rows, _ = rows_of_every_fft_class(tr, extra=[0, 11, 1279, 1280, 2559])
     op = oracle.OraclePlan(T, g.nx(), g.y(), with_tables=False)
     off = np.concatenate([[0], np.cumsum(g.nx())])
     v = gp.view(nf, -1)
@@ -571,8 +597,9 @@ def test_classic_reduced_gaussian_grid_against_oracle():
     g = atlas_amd.Grid("N1280")
     T, nf = 1279, 5
     sp = red_spectra(T, nf, seed=72)
-    gp = run_device(atlas_amd.Trans(g, T), nf, sp).reshape(nf, -1)
-    rows = [0, 300, 1279, 2559]
+    tr = atlas_amd.Trans(g, T)
+    gp = run_device(tr, nf, sp).reshape(nf, -1)
+    rows, _ = rows_of_every_fft_class(tr, extra=[0, 300, 1279, 2559])
     op = oracle.OraclePlan(T, g.nx(), g.y(), with_tables=False)
     off = np.concatenate([[0], np.cumsum(g.nx())])
     for r, ref in zip(rows, op.invtrans_rows(nf, sp, rows, use_fft=True)):

@@ -270,6 +270,35 @@ def test_fft_hybrid_phase_code_on_every_row_length_of_O1280():
     assert worst < 2e-15, worst
 
 
+def test_translocal_option_keys_are_accepted_at_the_c_abi():
+    """Every existing caller of trans::Trans(grid, T, option::type("local") | option::fft("FFTW") | ...) passes TransLocal's own
+    keys (option/TransOptions.cc:38-74, TransLocal.cc:61-110,326-335): the C ABI must not reject them as unknown.  Without a
+    device the constructor still fails -- but on the device, not on the key; an fft value the reference rejects
+    (TransLocal.cc:90-99) is rejected with its message, and a key nobody knows stays an error."""
+    g = atlas_amd.Grid("F8")
+
+    def new(cfg):
+        h = _lib.Trans_new_config(g._h, 7, cfg.encode(), None, 0)
+        if h:
+            note = _lib.last_note().decode()
+            _lib.Trans_delete(h)
+            return None, note
+        return _lib.last_error().decode(), None
+
+    err, note = new("type=local;fft=FFTW;matrix_multiply=lapack;precompute=1;warning=0;write_fft=/tmp/x.fft;flt=0;split_y=0")
+    if err is None:
+        for k in ("fft=FFTW", "matrix_multiply=lapack", "precompute=1", "warning=0", "write_fft=/tmp/x.fft"):
+            assert k in note, note
+    else:
+        assert "unknown config key" not in err and "FFT backend" not in err, err
+    err, _ = new("fft=FFT992")
+    assert err is not None and 'FFT backend "FFT992" is not one of the supported' in err
+    err, _ = new("no_such_key=1")
+    assert err is not None and "unknown config key 'no_such_key'" in err
+    err, note = new("fft=pocketfft")
+    assert err is None or "FFT backend" not in err
+
+
 def test_not_implemented_entry_points_behave_like_translocal():
     # TransLocal: dirtrans / adjoints are ATLAS_NOTIMPLEMENTED (TransLocal.cc:848-857,899-927,1599-1685)
     assert _lib.Trans_dirtrans_scalar(None, 1, None, None) != 0
