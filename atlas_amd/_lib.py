@@ -182,6 +182,9 @@ LegendreCacheCreator_estimate = _sig("atlas_amd__LegendreCacheCreator__estimate"
 LegendreCacheCreator_supported = _sig("atlas_amd__LegendreCacheCreator__supported", C.c_int, c_void_p)
 fft_host_row = _sig("atlas_amd__fft_host_row", C.c_int, C.c_int, c_void_p, C.c_int, c_void_p)
 fft_host_row_generic = _sig("atlas_amd__fft_host_row_generic", C.c_int, C.c_int, c_void_p, C.c_int, c_void_p)
+fft_host_row_bluestein = _sig("atlas_amd__fft_host_row_bluestein", C.c_int, C.c_int, c_void_p, C.c_int, c_void_p)
+fft_host_row_native = _sig("atlas_amd__fft_host_row_native", C.c_int, C.c_int, c_void_p, C.c_int, c_void_p)
+fft_plan_info = _sig("atlas_amd__fft_plan_info", C.c_int, C.c_int, C.c_int, c_void_p)
 fft_host_row_hybrid = _sig("atlas_amd__fft_host_row_hybrid", C.c_int, C.c_int, c_void_p, C.c_int, c_void_p)
 fft_host_row_coarse = _sig("atlas_amd__fft_host_row_coarse", C.c_int, C.c_int, c_void_p, C.c_int, c_void_p)
 

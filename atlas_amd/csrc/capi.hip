@@ -914,6 +914,9 @@ int atlas_amd__Trans__fft_row_classes(const atlas_amd_Trans* t, int out[]) {
         out[3 * j]     = pl.method;
         out[3 * j + 1] = pl.shape.M;
         out[3 * j + 2] = t->impl->fft_row_kernel(pl);
+        if (pl.method == fft::FFT_NATIVE) {   // every native half length is its own shape: the class is (first radix, stages)
+            out[3 * j + 1] = pl.nat.radix[0] * 10 + pl.nat.ns;
+        }
     }
     AA_CATCH_INT
 }
@@ -1008,6 +1011,55 @@ int atlas_amd__fft_host_row(int n, const double* modes, int mmax, double* out) {
     }
     fft::FftPlanSet ps = fft::make_fft_plans({n});
     fft::host_execute_row(ps, 0, reinterpret_cast<const fft::cplx*>(modes), mmax, out);
+    AA_CATCH_INT
+}
+int atlas_amd__fft_host_row_native(int n, const double* modes, int mmax, double* out) {
+    AA_TRY
+    if (n < 1 || !modes || !out) {
+        throw std::invalid_argument("fft_host_row_native: n >= 1 and non-null arrays are required");
+    }
+    fft::PlanOptions po;
+    po.native = true;
+    fft::FftPlanSet ps = fft::make_fft_plans({n}, po);
+    if (ps.plans.at(0).method != fft::FFT_NATIVE) {
+        throw std::invalid_argument("fft_host_row_native: row length " + std::to_string(n) + " has no native plan");
+    }
+    fft::host_execute_row(ps, 0, reinterpret_cast<const fft::cplx*>(modes), mmax, out);
+    AA_CATCH_INT
+}
+int atlas_amd__fft_host_row_bluestein(int n, const double* modes, int mmax, double* out) {
+    AA_TRY
+    if (n < 1 || !modes || !out) {
+        throw std::invalid_argument("fft_host_row_bluestein: n >= 1 and non-null arrays are required");
+    }
+    fft::PlanOptions po;
+    po.native = false;
+    fft::FftPlanSet ps = fft::make_fft_plans({n}, po);
+    fft::host_execute_row(ps, 0, reinterpret_cast<const fft::cplx*>(modes), mmax, out);
+    AA_CATCH_INT
+}
+int atlas_amd__fft_plan_info(int n, int native, int out[16]) {
+    AA_TRY
+    if (n < 1 || !out) {
+        throw std::invalid_argument("fft_plan_info: n >= 1 and a non-null array are required");
+    }
+    fft::PlanOptions po;
+    po.native                  = native != 0;
+    fft::FftPlanSet ps         = fft::make_fft_plans({n}, po);
+    const fft::FftRowPlan& pl = ps.plans.at(0);
+    for (int i = 0; i < 16; ++i) {
+        out[i] = 0;
+    }
+    out[0] = pl.method;
+    out[1] = pl.shape.M;
+    out[2] = pl.lds_complex;
+    out[3] = pl.shape.nstages;
+    for (int i = 0; i < pl.shape.nstages && i < 8; ++i) {
+        out[4 + i] = pl.shape.radix[i];
+    }
+    out[12] = pl.ct_k >= 0 ? 1 : 0;
+    out[13] = pl.method == fft::FFT_NATIVE ? pl.nat.pitch : 0;
+    out[14] = (int)ps.nat_table.size();
     AA_CATCH_INT
 }
 int atlas_amd__fft_host_row_hybrid(int n, const double* modes, int mmax, double* out) {

@@ -61,6 +61,22 @@ struct alignas(64) FftRowDesc {
     long long off_tw, off_pre, off_chirp, off_bhat_t;   // into FourierParams::table
 };
 
+// The same for a native mixed-radix row (fft_native.h): the stage list in execution order and the offsets of its tables, 128 bytes
+struct alignas(128) FftNatDesc {
+    int row;                 // latitude row (global index)
+    int mmax;                // highest kept wavenumber, already clamped to h
+    int h, n;
+    long long goff_rel;      // rowoff[row] - rowoff[lat0]
+    double coslatinv;        // 1 / cos(lat)
+    long long off_tw, off_pre;   // into FourierParams::table: exp(2 pi i t / h), t < h;  exp(2 pi i k / n), k < h
+    int perm;                // into FourierParams::nat_table: element the fold writes Z[k] to, k < h
+    int ns;                  // stages
+    int radix[fft::NAT_MAX_STAGES], nb[fft::NAT_MAX_STAGES], stride[fft::NAT_MAX_STAGES], tab[fft::NAT_MAX_STAGES];
+    int lds_elems;
+    int pad_;
+};
+static_assert(sizeof(FftNatDesc) == 128, "one 128-byte scalar load per workgroup");
+
 struct FourierParts {
     const double* base[fft::MAX_PARTS];
     const long long* rowoff[fft::MAX_PARTS];
@@ -69,6 +85,8 @@ struct FourierParts {
 
 struct FourierParams {
     const FftRowDesc* desc;                   // [nrows] of this launch (specialised Bluestein classes), else null
+    const FftNatDesc* ndesc;                  // [nrows] of this launch (native mixed-radix rows), else null
+    const uint32_t* nat_table;                // fold permutations and stage tables of the native rows (fft_plan.h: FftPlanSet::nat_table)
     // Fourier intermediate pieces, one per m-owner (see fft_core.h: RowIO).  Piece 0 travels in the kernel arguments; with more
     // than one piece the kernels read FourierParts from device memory (as kernel arguments the 16 x 3 entries sat in scalar
     // registers for the whole kernel and pushed ~200 scalar spill moves per wavefront into the vector ALU) [r3]

@@ -111,6 +111,9 @@ struct ModeReaderT {
         }
 #if defined(AA_FFT_ABLATE)
         if (p.abl & 1) ml = 0;
+        if (p.abl & 64) ml >>= 1;    // dev probes (results wrong): 2 / 4 / 8 lanes per 128-byte line -- how the gather's cost scales
+        if (p.abl & 128) ml >>= 2;   // with the number of distinct lines a request touches
+        if (p.abl & 256) ml >>= 3;
 #endif
         // wavenumber x record length as a 24-bit product (one full-rate instruction; the host checks (T + 1) * RP < 2^31,
         // trans.hip: fourier_fields): the 64-bit form cost the direct rows more integer multiplies than butterfly arithmetic
@@ -154,6 +157,59 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Gather of the kept modes X[0..mmax] of one (row, field) into LDS (raw[m], contiguous).  fp64: LDS-DMA, 16 bytes per
+// lane straight from the Fourier intermediate into LDS (no staging registers; destination = wave-uniform base + 16 * lane,
+// so lane l of wave w handles m = sweep * nt + 64 w + l; lanes beyond mmax re-read mode mmax into slots nobody reads).
+// fp32 intermediate: through registers (the 8-byte element has no DMA width).
+template <bool F32, class C>
+__device__ __forceinline__ void gather_modes_to_lds(const FourierParams& p, long long lat_local, int f, int mmax,
+                                                    C* raw, int tid, int nt) {
+    static_assert(F32 || sizeof(C) == 16, "the LDS-DMA gather moves 16-byte elements");
+    const ModeReaderT<(F32 ? 1 : 0)> rd{p, lat_local, 2 * f};
+    if (mmax < 0) {
+        return;
+    }
+    if constexpr (F32) {
+        // through registers, 8 sweeps of requests in flight before the first LDS store (left as one sweep per iteration the
+        // loop is a chain of dependent round trips: request, wait, store, next request)
+        constexpr int U = 8;
+        for (int m0 = 0; m0 <= mmax; m0 += U * nt) {
+            cplx v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int m = m0 + u * nt + tid;
+                v[u]        = rd(m <= mmax ? m : mmax);   // (float -> double; back to float for C = cplxf: folded away)
+            }
+            AA_SCHED_FENCE();
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int m = m0 + u * nt + tid;
+                if (m <= mmax) {
+                    raw[m] = C{(typename C::real)v[u].re, (typename C::real)v[u].im};
+                }
+            }
+        }
+        return;
+    }
+    for (int m0 = 0; m0 <= mmax; m0 += nt) {
+        const int m  = m0 + tid;
+        const int mc = m <= mmax ? m : mmax;
+        if constexpr (F32) {
+        }
+        else {
+            if (m <= mmax) {   // lanes past the last mode request nothing (their LDS slots belong to the caller: row_ct3 zeroes them)
+                const double* src = rd.address(mc);
+                cplx* dst         = raw + m0 + (tid & ~63);   // wave-uniform
+                __builtin_amdgcn_global_load_lds(
+                    reinterpret_cast<const __attribute__((address_space(1))) void*>(reinterpret_cast<uintptr_t>(src)),
+                    reinterpret_cast<__attribute__((address_space(3))) void*>(
+                        static_cast<unsigned>(reinterpret_cast<uintptr_t>(dst))),
+                    16, 0, 0);
+            }
+        }
+    }
 }
 
 // the [R0,16,16] rows of the LDS-heavy classes (see fft_kernel.hip: row_ct3)

@@ -163,59 +163,6 @@ __device__ __forceinline__ void for_each_phase(Fn&& fn) {
     }
 }
 
-// Gather of the kept modes X[0..mmax] of one (row, field) into LDS (raw[m], contiguous).  fp64: LDS-DMA, 16 bytes per
-// lane straight from the Fourier intermediate into LDS (no staging registers; destination = wave-uniform base + 16 * lane,
-// so lane l of wave w handles m = sweep * nt + 64 w + l; lanes beyond mmax re-read mode mmax into slots nobody reads).
-// fp32 intermediate: through registers (the 8-byte element has no DMA width).
-template <bool F32, class C>
-__device__ __forceinline__ void gather_modes_to_lds(const FourierParams& p, long long lat_local, int f, int mmax,
-                                                    C* raw, int tid, int nt) {
-    static_assert(F32 || sizeof(C) == 16, "the LDS-DMA gather moves 16-byte elements");
-    const ModeReaderT<(F32 ? 1 : 0)> rd{p, lat_local, 2 * f};
-    if (mmax < 0) {
-        return;
-    }
-    if constexpr (F32) {
-        // through registers, 8 sweeps of requests in flight before the first LDS store (left as one sweep per iteration the
-        // loop is a chain of dependent round trips: request, wait, store, next request)
-        constexpr int U = 8;
-        for (int m0 = 0; m0 <= mmax; m0 += U * nt) {
-            cplx v[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int m = m0 + u * nt + tid;
-                v[u]        = rd(m <= mmax ? m : mmax);   // (float -> double; back to float for C = cplxf: folded away)
-            }
-            AA_SCHED_FENCE();
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int m = m0 + u * nt + tid;
-                if (m <= mmax) {
-                    raw[m] = C{(typename C::real)v[u].re, (typename C::real)v[u].im};
-                }
-            }
-        }
-        return;
-    }
-    for (int m0 = 0; m0 <= mmax; m0 += nt) {
-        const int m  = m0 + tid;
-        const int mc = m <= mmax ? m : mmax;
-        if constexpr (F32) {
-        }
-        else {
-            if (m <= mmax) {   // lanes past the last mode request nothing (their LDS slots belong to the caller: row_ct3 zeroes them)
-                const double* src = rd.address(mc);
-                cplx* dst         = raw + m0 + (tid & ~63);   // wave-uniform
-                __builtin_amdgcn_global_load_lds(
-                    reinterpret_cast<const __attribute__((address_space(1))) void*>(reinterpret_cast<uintptr_t>(src)),
-                    reinterpret_cast<__attribute__((address_space(3))) void*>(
-                        static_cast<unsigned>(reinterpret_cast<uintptr_t>(dst))),
-                    16, 0, 0);
-            }
-        }
-    }
-}
-
 // ---- [R0,16,16] rows of the LDS-heavy classes (M >= 3840: two workgroups of four wavefronts per CU, 256 registers):
 // the whole row in one function, so that every table value is requested a phase (or more) before its use and the ones
 // used twice are kept.  Same arithmetic, in the same order, as row_phase_ct (the host emulation and the planner run that).

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <map>
+#include <functional>
 #include <stdexcept>
 
 namespace atlas_amd {
@@ -181,9 +182,159 @@ int hybrid_dense_radix(int h) {
     return h;
 }
 
+// ---- native mixed-radix rows (fft_native.h) ------------------------------------------------------------------------
+namespace {
+// rough vector-ALU instructions per point of a twiddled stage of radix r (butterfly + twiddle products + power chain + addresses)
+double nat_stage_cost(int r) {
+    switch (r) {
+        case 2: return 6;   case 3: return 8;   case 4: return 9;   case 5: return 12;  case 6: return 13;  case 7: return 18;
+        case 8: return 16;  case 9: return 18;  case 10: return 19; case 11: return 22; case 12: return 20; case 13: return 24;
+        case 15: return 22; case 16: return 20;
+    }
+    return 1e9;
+}
+}  // namespace
+
+bool make_native_shape(int h, NatShape& s, std::vector<uint32_t>& table) {
+    if (h < 6 || h > NAT_MAX_H || h % 2 != 0) {
+        return false;
+    }
+    // prime factors
+    std::vector<int> pf;
+    {
+        int r = h;
+        for (int p = 2; p * p <= r; ++p) {
+            while (r % p == 0) {
+                pf.push_back(p);
+                r /= p;
+            }
+        }
+        if (r > 1) {
+            pf.push_back(r);
+        }
+    }
+    int nbig = 0, big = 0;
+    for (int p : pf) {
+        if (p > 13) {
+            ++nbig;
+            big = p;
+        }
+    }
+    if (nbig > 1 || big > NAT_MAX_PRIME) {
+        return false;
+    }
+    const int max_nb = NAT_MAX_ROUNDS * NAT_NT;
+    // first stage (no twiddles): the big prime, else the largest odd radix that divides h
+    int RL = big;
+    if (RL == 0) {
+        for (int r : {15, 13, 11, 9, 7, 5, 3}) {
+            if (h % r == 0) {
+                RL = r;
+                break;
+            }
+        }
+    }
+    if (RL == 0 || !nat_radix_first_ok(RL) || h / RL > max_nb) {
+        return false;
+    }
+    // the other stages: ordered factorisations of Q = h / RL into at most NAT_MAX_STAGES - 1 radices of the menu, every stage
+    // with at most max_nb butterflies; fewest stages first, then the cheapest by nat_stage_cost
+    const int Q = h / RL;
+    const int menu[] = {16, 15, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
+    std::vector<int> best, cur;
+    double best_cost = 1e18;
+    std::function<void(int, double)> rec = [&](int rem, double cost) {
+        if (rem == 1) {
+            if (!cur.empty() && (best.empty() || cur.size() < best.size() || (cur.size() == best.size() && cost < best_cost))) {
+                best      = cur;
+                best_cost = cost;
+            }
+            return;
+        }
+        if ((int)cur.size() >= NAT_MAX_STAGES - 1) {
+            return;
+        }
+        for (int r : menu) {
+            if (rem % r == 0 && h / r <= max_nb) {
+                cur.push_back(r);
+                rec(rem / r, cost + nat_stage_cost(r));
+                cur.pop_back();
+            }
+        }
+    };
+    rec(Q, 0.);
+    if (best.empty()) {
+        return false;
+    }
+    // DIF order: best[0] = r_0 (last executed, fused with the store) ... ; prefer the largest radix last executed?  Any order of
+    // the same multiset costs the same arithmetic; the store stage wants few butterflies per worker: largest radix as r_0.
+    std::sort(best.begin(), best.end(), [](int a, int b) { return a > b; });
+    std::vector<int> dif(best);
+    dif.push_back(RL);
+    const int ns = (int)dif.size();
+    s            = NatShape{};
+    s.h          = h;
+    s.ns         = ns;
+    const int Ls0 = h / dif[0];
+    s.pitch       = (Ls0 % 2 == 0) ? Ls0 + 1 : Ls0;
+    auto nat_pos  = [&](int pos) { return (pos / Ls0) * s.pitch + pos % Ls0; };
+    s.lds_elems   = std::max(h + 1, dif[0] * s.pitch);
+    s.lds_elems   = (s.lds_elems + 15) / 16 * 16;
+    if (s.lds_elems > 65535) {
+        return false;
+    }
+    // fold permutation: frequency k -> element of the digit-reversed position (fft_core.h: pos_of_freq)
+    FftShape fs{};
+    fs.M       = h;
+    fs.nstages = ns;
+    for (int i = 0; i < ns; ++i) {
+        fs.radix[i] = dif[i];
+        fs.lsh[i]   = -1;
+    }
+    s.perm = (int)table.size();
+    for (int k = 0; k < h; ++k) {
+        table.push_back((uint32_t)nat_pos(pos_of_freq(fs, k)));
+    }
+    for (int e = 0; e < ns; ++e) {
+        const int i = ns - 1 - e;   // DIF index of execution stage e
+        int L = h;
+        for (int q = 0; q < i; ++q) {
+            L /= dif[q];
+        }
+        const int R  = dif[i];
+        const int Ls = L / R;
+        s.radix[e]   = R;
+        s.nb[e]      = h / R;
+        s.stride[e]  = (i == 0) ? s.pitch : Ls;
+        s.tab[e]     = (int)table.size();
+        if ((e == 0 && !nat_radix_first_ok(R)) || (e > 0 && !nat_radix_tw_ok(R)) || s.nb[e] > max_nb) {
+            throw std::logic_error("make_native_shape: stage outside the kernel's menu");
+        }
+        for (int b = 0; b < s.nb[e]; ++b) {
+            const int blk = b / Ls, j = b - blk * Ls;
+            const int pos = blk * L + j;
+            const int base = nat_pos(pos);
+            for (int q = 0; q < R; ++q) {
+                if (nat_pos(pos + q * Ls) != base + q * s.stride[e]) {
+                    throw std::logic_error("make_native_shape: a butterfly is not an arithmetic progression in LDS");
+                }
+            }
+            const int twidx = j * (h / L);
+            if (twidx >= h || twidx > 0xffff || base > 0xffff) {
+                throw std::logic_error("make_native_shape: table entry out of range");
+            }
+            table.push_back((uint32_t)base | ((uint32_t)twidx << 16));
+        }
+    }
+    return true;
+}
+
 FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, bool specialised_shapes) {
     PlanOptions opt;
     opt.specialised_shapes = specialised_shapes;
+    if (const char* e = std::getenv("ATLAS_AMD_FFT_NATIVE")) {   // native mixed-radix rows: opt-in
+        opt.native = atoi(e) != 0;
+    }
     if (const char* e = std::getenv("ATLAS_AMD_FFT_HYBRID")) {
 #if defined(ATLAS_AMD_EXPERIMENTS)
         opt.hybrid = atoi(e) != 0;
@@ -272,6 +423,39 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, const PlanOptions
                     }
                 }
             }
+        }
+        // native mixed-radix rows [r4]: every half length with a stage list (fft_native.h) that is not a length of the
+        // specialised direct family (those kernels are compile-time shaped throughout)
+        bool family_direct = false;
+        if (specialised_shapes) {
+            for (int f : {1, 3, 5, 9, 15}) {
+                if (h % f == 0) {
+                    const int k   = ilog2_exact(h / f);
+                    family_direct = family_direct || (k >= 0 && ct_supported(f, k));
+                }
+            }
+        }
+        bool native = false;
+        if (opt.native && specialised_shapes && Mcoarse == 0 && !family_direct && h >= opt.native_min_h && !opt.hybrid) {
+            native = make_native_shape(h, p.nat, ps.nat_table);
+        }
+        if (native) {
+            p.method      = FFT_NATIVE;
+            p.shape       = FftShape{};
+            p.shape.M     = h;
+            p.shape.nstages = p.nat.ns;
+            for (int i = 0; i < p.nat.ns; ++i) {   // DIF order, for introspection (the kernel runs from the tables)
+                p.shape.radix[i] = p.nat.radix[p.nat.ns - 1 - i];
+                p.shape.lsh[i]   = -1;
+            }
+            p.lds_complex = p.nat.lds_elems;
+            p.off_tw      = twiddles(h);
+            p.off_pre     = (int64_t)ps.table.size();
+            for (int k = 0; k < h; ++k) {
+                ps.table.push_back(unit_root(k, n));
+            }
+            ps.plans.push_back(p);
+            continue;
         }
         if (smooth_direct) {
             p.method = FFT_DIRECT;
@@ -445,6 +629,15 @@ void host_execute_row(const FftPlanSet& ps, int plan, const cplx* X, int mmax, d
             }
             y[k] = s;
         }
+        return;
+    }
+    if (p.method == FFT_NATIVE) {
+        std::vector<cplx> Xh(p.h + 1, cplx{0., 0.});
+        for (int m = 0; m <= std::min(mmax, p.h); ++m) {
+            Xh[m] = X[m];
+        }
+        nat_execute_row_host(p.nat, ps.nat_table.data(), ps.table.data() + p.off_tw, ps.table.data() + p.off_pre, Xh.data(),
+                             std::min(mmax, p.h), y);
         return;
     }
     if (p.method == FFT_HYBRID) {

@@ -10,6 +10,9 @@
 //   HYBRID    n even, h = A*B, B smooth, A = product of the primes > 5 of h, 7 <= A <= HYB_MAX_A :
 //                                          half-length complex FFT whose radix-A stage is a dense DFT on the matrix
 //                                          cores (fft_core.h: "HYBRID rows"), no Bluestein
+//   NATIVE    n even, h has only small prime factors -- any number of {2,...,13}, at most one prime 17..31 -- and is not a
+//             length of the specialised direct family : half-length complex mixed-radix DIT with the stage list chosen here and
+//             executed from tables by ONE kernel for every such shape (fft_native.h) [r4]
 //   BLUESTEIN n even otherwise            : half-length chirp-z with a {2,3,5}-smooth M >= 2h-1
 //   DFT       n odd                       : O(n*modes) direct sum (never hit by Gaussian grids)
 #pragma once
@@ -17,11 +20,12 @@
 #include <vector>
 
 #include "fft_core.h"
+#include "fft_native.h"
 
 namespace atlas_amd {
 namespace fft {
 
-enum FftMethod : int { FFT_DIRECT = 0, FFT_BLUESTEIN = 1, FFT_DFT = 2, FFT_HYBRID = 3, FFT_ODD = 4 };
+enum FftMethod : int { FFT_DIRECT = 0, FFT_BLUESTEIN = 1, FFT_DFT = 2, FFT_HYBRID = 3, FFT_ODD = 4, FFT_NATIVE = 5 };
 
 struct FftRowPlan {
     int n;              // row length (number of longitudes of the global row)
@@ -39,6 +43,7 @@ struct FftRowPlan {
     int hyb_Mt, hyb_Ks; // HYBRID: tiles of the padded (A+1)/2 x (A+1)/2 cos / sin matrices (16 rows, 4 columns)
     int hyb_raw;        // HYBRID: entries of the LDS staging area for the row's modes (after the padded_size(h) work area)
     int64_t off_cs;     // HYBRID: [Mt][Ks][64] {cos, sin} operand fragments
+    NatShape nat;       // NATIVE: stage list and table offsets (into FftPlanSet::nat_table)
 };
 struct PlanOptions {
     bool specialised_shapes = true;  // compile-time specialised kernel instances where they exist
@@ -52,12 +57,19 @@ struct PlanOptions {
     // a handful of launches.  Set by Trans for reduced grids of at most 704 points per row (a property of the GLOBAL grid, so
     // that every decomposition of one grid plans its rows alike); ATLAS_AMD_FFT_COARSE=0/1 overrides.
     bool coarse_classes     = false;
+    // native mixed-radix rows (fft_native.h) for every half length the planner finds a stage list for: opt-in
+    // (ATLAS_AMD_FFT_NATIVE=1) -- measured at parity with the Bluestein rows they replace (TL1279 -> O1280: 25 % of the points,
+    // 1.55 - 1.62 ms against 1.4 - 1.5 ms; the stage 6.60 - 6.65 against 6.61 - 6.67 ms; profiles/r04_fft_native.txt), so the
+    // default stays the kernels with three rounds of evidence behind them
+    bool native             = false;
+    int native_min_h        = 24;
 };
 int coarse_bluestein_length(int n);   // smallest of 256, 512, 1024, 2048 that is >= n (0: none)
 
 struct FftPlanSet {
     std::vector<FftRowPlan> plans;   // one per distinct n
     std::vector<cplx> table;         // all tables, concatenated (uploaded once)
+    std::vector<uint32_t> nat_table; // NATIVE rows: fold permutations and per-stage butterfly tables (fft_native.h: NatShape)
     int plan_index(int n) const;
 };
 
@@ -68,6 +80,9 @@ FftShape make_shape(int M, int max_pow2_radix = 16);  // M must be {2,3,5}-smoot
 FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, const PlanOptions& opt);
 FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, bool specialised_shapes = true);
 int hybrid_dense_radix(int h);  // product of the prime factors > 5 of h
+// stage list and tables of a native row of half length h (appended to `table`); false: h has no native plan (a prime factor
+// above NAT_MAX_PRIME, two primes above 13, a power of two, too long, or no stage list within the per-stage butterfly limit)
+bool make_native_shape(int h, NatShape& shape, std::vector<uint32_t>& table);
 
 // Host execution of one row with exactly the kernel's algorithm (used by CPU tests; NOT a product fallback:
 // nothing in the invtrans path calls it).  X: h+1 (or n/2+1) complex modes (zero beyond mmax); y: n reals.

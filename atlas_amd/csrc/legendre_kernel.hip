@@ -662,6 +662,25 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
                         sy = 0;
                         as = 0;
                     }
+#if defined(AA_LEG_LAYOUT_PROBE)
+                    // dev probe (results unusable by the Fourier stage): what the store side of a layout with several
+                    // wavenumbers of one field per 128-byte line costs: p.abl = 1: [2 m][4 fields], 2: [4 m][2 fields], 3: [8 m][1 field]
+                    if (p.abl >= 1 && p.abl <= 3) {
+                        const int mb   = 1 << p.abl;            // wavenumbers per line
+                        const int cw   = 16 >> p.abl;           // doubles of one wavenumber per line
+                        const int cb   = r / cw, cr = r - cb * cw;
+                        const long long mrow = (p.m_cnt + mb - 1) / mb;
+                        const long long on = (((long long)(jn - p.row_begin) * mrow + ml / mb) * (RP / cw) + cb) * 16 + (ml % mb) * cw + cr;
+                        const long long os = (((long long)(js - p.row_begin) * mrow + ml / mb) * (RP / cw) + cb) * 16 + (ml % mb) * cw + cr;
+                        if (st_n) {
+                            AA_LEG_STORE(p.F + on, sy + as);
+                        }
+                        if (st_s) {
+                            AA_LEG_STORE(p.F + os, sy - as);
+                        }
+                        continue;
+                    }
+#endif
                     if (st_n) {
                         AA_LEG_STORE(fn + r, sy + as);
                     }
@@ -728,6 +747,11 @@ static hipError_t launch_lean(LegendreParams p, int nitems, int nchunks, int chu
     p.chunk0        = chunk0;
     p.nchunks_run   = nrun;
     p.abl           = 0;
+#if defined(AA_LEG_LAYOUT_PROBE)
+    if (const char* e = std::getenv("ATLAS_AMD_LEG_LAYOUT_PROBE")) {
+        p.abl = atoi(e);
+    }
+#endif
     const int slots = (nitems + 7) / 8;
     hipLaunchKernelGGL(legendre_kernel_lean, dim3(slots * nrun * 8), dim3(L::NTHR), L::BYTES, stream, p);
     return hipGetLastError();

@@ -182,6 +182,7 @@ private:
     void* d_fftplans_    = nullptr;
     void* d_ffttable_    = nullptr;
     void* d_ffttable_f32_ = nullptr;   // float copy, uploaded by the first fp32 call
+    uint32_t* d_nat_table_ = nullptr;  // fold permutations and stage tables of the native mixed-radix rows (fft_native.h)
     int* d_row_plan_     = nullptr;
     int* d_row_mmax_     = nullptr;
     long long* d_rowoff_ = nullptr;
@@ -192,6 +193,8 @@ private:
         int ct_f, ct_k;  // specialised kernel instance, or ct_k < 0
         bool direct;     // specialised instance is the direct (no Bluestein) kernel
         bool hybrid = false;  // dense-stage rows (fft_rows_hyb_kernel)
+        bool native = false;  // native mixed-radix rows (fft_rows_nat_kernel): d_desc holds FftNatDesc records
+        bool native_bigp = false;   // ... whose first-stage radix is a prime 17 .. 31 (the kernel instance with 168 registers)
         int nrows;
         int* d_rows;
         void* d_desc = nullptr;   // FftRowDesc[nrows] for the specialised Bluestein kernels

@@ -31,6 +31,7 @@ hipError_t launch_fourier(const FourierParams& p, int lds_bytes, int nthreads, h
 hipError_t launch_fourier_ct(const FourierParams& p, int ctf, int ctk, int lds_bytes, int nthreads,
                              hipStream_t stream);
 hipError_t launch_fourier_hyb(const FourierParams& p, int lds_bytes, int nthreads, hipStream_t stream);
+hipError_t launch_fourier_nat(const FourierParams& p, int lds_bytes, int bigp, hipStream_t stream);   // fft_native.hip
 hipError_t launch_fourier_dct(const FourierParams& p, int ctf, int ctk, int lds_bytes, int nthreads,
                               hipStream_t stream);
 hipError_t launch_spectra_prepare(const double* vor, const double* div, const double* sp, double* out, int T, int nvd,
@@ -121,6 +122,9 @@ Trans::Trans(const grid::StructuredGrid& grid, int truncation, const TransConfig
         if (const char* e = std::getenv("ATLAS_AMD_FFT_HYBRID")) {      // A/B switch: 0 = Bluestein for every awkward row
             po.hybrid = atoi(e) != 0;
         }
+        if (const char* e = std::getenv("ATLAS_AMD_FFT_NATIVE")) {      // 1: native mixed-radix rows where a stage list exists (opt-in)
+            po.native = atoi(e) != 0;
+        }
         if (const char* e = std::getenv("ATLAS_AMD_FFT_HYB_MAXA")) {    // largest dense radix
             po.hybrid_max_a = atoi(e);
         }
@@ -176,6 +180,7 @@ void Trans::release() noexcept {
     fr(d_fftplans_);
     fr(d_ffttable_);
     fr(d_ffttable_f32_);
+    fr(d_nat_table_);
     fr(d_row_plan_);
     fr(d_row_mmax_);
     fr(d_rowoff_);
@@ -305,6 +310,13 @@ void Trans::download_legendre_table(double* out, size_t size_doubles) const {
     }
 }
 
+// LDS elements of a native row: the work array (the staging area of the gathered modes aliases it: whole 64-lane granules) + the
+// 64-element dump area of the L2 prefetch requests behind it (fft_native.hip)
+static int native_lds_elems(const fft::FftRowPlan& pl, int row_mmax) {
+    const int mmax = std::max(0, std::min(row_mmax, pl.h));
+    return std::max(pl.nat.lds_elems, (mmax + 1 + 63) / 64 * 64) + 64;
+}
+
 void Trans::upload() {
     // ---- Legendre table (tile-blocked), owned wavenumbers only ----
     bool on_device = cfg_.device_tables == 1;
@@ -391,6 +403,9 @@ void Trans::upload() {
     // ---- FFT plans / tables ----
     d_fftplans_ = dev_upload(fftplans_.plans.data(), fftplans_.plans.size());
     d_ffttable_ = dev_upload(fftplans_.table.data(), fftplans_.table.size());
+    if (!fftplans_.nat_table.empty()) {
+        d_nat_table_ = dev_upload(fftplans_.nat_table.data(), fftplans_.nat_table.size());
+    }
     std::vector<int> row_plan(geo_.nlats), row_mmax(geo_.nlats);
     std::vector<double> coslatinv(geo_.nlats);
     for (int j = 0; j < geo_.nlats; ++j) {
@@ -428,6 +443,25 @@ void Trans::upload() {
         }
         if (pl.method == fft::FFT_DIRECT && pl.ct_k >= 0) {
             by_class[{2, pl.shape.M}].push_back(j);  // specialised direct rows
+            continue;
+        }
+        if (pl.method == fft::FFT_NATIVE) {
+            // native mixed-radix rows: one kernel for every shape (two register classes: first-stage radix 3 .. 15 -- four
+            // workgroups per CU -- / prime 17 .. 31 -- three), launches bucketed by LDS footprint: 40 KiB (four workgroups per
+            // CU), 52 KiB (three), 80 KiB (two)
+            const int bigp  = pl.nat.radix[0] > 15 ? 1 : 0;
+            const int elems = native_lds_elems(pl, row_mmax[j]);
+            int cls         = 0;
+            for (int c : {2560, 3328, 5120}) {
+                if (elems <= c && !(bigp && c == 2560)) {
+                    cls = c;
+                    break;
+                }
+            }
+            if (cls == 0) {
+                throw std::runtime_error("row length " + std::to_string(pl.n) + " does not fit in LDS (160 KiB)");
+            }
+            by_class[{4 + bigp, cls}].push_back(j);
             continue;
         }
         if (pl.method == fft::FFT_HYBRID) {
@@ -476,6 +510,16 @@ void Trans::upload() {
         c.ct_f = c.ct_k = -1;
         c.direct = it->first.first == 2;
         c.hybrid = it->first.first == 3;
+        c.native = it->first.first == 4 || it->first.first == 5;
+        c.native_bigp = it->first.first == 5;
+        if (c.native) {
+            int lds = 0;
+            for (int j : it->second) {
+                lds = std::max(lds, native_lds_elems(fftplans_.plans[row_plan[j]], row_mmax[j]));
+            }
+            c.lds_bytes = lds * 16;
+            c.nthreads  = fft::NAT_NT;
+        }
         if (c.hybrid) {
             int lds = 0, nthr = 64;
             for (int j : it->second) {
@@ -491,7 +535,7 @@ void Trans::upload() {
             c.lds_bytes = lds * 16;
             c.nthreads  = nthr;
         }
-        if (it->first.first >= 1) {
+        if (it->first.first >= 1 && it->first.first <= 3) {
             const fft::FftRowPlan& pl = fftplans_.plans[row_plan[it->second[0]]];
             c.ct_f                    = pl.ct_f;
             c.ct_k                    = pl.ct_k;
@@ -521,6 +565,33 @@ void Trans::upload() {
             }
             c.d_desc = dev_upload(desc.data(), desc.size());
         }
+        if (c.native) {   // one 128-byte record per row (device_structs.h: FftNatDesc)
+            std::vector<FftNatDesc> desc(it->second.size());
+            for (size_t i = 0; i < desc.size(); ++i) {
+                const int j               = it->second[i];
+                const fft::FftRowPlan& pl = fftplans_.plans[row_plan[j]];
+                FftNatDesc& d             = desc[i];
+                std::memset(&d, 0, sizeof(d));
+                d.row       = j;
+                d.mmax      = std::min(row_mmax[j], pl.h);
+                d.h         = pl.h;
+                d.n         = pl.n;
+                d.goff_rel  = (long long)(geo_.rowoff[j] - geo_.rowoff[band_begin()]);
+                d.coslatinv = coslatinv[j];
+                d.off_tw    = pl.off_tw;
+                d.off_pre   = pl.off_pre;
+                d.perm      = pl.nat.perm;
+                d.ns        = pl.nat.ns;
+                for (int e = 0; e < fft::NAT_MAX_STAGES; ++e) {
+                    d.radix[e]  = e < pl.nat.ns ? pl.nat.radix[e] : 0;
+                    d.nb[e]     = e < pl.nat.ns ? pl.nat.nb[e] : 0;
+                    d.stride[e] = e < pl.nat.ns ? pl.nat.stride[e] : 0;
+                    d.tab[e]    = e < pl.nat.ns ? pl.nat.tab[e] : 0;
+                }
+                d.lds_elems = pl.nat.lds_elems;
+            }
+            c.d_desc = dev_upload(desc.data(), desc.size());
+        }
         classes_.push_back(c);
     }
 }
@@ -528,6 +599,9 @@ void Trans::upload() {
 int Trans::fft_row_kernel(const fft::FftRowPlan& pl) const {
     if (pl.method == fft::FFT_HYBRID) {
         return 3;
+    }
+    if (pl.method == fft::FFT_NATIVE) {
+        return 4;
     }
     if (use_ct_ && pl.ct_k >= 0 && pl.method == fft::FFT_BLUESTEIN) {
         return 1;
@@ -740,6 +814,8 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
         d_ffttable_f32_ = dev_upload(tf.data(), tf.size());
     }
     p.table_f32       = f32 ? (const fft::cplxf*)d_ffttable_f32_ : nullptr;
+    p.nat_table       = d_nat_table_;
+    p.ndesc           = nullptr;
     p.row_plan        = d_row_plan_;
     p.row_mmax        = d_row_mmax_;
     p.rowoff          = d_rowoff_;
@@ -800,8 +876,13 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
     for (const SizeClass& c : classes_) {
         p.rows  = c.d_rows;
         p.nrows = c.nrows;
-        p.desc  = (const FftRowDesc*)c.d_desc;
+        p.desc  = c.native ? nullptr : (const FftRowDesc*)c.d_desc;
+        p.ndesc = c.native ? (const FftNatDesc*)c.d_desc : nullptr;
         if (only_m && c.lds_bytes != fft::padded_size(only_m) * 16) {  // dev tool (tools/fft_phase_prof.py): one class
+            continue;
+        }
+        static const int only_native = std::getenv("ATLAS_AMD_FFT_ONLY_NATIVE") ? atoi(std::getenv("ATLAS_AMD_FFT_ONLY_NATIVE")) : 0;
+        if (only_native && !c.native) {   // dev tool: the native mixed-radix rows alone
             continue;
         }
         const int si = next++ % nstreams;
@@ -817,7 +898,10 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
                 used[si] = 1;
             }
         }
-        if (c.hybrid) {
+        if (c.native) {
+            HIP_CHECK(launch_fourier_nat(p, c.lds_bytes, c.native_bigp ? 1 : 0, st));
+        }
+        else if (c.hybrid) {
             HIP_CHECK(launch_fourier_hyb(p, c.lds_bytes, c.nthreads, st));
         }
         else if (c.ct_k >= 0 && use_ct_) {

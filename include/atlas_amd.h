@@ -287,7 +287,7 @@ int atlas_amd__Trans__fourier_device(atlas_amd_Trans* t, int nb_fields, int nb_v
 /* introspection used by tests */
 int atlas_amd__Trans__nlat0(const atlas_amd_Trans* t, int nlat0_out[] /* T+1 */);
 /* the Fourier kernel every latitude row of the grid takes: out[3 j] = method (csrc/fft_plan.h: FftMethod), out[3 j + 1] = transform
- * length M of the row's plan (Bluestein: the convolution length; direct / native rows: n/2), out[3 j + 2] = kernel
+ * length M of the row's plan (Bluestein: the convolution length; direct rows: n/2; native rows: 10 x first radix + stages), out[3 j + 2] = kernel
  * (0 run-time shaped, 1 specialised Bluestein, 2 specialised direct, 3 dense-stage experiment, 4 native mixed radix).  Parity tests
  * take one northern and one southern row of every (method, M, kernel) that is launched (TransLocal.cc:1155-1196 treats all rows alike) */
 int atlas_amd__Trans__fft_row_classes(const atlas_amd_Trans* t, int out[] /* 3 * nlats */);
@@ -322,6 +322,14 @@ int atlas_amd__legendre_gen_host_selfcheck(const atlas_amd_Grid* grid, int trunc
 int atlas_amd__fft_host_row(int n, const double* modes, int mmax, double* out);
 /* same through the generic (run-time shape) phase code even where a compile-time specialised instance exists */
 int atlas_amd__fft_host_row_generic(int n, const double* modes, int mmax, double* out);
+/* the same with the native mixed-radix rows (csrc/fft_native.h; opt-in, ATLAS_AMD_FFT_NATIVE=1) forced on -- an error if the
+ * length has no native plan -- / off [r4] */
+int atlas_amd__fft_host_row_native(int n, const double* modes, int mmax, double* out);
+int atlas_amd__fft_host_row_bluestein(int n, const double* modes, int mmax, double* out);
+/* the plan of row length n (native != 0: with the native rows enabled): out = {method (csrc/fft_plan.h: FftMethod), transform
+ * length M, LDS elements, number of stages, radix[0..7] (DIF order), specialised instance (0 / 1), LDS pitch of a native row's
+ * top-level blocks, entries of the native tables, 0} */
+int atlas_amd__fft_plan_info(int n, int native, int out[16]);
 /* same with the dense-stage ("hybrid") plan where the row length admits one: h = n/2 = A*B, A the product of the prime
  * factors > 5 of h (A <= 257), B {2,3,5}-smooth; other lengths take their usual plan */
 int atlas_amd__fft_host_row_hybrid(int n, const double* modes, int mmax, double* out);
