@@ -13,9 +13,13 @@
 //   * pack / unpack / adjoint accumulate / zero_halos (DevicePacker.hic:51-218) ..... HIP kernels, atlas_amd__HaloExchange__field_op
 //   * point-to-point exchange of the packed buffers (HaloExchange.h:333-369) ........ Atlas's eckit::mpi, on device buffers when
 //     MPI is GPU-aware (ATLAS_HAVE_GPU_AWARE_MPI), else on host copies -- exactly the reference's rule (:160-172)
-// (The library can also run the whole exchange itself over RCCL: atlas_amd__HaloExchange__setup_comm / __execute_comm,
-// INTEGRATION.md section 4; that path needs no MPI at all and is what the distributed transform uses.)
+//   * with -DATLAS_AMD_HALO_TRANSPORT_RCCL [r4] the library runs the WHOLE exchange itself: atlas_amd__HaloExchange__setup_comm
+//     (its own allToAll / allToAllv over the communicator) and atlas_amd__HaloExchange__execute_comm (pack kernel -> grouped
+//     ncclSend / ncclRecv over xGMI -> unpack kernel, asynchronous on the object's HIP stream).  eckit::mpi then only
+//     broadcasts RCCL's 128-byte unique id once, when the communicator is first needed; one rank per
+//     GPU, device-resident fields.  Default: the eckit::mpi transport above, exactly the reference's rule.
 #pragma once
+#include <climits>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -44,7 +48,14 @@ public:
             throw_Exception(atlas_amd__last_error(), Here());
         }
     }
-    virtual ~HaloExchangeMI355X() { atlas_amd__HaloExchange__delete(h_); }
+    virtual ~HaloExchangeMI355X() {
+        atlas_amd__HaloExchange__delete(h_);
+#if defined(ATLAS_AMD_HALO_TRANSPORT_RCCL)
+        if (rccl_) {
+            atlas_amd__Comm__delete(rccl_);
+        }
+#endif
+    }
     HaloExchangeMI355X(const HaloExchangeMI355X&)            = delete;
     HaloExchangeMI355X& operator=(const HaloExchangeMI355X&) = delete;
 
@@ -66,7 +77,30 @@ public:  // methods (HaloExchange.h:47-58)
         comm_  = &mpi::comm(mpi_comm);
         nproc  = int(comm().size());
         myproc = int(comm().rank());
+        if (size < 0 || size > idx_t(INT_MAX) || halo_begin < 0 || halo_begin > size) {
+            throw_Exception("HaloExchangeMI355X::setup: size / halo_begin outside the int range of the C ABI", Here());
+        }
         std::vector<int> ridx(remote_idx, remote_idx + size);   // idx_t may be 64 bit; the C ABI takes int
+#if defined(ATLAS_AMD_HALO_TRANSPORT_RCCL)
+        // the library's own transport: RCCL's unique id is created on rank 0 and broadcast over eckit::mpi -- the only MPI call
+        // of this object; setup_comm runs the two collectives of HaloExchange.cc:118,156-159 over the RCCL communicator
+        if (!rccl_) {
+            std::vector<char> id(size_t(atlas_amd__Comm__unique_id_bytes()));
+            if (myproc == 0) {
+                check(atlas_amd__Comm__get_unique_id(id.data()));
+            }
+            comm().broadcast(id.begin(), id.end(), 0);
+            rccl_ = atlas_amd__Comm__new_rccl(id.data(), nproc, myproc);
+            if (!rccl_) {
+                throw_Exception(atlas_amd__last_error(), Here());
+            }
+        }
+        check(atlas_amd__HaloExchange__setup_comm(h_, rccl_, part, ridx.data(), base, int(size), int(halo_begin)));
+        sendcnt_  = atlas_amd__HaloExchange__sendcnt(h_);
+        recvcnt_  = atlas_amd__HaloExchange__recvcnt(h_);
+        is_setup_ = true;
+        return;
+#endif
         check(atlas_amd__HaloExchange__setup_begin(h_, nproc, myproc, part, ridx.data(), base, int(size), int(halo_begin)));
         std::vector<int> recvcounts(nproc), sendcounts(nproc), recvdispls(nproc), senddispls(nproc);
         check(atlas_amd__HaloExchange__get(h_, "recvcounts", recvcounts.data()));
@@ -107,6 +141,21 @@ private:
         return std::is_same<T, int>::value ? 0 : std::is_same<T, long>::value ? 1 : std::is_same<T, float>::value ? 2 : 3;
     }
 
+    // device memory of a message buffer, released on every path out of exchange()
+    template <typename T>
+    struct DeviceBuffer {
+        T* ptr = nullptr;
+        size_t n = 0;
+        explicit DeviceBuffer(size_t count) : n(count) { util::allocate_devicemem(ptr, n); }
+        ~DeviceBuffer() {
+            if (ptr) {
+                util::delete_devicemem(ptr, n);
+            }
+        }
+        DeviceBuffer(const DeviceBuffer&)            = delete;
+        DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+    };
+
     // forward: pack(sendmap) -> send | recv -> unpack(recvmap)                  (HaloExchange.h:151-225)
     // adjoint: pack_adjoint(recvmap) -> send | recv -> unpack_adjoint(+= sendmap), zero_halos   (HaloExchange.h:227-290)
     template <typename DATA_TYPE, int RANK, typename ParallelDim>
@@ -115,46 +164,64 @@ private:
             throw_Exception("HaloExchange was not setup", Here());
         }
         // the packing kernels always run on the device; what the flag decides -- as in the reference -- is where the field
-        // and the message buffers live
+        // and the message buffers live.  A host-resident field (on_device == false) is given device storage for the duration
+        // of the call if it has none: the reference packs such a field on the host (HaloExchange.h:160-172), this backend has
+        // no host kernels.
         const bool device_msgs = on_device && ATLAS_HAVE_GPU_AWARE_MPI;
+        bool allocated_here    = false;
         if (on_device) {
+            ATLAS_ASSERT(field.deviceAllocated());
             ATLAS_ASSERT(field.deviceNeedsUpdate() == false);
         }
         else {
+            if (!field.deviceAllocated()) {
+                field.allocateDevice();
+                allocated_here = true;
+            }
             field.updateDevice();
         }
         auto view = array::make_device_view<DATA_TYPE, RANK>(field);
         constexpr int parallelDim = array::get_parallel_dim<ParallelDim>(view);
         int shape[RANK];
         long long strides[RANK];
-        idx_t var_size = 1;
+        size_t var_size = 1;
         for (int d = 0; d < RANK; ++d) {
+            if (view.shape(d) > idx_t(INT_MAX)) {
+                throw_Exception("HaloExchangeMI355X: field extent outside the int range of the C ABI", Here());
+            }
             shape[d]   = int(view.shape(d));
             strides[d] = (long long)view.stride(d);
             if (d != parallelDim) {
-                var_size *= view.shape(d);
+                var_size *= size_t(view.shape(d));
             }
         }
+#if defined(ATLAS_AMD_HALO_TRANSPORT_RCCL)
+        // pack -> grouped ncclSend / ncclRecv -> unpack inside the library, asynchronous on the object's stream
+        check(atlas_amd__HaloExchange__execute_comm(h_, rccl_, dtype<DATA_TYPE>(), view.data(), RANK, shape, strides, parallelDim,
+                                                    adjoint ? 1 : 0));
+        check(atlas_amd__HaloExchange__synchronize(h_));
+#else
         // sizes of the buffer that leaves / arrives: forward sends at sendmap, adjoint sends what sits at recvmap
-        const int out_size = (adjoint ? recvcnt_ : sendcnt_) * int(var_size);
-        const int in_size  = (adjoint ? sendcnt_ : recvcnt_) * int(var_size);
+        const size_t out_size = size_t(adjoint ? recvcnt_ : sendcnt_) * var_size;
+        const size_t in_size  = size_t(adjoint ? sendcnt_ : recvcnt_) * var_size;
+        if (out_size > size_t(INT_MAX) || in_size > size_t(INT_MAX)) {   // eckit::mpi counts and displacements are int
+            throw_Exception("HaloExchangeMI355X: a message buffer exceeds INT_MAX elements", Here());
+        }
         const std::vector<int>& out_counts = adjoint ? recvcounts_ : sendcounts_;
         const std::vector<int>& out_displs = adjoint ? recvdispls_ : senddispls_;
         const std::vector<int>& in_counts  = adjoint ? sendcounts_ : recvcounts_;
         const std::vector<int>& in_displs  = adjoint ? senddispls_ : recvdispls_;
-        DATA_TYPE *out_dev = nullptr, *in_dev = nullptr;
-        util::allocate_devicemem(out_dev, out_size);
-        util::allocate_devicemem(in_dev, in_size);
+        DeviceBuffer<DATA_TYPE> out_dev(out_size), in_dev(in_size);
         std::vector<DATA_TYPE> out_host, in_host;
         check(atlas_amd__HaloExchange__field_op(h_, adjoint ? 4 : 2, dtype<DATA_TYPE>(), view.data(), RANK, shape, strides,
-                                                parallelDim, out_dev, 1));
+                                                parallelDim, out_dev.ptr, 1));
         check(atlas_amd__HaloExchange__synchronize(h_));
-        DATA_TYPE* out_msg = out_dev;
-        DATA_TYPE* in_msg  = in_dev;
+        DATA_TYPE* out_msg = out_dev.ptr;
+        DATA_TYPE* in_msg  = in_dev.ptr;
         if (!device_msgs) {   // MPI on host copies of the packed buffers (ATLAS_HAVE_GPU_AWARE_MPI == 0)
             out_host.resize(out_size);
             in_host.resize(in_size);
-            check(atlas_amd__device_memcpy_d2h(out_host.data(), out_dev, size_t(out_size) * sizeof(DATA_TYPE)));
+            check(atlas_amd__device_memcpy_d2h(out_host.data(), out_dev.ptr, out_size * sizeof(DATA_TYPE)));
             out_msg = out_host.data();
             in_msg  = in_host.data();
         }
@@ -162,12 +229,12 @@ private:
         std::vector<eckit::mpi::Request> rreq(nproc), sreq(nproc);
         for (int p = 0; p < nproc; ++p) {                                                  // HaloExchange.h:333-345
             if (in_counts[p] > 0) {
-                rreq[p] = comm().iReceive(in_msg + in_displs[p] * var_size, size_t(in_counts[p] * var_size), p, tag);
+                rreq[p] = comm().iReceive(in_msg + size_t(in_displs[p]) * var_size, size_t(in_counts[p]) * var_size, p, tag);
             }
         }
         for (int p = 0; p < nproc; ++p) {                                                  // :347-369
             if (out_counts[p] > 0) {
-                sreq[p] = comm().iSend(out_msg + out_displs[p] * var_size, size_t(out_counts[p] * var_size), p, tag);
+                sreq[p] = comm().iSend(out_msg + size_t(out_displs[p]) * var_size, size_t(out_counts[p]) * var_size, p, tag);
             }
         }
         for (int p = 0; p < nproc; ++p) {
@@ -176,10 +243,10 @@ private:
             }
         }
         if (!device_msgs) {
-            check(atlas_amd__device_memcpy_h2d(in_dev, in_host.data(), size_t(in_size) * sizeof(DATA_TYPE)));
+            check(atlas_amd__device_memcpy_h2d(in_dev.ptr, in_host.data(), in_size * sizeof(DATA_TYPE)));
         }
         check(atlas_amd__HaloExchange__field_op(h_, adjoint ? 5 : 3, dtype<DATA_TYPE>(), view.data(), RANK, shape, strides,
-                                                parallelDim, in_dev, 1));
+                                                parallelDim, in_dev.ptr, 1));
         if (adjoint) {
             check(atlas_amd__HaloExchange__field_op(h_, 6, dtype<DATA_TYPE>(), view.data(), RANK, shape, strides, parallelDim,
                                                     nullptr, 1));
@@ -190,14 +257,13 @@ private:
                 comm().wait(sreq[p]);
             }
         }
-        util::delete_devicemem(out_dev, out_size);
-        util::delete_devicemem(in_dev, in_size);
-        if (on_device) {
-            field.setHostNeedsUpdate(true);
-        }
-        else {
-            field.setHostNeedsUpdate(true);
+#endif
+        field.setHostNeedsUpdate(true);
+        if (!on_device) {
             field.updateHost();
+            if (allocated_here) {
+                field.deallocateDevice();
+            }
         }
     }
 
@@ -209,6 +275,9 @@ private:  // data
     std::vector<int> sendcounts_, senddispls_, recvcounts_, recvdispls_;
     int nproc = 1, myproc = 0;
     const mpi::Comm* comm_ = nullptr;
+#if defined(ATLAS_AMD_HALO_TRANSPORT_RCCL)
+    atlas_amd_Comm* rccl_ = nullptr;   // the library's communicator (RCCL over xGMI), created at the first setup
+#endif
 };
 
 }  // namespace parallel

@@ -956,6 +956,9 @@ int atlas_amd__Trans__fft_phase_profile(atlas_amd_Trans* t, int enable, unsigned
 
 int atlas_amd__Trans__fft_trace(atlas_amd_Trans* t, unsigned long long words, unsigned long long* out) {
     AA_TRY
+    if (!t || !t->impl) {
+        throw std::invalid_argument("fft_trace: null Trans");
+    }
     t->impl->fft_trace(words, out);
     AA_CATCH_INT
 }

@@ -258,8 +258,9 @@ int atlas_amd__packed_transpose_messages(int nlats, const int row_mmax[], int co
                                          long long* send_end, long long* recv_begin, long long* recv_end, int* count,
                                          long long totals[2]) {
     DX_TRY
-    if (!row_mmax || !bands || !count || nparts < 1 || nlats < 0) {
-        throw std::invalid_argument("packed_transpose_messages: bad arguments");
+    if (!row_mmax || !bands || !count || nparts < 1 || nlats < 0 || capacity < 0 ||
+        (capacity > 0 && (!peer || !send_begin || !send_end || !recv_begin || !recv_end))) {
+        throw std::invalid_argument("packed_transpose_messages: bad arguments (null array with capacity > 0?)");
     }
     std::vector<int> b(bands, bands + nparts + 1), mm(row_mmax, row_mmax + nlats);
     const auto plan = atlas_amd::trans::make_packed_transpose_plan(mm, cols, b, nparts, part);

@@ -112,6 +112,8 @@ private:
     parallel::Comm& comm_;
     hipStream_t comm_stream_ = nullptr;
     int nf_cap_ = 0, nf_plan_ = 0, RP_ = 0;
+    size_t capF_ = 0, capS_ = 0, capR_ = 0;   // doubles allocated for F, S, R of each slot (high-water marks)
+    bool clip_noted_ = false;
     int64_t max_message_elems_ = int64_t(1) << 26;
     int64_t msgs_limit_        = 0;     // the limit msgs_ was built with
     bool poison_               = false; // ATLAS_AMD_DIST_POISON=1 (tests): F, S, R are filled with NaN before every transform

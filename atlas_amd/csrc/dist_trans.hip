@@ -221,7 +221,10 @@ void DistributedTrans::ensure(int nb_fields) {
         }
         RP_    = trans_.fourier_row_pitch(nb_fields);
         pplan_ = make_packed_transpose_plan(row_mmax, 2 * nb_fields, trans_.bands(), trans_.nparts(), trans_.part());
-        // device copies of the offsets: source side (pack kernel), destination side (Fourier kernels)
+        // device copies of the offsets: source side (pack kernel), destination side (Fourier kernels).  Their sizes do not
+        // depend on the field count: allocated once, rewritten in place (both streams are idle here), so that the pointers the
+        // Fourier stage's piece table is keyed by stay the same for every field count (a caller alternating between
+        // 137-level and surface fields used to add a piece table per call and, past eight, a device-wide synchronisation)
         const int P = trans_.nparts(), part = trans_.part();
         const int b0 = trans_.bands()[part], b1 = trans_.bands()[part + 1];
         std::vector<long long> src(pplan_.rowoff[part].begin(), pplan_.rowoff[part].end());
@@ -235,41 +238,78 @@ void DistributedTrans::ensure(int nb_fields) {
                 dst[(size_t)p * (b1 - b0) + r] = pplan_.rowoff[p][b0 + r] - pplan_.rowoff[p][b0];
             }
         }
-        (void)hipFree(d_rowoff_src_);
-        (void)hipFree(d_rowoff_dst_);
-        (void)hipFree(d_kept_);
-        d_rowoff_src_ = nullptr, d_rowoff_dst_ = nullptr, d_kept_ = nullptr;
-        HIP_CHECK(hipMalloc((void**)&d_rowoff_src_, src.size() * sizeof(long long)));
-        HIP_CHECK(hipMalloc((void**)&d_rowoff_dst_, dst.size() * sizeof(long long)));
-        HIP_CHECK(hipMalloc((void**)&d_kept_, kept.size() * sizeof(int)));
+        if (!d_rowoff_src_) {
+            HIP_CHECK(hipMalloc((void**)&d_rowoff_src_, src.size() * sizeof(long long)));
+            HIP_CHECK(hipMalloc((void**)&d_rowoff_dst_, dst.size() * sizeof(long long)));
+            HIP_CHECK(hipMalloc((void**)&d_kept_, kept.size() * sizeof(int)));
+        }
         HIP_CHECK(hipMemcpy(d_rowoff_src_, src.data(), src.size() * sizeof(long long), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(d_rowoff_dst_, dst.data(), dst.size() * sizeof(long long), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(d_kept_, kept.data(), kept.size() * sizeof(int), hipMemcpyHostToDevice));
-        for (Slot& s : slot_) {
-            for (double** ptr : {&s.F, &s.S, &s.R}) {
-                if (*ptr) {
-                    HIP_CHECK(hipFree(*ptr));
-                    *ptr = nullptr;
+        // F, S and R of both slots at their high-water sizes: reallocated only when a plan needs more
+        const size_t needF = std::max<size_t>(trans_.fourier_doubles(nb_fields), 1);
+        const size_t needS = (size_t)std::max<int64_t>(pplan_.send_total, 1);
+        const size_t needR = (size_t)std::max<int64_t>(pplan_.out_total, 1);
+        if (needF > capF_ || needS > capS_ || needR > capR_) {
+            capF_ = std::max(capF_, needF);
+            capS_ = std::max(capS_, needS);
+            capR_ = std::max(capR_, needR);
+            for (Slot& s : slot_) {
+                for (double** ptr : {&s.F, &s.S, &s.R}) {
+                    if (*ptr) {
+                        HIP_CHECK(hipFree(*ptr));
+                        *ptr = nullptr;
+                    }
                 }
+                HIP_CHECK(hipMalloc((void**)&s.F, capF_ * sizeof(double)));
+                HIP_CHECK(hipMalloc((void**)&s.S, capS_ * sizeof(double)));
+                HIP_CHECK(hipMalloc((void**)&s.R, capR_ * sizeof(double)));
+                s.used = false;
             }
-            HIP_CHECK(hipMalloc((void**)&s.F, std::max<size_t>(trans_.fourier_doubles(nb_fields), 1) * sizeof(double)));
-            HIP_CHECK(hipMalloc((void**)&s.S, std::max<int64_t>(pplan_.send_total, 1) * sizeof(double)));
-            HIP_CHECK(hipMalloc((void**)&s.R, std::max<int64_t>(pplan_.out_total, 1) * sizeof(double)));
-            s.used = false;
+            trans_.clear_fourier_parts_cache();   // keyed by the pointers that were just freed
         }
         nf_cap_  = nb_fields;
         nf_plan_ = nb_fields;
     }
     msgs_       = packed_transpose_messages(pplan_, trans_.bands(), trans_.nparts(), trans_.part(), max_message_elems_);
     msgs_limit_ = max_message_elems_;
+    // both ends of every pair must cut their runs alike: the number of pieces per pair follows from the message limit, which is
+    // a per-rank setting -- compare it (and the field count) across the ranks instead of finding out by a size-mismatch error, a hang
+    // or silently misplaced rows
+    {
+        const int P = comm_.size();
+        const int mine[4] = {(int)(max_message_elems_ & 0x7fffffff), (int)(max_message_elems_ >> 31), nb_fields,
+                             (int)(msgs_.size() / std::max(P, 1))};
+        std::vector<int> send((size_t)P * 4), recv((size_t)P * 4, 0);
+        for (int p = 0; p < P; ++p) {
+            std::copy(mine, mine + 4, send.begin() + (size_t)p * 4);
+        }
+        comm_.all_to_all(send.data(), recv.data(), 4);
+        for (int p = 0; p < P; ++p) {
+            if (!std::equal(mine, mine + 4, recv.begin() + (size_t)p * 4)) {
+                throw std::runtime_error("DistributedTrans: rank " + std::to_string(p) + " uses another message limit / field count "
+                                         "(set_max_message_elems must be called with the same value on every rank)");
+            }
+        }
+        int64_t biggest = 0;
+        for (const TransposeMsg& m : msgs_) {
+            biggest = std::max<int64_t>(biggest, m.send_end - m.send_begin);
+        }
+        if (biggest > max_message_elems_ && !clip_noted_) {   // K is capped by the rows of the smallest band
+            clip_noted_ = true;
+            std::fprintf(stderr, "[atlas_amd] DistributedTrans: message limit of %lld doubles cannot be honoured (largest message %lld): "
+                                 "a pair's run is cut into at most as many pieces as the smallest latitude band has rows\n",
+                         (long long)max_message_elems_, (long long)biggest);
+        }
+    }
 }
 
 // tests (ATLAS_AMD_DIST_POISON=1): every byte of the three buffers is NaN before the transform writes them, so a read of a
 // slot nobody wrote -- or an uninitialised byte on the wire -- shows up in the result
 void DistributedTrans::poison(Slot& s) {
-    HIP_CHECK(hipMemsetAsync(s.F, 0xFF, std::max<size_t>(trans_.fourier_doubles(nf_cap_), 1) * sizeof(double), trans_.stream()));
-    HIP_CHECK(hipMemsetAsync(s.S, 0xFF, std::max<int64_t>(pplan_.send_total, 1) * sizeof(double), trans_.stream()));
-    HIP_CHECK(hipMemsetAsync(s.R, 0xFF, std::max<int64_t>(pplan_.out_total, 1) * sizeof(double), trans_.stream()));
+    HIP_CHECK(hipMemsetAsync(s.F, 0xFF, capF_ * sizeof(double), trans_.stream()));
+    HIP_CHECK(hipMemsetAsync(s.S, 0xFF, capS_ * sizeof(double), trans_.stream()));
+    HIP_CHECK(hipMemsetAsync(s.R, 0xFF, capR_ * sizeof(double), trans_.stream()));
 }
 
 void DistributedTrans::legendre(int nb_fields, const double* sp_dev, Slot& s) {

@@ -778,6 +778,30 @@ static hipError_t launch_cfg(LegendreParamsT<Real> p, int nitems, int nchunks, i
     return hipGetLastError();
 }
 
+// The lean kernels request their operands with inline-assembly loads that complete asynchronously and count the waits by hand
+// (s_waitcnt vmcnt / lgkmcnt): correct only as long as the compiler never copies or spills one of those registers between the
+// request and the wait.  A spill shows as scratch memory: if a toolchain (another hipcc, other flags) gives a lean kernel a
+// private segment, it is not used -- the generic template (same arithmetic, same order, compiler-placed waits) takes over, with
+// one line on stderr.  Built and tested with ROCm 7.2.0 hipcc (AMD clang 22); the bitwise lean-vs-classic GPU test
+// (tests/test_gpu_trans.py::test_legendre_kernel_variants_are_bitwise_equal) runs in the default suite.  
+template <auto Kernel>
+static bool lean_kernel_usable(const char* name) {
+    static const bool ok = [name]() {
+        hipFuncAttributes fa{};
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(Kernel)) != hipSuccess) {
+            (void)hipGetLastError();
+            return true;   // no information: the kernel as tested
+        }
+        if (fa.localSizeBytes != 0) {
+            std::fprintf(stderr, "[atlas_amd] %s was compiled with %zu bytes of scratch (register spills): its hand-counted waits are "
+                                 "not safe with this toolchain, using the generic Legendre kernel instead\n", name, (size_t)fa.localSizeBytes);
+            return false;
+        }
+        return true;
+    }();
+    return ok;
+}
+
 // tiling for a given number of fields: rt = 16-column tiles; a workgroup covers NRG*RTW of them, the rest goes to
 // further column chunks (each chunk its own workgroup, re-reading the item's P block through L2).
 void legendre_tiling(int nf, int& rtw, int& nrg, int& nchunks) {
@@ -831,7 +855,7 @@ hipError_t launch_legendre(const LegendreParams& p, int nitems, int chunk0, int 
             chunk0 = 0;
             nrun   = nchunks;
         }
-        if (k == "lean") {
+        if (k == "lean" && lean_kernel_usable<&legendre_kernel_lean>("legendre_kernel_lean")) {
             return launch_lean(p, nitems, nchunks, chunk0, nrun, stream);
         }
 #if defined(ATLAS_AMD_EXPERIMENTS)
@@ -857,8 +881,12 @@ hipError_t launch_legendre(const LegendreParams& p, int nitems, int chunk0, int 
                 chunk0 = 0;
                 nrun   = nchunks;
             }
-            return rtw == 1 ? launch_lean_n<1, double>(p, nitems, nchunks, chunk0, nrun, stream)
-                            : launch_lean_n<2, double>(p, nitems, nchunks, chunk0, nrun, stream);
+            if (rtw == 1 && lean_kernel_usable<&legendre_kernel_lean_n<1, double>>("legendre_kernel_lean_n<1, double>")) {
+                return launch_lean_n<1, double>(p, nitems, nchunks, chunk0, nrun, stream);
+            }
+            if (rtw == 2 && lean_kernel_usable<&legendre_kernel_lean_n<2, double>>("legendre_kernel_lean_n<2, double>")) {
+                return launch_lean_n<2, double>(p, nitems, nchunks, chunk0, nrun, stream);
+            }
         }
     }
     return launch_legendre_t<double>(p, nitems, chunk0, nrun, stream);
@@ -870,7 +898,7 @@ hipError_t launch_legendre_f32(const LegendreParamsF32& p, int nitems, int chunk
     if (rtw == 3 && nrg == 2) {
         // the 96-column workgroup in its "lean" form for float as well [r3]; ATLAS_AMD_LEG_KERNEL=classic: the generic template
         const char* e = std::getenv("ATLAS_AMD_LEG_KERNEL");
-        if (!e || std::string(e) == "lean") {
+        if ((!e || std::string(e) == "lean") && lean_kernel_usable<&legendre_kernel_lean_f32>("legendre_kernel_lean_f32")) {
             if (nrun <= 0) {
                 chunk0 = 0;
                 nrun   = nchunks;
@@ -885,8 +913,12 @@ hipError_t launch_legendre_f32(const LegendreParamsF32& p, int nitems, int chunk
                 chunk0 = 0;
                 nrun   = nchunks;
             }
-            return rtw == 1 ? launch_lean_n<1, float>(p, nitems, nchunks, chunk0, nrun, stream)
-                            : launch_lean_n<2, float>(p, nitems, nchunks, chunk0, nrun, stream);
+            if (rtw == 1 && lean_kernel_usable<&legendre_kernel_lean_n<1, float>>("legendre_kernel_lean_n<1, float>")) {
+                return launch_lean_n<1, float>(p, nitems, nchunks, chunk0, nrun, stream);
+            }
+            if (rtw == 2 && lean_kernel_usable<&legendre_kernel_lean_n<2, float>>("legendre_kernel_lean_n<2, float>")) {
+                return launch_lean_n<2, float>(p, nitems, nchunks, chunk0, nrun, stream);
+            }
         }
     }
     return launch_legendre_t<float>(p, nitems, chunk0, nrun, stream);

@@ -220,6 +220,10 @@ private:
     std::vector<std::pair<std::vector<unsigned char>, void*>> parts_cache_;   // piece tables (device_structs.h: FourierParts)
     size_t parts_evict_ = 0;                                                  // on the device, by content
     const FourierParts* device_parts(const FourierParts& hp);
+public:
+    // the piece tables are cached by content (the producers' buffer pointers): a driver that frees those buffers drops them
+    void clear_fourier_parts_cache();
+private:
     unsigned long long trace_cap_ = 0;
     size_t vd_cap_      = 0;
     void ensure(double*& ptr, size_t& cap, size_t n);

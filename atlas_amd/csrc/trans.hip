@@ -121,6 +121,11 @@ Trans::Trans(const grid::StructuredGrid& grid, int truncation, const TransConfig
         po.max_mode           = geo_.T;
         if (const char* e = std::getenv("ATLAS_AMD_FFT_HYBRID")) {      // A/B switch: 0 = Bluestein for every awkward row
             po.hybrid = atoi(e) != 0;
+#if !defined(ATLAS_AMD_EXPERIMENTS)
+            if (po.hybrid) {   // the dense-stage kernel lives in tools/experiments: fail here, not at the first launch
+                throw std::runtime_error("ATLAS_AMD_FFT_HYBRID=1 needs a library built with -DATLAS_AMD_EXPERIMENTS (make -C atlas_amd/csrc experiments)");
+            }
+#endif
         }
         if (const char* e = std::getenv("ATLAS_AMD_FFT_NATIVE")) {      // 1: native mixed-radix rows where a stage list exists (opt-in)
             po.native = atoi(e) != 0;
@@ -739,6 +744,17 @@ void Trans::fourier_device_packed(int nb_fields, int nb_vordiv, const double* co
 
 // device copy of a piece table: the callers alternate between a few buffer sets (dist_trans.h slots), so a handful of tables
 // is kept by content; one that may still be read by kernels in flight is never overwritten without a device synchronisation
+void Trans::clear_fourier_parts_cache() {
+    synchronize();
+    for (auto& e : parts_cache_) {
+        if (e.second) {
+            (void)hipFree(e.second);
+        }
+    }
+    parts_cache_.clear();
+    parts_evict_ = 0;
+}
+
 const FourierParts* Trans::device_parts(const FourierParts& hp) {
     const unsigned char* bytes = reinterpret_cast<const unsigned char*>(&hp);
     for (auto& e : parts_cache_) {
