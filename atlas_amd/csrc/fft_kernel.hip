@@ -527,6 +527,105 @@ __global__ void AA_FFT_VGPR_CAP __launch_bounds__(S::NT, (FAST ? ((F32 && AA_FFT
     });
 }
 
+// ---- small reduced grids: the coarse Bluestein classes M = 256 / 512 / 1024 (fft_plan.h: PlanOptions::coarse_classes; all three
+// run with 64 workers) in ONE launch -- the workgroup derives its row's class from the row's half length and switches into the
+// instantiated body.  Three launches of a few microseconds of work each were most of the Fourier stage of TL159 -> O160
+// (BASELINE config C2).  Same row code as fft_rows_ct_kernel<S, F32, false>: bit-identical results.
+template <class S, bool F32, class C>
+__device__ __forceinline__ void coarse_row(const FourierParams& p, const FftRowDesc& d, int f, C* work, int tid) {
+    static_assert(S::NT == 64, "the coarse classes share a worker count");
+    constexpr int NPH    = fft::row_num_phases_ct<S>();
+    const long long goff = (long long)f * p.npts + d.goff_rel;
+    fft::RowTablesCtT<C> r;
+    r.n = d.n;
+    r.h = d.h;
+    const C* table;
+    if constexpr (std::is_same<C, cplx>::value) {
+        table = p.table;
+    }
+    else {
+        table = p.table_f32;
+    }
+    r.tw     = table + d.off_tw;
+    r.pre    = table + d.off_pre;
+    r.chirp  = table + d.off_chirp;
+    r.bhat_t = table + d.off_bhat_t;
+    fft::RowOut io;
+    io.mmax      = d.mmax;
+    io.y         = F32 ? reinterpret_cast<double*>(reinterpret_cast<float*>(p.gp) + goff) : p.gp + goff;
+    io.aligned16 = ((goff & 1) == 0);
+    io.f32       = F32 ? 1 : 0;
+    io.scale     = (f < p.scale_uv_fields) ? d.coslatinv : 1.0;
+    gather_modes_to_lds<F32>(p, (long long)(d.row - p.lat0), f, io.mmax, work, tid, S::NT);
+    __syncthreads();
+    for_each_phase<S, 0>([&](auto phc) {
+        constexpr int ph = decltype(phc)::value;
+        fft::row_phase_ct<S, true>(ph, tid, S::NT, r, work, io, work);
+        if constexpr (ph < NPH - 1) {
+            if constexpr (S::wave_local_middle() && ph >= 1 && ph <= NPH - 3) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            else {
+                __syncthreads();
+            }
+        }
+    });
+}
+
+template <bool F32>
+__global__ void __launch_bounds__(64, 3) fft_rows_coarse_kernel(FourierParams p) {
+    using C = std::conditional_t<(F32 && AA_FFT_F32_ARITH), fft::cplxf, cplx>;
+    extern __shared__ double lds_raw[];
+    C* work = reinterpret_cast<C*>(lds_raw);
+    int ri, f;
+    if (!fft_block_to_job_index(p, blockIdx.x, ri, f)) {
+        return;
+    }
+    const FftRowDesc d = p.desc[ri];
+    const int need     = 2 * d.h - 1;   // fft_plan.cpp: coarse_bluestein_length(2 h - 1)
+    if (need <= 256) {
+        coarse_row<fft::CtShape<1, 8>, F32>(p, d, f, work, (int)threadIdx.x);
+    }
+    else if (need <= 512) {
+        coarse_row<fft::CtShape<1, 9>, F32>(p, d, f, work, (int)threadIdx.x);
+    }
+    else {
+        coarse_row<fft::CtShape<1, 10>, F32>(p, d, f, work, (int)threadIdx.x);
+    }
+}
+
+hipError_t launch_fourier_coarse(const FourierParams& p, int lds_bytes, hipStream_t stream) {
+    if (!p.desc) {
+        return hipErrorInvalidValue;
+    }
+    const int ngr         = (p.f_end - p.f_begin + FGROUP - 1) / FGROUP;
+    const long long units = (long long)p.nrows * ngr;
+    const unsigned nblk   = (unsigned)((units + 7) / 8 * 64);
+    FourierParams q       = p;
+    q.nvirt               = nblk;
+    if (p.f32) {
+        if (AA_FFT_F32_ARITH) {
+            lds_bytes /= 2;
+            if (!p.table_f32) {
+                return hipErrorInvalidValue;
+            }
+        }
+        if (hipError_t e = ensure_dynamic_lds<&fft_rows_coarse_kernel<true>>(lds_bytes); e != hipSuccess) {
+            return e;
+        }
+        hipLaunchKernelGGL((fft_rows_coarse_kernel<true>), dim3(nblk), dim3(64), lds_bytes, stream, q);
+    }
+    else {
+        if (hipError_t e = ensure_dynamic_lds<&fft_rows_coarse_kernel<false>>(lds_bytes); e != hipSuccess) {
+            return e;
+        }
+        hipLaunchKernelGGL((fft_rows_coarse_kernel<false>), dim3(nblk), dim3(64), lds_bytes, stream, q);
+    }
+    return hipGetLastError();
+}
+
 // workers of a direct row: one butterfly per worker in every stage (max over the stages of M / radix, whole wavefronts)
 template <class S>
 constexpr int dct_workers() {

@@ -193,6 +193,7 @@ private:
         int ct_f, ct_k;  // specialised kernel instance, or ct_k < 0
         bool direct;     // specialised instance is the direct (no Bluestein) kernel
         bool hybrid = false;  // dense-stage rows (fft_rows_hyb_kernel)
+        bool coarse_fused = false;   // the coarse Bluestein classes 256 / 512 / 1024 of a small reduced grid in one launch
         bool native = false;  // native mixed-radix rows (fft_rows_nat_kernel): d_desc holds FftNatDesc records
         bool native_bigp = false;   // ... whose first-stage radix is a prime 17 .. 31 (the kernel instance with 168 registers)
         int nrows;

@@ -32,6 +32,7 @@ hipError_t launch_fourier_ct(const FourierParams& p, int ctf, int ctk, int lds_b
                              hipStream_t stream);
 hipError_t launch_fourier_hyb(const FourierParams& p, int lds_bytes, int nthreads, hipStream_t stream);
 hipError_t launch_fourier_nat(const FourierParams& p, int lds_bytes, int bigp, hipStream_t stream);   // fft_native.hip
+hipError_t launch_fourier_coarse(const FourierParams& p, int lds_bytes, hipStream_t stream);
 hipError_t launch_fourier_dct(const FourierParams& p, int ctf, int ctk, int lds_bytes, int nthreads,
                               hipStream_t stream);
 hipError_t launch_spectra_prepare(const double* vor, const double* div, const double* sp, double* out, int T, int nvd,
@@ -443,6 +444,13 @@ void Trans::upload() {
     for (int j = band_begin(); j < band_end(); ++j) {
         const fft::FftRowPlan& pl = fftplans_.plans[row_plan[j]];
         if (pl.method == fft::FFT_BLUESTEIN && pl.ct_k >= 0) {
+            // small reduced grids: the coarse classes 256 / 512 / 1024 share one launch (fft_kernel.hip: fft_rows_coarse_kernel);
+            // ATLAS_AMD_FFT_COARSE_FUSED=0: one launch per class as before (A/B)
+            static const bool fuse = !(std::getenv("ATLAS_AMD_FFT_COARSE_FUSED") && atoi(std::getenv("ATLAS_AMD_FFT_COARSE_FUSED")) == 0);
+            if (fft_coarse_ && fuse && pl.ct_f == 1 && pl.shape.M <= 1024 && pl.shape.M == fft::coarse_bluestein_length(2 * pl.h - 1)) {
+                by_class[{6, 1024}].push_back(j);
+                continue;
+            }
             by_class[{1, pl.shape.M}].push_back(j);
             continue;
         }
@@ -515,6 +523,7 @@ void Trans::upload() {
         c.ct_f = c.ct_k = -1;
         c.direct = it->first.first == 2;
         c.hybrid = it->first.first == 3;
+        c.coarse_fused = it->first.first == 6;
         c.native = it->first.first == 4 || it->first.first == 5;
         c.native_bigp = it->first.first == 5;
         if (c.native) {
@@ -551,7 +560,7 @@ void Trans::upload() {
             return na > nb || (na == nb && a < b);
         });
         c.d_rows = dev_upload(it->second.data(), it->second.size());
-        if (it->first.first == 1) {   // specialised Bluestein rows: one flat record per row (device_structs.h: FftRowDesc)
+        if (it->first.first == 1 || it->first.first == 6) {   // specialised Bluestein rows: one flat record per row (device_structs.h: FftRowDesc)
             std::vector<FftRowDesc> desc(it->second.size());
             for (size_t i = 0; i < desc.size(); ++i) {
                 const int j               = it->second[i];
@@ -916,6 +925,9 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
         }
         if (c.native) {
             HIP_CHECK(launch_fourier_nat(p, c.lds_bytes, c.native_bigp ? 1 : 0, st));
+        }
+        else if (c.coarse_fused) {
+            HIP_CHECK(launch_fourier_coarse(p, c.lds_bytes, st));
         }
         else if (c.hybrid) {
             HIP_CHECK(launch_fourier_hyb(p, c.lds_bytes, c.nthreads, st));

@@ -139,3 +139,41 @@ def test_adapter_trans_selects_the_target_as_translocal_does():
     assert "domain().global()" in src and "throw_NotImplemented" in src
     assert "std::unique_ptr<atlas_amd_Trans" in hdr and "std::unique_ptr<atlas_amd_Grid" in hdr
     assert "make_device_view<double, 1>" in src and "deviceAllocated()" in src      # device-resident fields stay on the device
+
+
+def _atlas_prefixes():
+    """install prefixes of Atlas and eckit from the environment (tools/adapter_ci.md), or None"""
+    atlas = os.environ.get("atlas_DIR") or os.environ.get("ATLAS_DIR")
+    if not atlas:
+        return None
+    for up in ("", "..", "../..", "../../.."):          # a prefix or its lib/cmake/atlas
+        cand = os.path.normpath(os.path.join(atlas, up))
+        if os.path.isfile(os.path.join(cand, "include", "atlas", "trans", "detail", "TransImpl.h")):
+            eckit = os.environ.get("eckit_DIR") or os.environ.get("ECKIT_DIR") or cand
+            for up2 in ("", "..", "../..", "../../.."):
+                c2 = os.path.normpath(os.path.join(eckit, up2))
+                if os.path.isdir(os.path.join(c2, "include", "eckit")):
+                    return cand, c2
+    return None
+
+
+@pytest.mark.skipif(_atlas_prefixes() is None, reason="no installed Atlas (atlas_DIR / ATLAS_DIR unset): the image has no ecbuild / eckit; "
+                                                      "see tools/adapter_ci.md")
+def test_adapter_compiles_against_an_installed_atlas(tmp_path):
+    """[r4] the compiler's front end instead of regular expressions: g++ -fsyntax-only of every adapter translation unit against
+    the installed Atlas / eckit headers -- overrides (const, default arguments), template deduction of make_device_view, the Plugin
+    base and REGISTER_LIBRARY -- and of the header-only halo exchange in both transports."""
+    import subprocess
+    atlas, eckit = _atlas_prefixes()
+    inc = ["-I", os.path.join(atlas, "include"), "-I", os.path.join(eckit, "include"), "-I", os.path.join(ROOT, "include"),
+           "-I", os.path.join(ROOT, "adapter")]
+    units = [os.path.join(ROOT, "adapter", f) for f in sorted(os.listdir(os.path.join(ROOT, "adapter"))) if f.endswith(".cc")]
+    assert len(units) >= 4
+    tu = tmp_path / "halo_tu.cc"
+    tu.write_text('#include "HaloExchangeMI355X.h"\n'
+                  "template void atlas::parallel::HaloExchangeMI355X::execute<double, 2>(atlas::array::Array&, bool) const;\n"
+                  "template void atlas::parallel::HaloExchangeMI355X::execute_adjoint<int, 1>(atlas::array::Array&, bool) const;\n")
+    jobs = [(u, []) for u in units] + [(str(tu), []), (str(tu), ["-DATLAS_AMD_HALO_TRANSPORT_RCCL"])]
+    for src, extra in jobs:
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall"] + extra + inc + [src], capture_output=True, text=True)
+        assert r.returncode == 0, f"{os.path.basename(src)} {extra}:\n{r.stderr[-4000:]}"

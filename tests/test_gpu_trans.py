@@ -298,6 +298,28 @@ def test_native_mixed_radix_rows_at_full_size_one_row_pair_per_shape_class(monke
         assert err < 1e-12, (r, tuple(tr.fft_row_classes()[r]), err)
 
 
+def test_coarse_row_classes_in_one_launch_are_bitwise_equal_to_one_launch_per_class(monkeypatch):
+    """[r4] small reduced grids (BASELINE C2: TL159 -> O160): the coarse Bluestein classes 256 / 512 / 1024 share ONE launch whose
+    workgroups switch into the instantiated body of their row's class (fft_rows_coarse_kernel); same row code, same bits as one
+    launch per class (ATLAS_AMD_FFT_COARSE_FUSED=0), fp64 and fp32, and the oracle agrees"""
+    g = atlas_amd.Grid("O160")
+    T, nf = 159, 11
+    sp = red_spectra(T, nf, seed=43)
+    sp32 = torch.from_numpy(sp.astype(np.float32)).cuda()
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("ATLAS_AMD_FFT_COARSE_FUSED", fused)
+        tr = atlas_amd.Trans(g, T)
+        cls = tr.fft_row_classes()
+        assert set(cls[:, 1]) <= {256, 512, 1024} and (cls[:, 2] == 1).all()
+        gp32 = torch.full((nf * g.size(),), float("nan"), dtype=torch.float32, device="cuda")
+        tr.invtrans(nf, sp32, gp32)
+        tr.synchronize()
+        outs[fused] = (run_device(tr, nf, sp), gp32.cpu().numpy())
+    assert np.array_equal(outs["1"][0], outs["0"][0]) and np.array_equal(outs["1"][1], outs["0"][1])
+    assert compute_rms(outs["1"][0], oracle.OraclePlan(T, g.nx(), g.y()).invtrans(nf, sp, use_fft=True)) < TOL
+
+
 def test_fourier_scheduling_switches_do_not_change_results(monkeypatch):
     """L2 prefetch of a later job's modes, row -> XCD affinity and the number of class streams only move work around:
     bit-identical grid points with them off (fft_kernel.hip: PrefetchJob, fft_device.h: fft_unit_to_job)."""
