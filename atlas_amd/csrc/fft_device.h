@@ -54,23 +54,38 @@ __device__ __forceinline__ bool fft_block_to_job_index(const FourierParams& p, i
     f = p.f_begin + fg * FGROUP + j;
     return f < p.f_end;
 }
+// (the kernels without a row record: direct rows, run-time shaped rows).  In the fp32 variant a 128-byte line of the intermediate
+// holds SIXTEEN fields (8 bytes per mode): the group that shares an XCD is then 16 fields wide -- with 8, the two halves of every
+// line went to two XCDs and were fetched from HBM twice (regular grids, BASELINE config C5) [r4]
+__device__ __forceinline__ int fft_job_group_log2(const FourierParams& p) {
+    return p.job_group_log2;
+}
 __device__ __forceinline__ bool fft_block_to_job(const FourierParams& p, int b, int& row, int& f) {
+    const int gl  = fft_job_group_log2(p);
+    const int gw  = 1 << gl;
     const int x   = b & 7;
     const int q   = b >> 3;
-    const int j   = q & 7;
-    const int u   = (q >> 3) * 8 + x;
-    const int ngr = (p.f_end - p.f_begin + FGROUP - 1) / FGROUP;
+    const int j   = q & (gw - 1);
+    const int u   = (q >> gl) * 8 + x;
+    const int ngr = (p.f_end - p.f_begin + gw - 1) >> gl;
     const int ri  = u / ngr;
     const int fg  = u - ri * ngr;
     if (ri >= p.nrows) {
         return false;
     }
-    f = p.f_begin + fg * FGROUP + j;
+    f = p.f_begin + fg * gw + j;
     if (f >= p.f_end) {
         return false;
     }
     row = p.rows[ri];
     return true;
+}
+// workgroups of a launch of those kernels (host)
+inline unsigned fft_job_blocks(int nrows, int nfields, int group_log2) {
+    const int gw          = 1 << group_log2;
+    const long long ngr   = (nfields + gw - 1) / gw;
+    const long long units = (long long)nrows * ngr;
+    return (unsigned)((units + 7) / 8 * 8 * gw);
 }
 
 // Input modes of one (row, field).  The Fourier intermediate may be split by zonal wavenumber over `nparts`

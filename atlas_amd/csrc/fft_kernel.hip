@@ -658,8 +658,14 @@ __device__ __forceinline__ void dct_for_each_mid_down(Fn&& fn) {
 // v_pk_{add,mul,fma}_f32); F32 && !F32A: float storage around fp64 arithmetic
 // wavefronts per SIMD a direct-row kernel is compiled for: 3 (168 registers), 2 where the first butterfly is too wide for that
 // (radix >= 15 in fp64 -- such rows are >= 60 KB of LDS: two workgroups per CU anyway -- or >= 20 in fp32: 30 - 310 spilled registers)
+#ifndef AA_DCT_F32_WPS
+#define AA_DCT_F32_WPS 3   // dev builds: wavefronts per SIMD the fp32-arithmetic direct rows are compiled for (A/B)
+#endif
 template <class S, bool F32A>
 constexpr int dct_waves_per_simd() {
+    if (F32A && AA_DCT_F32_WPS != 3) {
+        return AA_DCT_F32_WPS;
+    }
     return S::radix(0) >= (F32A ? 20 : 15) ? 2 : 3;
 }
 
@@ -916,9 +922,7 @@ static hipError_t launch_dct(const FourierParams& p, int lds_bytes, int nthreads
 
 hipError_t launch_fourier_dct(const FourierParams& p, int ctf, int ctk, int lds_bytes, int nthreads,
                               hipStream_t stream) {
-    const int ngr         = (p.f_end - p.f_begin + FGROUP - 1) / FGROUP;
-    const long long units = (long long)p.nrows * ngr;
-    const unsigned nblk   = (unsigned)((units + 7) / 8 * 64);
+    const unsigned nblk = fft_job_blocks(p.nrows, p.f_end - p.f_begin, p.job_group_log2);   // fft_device.h: fft_block_to_job
     AA_CT_DISPATCH(ctf, ctk, return launch_dct<S>(p, lds_bytes, nthreads, nblk, stream))
     return hipErrorInvalidValue;
 }
@@ -927,10 +931,8 @@ hipError_t launch_fourier(const FourierParams& p, int lds_bytes, int nthreads, h
     if (hipError_t e = ensure_dynamic_lds<&fft_rows_kernel>(lds_bytes); e != hipSuccess) {   // dyn_lds.h
         return e;
     }
-    const int ngr         = (p.f_end - p.f_begin + FGROUP - 1) / FGROUP;
-    const long long units = (long long)p.nrows * ngr;
-    const long long nblk  = (units + 7) / 8 * 64;
-    hipLaunchKernelGGL(fft_rows_kernel, dim3((unsigned)nblk), dim3(nthreads), lds_bytes, stream, p);
+    const unsigned nblk = fft_job_blocks(p.nrows, p.f_end - p.f_begin, p.job_group_log2);   // fft_device.h: fft_block_to_job
+    hipLaunchKernelGGL(fft_rows_kernel, dim3(nblk), dim3(nthreads), lds_bytes, stream, p);
     return hipGetLastError();
 }
 

@@ -196,6 +196,7 @@ private:
         bool coarse_fused = false;   // the coarse Bluestein classes 256 / 512 / 1024 of a small reduced grid in one launch
         bool native = false;  // native mixed-radix rows (fft_rows_nat_kernel): d_desc holds FftNatDesc records
         bool native_bigp = false;   // ... whose first-stage radix is a prime 17 .. 31 (the kernel instance with 168 registers)
+        int native_fpj   = 1;       // ... fields per workgroup (1 or 2)
         int nrows;
         int* d_rows;
         void* d_desc = nullptr;   // FftRowDesc[nrows] for the specialised Bluestein kernels

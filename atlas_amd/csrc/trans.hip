@@ -31,7 +31,7 @@ hipError_t launch_fourier(const FourierParams& p, int lds_bytes, int nthreads, h
 hipError_t launch_fourier_ct(const FourierParams& p, int ctf, int ctk, int lds_bytes, int nthreads,
                              hipStream_t stream);
 hipError_t launch_fourier_hyb(const FourierParams& p, int lds_bytes, int nthreads, hipStream_t stream);
-hipError_t launch_fourier_nat(const FourierParams& p, int lds_bytes, int bigp, hipStream_t stream);   // fft_native.hip
+hipError_t launch_fourier_nat(const FourierParams& p, int lds_bytes, int bigp, int fields_per_job, hipStream_t stream);   // fft_native.hip
 hipError_t launch_fourier_coarse(const FourierParams& p, int lds_bytes, hipStream_t stream);
 hipError_t launch_fourier_dct(const FourierParams& p, int ctf, int ctk, int lds_bytes, int nthreads,
                               hipStream_t stream);
@@ -316,11 +316,11 @@ void Trans::download_legendre_table(double* out, size_t size_doubles) const {
     }
 }
 
-// LDS elements of a native row: the work array (the staging area of the gathered modes aliases it: whole 64-lane granules) + the
-// 64-element dump area of the L2 prefetch requests behind it (fft_native.hip)
+// LDS elements of ONE work array of a native row (the staging area of the gathered modes aliases it: whole 64-lane granules); a
+// workgroup has one or two of them and the 64-element dump area of the L2 prefetch requests behind them (fft_native.hip)
 static int native_lds_elems(const fft::FftRowPlan& pl, int row_mmax) {
     const int mmax = std::max(0, std::min(row_mmax, pl.h));
-    return std::max(pl.nat.lds_elems, (mmax + 1 + 63) / 64 * 64) + 64;
+    return std::max(pl.nat.lds_elems, (mmax + 1 + 63) / 64 * 64);
 }
 
 void Trans::upload() {
@@ -459,14 +459,18 @@ void Trans::upload() {
             continue;
         }
         if (pl.method == fft::FFT_NATIVE) {
-            // native mixed-radix rows: one kernel for every shape (two register classes: first-stage radix 3 .. 15 -- four
-            // workgroups per CU -- / prime 17 .. 31 -- three), launches bucketed by LDS footprint: 40 KiB (four workgroups per
-            // CU), 52 KiB (three), 80 KiB (two)
+            // native mixed-radix rows: one kernel for every shape.  Two register classes (first-stage radix 3 .. 15: four
+            // workgroups per CU / prime 17 .. 31: three); launches bucketed by LDS footprint: 40 KiB (four per CU), 52 KiB (three),
+            // 80 KiB (two).  ATLAS_AMD_FFT_NATIVE_FPJ=2: two fields per workgroup where two work arrays fit 80 KiB -- measured
+            // slower (2.20 against 1.60 ms for the native rows of O1280, profiles/r04_fft_native.txt), bit-identical
+            static const int nat_fpj = std::getenv("ATLAS_AMD_FFT_NATIVE_FPJ") ? atoi(std::getenv("ATLAS_AMD_FFT_NATIVE_FPJ")) : 1;
             const int bigp  = pl.nat.radix[0] > 15 ? 1 : 0;
-            const int elems = native_lds_elems(pl, row_mmax[j]);
+            const int one   = native_lds_elems(pl, row_mmax[j]);
+            const int fpj   = (nat_fpj >= 2 && 2 * one + 64 <= 5120) ? 2 : 1;
+            const int elems = fpj * one + 64;
             int cls         = 0;
             for (int c : {2560, 3328, 5120}) {
-                if (elems <= c && !(bigp && c == 2560)) {
+                if (elems <= c && !((bigp || fpj == 2) && c == 2560)) {   // (three workgroups per CU by registers for those)
                     cls = c;
                     break;
                 }
@@ -474,7 +478,7 @@ void Trans::upload() {
             if (cls == 0) {
                 throw std::runtime_error("row length " + std::to_string(pl.n) + " does not fit in LDS (160 KiB)");
             }
-            by_class[{4 + bigp, cls}].push_back(j);
+            by_class[{10 + 2 * bigp + (fpj - 1), cls}].push_back(j);
             continue;
         }
         if (pl.method == fft::FFT_HYBRID) {
@@ -524,12 +528,13 @@ void Trans::upload() {
         c.direct = it->first.first == 2;
         c.hybrid = it->first.first == 3;
         c.coarse_fused = it->first.first == 6;
-        c.native = it->first.first == 4 || it->first.first == 5;
-        c.native_bigp = it->first.first == 5;
+        c.native = it->first.first >= 10 && it->first.first <= 13;
+        c.native_bigp = c.native && ((it->first.first - 10) & 2) != 0;
+        c.native_fpj  = c.native ? ((it->first.first - 10) & 1) + 1 : 1;
         if (c.native) {
             int lds = 0;
             for (int j : it->second) {
-                lds = std::max(lds, native_lds_elems(fftplans_.plans[row_plan[j]], row_mmax[j]));
+                lds = std::max(lds, c.native_fpj * native_lds_elems(fftplans_.plans[row_plan[j]], row_mmax[j]) + 64);
             }
             c.lds_bytes = lds * 16;
             c.nthreads  = fft::NAT_NT;
@@ -858,6 +863,10 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
     p.pf_dist         = 2;   // 16 jobs of the XCD ahead (profiles/r03_fft_experiments.txt, 12.)
     p.pf_sectors      = 1;
     p.row_affinity    = 1;
+    p.job_group_log2  = f32 ? 4 : 3;
+    if (const char* e = std::getenv("ATLAS_AMD_FFT_GROUP_LOG2")) {   // A/B
+        p.job_group_log2 = std::max(3, std::min(4, atoi(e)));
+    }
     if (const char* e = std::getenv("ATLAS_AMD_FFT_ROW_AFFINITY")) {
         p.row_affinity = atoi(e);
     }
@@ -924,7 +933,7 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
             }
         }
         if (c.native) {
-            HIP_CHECK(launch_fourier_nat(p, c.lds_bytes, c.native_bigp ? 1 : 0, st));
+            HIP_CHECK(launch_fourier_nat(p, c.lds_bytes, c.native_bigp ? 1 : 0, c.native_fpj, st));
         }
         else if (c.coarse_fused) {
             HIP_CHECK(launch_fourier_coarse(p, c.lds_bytes, st));

@@ -274,6 +274,9 @@ def test_native_mixed_radix_rows_against_the_oracle(monkeypatch):
     tr.synchronize()
     assert bool(torch.isfinite(gp32).all())
     assert compute_rms(gp32.cpu().numpy().astype(np.float64), ref32) < 2e-6
+    monkeypatch.setenv("ATLAS_AMD_FFT_NATIVE_FPJ", "2")                         # two fields per workgroup: same arithmetic per field
+    assert np.array_equal(run_device(atlas_amd.Trans(g, T), nf, sp), gp)
+    monkeypatch.delenv("ATLAS_AMD_FFT_NATIVE_FPJ")
     monkeypatch.delenv("ATLAS_AMD_FFT_NATIVE")
     assert (atlas_amd.Trans(g, T).fft_row_classes()[:, 2] != 4).all()          # opt-in: off by default
 
