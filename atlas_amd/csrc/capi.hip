@@ -1070,6 +1070,9 @@ int atlas_amd__fft_host_row_hybrid(int n, const double* modes, int mmax, double*
     if (n < 1 || !modes || !out) {
         throw std::invalid_argument("fft_host_row_hybrid: n >= 1 and non-null arrays are required");
     }
+#if !defined(ATLAS_AMD_EXPERIMENTS)
+    throw std::runtime_error("fft_host_row_hybrid: the dense-stage rows live in tools/experiments (make -C atlas_amd/csrc experiments)");
+#endif
     fft::PlanOptions po;
     po.hybrid       = true;
     po.hybrid_min_h = 2;

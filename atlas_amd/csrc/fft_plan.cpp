@@ -473,6 +473,7 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, const PlanOptions
             }
             p.shape = p.ct_k >= 0 ? make_ct_shape(p.ct_f, p.ct_k) : make_shape(h);
         }
+#if defined(ATLAS_AMD_EXPERIMENTS)
         else if (Mcoarse == 0 && opt.hybrid && h >= opt.hybrid_min_h && hybrid_dense_radix(h) <= std::min(opt.hybrid_max_a, HYB_MAX_A)) {
             p.method = FFT_HYBRID;
             p.hyb_A  = hybrid_dense_radix(h);
@@ -490,6 +491,7 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, const PlanOptions
                 L /= p.shape.radix[i];
             }
         }
+#endif
         else {
             p.method     = FFT_BLUESTEIN;
             const int Mb = Mcoarse > 0 ? Mcoarse : next_bluestein_length(2 * h - 1);
@@ -640,6 +642,7 @@ void host_execute_row(const FftPlanSet& ps, int plan, const cplx* X, int mmax, d
                              std::min(mmax, p.h), y);
         return;
     }
+#if defined(ATLAS_AMD_EXPERIMENTS)
     if (p.method == FFT_HYBRID) {
         RowTablesHyb r;
         r.n = p.n, r.h = p.h, r.A = p.hyb_A, r.B = p.hyb_B, r.Kp = (p.hyb_A + 1) / 2;
@@ -671,6 +674,7 @@ void host_execute_row(const FftPlanSet& ps, int plan, const cplx* X, int mmax, d
         }
         return;
     }
+#endif
     RowTables r;
     r.n      = p.n;
     r.h      = p.h;

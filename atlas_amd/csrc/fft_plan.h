@@ -21,6 +21,9 @@
 
 #include "fft_core.h"
 #include "fft_native.h"
+#if defined(ATLAS_AMD_EXPERIMENTS)
+#include "../../tools/experiments/fft_hybrid_core.h"
+#endif
 
 namespace atlas_amd {
 namespace fft {

@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
 //     address arithmetic: every LDS offset is an immediate);
 //   * columns beyond the last field load the last field instead of a zero word (their products land in the padding
 //     columns of F), which removes the per-lane pointer/step pairs.
-// -DAA_COEX (dev build, tools/r03_coex.sh): 136 registers per wavefront, so that a CU takes ONE workgroup of this kernel (two need
+// -DAA_COEX (dev build, tools/coex_probe.py): 136 registers per wavefront, so that a CU takes ONE workgroup of this kernel (two need
 // 4 x 136 registers per SIMD) and keeps 240 registers per SIMD and 112 KiB of LDS for a workgroup of the Fourier stage of another
 // transform -- the co-residency experiment of DESIGN 3.4
 #if defined(AA_COEX)

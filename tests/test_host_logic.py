@@ -283,47 +283,6 @@ def test_fft_phase_code_with_the_coarse_row_classes_of_small_reduced_grids():
     assert worst < 2e-15, worst
 
 
-HYBRID_LENGTHS = [28, 44, 52, 68, 76, 132, 140, 148, 244, 260, 404, 1004, 2 * 514, 4 * 61 * 10, 4 * 7 * 183, 4 * 1285,
-                  2 * 2 * 3 * 7 * 61, 4 * 1283]   # the last two: no dense-stage plan (A > 257), usual plan
-
-
-@pytest.mark.parametrize("n", HYBRID_LENGTHS)
-def test_fft_hybrid_phase_code_against_pocketfft(n):
-    """host run of the dense-stage rows of fft_core.h (fold + symmetric split, cos / sin matrix stage, native stages)"""
-    rng = np.random.default_rng(n)
-    nc = n // 2 + 1
-    for mmax in (nc - 1, max(0, n // 3), 0):
-        x = rng.standard_normal(nc) + 1j * rng.standard_normal(nc)
-        x[mmax + 1:] = 0
-        out = np.zeros(n)
-        _lib.check(_lib.fft_host_row_hybrid(n, np.ascontiguousarray(x).ctypes.data, mmax, out.ctypes.data))
-        xx = x.copy()
-        xx[0] = xx[0].real
-        xx[-1] = xx[-1].real
-        assert compute_rms(out, np.fft.irfft(xx, n) * n) < 2e-15, (n, mmax)
-
-
-def test_fft_hybrid_phase_code_on_every_row_length_of_O1280():
-    N, T = 1280, 1279
-    g = atlas_amd.Grid(f"O{N}")
-    rng = np.random.default_rng(7)
-    nx, y = g.nx(), g.y()
-    worst = 0.0
-    for j in range(N):
-        n = int(nx[j])
-        nc = n // 2 + 1
-        mmax = _lib.fourier_truncation(T, n, g.nxmax(), 2 * N, math.radians(y[j]), 0)
-        x = rng.standard_normal(nc) + 1j * rng.standard_normal(nc)
-        x[mmax + 1:] = 0
-        out = np.zeros(n)
-        _lib.check(_lib.fft_host_row_hybrid(n, np.ascontiguousarray(x).ctypes.data, mmax, out.ctypes.data))
-        xx = x.copy()
-        xx[0] = xx[0].real
-        xx[-1] = xx[-1].real
-        worst = max(worst, compute_rms(out, np.fft.irfft(xx, n) * n))
-    assert worst < 2e-15, worst
-
-
 def test_translocal_option_keys_are_accepted_at_the_c_abi():
     """Every existing caller of trans::Trans(grid, T, option::type("local") | option::fft("FFTW") | ...) passes TransLocal's own
     keys (option/TransOptions.cc:38-74, TransLocal.cc:61-110,326-335): the C ABI must not reject them as unknown.  Without a

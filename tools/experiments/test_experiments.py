@@ -23,6 +23,52 @@ pytestmark = pytest.mark.skipif("exp" not in os.environ.get("ATLAS_AMD_LIB", "")
                                 reason="needs ATLAS_AMD_LIB=.../libatlas_amd_exp.so (make -C atlas_amd/csrc experiments)")
 
 
+# ---- host run of the dense-stage rows (tools/experiments/fft_hybrid_core.h): no GPU needed, but an experiments build [moved here r4]
+import math  # noqa: E402
+
+from atlas_amd import _lib  # noqa: E402
+
+HYBRID_LENGTHS = [28, 44, 52, 68, 76, 132, 140, 148, 244, 260, 404, 1004, 2 * 514, 4 * 61 * 10, 4 * 7 * 183, 4 * 1285,
+                  2 * 2 * 3 * 7 * 61, 4 * 1283]   # the last two: no dense-stage plan (A > 257), usual plan
+
+
+@pytest.mark.parametrize("n", HYBRID_LENGTHS)
+def test_fft_hybrid_phase_code_against_pocketfft(n):
+    """host run of the dense-stage rows of fft_core.h (fold + symmetric split, cos / sin matrix stage, native stages)"""
+    rng = np.random.default_rng(n)
+    nc = n // 2 + 1
+    for mmax in (nc - 1, max(0, n // 3), 0):
+        x = rng.standard_normal(nc) + 1j * rng.standard_normal(nc)
+        x[mmax + 1:] = 0
+        out = np.zeros(n)
+        _lib.check(_lib.fft_host_row_hybrid(n, np.ascontiguousarray(x).ctypes.data, mmax, out.ctypes.data))
+        xx = x.copy()
+        xx[0] = xx[0].real
+        xx[-1] = xx[-1].real
+        assert compute_rms(out, np.fft.irfft(xx, n) * n) < 2e-15, (n, mmax)
+
+
+def test_fft_hybrid_phase_code_on_every_row_length_of_O1280():
+    N, T = 1280, 1279
+    g = atlas_amd.Grid(f"O{N}")
+    rng = np.random.default_rng(7)
+    nx, y = g.nx(), g.y()
+    worst = 0.0
+    for j in range(N):
+        n = int(nx[j])
+        nc = n // 2 + 1
+        mmax = _lib.fourier_truncation(T, n, g.nxmax(), 2 * N, math.radians(y[j]), 0)
+        x = rng.standard_normal(nc) + 1j * rng.standard_normal(nc)
+        x[mmax + 1:] = 0
+        out = np.zeros(n)
+        _lib.check(_lib.fft_host_row_hybrid(n, np.ascontiguousarray(x).ctypes.data, mmax, out.ctypes.data))
+        xx = x.copy()
+        xx[0] = xx[0].real
+        xx[-1] = xx[-1].real
+        worst = max(worst, compute_rms(out, np.fft.irfft(xx, n) * n))
+    assert worst < 2e-15, worst
+
+
 def test_hybrid_fourier_rows_equal_the_bluestein_rows(monkeypatch):
     """the dense-stage ("hybrid", opt-in) Fourier kernel -- radix-A DFT on the fp64 matrix cores + radix-{2..9} stages --
     against the Bluestein kernels on every row of O320 / TL319 and against the oracle on sampled rows"""

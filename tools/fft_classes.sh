@@ -1,8 +1,8 @@
 #!/bin/bash
 # Dev tool (GPU box): per-class Fourier kernel durations, classes serialised on one stream, for the current environment
-# usage: tools/r03_classes.sh <tag>
+# usage: tools/fft_classes.sh <tag>
 export TMPDIR=/tmp
-R=$PWD; O=$R/gpurun_out/r03cls_$1; rm -rf $O; mkdir -p $O
+R=$PWD; O=$R/gpurun_out/fft_classes_$1; rm -rf $O; mkdir -p $O
 cd /tmp
 ATLAS_AMD_FFT_STREAMS=1 timeout 300 rocprofv3 --kernel-trace -d $O/serial --output-format csv -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/serial.log 2>&1
 cd $R
