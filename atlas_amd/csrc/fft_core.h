@@ -79,9 +79,17 @@ AA_HD C cmulw(C a, typename C::real c, typename C::real s, int dir) {
 // XOR swizzle of the low 4 index bits with the next 4: a bijection inside every aligned block of 256 elements, so
 // the footprint stays exactly M (two M = 5120 rows fit the 160 KiB of a CU) while the power-of-two strides of the
 // radix-16/8/4 stages still spread over the 16-byte LDS slots.
+#if defined(AA_FFT_LDS_WRAP)
+// dev probe (results wrong by construction): every LDS index wrapped into AA_FFT_LDS_WRAP + 1 elements -- the same instruction stream
+// and LDS traffic with a fraction of the footprint: the UPPER BOUND of what a smaller exchange window (more jobs per CU) could buy
+AA_HD int PAD(int i) {
+    return (i ^ ((i >> 4) & 15)) & AA_FFT_LDS_WRAP;
+}
+#else
 AA_HD int PAD(int i) {
     return i ^ ((i >> 4) & 15);
 }
+#endif
 AA_HD int padded_size(int M) {
     return (M + 255) / 256 * 256;
 }

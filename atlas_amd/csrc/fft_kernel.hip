@@ -409,7 +409,10 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
 #define AA_FFT_VGPR_CAP
 #endif
 template <class S, bool F32, bool FAST>
-__global__ void AA_FFT_VGPR_CAP __launch_bounds__(S::NT, (FAST ? ((F32 && AA_FFT_F32_ARITH) ? AA_FFT_F32_FAST_WPS : S::WPS) : 3)) fft_rows_ct_kernel(FourierParams p) {
+#ifndef AA_FFT_PLAIN_WPS
+#define AA_FFT_PLAIN_WPS 3   // wavefronts per SIMD the plain (not row_ct3) Bluestein rows are compiled for (dev builds: 4)
+#endif
+__global__ void AA_FFT_VGPR_CAP __launch_bounds__(S::NT, (FAST ? ((F32 && AA_FFT_F32_ARITH) ? AA_FFT_F32_FAST_WPS : S::WPS) : AA_FFT_PLAIN_WPS)) fft_rows_ct_kernel(FourierParams p) {
     // the fp32 variant runs in fp32 arithmetic: float tables, 8-byte LDS elements, packed v_pk_*_f32 (-DAA_FFT_F32_FP64_ARITH:
     // float storage around fp64 arithmetic, the form of rounds 1 - 2)
     using C = std::conditional_t<(F32 && AA_FFT_F32_ARITH), fft::cplxf, cplx>;
@@ -526,6 +529,10 @@ __global__ void AA_FFT_VGPR_CAP __launch_bounds__(S::NT, (FAST ? ((F32 && AA_FFT
         }
     });
 }
+
+#if defined(ATLAS_AMD_EXPERIMENTS)
+#include "../../tools/experiments/fft_halfwin_rows.inc"   // [R0,16,16] rows with LDS as a half-row window: built, measured, lost [r4]
+#endif
 
 // ---- small reduced grids: the coarse Bluestein classes M = 256 / 512 / 1024 (fft_plan.h: PlanOptions::coarse_classes; all three
 // run with 64 workers) in ONE launch -- the workgroup derives its row's class from the row's half length and switches into the
@@ -842,6 +849,9 @@ static hipError_t launch_ct_t(FourierParams p, int lds_bytes, unsigned nblk, hip
     if (!p.desc) {
         return hipErrorInvalidValue;
     }
+#if defined(AA_FFT_LDS_WRAP)
+    lds_bytes = std::min(lds_bytes, (AA_FFT_LDS_WRAP + 1) * 16);   // dev probe: see fft_core.h PAD()
+#endif
     if (const char* e = std::getenv("ATLAS_AMD_FFT_LDS_PAD")) {  // dev tool: occupancy sensitivity (more LDS per workgroup)
         lds_bytes += atoi(e);
         (void)ensure_dynamic_lds<&fft_rows_ct_kernel<S, F32, FAST>>(lds_bytes);
@@ -878,6 +888,12 @@ static bool ct3_enabled_for(int M) {
 template <class S>
 static hipError_t launch_ct(const FourierParams& p, int lds_bytes, unsigned nblk, hipStream_t stream) {
     if constexpr (ct3_fast_path<S>()) {
+#if defined(ATLAS_AMD_EXPERIMENTS)
+        static const bool halfwin = std::getenv("ATLAS_AMD_FFT_HALFWIN") && atoi(std::getenv("ATLAS_AMD_FFT_HALFWIN")) != 0;
+        if (halfwin && !p.f32) {   // LDS as a half-row window: three workgroups per CU (tools/experiments/fft_halfwin_rows.inc)
+            return launch_cth<S>(p, nblk, stream);
+        }
+#endif
         if (ct3_enabled_for(S::M)) {
             return p.f32 ? launch_ct_t<S, true, true>(p, lds_bytes, nblk, stream)
                          : launch_ct_t<S, false, true>(p, lds_bytes, nblk, stream);

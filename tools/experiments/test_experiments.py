@@ -96,3 +96,16 @@ def test_legendre_experiment_kernels_are_bitwise_equal(case, monkeypatch):
     product_tests.test_legendre_kernel_variants_are_bitwise_equal.__wrapped__(case, monkeypatch) \
         if hasattr(product_tests.test_legendre_kernel_variants_are_bitwise_equal, "__wrapped__") \
         else product_tests.test_legendre_kernel_variants_are_bitwise_equal(case, monkeypatch)
+
+
+def test_half_window_bluestein_rows_are_bitwise_equal_to_the_product_rows(monkeypatch):
+    """[r4] the [R0,16,16] rows with LDS as a half-row exchange window (tools/experiments/fft_halfwin_rows.inc,
+    ATLAS_AMD_FFT_HALFWIN=1): same arithmetic in the same order as row_phase_ct / row_ct3 -- bit-identical grid points on TL1279 ->
+    O1280 (every class M >= 3840 occurs), 9 fields"""
+    g = atlas_amd.Grid("O1280")
+    T, nf = 1279, 9
+    sp = red_spectra(T, nf, seed=19)
+    ref = run_device(atlas_amd.Trans(g, T), nf, sp)
+    monkeypatch.setenv("ATLAS_AMD_FFT_HALFWIN", "1")
+    got = run_device(atlas_amd.Trans(g, T), nf, sp)
+    assert np.array_equal(got, ref)
