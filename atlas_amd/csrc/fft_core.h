@@ -414,11 +414,36 @@ AA_HD void dit_stage(C* d, int M, int L, int lsh, const C* __restrict__ tw, int 
 
 // the same two stages for one butterfly with the stage twiddle w1 = tw[j * tws] supplied by the caller (the specialised
 // device path loads it once per row and keeps it: the DIF and the DIT stage of one level use the same entry)
+// dev probes (device builds -DAA_PROBE_LDS2 / -DAA_PROBE_VALU2; results unchanged): the LDS reads, or the butterfly arithmetic, of the
+// two wave-local radix-16 levels of the [R0,16,16] rows issued TWICE -- which unit the stage's time follows
+#if defined(__HIP_DEVICE_COMPILE__) && defined(AA_PROBE_LDS2)
+#define AA_PROBE_EXTRA_READS(R_, d_, base_, Ls_)                                                         \
+    do {                                                                                                  \
+        C x2_[R_];                                                                                        \
+        _Pragma("unroll") for (int q_ = 0; q_ < R_; ++q_) x2_[q_] = d_[PAD((base_) + q_ * (Ls_))];        \
+        _Pragma("unroll") for (int q_ = 0; q_ < R_; ++q_) asm volatile("" ::"v"(x2_[q_].re), "v"(x2_[q_].im)); \
+    } while (0)
+#else
+#define AA_PROBE_EXTRA_READS(R_, d_, base_, Ls_) ((void)0)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && defined(AA_PROBE_VALU2)
+#define AA_PROBE_EXTRA_BFLY(R_, x_, dir_)                                                                 \
+    do {                                                                                                  \
+        C y2_[R_];                                                                                        \
+        _Pragma("unroll") for (int q_ = 0; q_ < R_; ++q_) { y2_[q_] = x_[q_]; asm volatile("" : "+v"(y2_[q_].re), "+v"(y2_[q_].im)); } \
+        bfly<R_>(y2_, dir_);                                                                              \
+        _Pragma("unroll") for (int q_ = 0; q_ < R_; ++q_) asm volatile("" ::"v"(y2_[q_].re), "v"(y2_[q_].im)); \
+    } while (0)
+#else
+#define AA_PROBE_EXTRA_BFLY(R_, x_, dir_) ((void)0)
+#endif
 template <int R, class C>
 AA_HD void dif_butterfly_w(C* d, int base, int Ls, C w1, int dir) {
     C x[R];
+    AA_PROBE_EXTRA_READS(R, d, base, Ls);
 #pragma unroll
     for (int q = 0; q < R; ++q) x[q] = d[PAD(base + q * Ls)];
+    AA_PROBE_EXTRA_BFLY(R, x, dir);
     bfly<R>(x, dir);
     d[PAD(base)] = x[0];
     if (dir < 0) w1.im = -w1.im;
@@ -433,7 +458,9 @@ AA_HD void dit_butterfly_w(C* d, int base, int Ls, C w1, int dir) {
     if (dir < 0) w1.im = -w1.im;
 #pragma unroll
     for (int q = 1; q < R; ++q) x[q] = d[PAD(base + q * Ls)];
+    AA_PROBE_EXTRA_READS(R, d, base, Ls);
     twiddle_apply<R>(x, w1);
+    AA_PROBE_EXTRA_BFLY(R, x, dir);
     bfly<R>(x, dir);
 #pragma unroll
     for (int q = 0; q < R; ++q) d[PAD(base + q * Ls)] = x[q];
