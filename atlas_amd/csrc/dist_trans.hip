@@ -119,6 +119,25 @@ std::vector<TransposeMsg> packed_transpose_messages(const PackedTransposePlan& p
     }
     int64_t K = std::max<int64_t>(1, (biggest + max_message_elems - 1) / max_message_elems);
     K         = std::max<int64_t>(1, std::min<int64_t>(K, std::max(minrows, 1)));
+    // the pieces of a run are cut at equal ROW counts and the rows of a band differ in kept wavenumbers (equatorial rows are the
+    // longest): raise K until the largest piece of any pair honours the limit, or a piece is a single row [r4].  Global quantities
+    // again (the plan holds the row offsets of every rank): both ends of a pair arrive at the same K.
+    auto largest_piece = [&](int64_t kk) {
+        int64_t worst = 0;
+        for (int q = 0; q < nparts; ++q) {
+            const int rows = bands[q + 1] - bands[q];
+            for (int p = 0; p < nparts; ++p) {
+                for (int64_t k = 0; k < kk; ++k) {
+                    const int a = (int)(rows * k / kk), b = (int)(rows * (k + 1) / kk);
+                    worst       = std::max(worst, pl.rowoff[p][bands[q] + b] - pl.rowoff[p][bands[q] + a]);
+                }
+            }
+        }
+        return worst;
+    };
+    while (K < std::max(minrows, 1) && largest_piece(K) > max_message_elems) {
+        ++K;
+    }
     std::vector<TransposeMsg> msgs;
     const int myrows = bands[part + 1] - bands[part];
     for (int64_t k = 0; k < K; ++k) {

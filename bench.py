@@ -389,6 +389,13 @@ def main():
             sync()
     else:
         import torch.distributed as dist
+        if "RANK" not in os.environ:   # --force-dist in a plain process: a one-rank group of its own
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                               "MASTER_PORT": str(sk.getsockname()[1])})
+            sk.close()
         if on_gpu:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:

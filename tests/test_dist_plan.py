@@ -334,8 +334,15 @@ def _packed_plan_py(row_mmax, cols, bands, nparts, part, maxmsg):
         off += int(rowoff[p, bands[part + 1]] - rowoff[p, bands[part]])
     biggest = max(int(rowoff[p, bands[q + 1]] - rowoff[p, bands[q]]) for p in range(nparts) for q in range(nparts))
     rows = [int(bands[q + 1] - bands[q]) for q in range(nparts)]
+    minrows = max(min([r for r in rows if r > 0], default=1), 1)
     K = max(1, -(-biggest // maxmsg))
-    K = max(1, min(K, max(min([r for r in rows if r > 0], default=1), 1)))
+    K = max(1, min(K, minrows))
+
+    def largest_piece(kk):      # [r4] pieces are cut at equal row counts: K grows until the largest piece honours the limit
+        return max(int(rowoff[p, bands[q] + rows[q] * (k + 1) // kk] - rowoff[p, bands[q] + rows[q] * k // kk])
+                   for q in range(nparts) for p in range(nparts) for k in range(kk))
+    while K < minrows and largest_piece(K) > maxmsg:
+        K += 1
     msgs = []
     for k in range(K):
         for peer in range(nparts):
@@ -369,6 +376,9 @@ def test_packed_transposition_messages(nparts, maxmsg):
             send[sb:se] += 1
             recv[rb:re] += 1
         assert (send == 1).all() and (recv == 1).all()
+        minrows = min(int(bands[q + 1] - bands[q]) for q in range(nparts) if bands[q + 1] > bands[q])
+        if len(got) // nparts < minrows:          # the limit is honoured unless a piece is already a single row of the smallest band
+            assert max(se - sb for _, sb, se, _, _ in got) <= maxmsg
         per_rank.append((got, rowoff, out_off))
     for a in range(nparts):
         for b in range(nparts):
