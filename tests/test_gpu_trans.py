@@ -252,7 +252,7 @@ def test_every_bluestein_row_shape_fp64_and_fp32(f, k):
 
 def test_native_mixed_radix_rows_against_the_oracle(monkeypatch):
     """[r4] ATLAS_AMD_FFT_NATIVE=1: rows whose half length has a native stage list take fft_rows_nat_kernel (one kernel for every
-    shape, csrc/fft_native.hip) instead of a Bluestein row.  The whole O320 / T319 field in fp64 against the oracle (19 fields:
+    shape, csrc/fft_native_impl.h) instead of a Bluestein row.  The whole O320 / T319 field in fp64 against the oracle (19 fields:
     two full field groups and one of three), repeated calls bit-identical (the kernel's L2 prefetch requests must not land in
     anybody's registers), and the fp32 variant against the fp64 device result of the float-rounded spectra."""
     monkeypatch.setenv("ATLAS_AMD_FFT_NATIVE", "1")

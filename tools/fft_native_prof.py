@@ -1,5 +1,5 @@
 """Dev tool (GPU box): the native mixed-radix rows alone (ATLAS_AMD_FFT_ONLY_NATIVE=1) -- stage time and the per-phase shader-clock
-breakdown of worker 0 (fft_native.hip: stamp): python tools/fft_native_prof.py [grid T nf]"""
+breakdown of worker 0 (fft_native_impl.h: stamp): python tools/fft_native_prof.py [grid T nf]"""
 import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
