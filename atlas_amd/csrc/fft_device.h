@@ -1,7 +1,8 @@
-// Device-side helpers shared by the Fourier kernels (fft_kernel.hip, fft_kernel_p.hip): block -> job maps, the reader of the
+// Device-side helpers shared by the Fourier kernels (fft_kernel.hip, fft_kernel_pairs.hip, fft_kernel_p.hip): block -> job maps, the reader of the
 // Fourier intermediate, LDS-only barriers.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "device_structs.h"
 
@@ -226,6 +227,49 @@ __device__ __forceinline__ void gather_modes_to_lds(const FourierParams& p, long
         }
     }
 }
+
+// ---- helpers of the direct rows (fft_kernel.hip: fft_rows_dct_kernel; fft_kernel_pairs.hip: the two-field fp32 form)
+// workers of a direct row: one butterfly per worker in every stage (max over the stages of M / radix, whole wavefronts)
+template <class S>
+constexpr int dct_workers() {
+    int w = 64;
+    for (int i = 0; i < S::NS; ++i) {
+        const int nb = (S::M / S::radix(i) + 63) / 64 * 64;
+        w            = nb > w ? nb : w;
+    }
+    return w;
+}
+
+// compile-time loops over the middle DIT stages I = 1 .. NS-2 of a reversed shape (up / down)
+template <class SR, int I, class Fn>
+__device__ __forceinline__ void dct_for_each_mid(Fn&& fn) {
+    if constexpr (I <= SR::NS - 2) {
+        fn(std::integral_constant<int, I>{});
+        dct_for_each_mid<SR, I + 1>(fn);
+    }
+}
+template <class SR, int I, class Fn>
+__device__ __forceinline__ void dct_for_each_mid_down(Fn&& fn) {
+    if constexpr (I >= 1) {
+        fn(std::integral_constant<int, I>{});
+        dct_for_each_mid_down<SR, I - 1>(fn);
+    }
+}
+
+// wavefronts per SIMD a direct-row kernel is compiled for: 3 (168 registers), 2 where the first butterfly is too wide for that
+// (radix >= 15 with 16-byte elements -- such rows are >= 60 KB of LDS: two workgroups per CU anyway -- or >= 20 with 8-byte elements:
+// 30 - 310 spilled registers)
+#ifndef AA_DCT_F32_WPS
+#define AA_DCT_F32_WPS 3   // dev builds: wavefronts per SIMD the fp32-arithmetic direct rows are compiled for (A/B)
+#endif
+template <class S, bool F32A>
+constexpr int dct_waves_per_simd() {
+    if (F32A && AA_DCT_F32_WPS != 3) {
+        return AA_DCT_F32_WPS;
+    }
+    return S::radix(0) >= (F32A ? 20 : 15) ? 2 : 3;
+}
+
 
 // the [R0,16,16] rows of the LDS-heavy classes (see fft_kernel.hip: row_ct3)
 template <class S>

@@ -633,49 +633,10 @@ hipError_t launch_fourier_coarse(const FourierParams& p, int lds_bytes, hipStrea
     return hipGetLastError();
 }
 
-// workers of a direct row: one butterfly per worker in every stage (max over the stages of M / radix, whole wavefronts)
-template <class S>
-constexpr int dct_workers() {
-    int w = 64;
-    for (int i = 0; i < S::NS; ++i) {
-        const int nb = (S::M / S::radix(i) + 63) / 64 * 64;
-        w            = nb > w ? nb : w;
-    }
-    return w;
-}
-
-// compile-time loops over the middle DIT stages I = 1 .. NS-2 of a reversed shape (up / down)
-template <class SR, int I, class Fn>
-__device__ __forceinline__ void dct_for_each_mid(Fn&& fn) {
-    if constexpr (I <= SR::NS - 2) {
-        fn(std::integral_constant<int, I>{});
-        dct_for_each_mid<SR, I + 1>(fn);
-    }
-}
-template <class SR, int I, class Fn>
-__device__ __forceinline__ void dct_for_each_mid_down(Fn&& fn) {
-    if constexpr (I >= 1) {
-        fn(std::integral_constant<int, I>{});
-        dct_for_each_mid_down<SR, I - 1>(fn);
-    }
-}
-
 // ---- compile-time specialised direct rows (fft_core.h: row_phase_dct): regular grids, smooth rows of reduced grids.
 // F32A: the fp32 variant in fp32 ARITHMETIC (float tables, 8-byte LDS elements; the (re, im) pairs compile to packed
 // v_pk_{add,mul,fma}_f32); F32 && !F32A: float storage around fp64 arithmetic
-// wavefronts per SIMD a direct-row kernel is compiled for: 3 (168 registers), 2 where the first butterfly is too wide for that
-// (radix >= 15 in fp64 -- such rows are >= 60 KB of LDS: two workgroups per CU anyway -- or >= 20 in fp32: 30 - 310 spilled registers)
-#ifndef AA_DCT_F32_WPS
-#define AA_DCT_F32_WPS 3   // dev builds: wavefronts per SIMD the fp32-arithmetic direct rows are compiled for (A/B)
-#endif
-template <class S, bool F32A>
-constexpr int dct_waves_per_simd() {
-    if (F32A && AA_DCT_F32_WPS != 3) {
-        return AA_DCT_F32_WPS;
-    }
-    return S::radix(0) >= (F32A ? 20 : 15) ? 2 : 3;
-}
-
+// (workers, stage loops and the wavefronts per SIMD the kernel is compiled for: fft_device.h)
 template <class S, bool F32, bool F32A>
 __global__ void __launch_bounds__(FFT_MAX_NTHR, (dct_waves_per_simd<S, F32A>())) fft_rows_dct_kernel(FourierParams p) {
     using C = std::conditional_t<F32A, fft::cplxf, cplx>;
@@ -936,8 +897,15 @@ static hipError_t launch_dct(const FourierParams& p, int lds_bytes, int nthreads
     return launch_dct_t<S, false, false>(p, lds_bytes, nthreads, nblk, stream);
 }
 
+// fft_kernel_pairs.hip: the fp32 variant's direct rows, two fields per job
+bool fourier_pairs_usable(const FourierParams& p, int ctf, int ctk);
+hipError_t launch_fourier_dct_pairs(const FourierParams& p, int ctf, int ctk, int lds_bytes, hipStream_t stream);
+
 hipError_t launch_fourier_dct(const FourierParams& p, int ctf, int ctk, int lds_bytes, int nthreads,
                               hipStream_t stream) {
+    if (AA_FFT_F32_ARITH && fourier_pairs_usable(p, ctf, ctk)) {
+        return launch_fourier_dct_pairs(p, ctf, ctk, lds_bytes, stream);
+    }
     const unsigned nblk = fft_job_blocks(p.nrows, p.f_end - p.f_begin, p.job_group_log2);   // fft_device.h: fft_block_to_job
     AA_CT_DISPATCH(ctf, ctk, return launch_dct<S>(p, lds_bytes, nthreads, nblk, stream))
     return hipErrorInvalidValue;

@@ -609,6 +609,30 @@ def test_fp32_variant_against_fp64(gridname, T, nf):
     assert np.array_equal(host, gp.cpu().numpy())
 
 
+@pytest.mark.parametrize("gridname,T,nf", [("F320", 319, 9), ("F64", 63, 1), ("F160", 159, 34), ("O160", 159, 7)])
+def test_fp32_two_field_jobs_against_the_one_field_form(gridname, T, nf, monkeypatch):
+    """[r4] The fp32 variant's direct rows take TWO fields per job (csrc/fft_pair.h, fft_kernel_pairs.hip: lane x / lane y of packed
+    fp32 instructions, the pair's 16 bytes gathered by one LDS-DMA request): odd field counts (the last job's second lane is not
+    stored), a single field, a reduced grid whose smooth rows are direct.  Against the fp64 device result of the float-rounded
+    spectra (2e-6), against the one-field form (ATLAS_AMD_FFT_F32_PAIRS=0; same arithmetic, other instruction selection: 1e-6 of
+    the largest value), and the array next to the last field stays untouched."""
+    g, tr = get_trans(gridname, T)
+    sp32 = red_spectra(T, nf, seed=77).astype(np.float32)
+    ref = run_device(tr, nf, sp32.astype(np.float64))
+    guard = g.size()
+    out = {}
+    for pairs in ("1", "0"):
+        monkeypatch.setenv("ATLAS_AMD_FFT_F32_PAIRS", pairs)
+        gp = torch.full(((nf + 1) * g.size(),), float("nan"), dtype=torch.float32, device="cuda")
+        tr.invtrans(nf, torch.from_numpy(sp32).cuda(), gp[:nf * g.size()])
+        tr.synchronize()
+        assert bool(torch.isnan(gp[nf * g.size():]).all()), "wrote past the last field"
+        out[pairs] = gp[:nf * g.size()].cpu().numpy().astype(np.float64)
+        assert compute_rms(out[pairs], ref) < 2e-6, pairs
+    assert np.abs(out["1"] - out["0"]).max() <= 1e-6 * np.abs(ref).max()
+    assert guard > 0
+
+
 # ---------------------------------------------------------------- BASELINE configs at their own sizes
 def test_config_C4_batch_of_ten_transforms_sampled_rows(trans_full):
     """BASELINE config C4's call: TL1279 -> O1280, 10 x 137 = 1370 fields in ONE invtrans (18 GB of spectra, 72 GB of
