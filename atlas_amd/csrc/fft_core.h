@@ -356,8 +356,9 @@ AA_HD void split_index(int b, int Ls, int lsh, int& blk, int& j) {
 }
 
 // ---- one DIF stage: blocks of length L, radix R; twiddle table of M entries, w_L^j = tw[j * M/L] ---------------
-template <int R, class C>
-AA_HD void dif_stage(C* d, int M, int L, int lsh, const C* __restrict__ tw, int dir, int t, int nt) {
+// (TW: what the table is read through -- a pointer, or the both-lanes accessor of the two-field fp32 form, fft_pair.h)
+template <int R, class C, class TW>
+AA_HD void dif_stage(C* d, int M, int L, int lsh, TW tw, int dir, int t, int nt) {
     const int Ls  = L / R;
     const int tws = M / L;
     const int nb  = M / R;
@@ -383,9 +384,14 @@ AA_HD void dif_stage(C* d, int M, int L, int lsh, const C* __restrict__ tw, int 
         }
     }
 }
-// ---- one DIT stage (inverse of the DIF stage with the same L, R): twiddle first, then butterfly --------------
+// the usual form: a table of the row's own complex type (the explicit table type keeps the __restrict__)
 template <int R, class C>
-AA_HD void dit_stage(C* d, int M, int L, int lsh, const C* __restrict__ tw, int dir, int t, int nt) {
+AA_HD void dif_stage(C* d, int M, int L, int lsh, const C* __restrict__ tw, int dir, int t, int nt) {
+    dif_stage<R, C, const C* __restrict__>(d, M, L, lsh, tw, dir, t, nt);
+}
+// ---- one DIT stage (inverse of the DIF stage with the same L, R): twiddle first, then butterfly --------------
+template <int R, class C, class TW>
+AA_HD void dit_stage(C* d, int M, int L, int lsh, TW tw, int dir, int t, int nt) {
     const int Ls  = L / R;
     const int tws = M / L;
     const int nb  = M / R;
@@ -410,6 +416,11 @@ AA_HD void dit_stage(C* d, int M, int L, int lsh, const C* __restrict__ tw, int 
 #pragma unroll
         for (int q = 0; q < R; ++q) d[PAD(base + q * Ls)] = x[q];
     }
+}
+// the usual form: a table of the row's own complex type (the explicit table type keeps the __restrict__)
+template <int R, class C>
+AA_HD void dit_stage(C* d, int M, int L, int lsh, const C* __restrict__ tw, int dir, int t, int nt) {
+    dit_stage<R, C, const C* __restrict__>(d, M, L, lsh, tw, dir, t, nt);
 }
 
 // the same two stages for one butterfly with the stage twiddle w1 = tw[j * tws] supplied by the caller (the specialised
@@ -575,6 +586,10 @@ struct RowOut {
     int aligned16;           // the row starts on a pair boundary (16 bytes; 8 bytes for f32): pairs are stored whole
     int f32 = 0;             // y points to float (fp32 variant: fp32 in HBM, the FFT arithmetic stays fp64)
     double scale;            // 1/cos(lat) for the u,v fields of the vor/div path (TransLocal.cc:1443-1469), else 1
+    // two-field fp32 form (fft_pair.h): lane x goes to y, lane y to (float*)y + pair_stride if pair_b is set
+    long long pair_stride = 0;
+    int pair_b            = 0;
+    int pair_b_aligned    = 0;
 };
 
 struct alignas(8) fpair {
@@ -913,14 +928,21 @@ struct CtShape {
 #define AA_ABL(r, bit) 1
 #endif
 
+// what a row reads its tables through: a pointer to its own complex type, except for the two-field fp32 form (fft_pair.h), whose
+// table values are one float complex for both lanes
+template <class C>
+struct table_ptr_of {
+    using type = const C*;
+};
 template <class C>
 struct RowTablesCtT {
+    using table_ptr = typename table_ptr_of<C>::type;
     int abl = 0;
     int n, h;
-    const C* tw;       // [M]
-    const C* pre;      // [h]
-    const C* chirp;    // [h]
-    const C* bhat_t;   // [R_last][M / R_last]  filter spectrum, transposed for the fused middle stage
+    table_ptr tw;       // [M]
+    table_ptr pre;      // [h]
+    table_ptr chirp;    // [h]
+    table_ptr bhat_t;   // [R_last][M / R_last]  filter spectrum, transposed for the fused middle stage
 };
 using RowTablesCt = RowTablesCtT<cplx>;
 
@@ -943,6 +965,11 @@ AA_HD constexpr int row_num_phases_ct() {
 
 // ---- the row's kept modes are fetched ONCE per row into an LDS staging area `raw` before phase 0, which needs every
 //      mode twice (X[k] and X[h-k]).  Device: fft_kernel.hip (LDS-DMA gather); host emulation: plain copy.
+// element k of the staging area (the two-field fp32 form stores the intermediate's own order there: fft_pair.h overloads both)
+template <class C>
+AA_HD C raw_elem(const C* raw, int k) {
+    return raw[k];
+}
 template <class C>
 AA_HD C ct_raw_mode(const C* raw, int mmax, int m, int h) {
     C v = m <= mmax ? raw[m] : C{0, 0};

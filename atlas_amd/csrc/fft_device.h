@@ -140,6 +140,11 @@ struct ModeReaderT {
         o = (lat_local * cnt) * p.RP + f2 + (long long)__umul24((unsigned)ml, (unsigned)p.RP);
         return base;
     }
+    __device__ __forceinline__ const char* byte_address(int m) const {   // either storage (STORAGE 0 / 1)
+        long long o;
+        gdouble_ptr base = locate(m, o);
+        return STORAGE == 1 ? (const char*)((const float*)base + o) : (const char*)((const double*)base + o);
+    }
     __device__ __forceinline__ const double* address(int m) const {   // fp64 storage only
         long long o;
         gdouble_ptr base = locate(m, o);

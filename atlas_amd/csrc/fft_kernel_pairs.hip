@@ -1,7 +1,9 @@
-// Fourier stage of the fp32 variant, two fields per job [r4] (fft_pair.h): the direct rows (regular grids -- BASELINE config C5,
-// TL1279 -> F1280 -- and the smooth rows of reduced grids).  The kernel is fft_rows_dct_kernel's main branch (fft_kernel.hip) on
-// the pair type: phase 0 from an LDS staging area filled by 16-byte LDS-DMA requests, one butterfly per worker and stage, twiddles
-// requested before the gather is waited for, the last stage fused with the store.
+// Fourier stage of the fp32 variant, two fields per job [r4] (fft_pair.h).
+//   * the direct rows (regular grids -- BASELINE config C5, TL1279 -> F1280 -- and the smooth rows of reduced grids):
+//     fft_rows_dct_kernel's main branch (fft_kernel.hip) on the pair type: phase 0 from an LDS staging area filled by 16-byte LDS-DMA
+//     requests, one butterfly per worker and stage, twiddles requested before the gather is waited for, last stage fused with the store;
+//   * the specialised Bluestein rows (reduced grids): fft_rows_ct_kernel's body on the pair type -- row_ct3 (fft_ct_rows.h) for the
+//     [R0,16,16] classes, the phase loop of row_phase_ct (fft_core.h) for the others; same row records, same (float) tables.
 //
 // Reference being replaced: TransLocal::invtrans_fourier_regular / _reduced (src/atlas/trans/local/TransLocal.cc:1101-1196), one
 // c2r FFT per (latitude, field).
@@ -12,7 +14,8 @@
 #include "device_structs.h"
 #include "dyn_lds.h"
 #include "fft_device.h"
-#include "fft_pair.h"
+#include "fft_pair.h"      // before fft_ct_rows.h: the pair overloads of the store and of the staging reads
+#include "fft_ct_rows.h"
 
 namespace atlas_amd {
 namespace trans {
@@ -40,11 +43,13 @@ __device__ __forceinline__ bool fft_block_to_pair_job(const FourierParams& p, in
     return true;
 }
 
-// Gather of the kept modes of a field pair: the LDS-DMA form of gather_modes_to_lds (fft_device.h) on the float intermediate --
+// Gather of the kept modes of a field pair (overload of fft_device.h: gather_modes_to_lds, chosen by the element type): its LDS-DMA form on the float intermediate --
 // 16 bytes per lane = (re, im) of field f and of field f + 1 (f even: the request is 16-byte aligned, the record pitch is a multiple
 // of 16 floats).
-__device__ __forceinline__ void gather_pair_modes_to_lds(const FourierParams& p, long long lat_local, int f, int mmax, fft::cplxp* raw,
-                                                         int tid, int nt) {
+template <bool F32>
+__device__ __forceinline__ void gather_modes_to_lds(const FourierParams& p, long long lat_local, int f, int mmax, fft::cplxp* raw,
+                                                    int tid, int nt) {
+    static_assert(F32, "a field pair is the fp32 variant");
     const ModeReaderT<1> rd{p, lat_local, 2 * f};
     typedef const __attribute__((address_space(1))) float* gfloat_ptr;
     for (int m0 = 0; m0 <= mmax; m0 += nt) {
@@ -73,8 +78,19 @@ __device__ __forceinline__ void store_field_pair(float* y, bool aligned, int k, 
     }
 }
 
+// wavefronts per SIMD the pair form of a direct row is compiled for: as the fp64 rows (same element size); dev builds
+// -DAA_DCT_PAIR_WPS4: four for the shapes of which four rows fit the LDS of a CU (M <= 2560, no staging slot beyond the row)
 template <class S>
-__global__ void __launch_bounds__(FFT_MAX_NTHR, (dct_waves_per_simd<S, false>())) fft_rows_dct_pair_kernel(FourierParams p) {
+constexpr int dct_pair_waves_per_simd() {
+#if defined(AA_DCT_PAIR_WPS4)
+    if (S::M <= 2560 && dct_workers<S>() <= 256) {
+        return 4;
+    }
+#endif
+    return dct_waves_per_simd<S, false>();
+}
+template <class S>
+__global__ void __launch_bounds__((dct_pair_waves_per_simd<S>() == 4 ? 256 : FFT_MAX_NTHR), (dct_pair_waves_per_simd<S>())) fft_rows_dct_pair_kernel(FourierParams p) {
     using C  = fft::cplxp;
     using TC = fft::cplxf;   // tables: one float complex for both lanes
     using fft::both;
@@ -105,7 +121,7 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR, (dct_waves_per_simd<S, false>())
     constexpr int RL  = SR::radix(SR::NS - 1);
     constexpr int nbl = S::M / RL;
     static_assert(dct_workers<S>() <= FFT_MAX_NTHR, "one butterfly per worker and stage");   // (launch_dct_pair: dct_pair_shape)
-    gather_pair_modes_to_lds(p, (long long)(row - p.lat0), f, mmax, work, tid, nt);
+    gather_modes_to_lds<true>(p, (long long)(row - p.lat0), f, mmax, work, tid, nt);
     const bool act = tid < nbl;
     const int bp   = act ? tid : 0;
     // c2r factors and the stage twiddles of this worker's butterflies, as table values (8 bytes each), before the gather is waited for
@@ -197,7 +213,9 @@ constexpr bool dct_pair_shape() {
 template <class S>
 static hipError_t launch_dct_pair(const FourierParams& p, int lds_bytes, hipStream_t stream) {
     if constexpr (dct_pair_shape<S>()) {
-        lds_bytes += 256;   // staging of phase 0: modes 0..mmax, mmax <= M (one element more than the work array)
+        if (p.T >= S::M) {
+            lds_bytes += 256;   // staging of phase 0: modes 0..mmax, mmax <= M: one element more than the work array if the truncation reaches M
+        }
         if (hipError_t e = ensure_dynamic_lds<&fft_rows_dct_pair_kernel<S>>(lds_bytes); e != hipSuccess) {   // dyn_lds.h
             return e;
         }
@@ -211,17 +229,152 @@ static hipError_t launch_dct_pair(const FourierParams& p, int lds_bytes, hipStre
     }
 }
 
-// Can this launch take the two-field form?  (fft_kernel.hip: launch_fourier_dct asks; ATLAS_AMD_FFT_F32_PAIRS=0 switches it off.)
-// The pair's 16 bytes must be one aligned element of a single-piece intermediate: first field even, no m-sharded pieces, no packed runs.
-bool fourier_pairs_usable(const FourierParams& p, int ctf, int ctk) {
+// ---- specialised Bluestein rows --------------------------------------------------------------------------------------------------
+// workgroup -> (row index of the launch's list, first field of the pair): fft_block_to_job_index (fft_device.h) with the pair as the unit
+__device__ __forceinline__ bool fft_block_to_pair_job_index(const FourierParams& p, int b, int& ri, int& f) {
+    const int x     = b & 7;
+    const int q     = b >> 3;
+    const int j     = q & 7;
+    const int npair = (p.f_end - p.f_begin + 1) >> 1;
+    const int ngr   = (npair + 7) >> 3;
+    int fg;
+    if (!fft_unit_to_job(p, ngr, x, q >> 3, ri, fg)) {
+        return false;
+    }
+    const int pi = fg * 8 + j;
+    if (pi >= npair) {
+        return false;
+    }
+    f = p.f_begin + 2 * pi;
+    return true;
+}
+
+#ifndef AA_FFT_PLAIN_WPS
+#define AA_FFT_PLAIN_WPS 3   // as fft_kernel.hip: wavefronts per SIMD of the rows that are not row_ct3
+#endif
+template <class S, bool FAST>
+__global__ void __launch_bounds__(S::NT, (FAST ? S::WPS : AA_FFT_PLAIN_WPS)) fft_rows_ct_pair_kernel(FourierParams p) {
+    using C = fft::cplxp;
+    extern __shared__ double lds_raw[];
+    C* work = reinterpret_cast<C*>(lds_raw);
+    int ri, f;
+    if (!fft_block_to_pair_job_index(p, blockIdx.x, ri, f)) {
+        return;
+    }
+    const int tid        = threadIdx.x;
+    constexpr int nt     = S::NT;
+    constexpr int NPH    = fft::row_num_phases_ct<S>();
+    const FftRowDesc d   = p.desc[ri];   // one 64-byte scalar load: everything about the row
+    const long long goff = (long long)f * p.npts + d.goff_rel;
+    fft::RowTablesCtT<C> r;
+#if defined(AA_FFT_ABLATE)
+    r.abl = p.abl;
+#endif
+    r.n = d.n;
+    r.h = d.h;
+    const fft::PairTable table{p.table_f32};
+    r.tw     = table + d.off_tw;
+    r.pre    = table + d.off_pre;
+    r.chirp  = table + d.off_chirp;
+    r.bhat_t = table + d.off_bhat_t;
+    fft::RowOut io;
+    io.mmax           = d.mmax;
+    io.y              = reinterpret_cast<double*>(reinterpret_cast<float*>(p.gp) + goff);
+    io.aligned16      = ((goff & 1) == 0);
+    io.f32            = 1;
+    io.scale          = (f < p.scale_uv_fields) ? d.coslatinv : 1.0;   // (an even number of wind fields: fourier_pairs_usable)
+    io.pair_stride    = p.npts;
+    io.pair_b         = f + 1 < p.f_end;
+    io.pair_b_aligned = (((goff + p.npts) & 1) == 0);
+    if constexpr (FAST && ct3_fast_path<S>()) {
+        // the lines (sixteen fields x one wavenumber) a later job of this XCD will gather: requested into L2 by the eight pair jobs of
+        // this group together (fft_kernel.hip does the same for the eight fields of an fp64 group)
+        PrefetchJob pfj{-1, 0, 0, 0, 1};
+        if (p.pf_dist > 0) {
+            const int npair = (p.f_end - p.f_begin + 1) >> 1;
+            const int ngr   = (npair + 7) >> 3;
+            const int pi    = (f - p.f_begin) >> 1;
+            const int fg    = pi >> 3;
+            int ri2, fg2;
+            if (fft_unit_to_job(p, ngr, blockIdx.x & 7, (blockIdx.x >> 6) + p.pf_dist, ri2, fg2)) {
+                const int left = npair - fg * 8;
+                pfj.lat_local  = p.desc[ri2].row - p.lat0;
+                pfj.mmax       = p.desc[ri2].mmax;
+                pfj.f0         = p.f_begin + fg2 * 16;
+                pfj.j          = pi - fg * 8;
+                pfj.nj         = left < 8 ? left : 8;
+            }
+        }
+        row_ct3<S, true>(p, r, io, (long long)(d.row - p.lat0), f, work, tid, pfj, [](int) {});
+        return;
+    }
+    else {
+        gather_modes_to_lds<true>(p, (long long)(d.row - p.lat0), f, io.mmax, work, tid, nt);
+        __syncthreads();
+        for_each_phase<S, 0>([&](auto phc) {
+            constexpr int ph = decltype(phc)::value;
+            fft::row_phase_ct<S, true>(ph, tid, nt, r, work, io, work);
+            if constexpr (ph < NPH - 1) {
+                if constexpr (S::wave_local_middle() && ph >= 1 && ph <= NPH - 3) {
+                    wave_lds_fence();   // producer and consumer lanes of the next phase are in this wavefront (fft_kernel.hip)
+                }
+                else {
+                    __syncthreads();
+                }
+            }
+        });
+    }
+}
+
+template <class S, bool FAST>
+static hipError_t launch_ct_pair_t(FourierParams p, int lds_bytes, unsigned nblk, hipStream_t stream) {
+    if (hipError_t e = ensure_dynamic_lds<&fft_rows_ct_pair_kernel<S, FAST>>(lds_bytes); e != hipSuccess) {   // dyn_lds.h
+        return e;
+    }
+    p.nvirt = nblk;
+    hipLaunchKernelGGL((fft_rows_ct_pair_kernel<S, FAST>), dim3(nblk), dim3(S::NT), lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
+template <class S>
+static hipError_t launch_ct_pair(const FourierParams& p, int lds_bytes, unsigned nblk, hipStream_t stream) {
+    if constexpr (ct3_fast_path<S>()) {
+        return launch_ct_pair_t<S, true>(p, lds_bytes, nblk, stream);
+    }
+    else {
+        return launch_ct_pair_t<S, false>(p, lds_bytes, nblk, stream);
+    }
+}
+
+hipError_t launch_fourier_ct_pairs(const FourierParams& p, int ctf, int ctk, int lds_bytes, hipStream_t stream) {
+    if (!p.desc) {
+        return hipErrorInvalidValue;
+    }
+    const int npair       = (p.f_end - p.f_begin + 1) / 2;
+    const long long units = (long long)p.nrows * ((npair + 7) / 8);
+    const unsigned nblk   = (unsigned)((units + 7) / 8 * 64);
+    AA_CT_DISPATCH(ctf, ctk, return launch_ct_pair<S>(p, lds_bytes, nblk, stream))
+    return hipErrorInvalidValue;
+}
+
+// Can this launch take the two-field form?  (fft_kernel.hip: launch_fourier_dct / launch_fourier_ct ask; ATLAS_AMD_FFT_F32_PAIRS=0
+// switches it off.)  The pair's 16 bytes must be one aligned element of a single-piece intermediate: first field even, no m-sharded
+// pieces, no packed runs; the wind fields (scaled by 1 / cos(lat)) must not end inside a pair.
+static bool pairs_usable(const FourierParams& p) {
     const char* e = std::getenv("ATLAS_AMD_FFT_F32_PAIRS");   // read per launch: the tests switch it between calls
     const bool on = !(e && atoi(e) == 0);
-    if (!on || !p.f32 || !p.table_f32 || (p.f_begin & 1) || p.nparts > 1 || p.packed_cols || (p.RP & 3)) {
+    return on && p.f32 && p.table_f32 && !(p.f_begin & 1) && !(p.scale_uv_fields & 1) && p.nparts <= 1 && !p.packed_cols && !(p.RP & 3);
+}
+bool fourier_pairs_usable(const FourierParams& p, int ctf, int ctk) {   // direct rows
+    if (!pairs_usable(p)) {
         return false;
     }
     bool fits = false;
     AA_CT_DISPATCH(ctf, ctk, fits = dct_pair_shape<S>())
     return fits;
+}
+bool fourier_ct_pairs_usable(const FourierParams& p) {   // specialised Bluestein rows: every shape
+    return pairs_usable(p) && p.desc != nullptr;
 }
 
 hipError_t launch_fourier_dct_pairs(const FourierParams& p, int ctf, int ctk, int lds_bytes, hipStream_t stream) {

@@ -38,15 +38,67 @@ AA_HD cplxp both(cplxf w) {
     return cplxp{f32x2(w.re), f32x2(w.im)};
 }
 
-// mode m of the gathered pair: the staging area holds the intermediate's own order (re a, im a, re b, im b)
-AA_HD cplxp pair_raw_mode(const cplxp* raw, int mmax, int m, int h) {
+// the row tables of a pair: float complex values, read into both lanes
+struct PairTable {
+    const cplxf* p;
+    AA_HD cplxp operator[](long long i) const { return both(p[i]); }
+    AA_HD PairTable operator+(long long o) const { return PairTable{p + o}; }
+};
+template <>
+struct table_ptr_of<cplxp> {
+    using type = PairTable;
+};
+
+// element k of the staging area: it holds the intermediate's own order (re a, im a, re b, im b)
+AA_HD cplxp raw_elem(const cplxp* raw, int k) {
     typedef float v4 __attribute__((ext_vector_type(4)));
-    const v4 q = *reinterpret_cast<const v4*>(raw + (m <= mmax ? m : mmax));
-    cplxp v    = m <= mmax ? cplxp{f32x2(q.x, q.z), f32x2(q.y, q.w)} : cplxp{0, 0};
+    const v4 q = *reinterpret_cast<const v4*>(raw + k);
+    return cplxp{f32x2(q.x, q.z), f32x2(q.y, q.w)};
+}
+// mode m of the gathered pair (fft_core.h: ct_raw_mode; this overload is found by argument type)
+AA_HD cplxp ct_raw_mode(const cplxp* raw, int mmax, int m, int h) {
+    cplxp v = raw_elem(raw, m <= mmax ? m : mmax);
+    if (m > mmax) {
+        v = cplxp{0, 0};
+    }
     if (m == 0 || m == h) {
         v.im = 0;   // conventions of row_mode()
     }
     return v;
+}
+AA_HD cplxp pair_raw_mode(const cplxp* raw, int mmax, int m, int h) {
+    return ct_raw_mode(raw, mmax, m, h);
+}
+
+// y[2k], y[2k+1] of both fields (fft_core.h: store_pair_t; RowOut::pair_*).  ALIGNED is field a's flavour.
+template <bool F32, bool ALIGNED>
+__device__ __forceinline__ void store_pair_t(const RowOut& io, int64_t k, cplxp z) {
+    if (!F32) {
+        return;   // (with_store_flavour instantiates the fp64 flavours too: never taken, a field pair is the fp32 variant)
+    }
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    float* ya = reinterpret_cast<float*>(io.y);
+    if (ALIGNED) {
+        __builtin_nontemporal_store(f2_t{z.re.v.x, z.im.v.x}, reinterpret_cast<f2_t*>(ya + 2 * k));
+    }
+    else {
+        __builtin_nontemporal_store(z.re.v.x, ya + 2 * k);
+        __builtin_nontemporal_store(z.im.v.x, ya + 2 * k + 1);
+    }
+    if (io.pair_b) {
+        float* yb = ya + io.pair_stride;
+        if (io.pair_b_aligned) {
+            __builtin_nontemporal_store(f2_t{z.re.v.y, z.im.v.y}, reinterpret_cast<f2_t*>(yb + 2 * k));
+        }
+        else {
+            __builtin_nontemporal_store(z.re.v.y, yb + 2 * k);
+            __builtin_nontemporal_store(z.im.v.y, yb + 2 * k + 1);
+        }
+    }
+}
+
+__device__ __forceinline__ void pin_register(f32x2& x) {   // trace builds (fft_ct_rows.h: AA_PIN)
+    asm volatile("" : "+v"(x.v));
 }
 
 }  // namespace fft

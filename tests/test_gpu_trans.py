@@ -609,11 +609,12 @@ def test_fp32_variant_against_fp64(gridname, T, nf):
     assert np.array_equal(host, gp.cpu().numpy())
 
 
-@pytest.mark.parametrize("gridname,T,nf", [("F320", 319, 9), ("F64", 63, 1), ("F160", 159, 34), ("O160", 159, 7)])
+@pytest.mark.parametrize("gridname,T,nf", [("F320", 319, 9), ("F64", 63, 1), ("F160", 159, 34), ("O160", 159, 7), ("O320", 319, 19),
+                                           ("N320", 319, 4)])
 def test_fp32_two_field_jobs_against_the_one_field_form(gridname, T, nf, monkeypatch):
-    """[r4] The fp32 variant's direct rows take TWO fields per job (csrc/fft_pair.h, fft_kernel_pairs.hip: lane x / lane y of packed
-    fp32 instructions, the pair's 16 bytes gathered by one LDS-DMA request): odd field counts (the last job's second lane is not
-    stored), a single field, a reduced grid whose smooth rows are direct.  Against the fp64 device result of the float-rounded
+    """[r4] The fp32 variant's direct and specialised Bluestein rows take TWO fields per job (csrc/fft_pair.h, fft_kernel_pairs.hip:
+    lane x / lane y of packed fp32 instructions, the pair's 16 bytes gathered by one LDS-DMA request): odd field counts (the last
+    job's second lane is not stored), a single field, reduced grids (direct smooth rows, Bluestein rows plain and row_ct3).  Against the fp64 device result of the float-rounded
     spectra (2e-6), against the one-field form (ATLAS_AMD_FFT_F32_PAIRS=0; same arithmetic, other instruction selection: 1e-6 of
     the largest value), and the array next to the last field stays untouched."""
     g, tr = get_trans(gridname, T)
