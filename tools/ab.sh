@@ -14,6 +14,7 @@
 #   tools/ab.sh abl:ATLAS_AMD_FFT_ONLY_M=5120,ATLAS_AMD_FFT_STREAMS=1,ATLAS_AMD_FFT_ABLATE=32 ...        one row class
 #   tools/ab.sh -c C2 product:ATLAS_AMD_FFT_COARSE_FUSED=1 product:ATLAS_AMD_FFT_COARSE_FUSED=0
 #   tools/ab.sh -c C5,C4f32 product:ATLAS_AMD_FFT_GROUP_LOG2=3 product:ATLAS_AMD_FFT_GROUP_LOG2=4
+#   tools/ab.sh -c C5,C4f32,C5n product:ATLAS_AMD_FFT_F32_PAIRS=0 product:ATLAS_AMD_FFT_F32_PAIRS=1                 fp32 rows: one / two fields per job
 #   tools/ab.sh -c C5 product:ATLAS_AMD_LEG_CFG=3,2 product:ATLAS_AMD_LEG_CFG=5,2                        (a comma inside a value: use ';')
 export TMPDIR=/tmp
 REPS=2; CFG=""; STEPS=10
