@@ -52,6 +52,16 @@ def diag_mfma_f64_rate(target_ms=25.0, repeats=3):
     return out.value
 
 
+_diag_mfma_f32_rate = _sig("atlas_amd__diag_mfma_f32_rate", C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double))
+
+
+def diag_mfma_f32_rate(target_ms=25.0, repeats=3):
+    """TFLOP/s the current device sustains on v_mfma_f32_16x16x4_f32 alone (the fp32 variant's Legendre instruction)"""
+    out = C.c_double(0.0)
+    check(_diag_mfma_f32_rate(float(target_ms), int(repeats), C.byref(out)))
+    return out.value
+
+
 class torch_stream_order:
     """`with torch_stream_order(obj_stream):` -- device tensors handed to the library were produced on torch's current
     stream and will be consumed there: the object's stream first waits for torch's stream, and torch's stream then waits

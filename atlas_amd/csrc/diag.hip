@@ -65,14 +65,47 @@ __global__ void __launch_bounds__(256) mfma_f64_rate_kernel(double* out, int ite
     out[blockIdx.x * blockDim.x + threadIdx.x] = t;
 }
 
+// the same for v_mfma_f32_16x16x4_f32 (the Legendre stage of the fp32 variant) [r4]
+typedef float f4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) mfma_f32_rate_kernel(double* out, int iters) {
+    uint64_t s = 88172645463325252ull + (blockIdx.x * 256 + threadIdx.x) * 2654435761ull;
+    float a[4], b[4];
+    for (int i = 0; i < 4; ++i) {
+        a[i] = (float)random_operand(s);
+        b[i] = (float)random_operand(s);
+    }
+    f4 acc[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        acc[i] = f4{0, 0, 0, 0};
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b[(k + i) & 3], acc[i], 0, 0, 0);
+            }
+        }
+    }
+    double t = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        t += (double)acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = t;
+}
+
 }  // namespace diag
 }  // namespace atlas_amd
 
-extern "C" int atlas_amd__diag_mfma_f64_rate(double target_ms, int repeats, double* tflops_out) {
+// cycles_per_mfma: 64 (fp64 16x16x4) / 32 (fp32 16x16x4) at the datasheet rate -- sizes the kernel for target_ms
+static int diag_mfma_rate(void (*kernel)(double*, int), double cycles_per_mfma, const char* what, double target_ms, int repeats,
+                          double* tflops_out) {
     try {
         using namespace atlas_amd::diag;
         if (!tflops_out || repeats < 1 || !(target_ms > 0)) {
-            throw std::invalid_argument("diag_mfma_f64_rate: target_ms > 0, repeats >= 1, tflops_out != NULL");
+            throw std::invalid_argument(std::string(what) + ": target_ms > 0, repeats >= 1, tflops_out != NULL");
         }
         hipDeviceProp_t prop;
         int dev = 0;
@@ -84,12 +117,12 @@ extern "C" int atlas_amd__diag_mfma_f64_rate(double target_ms, int repeats, doub
         hipEvent_t e0, e1;
         DG_CHECK(hipEventCreate(&e0));
         DG_CHECK(hipEventCreate(&e1));
-        // 24 MFMAs of 64 cycles per iteration and wavefront, 4 wavefronts per SIMD; sized for the datasheet clock
-        const int iters = std::max(1, int(target_ms * 1e-3 * 2.4e9 / (24.0 * 64.0 * 4.0)));
+        // 24 MFMAs per iteration and wavefront, 4 wavefronts per SIMD; sized for the datasheet clock
+        const int iters = std::max(1, int(target_ms * 1e-3 * 2.4e9 / (24.0 * cycles_per_mfma * 4.0)));
         double best     = 0;
         for (int r = 0; r < repeats + 1; ++r) {  // the first launch is the warm-up
             DG_CHECK(hipEventRecord(e0, 0));
-            hipLaunchKernelGGL(mfma_f64_rate_kernel, dim3(nblk), dim3(256), 0, 0, d_out, iters);
+            hipLaunchKernelGGL(kernel, dim3(nblk), dim3(256), 0, 0, d_out, iters);
             DG_CHECK(hipGetLastError());
             DG_CHECK(hipEventRecord(e1, 0));
             DG_CHECK(hipEventSynchronize(e1));
@@ -110,4 +143,11 @@ extern "C" int atlas_amd__diag_mfma_f64_rate(double target_ms, int repeats, doub
         return 1;
     }
     return 0;
+}
+
+extern "C" int atlas_amd__diag_mfma_f64_rate(double target_ms, int repeats, double* tflops_out) {
+    return diag_mfma_rate(atlas_amd::diag::mfma_f64_rate_kernel, 64.0, "diag_mfma_f64_rate", target_ms, repeats, tflops_out);
+}
+extern "C" int atlas_amd__diag_mfma_f32_rate(double target_ms, int repeats, double* tflops_out) {
+    return diag_mfma_rate(atlas_amd::diag::mfma_f32_rate_kernel, 32.0, "diag_mfma_f32_rate", target_ms, repeats, tflops_out);
 }

@@ -342,6 +342,14 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
 // v_mfma_f32_16x16x4_f32 -- and the summation order of legendre_kernel<3, 2, float> (bit-identical results).
 // RTW = 16-column tiles per wavefront (1, 2 or 3; two column groups: 32 / 64 / 96 columns per workgroup) -- whatever
 // legendre_tiling() chooses for the field count, as long as the workgroup has its two column groups.
+// compile-time loop i = I .. N-1 (the hand-counted waits below are immediates that depend on the step)
+template <int I, int N, class Fn>
+__device__ __forceinline__ void lean_static_for(Fn&& fn) {
+    if constexpr (I < N) {
+        fn(std::integral_constant<int, I>{});
+        lean_static_for<I + 1, N>(fn);
+    }
+}
 template <int RTW, class Real>
 __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p) {
     using L  = LegLds<RTW, 2, Real>;
@@ -473,8 +481,15 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
             szero[SET] = z;
             sedge[SET] = true;
         }
+#if defined(AA_LEG_PROBE_FIXED_OPERANDS)
+        // dev probe (results wrong): bit 0 -- every stage re-reads the FIRST table tile of the item (cache hits instead of the HBM / L2
+        // stream), bit 1 -- likewise the spectra: what the latency of the operand streams costs behind a three-stage look-ahead
+        if (!(AA_LEG_PROBE_FIXED_OPERANDS & 1)) pbase += KB * BN;
+        if (!(AA_LEG_PROBE_FIXED_OPERANDS & 2)) sbase -= sstride;
+#else
         pbase += KB * BN;
         sbase -= sstride;
+#endif
     };
     const unsigned plds_b = (unsigned)EB * (unsigned)plds;
     unsigned slds_b[RTW];
@@ -550,18 +565,31 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
     const int b_off = L::P_ELEM + (lane >> 4) * L::SSTR + rg * RTW * 16 + (lane & 15);
     const bool lat_active = lt * 16 < it.nrows;
 
-    // four steps (parity, 4 wavenumbers) of one A and three B fragments and three MFMAs; the fragments of step t + 1
-    // are requested before the MFMAs of step t
+    // four steps (parity, 4 wavenumbers) of one A and three B fragments and three MFMAs; the fragments of step t + D are requested
+    // before the MFMAs of step t, D = 1.  [r4] In fp32 a step's three MFMAs are 96 cycles of matrix pipe (192 in fp64), shorter than an
+    // LDS round trip under load -- but two or three steps in flight (-DAA_LEG_FRAG_DEPTH=2 / 3) measured 5.87 -> 5.91 / 6.38 ms on
+    // TL1279 -> F1280 / 137 levels: the other five wavefronts of the SIMD already cover the round trip (profiles/r04_fft_native.txt)
     const unsigned a_b = (unsigned)EB * (unsigned)a_off, b_b = (unsigned)EB * (unsigned)b_off;
     auto mma_steps = [&](auto bufc) {
         constexpr int buf = decltype(bufc)::value;
         constexpr int NKS = KB / 4;
-        Real a[2], b[2][RTW];
+        constexpr int NST = 2 * NKS;                 // steps of a stage
+#if defined(AA_LEG_FRAG_DEPTH)
+        constexpr int D   = AA_LEG_FRAG_DEPTH;       // dev builds: A/B
+#else
+        constexpr int D   = 1;                       // steps of fragment reads in flight
+#endif
+        static_assert(D >= 1 && D < NST && D * (1 + RTW) <= 15, "lgkmcnt is a 4-bit counter");
+        Real a_[D + 1], b_[D + 1][RTW];
         // fragment reads as asm with immediate offsets (the compiler pairs them into ds_read2 and pays a VALU add per pair
-        // for the base); their completion is counted by hand: 1 + RTW reads per step, one step in flight
-        auto fetch = [&](int t, int slot) {
-            const int par = t / NKS, ks = t % NKS;
+        // for the base); their completion is counted by hand: 1 + RTW reads per step, D steps in flight
+        auto fetch = [&](auto tc) {
+            constexpr int t    = decltype(tc)::value;
+            constexpr int slot = t % (D + 1);
+            constexpr int par = t / NKS, ks = t % NKS;
             const unsigned ab = a_b, bb = b_b;
+            Real(&a)[D + 1]      = a_;   // (named references: clang does not capture an array that a generic lambda only uses as an
+            Real(&b)[D + 1][RTW] = b_;   //  asm output operand)
             if constexpr (F64) {
                 asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a[slot]) : "v"(ab), "n"((buf * L::STAGE + (par * KB + ks * 4) * PSTR) * EB) : "memory");
             }
@@ -584,23 +612,22 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
                 }
             }
         };
-        fetch(0, 0);
-#pragma unroll
-        for (int t = 0; t < 2 * NKS; ++t) {
-            if (t + 1 < 2 * NKS) {
-                fetch(t + 1, (t + 1) & 1);
-                __builtin_amdgcn_s_waitcnt((15) | (3 << 14) | (7 << 4) | ((1 + RTW) << 8));   // lgkmcnt(1 + RTW)
+        lean_static_for<0, D>([&](auto tc) { fetch(tc); });
+        lean_static_for<0, NST>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            if constexpr (t + D < NST) {
+                fetch(std::integral_constant<int, t + D>{});
             }
-            else {
-                AA_WAIT_LGKMCNT0();
-            }
+            // younger steps still in flight behind step t: D, fewer at the end of the stage
+            constexpr int younger = (NST - 1 - t) < D ? (NST - 1 - t) : D;
+            __builtin_amdgcn_s_waitcnt((15) | (3 << 14) | (7 << 4) | ((younger * (1 + RTW)) << 8));   // lgkmcnt(younger * (1 + RTW))
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < RTW; ++j) {
-                acc[t / NKS][j] = RT::mma(a[t & 1], b[t & 1][j], acc[t / NKS][j]);
+                acc[t / NKS][j] = RT::mma(a_[t % (D + 1)], b_[t % (D + 1)][j], acc[t / NKS][j]);
             }
             __builtin_amdgcn_sched_barrier(0);
-        }
+        });
     };
     // stage s is multiplied from LDS buffer s & 1; beside it stage s + 3 is requested into the register set that stage s
     // left (s % 3), and afterwards stage s + 1 goes from its set to the other buffer
@@ -617,7 +644,13 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
             const int last = s + 3 < nstage ? s + 3 : nstage - 1;   // last stage requested so far
             store_stage(std::integral_constant<int, buf ^ 1>{}, std::integral_constant<int, (SET + 1) % 3>{}, last - (s + 1));
         }
+#if defined(AA_LEG_PROBE_NOBARRIER)
+        // dev probe (results wrong): the stage loop without its workgroup barrier -- what the synchronisation of the eight wavefronts
+        // after every stage costs (the fp32 variant has half the matrix time per stage to hide it behind)
+        asm volatile("" ::: "memory");
+#else
         __syncthreads();
+#endif
     };
     for (int s = 0; s < nstage; s += 6) {
         run_stage(s, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
@@ -638,11 +671,21 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
         }
     }
 
+#if defined(AA_LEG_PROBE_NO_EPILOGUE)
+    // dev probe (results wrong): no merge, no stores -- what the epilogue of a work item costs
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < RTW; ++j) asm volatile("" ::"v"(acc[q][j]));
+    return;
+#endif
     // ---- epilogue: merge hemispheres and store (as legendre_kernel) ----
     const int nlats  = p.nlats;
     const int jleg0  = p.nlat0[m] + it.tile * BN;
     const long long RP = p.RP;
     const int ml       = m / p.m_div;
+    // (fp32 with the MFMA operands exchanged -- C^T in the accumulators: a lane holds four consecutive columns of one latitude, one
+    // 16-byte store per tile and hemisphere instead of four 4-byte stores -- measured 5.98 -> 6.08 ms on TL1279 -> F1280: not kept [r4])
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int c = lt * 16 + RT::row_of(lane, g);

@@ -57,6 +57,8 @@ int atlas_amd__set_device(int device);
 /* measurement aid (bench.py): TFLOP/s this device sustains on v_mfma_f64_16x16x4_f64 alone, best of `repeats` kernels of
  * about target_ms each on the current device's default stream (4 wavefronts per SIMD, random operands) */
 int atlas_amd__diag_mfma_f64_rate(double target_ms, int repeats, double* tflops_out);
+/* the same for v_mfma_f32_16x16x4_f32, the instruction of the fp32 variant's Legendre stage [r4] */
+int atlas_amd__diag_mfma_f32_rate(double target_ms, int repeats, double* tflops_out);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Grid description.  Replaces the `const Grid::Implementation*` argument of atlas__Trans__new

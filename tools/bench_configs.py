@@ -82,6 +82,14 @@ def run(name, grid, T, nf, f32, steps, warmup):
         {"kernel": "Fourier stage (all row classes)", "bound": "hbm", "achieved": fft_gbs, "peak": HBM_PEAK, "unit": "GB/s",
          "frac": fft_gbs / HBM_PEAK, "avg_ms": fft_ms, "traffic": None},
     ]
+    try:   # what this box sustains on the Legendre stage's MFMA instruction alone (csrc/diag.hip), beside the datasheet peak
+        from atlas_amd import _lib
+        sustained = _lib.diag_mfma_f32_rate(25.0, 3) if f32 else _lib.diag_mfma_f64_rate(25.0, 3)
+        kernels[0]["peak_sustained_measured"] = sustained
+        kernels[0]["frac_of_sustained"] = leg_tf / sustained
+    except Exception as e:
+        kernels[0]["peak_sustained_measured"] = None
+        kernels[0]["peak_sustained_error"] = f"{type(e).__name__}: {e}"
     cands = [k for k in kernels if k["avg_ms"] >= 0.25 * (leg_ms + fft_ms)] or kernels
     dom = min(cands, key=lambda k: k["frac"])
     per137 = nf / 137.0 if nf % 137 == 0 else 1.0
