@@ -405,7 +405,15 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
     typedef int i4_t __attribute__((ext_vector_type(4)));
     typedef int i2_t __attribute__((ext_vector_type(2)));
     using preg_t = std::conditional_t<F64, i4_t, i2_t>;   // two table elements
-    constexpr int NSET = 3;   // register sets: the stage being written to LDS and the ones still in flight
+    // register sets: the stage being written to LDS and the ones still in flight = stages of look-ahead of the operand streams.
+    // 3 (fp64, 122 registers: a fourth set would cost the fourth wavefront per SIMD).  fp32 [r4]: dev builds -DAA_LEG_F32_NSET=4 / 5
+    // measured 5.89 / 6.41 against 5.90 ms on TL1279 -> F1280: the operand streams are not a latency the look-ahead could cover
+    // (profiles/r04_legendre_f32_probes.txt)
+#ifndef AA_LEG_F32_NSET
+#define AA_LEG_F32_NSET 3
+#endif
+    constexpr int NSET = F64 ? 3 : AA_LEG_F32_NSET;
+    static_assert(NSET >= 3 && NSET <= 6 && (NSET - 1) * (1 + RTW) <= 63, "vmcnt is a 6-bit counter");
     preg_t preg[NSET];
     Real sreg[NSET][RTW];
     // table element pair 2 tid of the stage tile [2 parities][8 k][64 latitudes]
@@ -439,9 +447,9 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
     const Real* sbase = sp + (long long)(ntop_lo - 2 * (KB - 1) - m) * 2 * nf;
     const long long sstride = (long long)4 * KB * nf;   // 2 KB wavenumbers down
 
-    unsigned szero[NSET] = {0, 0, 0};   // bit i: element i of the staged stage is outside [m, nmax]
-    bool sedge[NSET]     = {false, false, false};
-    // stage t travels through register set t % 3 into LDS buffer t & 1; it is requested three stages before it is used
+    unsigned szero[NSET] = {};   // bit i: element i of the staged stage is outside [m, nmax]
+    bool sedge[NSET]     = {};
+    // stage t travels through register set t % NSET into LDS buffer t & 1; it is requested NSET stages before it is used
     auto load_stage = [&](int s, auto setc) {   // must be called for s = 0, 1, 2, ... in order
         constexpr int SET = decltype(setc)::value;
         if constexpr (F64) {
@@ -502,7 +510,10 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
         constexpr int buf = decltype(bufc)::value;
         constexpr int SET = decltype(setc)::value;
         // the loads above are invisible to the compiler's own s_waitcnt placement: count them
-        if (younger_in_flight >= 2) {
+        if (NSET > 3 && younger_in_flight >= 3) {
+            AA_WAIT_VMCNT((NSET > 3 ? 3 : 2) * LPS);
+        }
+        else if (younger_in_flight >= 2) {
             AA_WAIT_VMCNT(2 * LPS);
         }
         else if (younger_in_flight == 1) {
@@ -558,7 +569,14 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
     if (nstage > 2) {
         load_stage(2, std::integral_constant<int, 2>{});
     }
-    store_stage(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, (nstage < 3 ? nstage : 3) - 1);
+    if constexpr (NSET > 3) {
+        lean_static_for<3, NSET>([&](auto ic) {
+            if (nstage > decltype(ic)::value) {
+                load_stage(decltype(ic)::value, ic);
+            }
+        });
+    }
+    store_stage(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, (nstage < NSET ? nstage : NSET) - 1);
     __syncthreads();
 
     const int a_off = (lane >> 4) * PSTR + lt * 16 + (lane & 15);
@@ -629,20 +647,20 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
             __builtin_amdgcn_sched_barrier(0);
         });
     };
-    // stage s is multiplied from LDS buffer s & 1; beside it stage s + 3 is requested into the register set that stage s
-    // left (s % 3), and afterwards stage s + 1 goes from its set to the other buffer
+    // stage s is multiplied from LDS buffer s & 1; beside it stage s + NSET is requested into the register set that stage s
+    // left (s % NSET), and afterwards stage s + 1 goes from its set to the other buffer
     auto run_stage = [&](int s, auto bufc, auto setc) {
         constexpr int buf = decltype(bufc)::value;
         constexpr int SET = decltype(setc)::value;
-        if (s + 3 < nstage) {
-            load_stage(s + 3, setc);
+        if (s + NSET < nstage) {
+            load_stage(s + NSET, setc);
         }
         if (lat_active) {
             mma_steps(bufc);
         }
         if (s + 1 < nstage) {
-            const int last = s + 3 < nstage ? s + 3 : nstage - 1;   // last stage requested so far
-            store_stage(std::integral_constant<int, buf ^ 1>{}, std::integral_constant<int, (SET + 1) % 3>{}, last - (s + 1));
+            const int last = s + NSET < nstage ? s + NSET : nstage - 1;   // last stage requested so far
+            store_stage(std::integral_constant<int, buf ^ 1>{}, std::integral_constant<int, (SET + 1) % NSET>{}, last - (s + 1));
         }
 #if defined(AA_LEG_PROBE_NOBARRIER)
         // dev probe (results wrong): the stage loop without its workgroup barrier -- what the synchronisation of the eight wavefronts
@@ -652,22 +670,35 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
         __syncthreads();
 #endif
     };
-    for (int s = 0; s < nstage; s += 6) {
-        run_stage(s, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-        if (s + 1 < nstage) {
-            run_stage(s + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    if constexpr (NSET == 3) {   // (written out: the fp64 kernel stays instruction for instruction the one of round 3)
+        for (int s = 0; s < nstage; s += 6) {
+            run_stage(s, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            if (s + 1 < nstage) {
+                run_stage(s + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+            }
+            if (s + 2 < nstage) {
+                run_stage(s + 2, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+            }
+            if (s + 3 < nstage) {
+                run_stage(s + 3, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+            }
+            if (s + 4 < nstage) {
+                run_stage(s + 4, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            }
+            if (s + 5 < nstage) {
+                run_stage(s + 5, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+            }
         }
-        if (s + 2 < nstage) {
-            run_stage(s + 2, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
-        }
-        if (s + 3 < nstage) {
-            run_stage(s + 3, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
-        }
-        if (s + 4 < nstage) {
-            run_stage(s + 4, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-        }
-        if (s + 5 < nstage) {
-            run_stage(s + 5, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+    }
+    else {
+        constexpr int PERIOD = (NSET % 2 == 0) ? NSET : 2 * NSET;   // stages after which (LDS buffer, register set) repeat
+        for (int s = 0; s < nstage; s += PERIOD) {
+            lean_static_for<0, PERIOD>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if (i == 0 || s + i < nstage) {
+                    run_stage(s + i, std::integral_constant<int, (i & 1)>{}, std::integral_constant<int, i % NSET>{});
+                }
+            });
         }
     }
 
@@ -750,6 +781,16 @@ template <int RTW, class Real>
 __global__ void __launch_bounds__(512, 4) legendre_kernel_lean_n(LegendreParamsT<Real> p) {
     legendre_lean_body<RTW, Real>(p);
 }
+// dev tool (occupancy sensitivity of the lean kernels): ATLAS_AMD_LEG_LDS_PAD=<bytes> more dynamic LDS per workgroup, i.e. fewer
+// workgroups per CU (profiles/r04_legendre_f32_probes.txt)
+template <auto Kernel>
+static int lean_lds_pad(int bytes) {
+    static const int pad = std::getenv("ATLAS_AMD_LEG_LDS_PAD") ? atoi(std::getenv("ATLAS_AMD_LEG_LDS_PAD")) : 0;
+    if (pad > 0) {
+        (void)ensure_dynamic_lds<Kernel>(bytes + pad);
+    }
+    return pad > 0 ? pad : 0;
+}
 template <int RTW, class Real>
 static hipError_t launch_lean_n(LegendreParamsT<Real> p, int nitems, int nchunks, int chunk0, int nrun, hipStream_t stream) {
     using L = LegLds<RTW, 2, Real>;
@@ -777,7 +818,7 @@ static hipError_t launch_lean_f32(LegendreParamsF32 p, int nitems, int nchunks, 
     p.nchunks_run   = nrun;
     p.abl           = 0;
     const int slots = (nitems + 7) / 8;
-    hipLaunchKernelGGL(legendre_kernel_lean_f32, dim3(slots * nrun * 8), dim3(L::NTHR), L::BYTES, stream, p);
+    hipLaunchKernelGGL(legendre_kernel_lean_f32, dim3(slots * nrun * 8), dim3(L::NTHR), L::BYTES + lean_lds_pad<&legendre_kernel_lean_f32>(L::BYTES), stream, p);
     return hipGetLastError();
 }
 static hipError_t launch_lean(LegendreParams p, int nitems, int nchunks, int chunk0, int nrun, hipStream_t stream) {
@@ -796,7 +837,7 @@ static hipError_t launch_lean(LegendreParams p, int nitems, int nchunks, int chu
     }
 #endif
     const int slots = (nitems + 7) / 8;
-    hipLaunchKernelGGL(legendre_kernel_lean, dim3(slots * nrun * 8), dim3(L::NTHR), L::BYTES, stream, p);
+    hipLaunchKernelGGL(legendre_kernel_lean, dim3(slots * nrun * 8), dim3(L::NTHR), L::BYTES + lean_lds_pad<&legendre_kernel_lean>(L::BYTES), stream, p);
     return hipGetLastError();
 }
 
