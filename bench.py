@@ -658,7 +658,9 @@ def main():
                 out["roofline"][k] = dominant[k]
         out["roofline"]["traffic_source"] = (f"profiles/{traffic['_profile']} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same "
                                              f"kernel sources)" if traffic.get("_profile") else
-                                             "none: no committed PMC profile matches these kernel sources")
+                                             ("none: the committed PMC passes profile the single-GPU workload, not the distributed one"
+                                              if (world > 1 or use_dist) else
+                                              "none: no committed PMC profile matches these kernel sources"))
         if crosscheck is not None:
             out["multi_gpu_crosscheck"] = crosscheck
         if alt is not None:
