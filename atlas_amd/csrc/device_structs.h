@@ -111,6 +111,8 @@ struct FourierParams {
     int pf_dist;                      // L2 prefetch of the modes of the job 8 * pf_dist further on (same XCD); 0: off
     int pf_sectors;                   // requests per 128-byte line of that prefetch (1, 2 or 4)
     int row_affinity;                 // FftRowDesc kernels: a row's field groups all on one XCD (fft_device.h: fft_unit_to_job)
+    int coarse_n[3];                  // fft_rows_coarse_kernel: rows of the launch's list with Bluestein length 1024 / 512 / 256, in this order
+                                      // (the list is sorted by descending row length); all zero: one field per workgroup as in round 3
     int job_group_log2;               // kernels without a row record: log2 of the fields per job group (3; fp32 variant: 4 -- a 128-byte line
                                       // of the intermediate holds 16 fields there)
     int T;

@@ -970,6 +970,21 @@ template <class C>
 AA_HD C raw_elem(const C* raw, int k) {
     return raw[k];
 }
+// (RAW: what the staging area is read through -- a pointer, or StridedRaw for rows that share a wavefront)
+template <class C>
+struct StridedRaw {   // several fields of one row staged side by side: mode m of field `off` is p[m * stride + off]
+    const C* p;
+    int stride, off;
+    AA_HD C operator[](int m) const { return p[m * stride + off]; }
+};
+template <class C>
+AA_HD C ct_raw_mode(StridedRaw<C> raw, int mmax, int m, int h) {
+    C v = m <= mmax ? raw[m] : C{0, 0};
+    if (m == 0 || m == h) {
+        v.im = 0;   // conventions of row_mode()
+    }
+    return v;
+}
 template <class C>
 AA_HD C ct_raw_mode(const C* raw, int mmax, int m, int h) {
     C v = m <= mmax ? raw[m] : C{0, 0};
@@ -983,8 +998,8 @@ AA_HD C ct_raw_mode(const C* raw, int mmax, int m, int h) {
 // registers.  M >= 2h-1 and M even: h <= M/2, so the inputs q >= NZ = ceil(R0/2) are zero padding for every b.  The
 // table loads are issued in batches of NB elements ahead of a scheduling fence: left alone, the compiler serialises
 // them one round trip at a time to save registers.
-template <class S, class C>
-AA_HD void ct_phase0_compute(int b, const RowTablesCtT<C>& r, const C* raw, const RowOut& io, C* x) {
+template <class S, class C, class RAW>
+AA_HD void ct_phase0_compute(int b, const RowTablesCtT<C>& r, RAW raw, const RowOut& io, C* x) {
     constexpr int M   = S::M;
     constexpr int R0  = S::radix(0);
     constexpr int Ls0 = M / R0;
@@ -1026,8 +1041,9 @@ AA_HD void ct_phase0_compute(int b, const RowTablesCtT<C>& r, const C* raw, cons
 
 // RAW_ALIASES_WORK: the staging area lives inside `work` (device: LDS is the scarce resource), so every worker
 // finishes reading it before anybody writes stage-0 results; needs nt == S::NT.
-template <class S, bool RAW_ALIASES_WORK, class C>
-AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCtT<C>& r, const C* raw, const RowOut& io,
+// NTW: workers of one row (S::NT; fewer where several short rows share a wavefront: fft_kernel.hip, coarse classes)
+template <class S, bool RAW_ALIASES_WORK, int NTW = S::NT, class C, class RAW>
+AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCtT<C>& r, RAW raw, const RowOut& io,
                         C* work) {
     using Real        = typename C::real;
     constexpr int M   = S::M;
@@ -1039,11 +1055,11 @@ AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCtT<C>& r, const C
     if (ph == 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (RAW_ALIASES_WORK) {
-            constexpr int NBUT = (Ls0 + S::NT - 1) / S::NT;
+            constexpr int NBUT = (Ls0 + NTW - 1) / NTW;
             C x[NBUT][R0];
 #pragma unroll
             for (int ib = 0; ib < NBUT; ++ib) {
-                const int b = t + ib * S::NT;
+                const int b = t + ib * NTW;
                 if (b < Ls0) {
                     ct_phase0_compute<S>(b, r, raw, io, x[ib]);
                 }
@@ -1051,7 +1067,7 @@ AA_HD void row_phase_ct(int ph, int t, int nt, const RowTablesCtT<C>& r, const C
             __syncthreads();
 #pragma unroll
             for (int ib = 0; ib < NBUT; ++ib) {
-                const int b = t + ib * S::NT;
+                const int b = t + ib * NTW;
                 if (b < Ls0) {
 #pragma unroll
                     for (int q = 0; q < R0; ++q) work[PAD(b + q * Ls0)] = x[ib][q];

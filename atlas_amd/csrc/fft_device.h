@@ -22,9 +22,14 @@ constexpr int FGROUP   = 8;  // fields whose modes share one 128-byte line of F
 // p.row_affinity: the rows in full sets of 8 stay on ONE XCD each (row 8 k + x on XCD x), so that a row's tables (chirp, c2r
 // factors, filter spectrum: 130 - 200 KB) are fetched into one L2 instead of all eight; the last nrows % 8 rows are dealt
 // out by field group as before (balance).
+__device__ __forceinline__ bool fft_unit_to_job_n(int row_affinity, int nrows, int ngr, int x, int idx, int& ri, int& fg);
 __device__ __forceinline__ bool fft_unit_to_job(const FourierParams& p, int ngr, int x, int idx, int& ri, int& fg) {
-    if (p.row_affinity) {
-        const int nfull = p.nrows & ~7;
+    return fft_unit_to_job_n(p.row_affinity, p.nrows, ngr, x, idx, ri, fg);
+}
+// (the same for a sub-list of `nrows` rows: fft_rows_coarse_multi_kernel)
+__device__ __forceinline__ bool fft_unit_to_job_n(int row_affinity, int nrows, int ngr, int x, int idx, int& ri, int& fg) {
+    if (row_affinity) {
+        const int nfull = nrows & ~7;
         const int main_ = (nfull >> 3) * ngr;
         if (idx < main_) {
             const int k = idx / ngr;
@@ -36,12 +41,12 @@ __device__ __forceinline__ bool fft_unit_to_job(const FourierParams& p, int ngr,
         const int k = u / ngr;
         ri          = nfull + k;
         fg          = u - k * ngr;
-        return ri < p.nrows;
+        return ri < nrows;
     }
     const int u = idx * 8 + x;
     ri          = u / ngr;
     fg          = u - ri * ngr;
-    return ri < p.nrows;
+    return ri < nrows;
 }
 __device__ __forceinline__ bool fft_block_to_job_index(const FourierParams& p, int b, int& ri, int& f) {
     const int x   = b & 7;

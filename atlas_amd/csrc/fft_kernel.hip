@@ -353,6 +353,134 @@ __global__ void __launch_bounds__(64, 3) fft_rows_coarse_kernel(FourierParams p)
     }
 }
 
+// ---- [r4] the same classes with SEVERAL FIELDS OF A ROW PER WAVEFRONT (fp64): a row of Bluestein length 256 has 16 butterflies per
+// stage, one of length 512 has 32 in its middle stages -- a 64-lane workgroup per (row, field) left three quarters / half of its lanes
+// idle.  Four (M = 256) or two (M = 512) consecutive fields of the row now share the wavefront: 16 / 32 workers each, every field with
+// its own work array inside the workgroup's 16 KB, the same row code (row_phase_ct with NTW workers per row) -- a quarter / half of the
+// jobs, each as long as before.  The fields' modes are gathered together: lane l requests mode m0 + l / NF of field f0 + l % NF (16 NF
+// contiguous bytes of the intermediate per mode, LDS slot m NF + field: linear in the lane, as LDS-DMA needs it) and phase 0 reads its
+// field through a strided view.  Per (row, field) the arithmetic is that of coarse_row: bit-identical results.
+template <class S, int NF>
+__device__ __forceinline__ void coarse_row_multi(const FourierParams& p, const FftRowDesc& d, int f0, cplx* work, int tid) {
+    using C = cplx;
+    static_assert(S::NT == 64 && 64 % NF == 0, "the fields of a job share one wavefront");
+    constexpr int SG  = 64 / NF;   // workers per field
+    constexpr int NPH = fft::row_num_phases_ct<S>();
+    const int sub = tid / SG, t = tid - sub * SG;
+    const int f   = f0 + sub;
+    const long long goff = (long long)f * p.npts + d.goff_rel;
+    fft::RowTablesCtT<C> r;
+    r.n      = d.n;
+    r.h      = d.h;
+    r.tw     = p.table + d.off_tw;
+    r.pre    = p.table + d.off_pre;
+    r.chirp  = p.table + d.off_chirp;
+    r.bhat_t = p.table + d.off_bhat_t;
+    fft::RowOut io;
+    io.mmax      = d.mmax;
+    io.y         = p.gp + goff;
+    io.aligned16 = ((goff & 1) == 0);
+    io.f32       = 0;
+    io.scale     = (f < p.scale_uv_fields) ? d.coslatinv : 1.0;
+    {
+        const ModeReaderT<0> rd{p, (long long)(d.row - p.lat0), 2 * f0};
+        const int jm = tid / NF, fs = tid - jm * NF;
+        for (int m0 = 0; m0 <= io.mmax; m0 += SG) {
+            const int m = m0 + jm;
+            if (m <= io.mmax) {
+                const double* src = rd.address(m) + 2 * fs;
+                cplx* dst         = work + m0 * NF;   // wave-uniform; lane l lands in slot m0 NF + l = (m0 + l / NF) NF + l % NF
+                __builtin_amdgcn_global_load_lds(
+                    reinterpret_cast<const __attribute__((address_space(1))) void*>(reinterpret_cast<uintptr_t>(src)),
+                    reinterpret_cast<__attribute__((address_space(3))) void*>(static_cast<unsigned>(reinterpret_cast<uintptr_t>(dst))),
+                    16, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    const fft::StridedRaw<C> raw{work, NF, sub};
+    C* mine = work + sub * fft::padded_size(S::M);
+    for_each_phase<S, 0>([&](auto phc) {
+        constexpr int ph = decltype(phc)::value;
+        fft::row_phase_ct<S, true, SG>(ph, t, SG, r, raw, io, mine);
+        if constexpr (ph < NPH - 1) {
+            if constexpr (S::wave_local_middle() && ph >= 1 && ph <= NPH - 3) {
+                wave_lds_fence();
+            }
+            else {
+                __syncthreads();
+            }
+        }
+    });
+}
+
+// rows of the launch's list: [0, n0) Bluestein length 1024 (eight jobs per field group), [n0, n0 + n1) 512 (four jobs of two fields),
+// the rest 256 (two jobs of four fields); the block ranges of the three follow one another
+__host__ __device__ inline unsigned coarse_class_blocks(int nrows, int ngr, int jobs_per_group) {
+    const long long units = (long long)nrows * ngr;
+    return (unsigned)((units + 7) / 8 * 8 * jobs_per_group);
+}
+// (two wavefronts per SIMD: 223 registers -- the fields of a job differ per lane, so what coarse_row keeps in scalar registers (output
+// pointer, scale, work array base) are vector registers here; at 168 the two shared bodies spill 40 - 55.  Eight instead of ten 16-KB
+// workgroups per CU.)
+__global__ void __launch_bounds__(64, 2) fft_rows_coarse_multi_kernel(FourierParams p) {
+    extern __shared__ double lds_raw[];
+    cplx* work    = reinterpret_cast<cplx*>(lds_raw);
+    const int ngr = (p.f_end - p.f_begin + FGROUP - 1) / FGROUP;
+    unsigned b    = blockIdx.x;
+    int cls = 0, row0 = 0;
+    for (; cls < 2; ++cls) {
+        const unsigned nb = coarse_class_blocks(p.coarse_n[cls], ngr, 8 >> cls);
+        if (b < nb) {
+            break;
+        }
+        b -= nb;
+        row0 += p.coarse_n[cls];
+    }
+    const int jpg = 8 >> cls;   // jobs per field group: 8, 4, 2
+    const int nfj = 1 << cls;   // fields per job:       1, 2, 4
+    const int x   = b & 7;
+    const int q   = b >> 3;
+    const int j   = q % jpg;
+    int ril, fg;
+    if (!fft_unit_to_job_n(p.row_affinity, p.coarse_n[cls], ngr, x, q / jpg, ril, fg)) {
+        return;
+    }
+    const int f0 = p.f_begin + fg * FGROUP + j * nfj;
+    if (f0 >= p.f_end) {
+        return;
+    }
+    const FftRowDesc d = p.desc[row0 + ril];
+    const int tid      = (int)threadIdx.x;
+    if (cls == 0) {
+        coarse_row<fft::CtShape<1, 10>, false>(p, d, f0, work, tid);
+    }
+    else if (f0 + nfj > p.f_end) {
+        // a job at the end of the fields that is not full: its fields one after the other (written out: as the body of a loop the row
+        // code spills -- everything in it becomes loop-invariant and is hoisted)
+        if (cls == 1) {
+            coarse_row<fft::CtShape<1, 9>, false>(p, d, f0, work, tid);
+        }
+        else {
+            coarse_row<fft::CtShape<1, 8>, false>(p, d, f0, work, tid);
+            if (f0 + 1 < p.f_end) {
+                __syncthreads();
+                coarse_row<fft::CtShape<1, 8>, false>(p, d, f0 + 1, work, tid);
+            }
+            if (f0 + 2 < p.f_end) {
+                __syncthreads();
+                coarse_row<fft::CtShape<1, 8>, false>(p, d, f0 + 2, work, tid);
+            }
+        }
+    }
+    else if (cls == 1) {
+        coarse_row_multi<fft::CtShape<1, 9>, 2>(p, d, f0, work, tid);
+    }
+    else {
+        coarse_row_multi<fft::CtShape<1, 8>, 4>(p, d, f0, work, tid);
+    }
+}
+
 hipError_t launch_fourier_coarse(const FourierParams& p, int lds_bytes, hipStream_t stream) {
     if (!p.desc) {
         return hipErrorInvalidValue;
@@ -362,6 +490,18 @@ hipError_t launch_fourier_coarse(const FourierParams& p, int lds_bytes, hipStrea
     const unsigned nblk   = (unsigned)((units + 7) / 8 * 64);
     FourierParams q       = p;
     q.nvirt               = nblk;
+    // fp64: several fields of a short row per wavefront (fft_rows_coarse_multi_kernel); ATLAS_AMD_FFT_COARSE_MULTI=0: one field per workgroup
+    const char* em = std::getenv("ATLAS_AMD_FFT_COARSE_MULTI");
+    if (!p.f32 && !(em && atoi(em) == 0) && p.coarse_n[0] + p.coarse_n[1] + p.coarse_n[2] == p.nrows && p.nparts <= 1 && !p.packed_cols) {
+        if (hipError_t e = ensure_dynamic_lds<&fft_rows_coarse_multi_kernel>(lds_bytes); e != hipSuccess) {
+            return e;
+        }
+        const unsigned nb = coarse_class_blocks(p.coarse_n[0], ngr, 8) + coarse_class_blocks(p.coarse_n[1], ngr, 4) +
+                            coarse_class_blocks(p.coarse_n[2], ngr, 2);
+        q.nvirt = nb;
+        hipLaunchKernelGGL(fft_rows_coarse_multi_kernel, dim3(nb), dim3(64), lds_bytes, stream, q);
+        return hipGetLastError();
+    }
     if (p.f32) {
         if (AA_FFT_F32_ARITH) {
             lds_bytes /= 2;

@@ -194,6 +194,7 @@ private:
         bool direct;     // specialised instance is the direct (no Bluestein) kernel
         bool hybrid = false;  // dense-stage rows (fft_rows_hyb_kernel)
         bool coarse_fused = false;   // the coarse Bluestein classes 256 / 512 / 1024 of a small reduced grid in one launch
+        int coarse_n[3]   = {0, 0, 0};   // ... rows of Bluestein length 1024 / 512 / 256 in the (sorted) list
         bool native = false;  // native mixed-radix rows (fft_rows_nat_kernel): d_desc holds FftNatDesc records
         bool native_bigp = false;   // ... whose first-stage radix is a prime 17 .. 31 (the kernel instance with 168 registers)
         int native_fpj   = 1;       // ... fields per workgroup (1 or 2)

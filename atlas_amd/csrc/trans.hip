@@ -565,6 +565,18 @@ void Trans::upload() {
             return na > nb || (na == nb && a < b);
         });
         c.d_rows = dev_upload(it->second.data(), it->second.size());
+        c.coarse_n[0] = c.coarse_n[1] = c.coarse_n[2] = 0;
+        if (c.coarse_fused) {   // rows per Bluestein length 1024 / 512 / 256: contiguous in the list (sorted by descending row length)
+            int last = 1024;
+            for (int j : it->second) {
+                const int M = fft::coarse_bluestein_length(2 * fftplans_.plans[row_plan[j]].h - 1);
+                if (M > last || (M != 1024 && M != 512 && M != 256)) {
+                    throw std::logic_error("coarse Fourier classes: row list not sorted by Bluestein length");
+                }
+                last = M;
+                ++c.coarse_n[M == 1024 ? 0 : (M == 512 ? 1 : 2)];
+            }
+        }
         if (it->first.first == 1 || it->first.first == 6) {   // specialised Bluestein rows: one flat record per row (device_structs.h: FftRowDesc)
             std::vector<FftRowDesc> desc(it->second.size());
             for (size_t i = 0; i < desc.size(); ++i) {
@@ -910,6 +922,9 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
     for (const SizeClass& c : classes_) {
         p.rows  = c.d_rows;
         p.nrows = c.nrows;
+        p.coarse_n[0] = c.coarse_n[0];
+        p.coarse_n[1] = c.coarse_n[1];
+        p.coarse_n[2] = c.coarse_n[2];
         p.desc  = c.native ? nullptr : (const FftRowDesc*)c.d_desc;
         p.ndesc = c.native ? (const FftNatDesc*)c.d_desc : nullptr;
         if (only_m && c.lds_bytes != fft::padded_size(only_m) * 16) {  // dev tool (tools/fft_phase_prof.py): one class

@@ -323,6 +323,36 @@ def test_coarse_row_classes_in_one_launch_are_bitwise_equal_to_one_launch_per_cl
     assert compute_rms(outs["1"][0], oracle.OraclePlan(T, g.nx(), g.y()).invtrans(nf, sp, use_fft=True)) < TOL
 
 
+@pytest.mark.parametrize("nf", [1, 2, 4, 6, 13, 60])
+def test_several_fields_of_a_short_row_per_wavefront_are_bitwise_equal_to_one_field_per_workgroup(nf, monkeypatch):
+    """[r4] the coarse classes of small reduced grids: four (Bluestein length 256) / two (512) consecutive fields of a row share a
+    wavefront (fft_kernel.hip: fft_rows_coarse_multi_kernel -- every field its own work array and 16 / 32 workers, the fields' modes
+    gathered together and read through a strided view; jobs at the end of the fields that are not full run their fields one after the
+    other).  Same arithmetic per (row, field): the same bits as ATLAS_AMD_FFT_COARSE_MULTI=0 (BASELINE C2's grid; field counts with full
+    and ragged last groups), and the vor/div call with its scaled wind fields."""
+    g = atlas_amd.Grid("O160")
+    T = 159
+    tr = atlas_amd.Trans(g, T)
+    sp = red_spectra(T, nf, seed=90 + nf)
+    outs = {}
+    for multi in ("1", "0"):
+        monkeypatch.setenv("ATLAS_AMD_FFT_COARSE_MULTI", multi)
+        outs[multi] = run_device(tr, nf, sp)
+    assert np.array_equal(outs["1"], outs["0"])
+    assert compute_rms(outs["1"], oracle.OraclePlan(T, g.nx(), g.y()).invtrans(nf, sp, use_fft=True)) < TOL
+    if nf in (2, 13):
+        nvd = 3
+        vor, div = red_spectra(T, nvd, seed=7), red_spectra(T, nvd, seed=8)
+        res = {}
+        for multi in ("1", "0"):
+            monkeypatch.setenv("ATLAS_AMD_FFT_COARSE_MULTI", multi)
+            gp = torch.full(((nf + 2 * nvd) * g.size(),), float("nan"), dtype=torch.float64, device="cuda")
+            tr.invtrans(nf, dev(sp), nvd, dev(vor), dev(div), gp)
+            tr.synchronize()
+            res[multi] = gp.cpu().numpy()
+        assert np.isfinite(res["1"]).all() and np.array_equal(res["1"], res["0"])
+
+
 def test_fourier_scheduling_switches_do_not_change_results(monkeypatch):
     """L2 prefetch of a later job's modes, row -> XCD affinity and the number of class streams only move work around:
     bit-identical grid points with them off (fft_kernel.hip: PrefetchJob, fft_device.h: fft_unit_to_job)."""
