@@ -3,6 +3,7 @@
 // the LDS-heavy classes as one function.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <type_traits>
 
 #include "device_structs.h"
@@ -271,6 +272,29 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
     }
     AA_STAMP_N(7);
     AA_STAMP_0(15);
+}
+
+// Host side of row_ct3's L2 prefetch: its requests are plain loads into a register nobody reads, written as inline assembly so that no
+// wait is generated for them -- safe only while the register allocator never moves that register, i.e. in a kernel WITHOUT spills (a
+// spilling kernel corrupted results in round 4's native-row experiments).  The instances are built without scratch by the toolchain this
+// was developed with (ROCm 7.2.0); should another compiler spill one, the launcher switches the prefetch of that instance off
+// (same results, the round-3 speed of the class without its prefetch) and says so once.  (first item, for the Fourier kernels.)
+template <auto Kernel>
+static bool ct3_prefetch_safe(const char* what) {
+    static const bool ok = [what]() {
+        hipFuncAttributes fa{};
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(Kernel)) != hipSuccess) {
+            (void)hipGetLastError();
+            return true;   // no information: the kernel as tested
+        }
+        if (fa.localSizeBytes != 0) {
+            std::fprintf(stderr, "[atlas_amd] a row_ct3 Fourier kernel (%s) was compiled with %zu bytes of scratch: its L2 prefetch is switched off\n",
+                         what, (size_t)fa.localSizeBytes);
+            return false;
+        }
+        return true;
+    }();
+    return ok;
 }
 
 }  // namespace trans

@@ -709,6 +709,9 @@ static hipError_t launch_ct_t(FourierParams p, int lds_bytes, unsigned nblk, hip
     }
     const unsigned grid = nblk;
     p.nvirt             = nblk;
+    if (FAST && !ct3_prefetch_safe<&fft_rows_ct_kernel<S, F32, FAST>>("one field per job")) {   // fft_ct_rows.h
+        p.pf_dist = 0;
+    }
     static const bool debug = std::getenv("ATLAS_AMD_FFT_DEBUG") != nullptr;
     if (debug) {
         int per_cu = -1;

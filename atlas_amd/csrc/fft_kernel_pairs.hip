@@ -332,6 +332,9 @@ static hipError_t launch_ct_pair_t(FourierParams p, int lds_bytes, unsigned nblk
         return e;
     }
     p.nvirt = nblk;
+    if (FAST && !ct3_prefetch_safe<&fft_rows_ct_pair_kernel<S, FAST>>("two fields per job")) {   // fft_ct_rows.h
+        p.pf_dist = 0;
+    }
     hipLaunchKernelGGL((fft_rows_ct_pair_kernel<S, FAST>), dim3(nblk), dim3(S::NT), lds_bytes, stream, p);
     return hipGetLastError();
 }
