@@ -32,12 +32,22 @@
 #include "device_structs.h"
 #include "dyn_lds.h"
 
-// the Fourier intermediate is written once and read once, by another kernel, after everything else of this launch
+// the Fourier intermediate is written once and read once, by another kernel, after everything else of this launch: streaming stores in
+// fp64, where a store instruction's 16 lanes x 8 bytes are a whole 128-byte line.  In the fp32 variant they are HALF a line (16 x 4 bytes;
+// the other half comes from the next tile's instruction), and streaming half lines measured slower than letting L2 combine them [r4]:
+// TL1279 -> F1280 / O1280 in fp32, Legendre stage 5.88 -> 5.68 / 4.79 -> 4.65 ms; written bytes by the counters 4.88 GB for 3.77 GB
+// of intermediate with the streaming form (profiles/r04_legendre_f32_probes.txt).  -DAA_LEG_PLAIN_STORE: plain stores in fp64 as well.
+template <class T>
+__device__ __forceinline__ void leg_store(T* ptr, T v) {
 #if !defined(AA_LEG_PLAIN_STORE)
-#define AA_LEG_STORE(ptr, v) __builtin_nontemporal_store((v), (ptr))
-#else
-#define AA_LEG_STORE(ptr, v) (*(ptr) = (v))
+    if constexpr (sizeof(T) == 8) {
+        __builtin_nontemporal_store(v, ptr);
+        return;
+    }
 #endif
+    *ptr = v;
+}
+#define AA_LEG_STORE(ptr, v) leg_store((ptr), (v))
 
 namespace atlas_amd {
 namespace trans {
