@@ -938,6 +938,16 @@ int atlas_amd__Trans__timings(atlas_amd_Trans* t, double out[4], int reset) {
     }
     AA_CATCH_INT
 }
+int atlas_amd__Trans__timings_vordiv(atlas_amd_Trans* t, double out[2], int reset) {
+    AA_TRY
+    trans::StageTimings s = t->impl->timings();
+    out[0]                = s.prepare_ms;
+    out[1]                = s.prepare_calls;
+    if (reset) {
+        t->impl->reset_timings();
+    }
+    AA_CATCH_INT
+}
 int atlas_amd__Trans__set_profile(atlas_amd_Trans* t, int on) {
     AA_TRY
     t->impl->synchronize();

@@ -20,6 +20,26 @@ __device__ __forceinline__ void pin_register(float& x) {
     asm volatile("" : "+v"(x));
 }
 
+// The stage-0 butterfly of a [R0,16,16] row addresses its R0 elements as PAD(t) + 256 q: one address register and immediate offsets
+// q * 256 * sizeof(C).  The offset field of the LDS instructions is 16 bits: with 16-byte elements the slots q >= 16 (R0 = 18, 20,
+// 24: M = 4608, 5120, 6144) are out of its reach, hipcc then forms one address per such slot, finds the same addresses in phase 0
+// (writes) and phase 4 (reads) and keeps them alive in between -- through the two widest phases, i.e. in scratch (4 / 4 / 11
+// spilled registers in the round-4 binary).  A second base, PAD(t) + 16 * 256, made opaque at each of the two sites: the far slots
+// are immediate offsets again, nothing crosses the phases.
+template <class C, int R0>
+__device__ __forceinline__ int lds_far_slot(int pt) {
+    int v = pt;
+    if constexpr (sizeof(C) * 256 * (R0 - 1) > 65535) {
+        v = pt + 16 * 256;
+        asm volatile("" : "+v"(v));
+    }
+    return v;
+}
+template <class C>
+__device__ __forceinline__ int lds_far_pick(int q, int pt, int pth) {
+    return (sizeof(C) * 256 * q > 65535) ? pth + (q - 16) * 256 : pt + q * 256;
+}
+
 // ---- compile-time specialised Bluestein rows (fft_core.h: row_phase_ct) -------------------------------------------
 template <int NPH, int PH, class Fn>
 __device__ __forceinline__ void for_each_phase_n(Fn&& fn) {
@@ -68,6 +88,22 @@ struct PrefetchJob {
 #define AA_STAMP_0(k) ((void)0)
 #define AA_PIN(x, n) ((void)0)
 #endif
+#ifndef AA_CT3_FLT_LATE
+#define AA_CT3_FLT_LATE 1
+#endif
+// Rows whose middle stages have more than 256 butterflies (M = 4608, 5120, 6144) give the first wavefront(s) a second round.  Both
+// rounds use the powers wm^2 .. wm^15 of the level-1 twiddle: left alone, hipcc computes the 14 powers once, ahead of the first
+// round, and keeps them (56 registers) beside the round's 16 elements and the 16 filter values in flight -- more than the register
+// file holds (a filter value went to scratch right after its request, with a wait for it in front of the phase-1 barrier).
+// Each round gets its own opaque copy of wm: the powers are formed where they are used.
+template <int NBM, class C>
+__device__ __forceinline__ C round_twiddle(C w) {
+    if constexpr (NBM > 1) {
+        pin_register(w.re);
+        pin_register(w.im);
+    }
+    return w;
+}
 template <class S, bool F32, class C, class Stamp>
 __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTablesCtT<C>& r, const fft::RowOut& io,
                                         long long lat_local, int f, C* work, int t, const PrefetchJob& pfj, Stamp&& stamp) {
@@ -179,17 +215,22 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
         AA_STAMP_0(8);
         lds_barrier();   // the staging area aliases the work array: everybody has read it
         AA_STAMP_0(9);
+        const int pth = lds_far_slot<C, R0>(pt);
 #pragma unroll
-        for (int q = 0; q < R0; ++q) work[pt + q * 256] = x[q];
+        for (int q = 0; q < R0; ++q) work[lds_far_pick<C>(q, pt, pth)] = x[q];
 #if defined(AA_FFT_TRACE_PH0)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
         AA_STAMP_0(10);
     }
     // filter spectrum of the first middle butterfly: in flight during phase 1
+    // (the widest first butterflies leave phase 1 no room for all 16 values beside its own 16 elements: the last FLT_LATE of them
+    // are requested behind phase 1 -- they are also the last ones phase 2 uses -- instead of being spilled and reloaded)
+    constexpr int FLT_LATE  = (sizeof(C) == 16 && R0 >= 20) ? AA_CT3_FLT_LATE : 0;
+    constexpr bool W0_AGAIN = (sizeof(C) == 16 && R0 == 20);
     C flt[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) flt[q] = r.bhat_t[(q * NMID + t) * AA_ABL(r, 2)];
+    for (int q = 0; q < 16 - FLT_LATE; ++q) flt[q] = r.bhat_t[(q * NMID + t) * AA_ABL(r, 2)];
     AA_SCHED_FENCE();
     AA_STAMP_0(11);
     lds_barrier();
@@ -200,9 +241,12 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
     for (int ib = 0; ib < NBM; ++ib) {
         const int b = t + ib * NT;
         if (b < NMID) {
-            fft::dif_butterfly_w<16>(work, (b >> 4) * 256 + (b & 15), 16, wm, -1);
+            fft::dif_butterfly_w<16>(work, (b >> 4) * 256 + (b & 15), 16, round_twiddle<NBM>(wm), -1);
         }
     }
+#pragma unroll
+    for (int q = 16 - FLT_LATE; q < 16; ++q) flt[q] = r.bhat_t[(q * NMID + t) * AA_ABL(r, 2)];
+    AA_SCHED_FENCE();
     wave_lds_fence();
     AA_STAMP_N(4);
     AA_STAMP_0(13);
@@ -236,13 +280,19 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
     for (int q = 0; q < NZ; ++q) {
         Ch[q] = r.chirp[(t + q * 256) * AA_ABL(r, 3)];
     }
+    // (the widest rows request the stage-0 twiddle again as well instead of keeping it through the middle phases: four registers
+    // that phase 1 of M = 5120 does not have)
+    C w0b = w0;
+    if constexpr (W0_AGAIN) {
+        w0b = r.tw[t];
+    }
     AA_SCHED_FENCE();
     // ---- phase 3: DIT level 1
 #pragma unroll
     for (int ib = 0; ib < NBM; ++ib) {
         const int b = t + ib * NT;
         if (b < NMID) {
-            fft::dit_butterfly_w<16>(work, (b >> 4) * 256 + (b & 15), 16, wm, +1);
+            fft::dit_butterfly_w<16>(work, (b >> 4) * 256 + (b & 15), 16, round_twiddle<NBM>(wm), +1);
         }
     }
     lds_barrier();
@@ -250,9 +300,10 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
     // ---- phase 4: DIT stage 0 + chirp + store (outputs q >= NZ are padding: their butterfly arithmetic is dead)
     {
         C x[R0];
+        const int pth = lds_far_slot<C, R0>(pt);
 #pragma unroll
-        for (int q = 0; q < R0; ++q) x[q] = work[pt + q * 256];
-        fft::twiddle_apply<R0>(x, w0);
+        for (int q = 0; q < R0; ++q) x[q] = work[lds_far_pick<C>(q, pt, pth)];
+        fft::twiddle_apply<R0>(x, w0b);
         fft::bfly<R0>(x, +1);
 #pragma unroll
         for (int q = 0; q < NZ; ++q) {

@@ -48,6 +48,8 @@ struct TransConfig {
 struct StageTimings {
     double legendre_ms = 0, fourier_ms = 0;
     int legendre_calls = 0, fourier_calls = 0;
+    double prepare_ms = 0;   // vor/div calls: spectra_prepare (extend_truncation + vd2uv + field interleave, vd2uv_kernel.hip)
+    int prepare_calls = 0;
 };
 
 struct FourierParts;

@@ -1118,6 +1118,10 @@ void Trans::collect_timings() {
             timings_.legendre_ms += ms;
             timings_.legendre_calls++;
         }
+        else if (ev_kind_[i / 2] == 2) {
+            timings_.prepare_ms += ms;
+            timings_.prepare_calls++;
+        }
         else {
             timings_.fourier_ms += ms;
             timings_.fourier_calls++;
@@ -1291,7 +1295,9 @@ void Trans::invtrans_device(int nb_scalar, const double* sp_dev, int nb_vordiv, 
         const int nall    = 2 * nb_vordiv + nb_scalar;
         const size_t nout = size_t(T + 2) * size_t(T + 3) * size_t(nall);
         ensure(d_all_, all_cap_, nout);
+        timed_begin(2);
         HIP_CHECK(launch_spectra_prepare(vor_dev, div_dev, sp_dev, d_all_, T, nb_vordiv, nb_scalar, stream_));
+        timed_end();
         invtrans_uv_device(T + 1, nall, nb_vordiv, d_all_, gp_dev);  // TransLocal.cc:1590
     }
     else if (nb_scalar > 0) {

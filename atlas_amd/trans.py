@@ -245,9 +245,11 @@ class Trans:
 
     def timings(self, reset=False):
         out = (C.c_double * 4)()
+        vd = (C.c_double * 2)()
+        _lib.check(_lib.Trans_timings_vordiv(self._h, vd, 0))
         _lib.check(_lib.Trans_timings(self._h, out, int(reset)))
         return {"legendre_ms": out[0], "legendre_calls": int(out[1]), "fourier_ms": out[2],
-                "fourier_calls": int(out[3])}
+                "fourier_calls": int(out[3]), "prepare_ms": vd[0], "prepare_calls": int(vd[1])}
 
     # ---- Legendre cache (TransLocal.cc:608-647) ----
     def legendre_cache(self):

@@ -298,6 +298,9 @@ int64_t atlas_amd__Trans__legendre_table_bytes(const atlas_amd_Trans* t);
 /* accumulated kernel times from HIP events on the Trans stream (profile=1):
  * out = {legendre_ms, legendre_calls, fourier_ms, fourier_calls}; reset != 0 clears the accumulators */
 int atlas_amd__Trans__timings(atlas_amd_Trans* t, double out[4], int reset);
+/* the same for the stage only the vor/div calls have -- extend_truncation + vd2uv + field interleave in one kernel
+ * (TransLocal.cc:1496-1581, VorDivToUVLocal.cc:62-184): out = {prepare_ms, prepare_calls} */
+int atlas_amd__Trans__timings_vordiv(atlas_amd_Trans* t, double out[2], int reset);
 int atlas_amd__Trans__set_profile(atlas_amd_Trans* t, int on);
 /* dev profiling of the FFT kernel: if out != NULL read the 64 per-phase shader-clock accumulators (slots 0..31
  * Bluestein rows, 32..63 direct rows), then enable (and zero) or disable the accumulation */

@@ -57,6 +57,7 @@ def lib():
         L.orc_invtrans_fourier.argtypes = [vp, i, vp, vp, i]
         L.orc_invtrans_rows.argtypes = [vp, i, i, vp, i, vp, vp, i]
         L.orc_invtrans_vordiv.argtypes = [vp, i, vp, i, vp, vp, vp, i]
+        L.orc_invtrans_vordiv_rows.argtypes = [vp, i, vp, i, vp, vp, i, vp, vp, i]
         L.orc_vd2uv.argtypes = [i, i, vp, vp, vp, vp]
         L.orc_gemm.argtypes = [i, sz, i, vp, vp, vp]
         L.orc_c2r_direct.argtypes = [i, vp, vp]
@@ -198,6 +199,33 @@ class OraclePlan:
             res.append(out[off:off + nf * n].reshape(nf, n))
             off += nf * n
         return res
+
+
+    def invtrans_vordiv_rows(self, ns, sp, nvd, vor, div, rows, use_fft=False):
+        """rows `rows` of TransLocal::invtrans(ns, sp, nvd, vor, div, gp) without tables (full-size parity of the vor/div
+        path): list of arrays [2 nvd + ns][nx(row)], fields ordered [u..][v..][scalars..] (TransLocal.cc:1523-1597,1443-1469)"""
+        OraclePlan_rows_check(self, rows)
+        vor = np.ascontiguousarray(vor, dtype=np.float64)
+        div = np.ascontiguousarray(div, dtype=np.float64)
+        assert vor.size == self.nspec(nvd) and div.size == self.nspec(nvd)
+        sp_c = np.ascontiguousarray(sp, dtype=np.float64) if ns > 0 else None
+        assert ns == 0 or sp_c.size == self.nspec(ns)
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        nall = 2 * nvd + ns
+        out = np.zeros(int(sum(nall * int(self.nx[r]) for r in rows)))
+        lib().orc_invtrans_vordiv_rows(self._h, ns, sp_c.ctypes.data if ns > 0 else None, nvd, vor.ctypes.data,
+                                       div.ctypes.data, len(rows), rows.ctypes.data, out.ctypes.data, int(use_fft))
+        res, off = [], 0
+        for r in rows:
+            n = int(self.nx[r])
+            res.append(out[off:off + nall * n].reshape(nall, n))
+            off += nall * n
+        return res
+
+
+def OraclePlan_rows_check(plan, rows):
+    rows = np.asarray(rows)
+    assert rows.size > 0 and rows.min() >= 0 and rows.max() < plan.nlats
 
 
 def vd2uv(trc, nf, vor, div):

@@ -938,3 +938,58 @@ void orc_invtrans_vordiv(const orc_plan* p, int ns, const double* sp, int nvd, c
     orc_invtrans_uv(p, T + 1, nall, nvd, all, gp, use_fft);
     free(vor_e); free(div_e); free(U); free(V); free(sc_e); free(all);
 }
+
+/* Row-sampled twin of orc_invtrans_vordiv for FULL-SIZE parity of the vor/div path (no 8 GB table): the merged spectra
+ * [U fields][V fields][scalar fields] at truncation T+1 exactly as above (extend_truncation TransLocal.cc:1496-1519,
+ * vd2uv VorDivToUVLocal.cc:62-184, interleave TransLocal.cc:1555-1581), the rows through orc_invtrans_rows with the call's
+ * truncation T+1 (so that every m <= T survives and the n = T+1 column of U, V enters, TransLocal.cc:970-997), then the
+ * first 2 nvd fields times 1/cos(clamped latitude) (TransLocal.cc:1443-1469).  out is [nrows][2 nvd + ns][nx(row)]. */
+void orc_invtrans_vordiv_rows(const orc_plan* p, int ns, const double* sp, int nvd, const double* vor, const double* div,
+                              int nrows, const int* rows, double* out, int use_fft) {
+    const int T = p->T;
+    if (nvd <= 0) {
+        if (ns > 0) orc_invtrans_rows(p, T, ns, sp, nrows, rows, out, use_fft);
+        return;
+    }
+    size_t next   = (size_t)(T + 2) * (T + 3);
+    double* vor_e = (double*)malloc(sizeof(double) * next * nvd);
+    double* div_e = (double*)malloc(sizeof(double) * next * nvd);
+    double* U     = (double*)calloc(next * nvd, sizeof(double));
+    double* V     = (double*)calloc(next * nvd, sizeof(double));
+    orc_extend_truncation(T, nvd, vor, vor_e);
+    orc_extend_truncation(T, nvd, div, div_e);
+    orc_vd2uv(T + 1, nvd, vor_e, div_e, U, V);
+    free(vor_e);
+    free(div_e);
+    double* sc_e = NULL;
+    if (ns > 0) {
+        sc_e = (double*)malloc(sizeof(double) * next * ns);
+        orc_extend_truncation(T, ns, sp, sc_e);
+    }
+    int nall    = 2 * nvd + ns;
+    double* all = (double*)malloc(sizeof(double) * next * nall);
+    size_t k = 0, i = 0, j = 0, l = 0;
+    for (int m = 0; m <= T + 1; ++m)
+        for (int n = m; n <= T + 1; ++n)
+            for (int imag = 0; imag < 2; ++imag) {
+                for (int f = 0; f < nvd; ++f) all[k++] = U[i++];
+                for (int f = 0; f < nvd; ++f) all[k++] = V[j++];
+                for (int f = 0; f < ns; ++f) all[k++] = sc_e[l++];
+            }
+    free(U);
+    free(V);
+    free(sc_e);
+    orc_invtrans_rows(p, T + 1, nall, all, nrows, rows, out, use_fft);
+    free(all);
+    size_t off = 0;
+    for (int r = 0; r < nrows; ++r) {
+        int jlat   = rows[r];
+        double lat = p->lat_deg[jlat];
+        if (lat > ORC_LATPOLE) lat = ORC_LATPOLE;
+        if (lat < -ORC_LATPOLE) lat = -ORC_LATPOLE;
+        double inv = 1. / cos(lat * ORC_DEG2RAD);
+        size_t nx  = (size_t)p->nx[jlat];
+        for (size_t q = 0; q < (size_t)2 * nvd * nx; ++q) out[off + q] *= inv;
+        off += (size_t)nall * nx;
+    }
+}

@@ -11,6 +11,10 @@ Template: the reference's own benchmark driver, src/sandbox/benchmark_trans/atla
   C5        TL1279 -> F1280 ("N1280 full"), 137 levels, fp32 (configs[4]);  C5f64: the same grid in fp64
   C5n       TL1279 -> N1280 (classic reduced Gaussian), fp32
   C4f32     TL1279 -> O1280, 137 levels, fp32 (the headline grid in the precision of C5; not a BASELINE configuration)
+  C4vd      TL1279 -> O1280, nscalar 137 + nvordiv 137 in ONE invtrans(nb_scalar, sp, nb_vordiv, vor, div, gp): the other axis of the
+            reference's benchmark (atlas-benchmark-trans.cc:66-76,148-149 `--nscalar --nvordiv`; TransLocal.cc:1523-1597): 411 output
+            fields (137 u, 137 v, 137 scalars); stage times incl. the spectra_prepare kernel (extend_truncation + vd2uv + interleave)
+  C2vd      TL159 -> O160, nscalar 60 + nvordiv 60
 """
 import argparse
 import json
@@ -32,10 +36,12 @@ CONFIGS = {
     "C5f64": ("F1280", 1279, 137, False, 10, 3),
     "C5n": ("N1280", 1279, 137, True, 10, 3),
     "C4f32": ("O1280", 1279, 137, True, 10, 3),
+    "C4vd": ("O1280", 1279, 137, False, 8, 2, 137),
+    "C2vd": ("O160", 159, 60, False, 20, 5, 60),
 }
 
 
-def run(name, grid, T, nf, f32, steps, warmup):
+def run(name, grid, T, nf, f32, steps, warmup, nvd=0):
     import numpy as np
     import torch
     import atlas_amd
@@ -52,16 +58,23 @@ def run(name, grid, T, nf, f32, steps, warmup):
         sp = blk.repeat(1, (nf + 136) // 137)[:, :nf].contiguous().reshape(-1)
         del blk
     dt_t = torch.float32 if f32 else torch.float64
+    ns, nf = nf, nf + 2 * nvd          # a vor/div call transforms 2 nvd wind fields + ns scalars (TransLocal.cc:1523-1597)
     gp = torch.zeros(nf * g.size(), dtype=dt_t, device="cuda")
     if f32:
         sp = sp.to(torch.float32)
+    if nvd:
+        vor = torch.from_numpy(red_spectra(T, nvd, seed=2)).cuda()
+        div = torch.from_numpy(red_spectra(T, nvd, seed=3)).cuda()
+        call = lambda: tr.invtrans(ns, sp, nvd, vor, div, gp)
+    else:
+        call = lambda: tr.invtrans(nf, sp, gp)
     for _ in range(warmup):
-        tr.invtrans(nf, sp, gp)
+        call()
     torch.cuda.synchronize()
     tr.timings(reset=True)
     t0 = time.perf_counter()
     for _ in range(steps):
-        tr.invtrans(nf, sp, gp)
+        call()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tm = tr.timings()
@@ -71,7 +84,7 @@ def run(name, grid, T, nf, f32, steps, warmup):
     nlat0 = tr.nlat0()
     kept = float(sum(int(nlat0[m] < ny // 2) * 2 * (ny // 2 - int(nlat0[m])) for m in range(T + 1)))
     esz = 4 if f32 else 8
-    leg_flops = tr.legendre_flops(nf)
+    leg_flops = tr.legendre_flops(nf)   # (a vor/div call runs this stage at truncation T + 1: + 0.2 % that are not counted)
     fft_bytes = kept * nf * 2 * esz + nf * g.size() * esz
     leg_tf = leg_flops / (leg_ms * 1e-3) / 1e12
     fft_gbs = fft_bytes / (fft_ms * 1e-3) / 1e9
@@ -104,6 +117,19 @@ def run(name, grid, T, nf, f32, steps, warmup):
         "roofline": {k: dom[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_ms")},
         "roofline_kernels": kernels,
     }
+    if nvd:
+        prep_ms = tm["prepare_ms"] / max(tm["prepare_calls"], 1)
+        ncoef = (T + 1) * (T + 2)
+        prep_bytes = (2 * nvd + ns) * ncoef * 8 + (2 * nvd + ns) * (T + 2) * (T + 3) * 8   # vor, div, sp read; merged spectra written
+        out["metric"] = f"inverse SH transforms/sec (T{T}, {grid}, nscalar {ns} + nvordiv {nvd})"
+        out["value"] = steps * (nf / 137.0 if nf % 137 == 0 else 1.0) / dt
+        out["config"]["workload"] = (f"TransLocal invtrans(nb_scalar={ns}, sp, nb_vordiv={nvd}, vor, div, gp) T{T} -> {grid}: {nf} output "
+                                     f"fields (u, v, scalars) in one call" + ("; value counts 137-level output fields" if nf % 137 == 0 else ""))
+        out["config"].update({"nb_scalar": ns, "nb_vordiv": nvd, "fields": nf})
+        out["roofline_kernels"].append(
+            {"kernel": "spectra_prepare_kernel (extend_truncation + vd2uv + interleave)", "bound": "hbm",
+             "achieved": prep_bytes / (prep_ms * 1e-3) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",
+             "frac": prep_bytes / (prep_ms * 1e-3) / 1e9 / HBM_PEAK, "avg_ms": prep_ms, "traffic": None})
     if nf > 200:   # field k and field k + 137 carry the same spectra: the results must be identical bits
         v = gp.reshape(nf, -1)
         out["config"]["tiled_fields_identical"] = bool(torch.equal(v[3], v[3 + 137]))
