@@ -110,6 +110,8 @@ struct FourierParams {
     int jobs;                         // tools/experiments/fft_kernel_p.hip only (field groups a workgroup walks through); 1
     int pf_dist;                      // L2 prefetch of the modes of the job 8 * pf_dist further on (same XCD); 0: off
     int pf_sectors;                   // requests per 128-byte line of that prefetch (1, 2 or 4)
+    int mid_rot;                      // row_ct3 rows with more than 256 middle butterflies: the wavefront that takes the second round rotates
+                                      // with the job (0: always the first wavefront -- on the SIMD that holds the first wavefront of both jobs of a CU)
     int row_affinity;                 // FftRowDesc kernels: a row's field groups all on one XCD (fft_device.h: fft_unit_to_job)
     int coarse_n[3];                  // fft_rows_coarse_kernel: rows of the launch's list with Bluestein length 1024 / 512 / 256, in this order
                                       // (the list is sorted by descending row length); all zero: one field per workgroup as in round 3

@@ -115,6 +115,10 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
     constexpr int NMID = M / 16;                      // butterflies of a middle stage
     constexpr int NBM  = (NMID + NT - 1) / NT;        // rounds of the middle stages (2 for M > 4096: first wavefront only)
     const int h        = r.h;
+    // rounds ib >= 1 of the middle phases (NBM > 1): worker (t + 64 * rot) % 256 takes butterfly 256 ib + that index.  Whole wavefronts
+    // rotate, so the 16 workers of a block of 256 points stay in one wavefront (the middle phases are wavefront-local), and the same
+    // worker takes the same butterfly in phases 1, 2 and 3.
+    const int trot     = (NBM > 1 && p.mid_rot) ? ((t + 64 * (((int)blockIdx.x >> 3) + ((int)blockIdx.x >> 8))) & (NT - 1)) : t;
     const int pt       = fft::PAD(t);   // t < 256: PAD(t + 256 q) = PAD(t) + 256 q (the swizzle stays inside blocks of 256)
     static_assert(NT == 256, "stage-0 butterfly b == worker t");
 #if defined(AA_FFT_ABLATE)
@@ -226,7 +230,7 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
     // filter spectrum of the first middle butterfly: in flight during phase 1
     // (the widest first butterflies leave phase 1 no room for all 16 values beside its own 16 elements: the last FLT_LATE of them
     // are requested behind phase 1 -- they are also the last ones phase 2 uses -- instead of being spilled and reloaded)
-    constexpr int FLT_LATE  = (sizeof(C) == 16 && R0 >= 20) ? AA_CT3_FLT_LATE : 0;
+    constexpr int FLT_LATE  = (sizeof(C) == 16 && R0 >= 18) ? AA_CT3_FLT_LATE : 0;
     constexpr bool W0_AGAIN = (sizeof(C) == 16 && R0 == 20);
     C flt[16];
 #pragma unroll
@@ -239,7 +243,7 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
     // ---- phase 1: DIF level 1 (blocks of 256 = 16 consecutive workers, radix 16, stride 16)
 #pragma unroll
     for (int ib = 0; ib < NBM; ++ib) {
-        const int b = t + ib * NT;
+        const int b = (ib ? trot : t) + ib * NT;
         if (b < NMID) {
             fft::dif_butterfly_w<16>(work, (b >> 4) * 256 + (b & 15), 16, round_twiddle<NBM>(wm), -1);
         }
@@ -253,7 +257,7 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
     // ---- phase 2: last DIF stage * filter spectrum * first DIT stage (16 contiguous elements, no twiddles)
 #pragma unroll
     for (int ib = 0; ib < NBM; ++ib) {
-        const int b = t + ib * NT;
+        const int b = (ib ? trot : t) + ib * NT;
         if (b < NMID) {
             if (ib > 0) {
 #pragma unroll
@@ -290,7 +294,7 @@ __device__ __forceinline__ void row_ct3(const FourierParams& p, const fft::RowTa
     // ---- phase 3: DIT level 1
 #pragma unroll
     for (int ib = 0; ib < NBM; ++ib) {
-        const int b = t + ib * NT;
+        const int b = (ib ? trot : t) + ib * NT;
         if (b < NMID) {
             fft::dit_butterfly_w<16>(work, (b >> 4) * 256 + (b & 15), 16, round_twiddle<NBM>(wm), +1);
         }

@@ -875,6 +875,10 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
     p.pf_dist         = 2;   // 16 jobs of the XCD ahead (profiles/r03_fft_experiments.txt, 12.)
     p.pf_sectors      = 1;
     p.row_affinity    = 1;
+    p.mid_rot         = 0;
+    if (const char* e = std::getenv("ATLAS_AMD_FFT_MIDROT")) {   // A/B
+        p.mid_rot = atoi(e);
+    }
     p.job_group_log2  = f32 ? 4 : 3;
     if (const char* e = std::getenv("ATLAS_AMD_FFT_GROUP_LOG2")) {   // A/B
         p.job_group_log2 = std::max(3, std::min(4, atoi(e)));

@@ -425,6 +425,20 @@ def test_full_size_sampled_rows_against_oracle(trans_full):
     print(f"full size: {len(rows)} rows of {len(classes)} classes, worst rel-rms {worst:.2e}")
 
 
+def test_full_size_rotated_second_round_is_bitwise_equal(trans_full, monkeypatch):
+    """ATLAS_AMD_FFT_MIDROT: in the row_ct3 rows with more than 256 middle butterflies (M = 4608 / 5120 / 6144) the wavefront that
+    takes the second round rotates with the job -- other workers, the same butterflies: identical bits (fft_ct_rows.h: trot)"""
+    g, tr = trans_full
+    T, nf = 1279, 11
+    sp = red_spectra(T, nf, seed=91)
+    outs = {}
+    for rot in ("0", "1"):
+        monkeypatch.setenv("ATLAS_AMD_FFT_MIDROT", rot)
+        outs[rot] = run_device(tr, nf, sp)
+    monkeypatch.delenv("ATLAS_AMD_FFT_MIDROT")
+    assert np.array_equal(outs["0"], outs["1"])
+
+
 def test_full_size_linearity(trans_full):
     g, tr = trans_full
     T, nf = 1279, 16
