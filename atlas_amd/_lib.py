@@ -176,6 +176,7 @@ Trans_legendre_table_download = _sig("atlas_amd__Trans__legendre_table_download"
 legendre_gen_host_selfcheck = _sig("atlas_amd__legendre_gen_host_selfcheck", C.c_int, c_void_p, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong))
 Trans_timings = _sig("atlas_amd__Trans__timings", C.c_int, c_void_p, c_void_p, C.c_int)
+Trans_fourier_launch_plan = _sig("atlas_amd__Trans__fourier_launch_plan", C.c_int, c_void_p, c_void_p)
 Trans_timings_vordiv = _sig("atlas_amd__Trans__timings_vordiv", C.c_int, c_void_p, c_void_p, C.c_int)
 Trans_set_profile = _sig("atlas_amd__Trans__set_profile", C.c_int, c_void_p, C.c_int)
 Trans_fft_phase_profile = _sig("atlas_amd__Trans__fft_phase_profile", C.c_int, c_void_p, C.c_int, c_void_p)

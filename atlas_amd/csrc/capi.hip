@@ -938,6 +938,14 @@ int atlas_amd__Trans__timings(atlas_amd_Trans* t, double out[4], int reset) {
     }
     AA_CATCH_INT
 }
+int atlas_amd__Trans__fourier_launch_plan(const atlas_amd_Trans* t, int out[3]) {
+    AA_TRY
+    if (!t || !t->impl || !out) {
+        throw std::invalid_argument("fourier_launch_plan: null argument");
+    }
+    t->impl->fourier_launch_plan(out);
+    AA_CATCH_INT
+}
 int atlas_amd__Trans__timings_vordiv(atlas_amd_Trans* t, double out[2], int reset) {
     AA_TRY
     trans::StageTimings s = t->impl->timings();

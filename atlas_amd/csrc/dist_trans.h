@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <set>
+#include <utility>
 #include <vector>
 
 #include "comm.h"
@@ -86,8 +88,9 @@ public:
     void invtrans_many_halo(int ntransforms, int nb_fields, const double* const* sp_dev, double* const* gp_dev,
                             parallel::HaloExchange& hx, double* const* field_dev);
     hipStream_t comm_stream() const { return comm_stream_; }
-    // largest message of the transposition in doubles (default 512 MiB).  MUST be the same on every rank (both ends of a
-    // pair cut their slabs alike); takes effect at the next transform (the message list is rebuilt).
+    // largest message of the transposition in doubles (default 512 MiB).  COLLECTIVE: called by every rank of the communicator with
+    // the same value (both ends of a pair cut their runs alike) -- the ranks compare it inside the call and a mismatch throws on every
+    // rank; takes effect at the next transform (the message list is rebuilt).
     void set_max_message_elems(int64_t elems);
     int64_t max_message_elems() const { return max_message_elems_; }
     const PackedTransposePlan& packed_plan() const { return pplan_; }
@@ -101,6 +104,8 @@ private:
         bool used = false;
     };
     void ensure(int nb_fields);
+    void check_ranks_agree(int nb_fields);
+    std::set<std::pair<int, int64_t>> checked_;   // (field count, message limit) pairs the ranks have compared
     void legendre(int nb_fields, const double* sp_dev, Slot& s);
     bool sharded_input_ = false;   // set for the duration of invtrans_many_sharded
     void poison(Slot& s);

@@ -222,6 +222,29 @@ void DistributedTrans::set_max_message_elems(int64_t elems) {
         throw std::invalid_argument("DistributedTrans: the message limit must be at least one element");
     }
     max_message_elems_ = elems;   // ensure() rebuilds the message list when it differs from the one in use
+    // COLLECTIVE: every rank of the communicator calls this, with the same value -- compared here, where all of them are, and not
+    // inside the next transform (a check that only the ranks with a changed setting enter pairs its all-to-all with
+    // the other ranks' data messages)
+    check_ranks_agree(0);
+}
+
+// the ranks compare (message limit, field count): an all-to-all of three ints; every rank takes part or none
+void DistributedTrans::check_ranks_agree(int nb_fields) {
+    HIP_CHECK(hipStreamSynchronize(comm_stream_));
+    const int P       = comm_.size();
+    const int mine[3] = {(int)(max_message_elems_ & 0x7fffffff), (int)(max_message_elems_ >> 31), nb_fields};
+    std::vector<int> send((size_t)P * 3), recv((size_t)P * 3, 0);
+    for (int p = 0; p < P; ++p) {
+        std::copy(mine, mine + 3, send.begin() + (size_t)p * 3);
+    }
+    comm_.all_to_all(send.data(), recv.data(), 3);
+    for (int p = 0; p < P; ++p) {
+        if (!std::equal(mine, mine + 3, recv.begin() + (size_t)p * 3)) {
+            throw std::runtime_error("DistributedTrans: rank " + std::to_string(p) + " uses another message limit / field count "
+                                     "(set_max_message_elems is collective: the same value on every rank)");
+        }
+    }
+    checked_.insert({nb_fields, max_message_elems_});
 }
 
 void DistributedTrans::ensure(int nb_fields) {
@@ -292,24 +315,15 @@ void DistributedTrans::ensure(int nb_fields) {
     }
     msgs_       = packed_transpose_messages(pplan_, trans_.bands(), trans_.nparts(), trans_.part(), max_message_elems_);
     msgs_limit_ = max_message_elems_;
-    // both ends of every pair must cut their runs alike: the number of pieces per pair follows from the message limit, which is
-    // a per-rank setting -- compare it (and the field count) across the ranks instead of finding out by a size-mismatch error, a hang
-    // or silently misplaced rows
+    // both ends of every pair must cut their runs alike: the number of pieces per pair follows from the message limit and the
+    // field count.  The limit is compared where it is set (set_max_message_elems, collective); a (field count, limit) pair is
+    // compared across the ranks the FIRST time it is used -- every rank gets here then, because the transform itself is called by
+    // all of them with one field count -- and remembered: a caller alternating between 137-level and surface fields pays the
+    // blocking all-to-all twice, not per call
+    if (!checked_.count({nb_fields, max_message_elems_})) {
+        check_ranks_agree(nb_fields);
+    }
     {
-        const int P = comm_.size();
-        const int mine[4] = {(int)(max_message_elems_ & 0x7fffffff), (int)(max_message_elems_ >> 31), nb_fields,
-                             (int)(msgs_.size() / std::max(P, 1))};
-        std::vector<int> send((size_t)P * 4), recv((size_t)P * 4, 0);
-        for (int p = 0; p < P; ++p) {
-            std::copy(mine, mine + 4, send.begin() + (size_t)p * 4);
-        }
-        comm_.all_to_all(send.data(), recv.data(), 4);
-        for (int p = 0; p < P; ++p) {
-            if (!std::equal(mine, mine + 4, recv.begin() + (size_t)p * 4)) {
-                throw std::runtime_error("DistributedTrans: rank " + std::to_string(p) + " uses another message limit / field count "
-                                         "(set_max_message_elems must be called with the same value on every rank)");
-            }
-        }
         int64_t biggest = 0;
         for (const TransposeMsg& m : msgs_) {
             biggest = std::max<int64_t>(biggest, m.send_end - m.send_begin);

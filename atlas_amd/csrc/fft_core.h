@@ -90,14 +90,14 @@ AA_HD int PAD(int i) {
     return i ^ ((i >> 4) & 15);
 }
 #endif
-AA_HD int padded_size(int M) {
+AA_HD constexpr int padded_size(int M) {
     return (M + 255) / 256 * 256;
 }
 #else
 AA_HD int PAD(int i) {
     return i + (i >> 4);
 }
-AA_HD int padded_size(int M) {
+AA_HD constexpr int padded_size(int M) {
     return M + (M >> 4) + 1;
 }
 #endif

@@ -187,7 +187,8 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 // Gather of the kept modes X[0..mmax] of one (row, field) into LDS (raw[m], contiguous).  fp64: LDS-DMA, 16 bytes per
 // lane straight from the Fourier intermediate into LDS (no staging registers; destination = wave-uniform base + 16 * lane,
-// so lane l of wave w handles m = sweep * nt + 64 w + l; lanes beyond mmax re-read mode mmax into slots nobody reads).
+// so lane l of wave w handles m = sweep * nt + 64 w + l; lanes beyond mmax request NOTHING: their LDS slots keep what the caller
+// put there -- a caller that reads them (row_ct3's unmasked phase 0) zero-fills them itself).
 // fp32 intermediate: through registers (the 8-byte element has no DMA width).
 template <bool F32, class C>
 __device__ __forceinline__ void gather_modes_to_lds(const FourierParams& p, long long lat_local, int f, int mmax,

@@ -364,6 +364,9 @@ template <class S, int NF>
 __device__ __forceinline__ void coarse_row_multi(const FourierParams& p, const FftRowDesc& d, int f0, cplx* work, int tid) {
     using C = cplx;
     static_assert(S::NT == 64 && 64 % NF == 0, "the fields of a job share one wavefront");
+    // every field has a work array of its own inside the launch's LDS, which is sized for ONE row of 1024 points (with
+    // -DAA_FFT_LDS_SWIZZLE=0 the padded arrays of four 256-point rows would overrun it)
+    static_assert(NF * fft::padded_size(S::M) <= fft::padded_size(1024), "the fields' work arrays fit the launch's LDS");
     constexpr int SG  = 64 / NF;   // workers per field
     constexpr int NPH = fft::row_num_phases_ct<S>();
     const int sub = tid / SG, t = tid - sub * SG;

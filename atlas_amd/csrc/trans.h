@@ -205,6 +205,17 @@ private:
         void* d_desc = nullptr;   // FftRowDesc[nrows] for the specialised Bluestein kernels
     };
     std::vector<SizeClass> classes_;
+public:
+    // launches of one Fourier stage (one per row class) and, of those, launches that take two fields per workgroup (native rows)
+    void fourier_launch_plan(int out[3]) const {
+        out[0] = (int)classes_.size();
+        out[1] = out[2] = 0;
+        for (const SizeClass& c : classes_) {
+            out[1] += c.coarse_fused ? 1 : 0;
+            out[2] += (c.native && c.native_fpj == 2) ? 1 : 0;
+        }
+    }
+private:
     double* d_fourier_  = nullptr;
     size_t fourier_cap_ = 0;
     double* d_sp_       = nullptr;

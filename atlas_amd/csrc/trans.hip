@@ -446,7 +446,8 @@ void Trans::upload() {
         if (pl.method == fft::FFT_BLUESTEIN && pl.ct_k >= 0) {
             // small reduced grids: the coarse classes 256 / 512 / 1024 share one launch (fft_kernel.hip: fft_rows_coarse_kernel);
             // ATLAS_AMD_FFT_COARSE_FUSED=0: one launch per class as before (A/B)
-            static const bool fuse = !(std::getenv("ATLAS_AMD_FFT_COARSE_FUSED") && atoi(std::getenv("ATLAS_AMD_FFT_COARSE_FUSED")) == 0);
+            // (read per Trans object, not once per process: the bitwise tests build one object per setting -- ADVICE r4)
+            const bool fuse = !(std::getenv("ATLAS_AMD_FFT_COARSE_FUSED") && atoi(std::getenv("ATLAS_AMD_FFT_COARSE_FUSED")) == 0);
             if (fft_coarse_ && fuse && pl.ct_f == 1 && pl.shape.M <= 1024 && pl.shape.M == fft::coarse_bluestein_length(2 * pl.h - 1)) {
                 by_class[{6, 1024}].push_back(j);
                 continue;
@@ -463,7 +464,7 @@ void Trans::upload() {
             // workgroups per CU / prime 17 .. 31: three); launches bucketed by LDS footprint: 40 KiB (four per CU), 52 KiB (three),
             // 80 KiB (two).  ATLAS_AMD_FFT_NATIVE_FPJ=2: two fields per workgroup where two work arrays fit 80 KiB -- measured
             // slower (2.20 against 1.60 ms for the native rows of O1280, profiles/r04_fft_native.txt), bit-identical
-            static const int nat_fpj = std::getenv("ATLAS_AMD_FFT_NATIVE_FPJ") ? atoi(std::getenv("ATLAS_AMD_FFT_NATIVE_FPJ")) : 1;
+            const int nat_fpj = std::getenv("ATLAS_AMD_FFT_NATIVE_FPJ") ? atoi(std::getenv("ATLAS_AMD_FFT_NATIVE_FPJ")) : 1;
             const int bigp  = pl.nat.radix[0] > 15 ? 1 : 0;
             const int one   = native_lds_elems(pl, row_mmax[j]);
             const int fpj   = (nat_fpj >= 2 && 2 * one + 64 <= 5120) ? 2 : 1;

@@ -58,7 +58,10 @@ class Trans:
                 raise ValueError("give rows= or domain=, not both")
             cfg += ";domain=" + ",".join(repr(float(v)) for v in domain)
         for k, v in options.items():   # atlas option:: keys (fft="FFTW", matrix_multiply=..., warning=0, ...): passed through
-            cfg += f";{k}={int(v) if isinstance(v, bool) else v}"
+            v = int(v) if isinstance(v, bool) else v
+            if ";" in str(k) or "=" in str(k) or ";" in str(v):   # the config string is ';'-separated key=value items
+                raise ValueError(f"option {k!r}={v!r}: ';' cannot be passed through the configuration string")
+            cfg += f";{k}={v}"
         cache_ptr, cache_size = None, 0
         if legendre_cache is not None:
             self._cache = np.ascontiguousarray(np.frombuffer(legendre_cache, dtype=np.uint8))
@@ -302,6 +305,12 @@ class Trans:
         out = np.zeros((len(self.grid.nx()), 3), dtype=np.int32)
         _lib.check(_lib.Trans_fft_row_classes(self._h, out.ctypes.data))
         return out
+
+    def fourier_launch_plan(self):
+        """{launches of one Fourier stage, the fused coarse-class launch among them, native-row launches with two fields per workgroup}"""
+        out = (C.c_int * 3)()
+        _lib.check(_lib.Trans_fourier_launch_plan(self._h, out))
+        return {"launches": out[0], "coarse_fused": out[1], "native_two_fields": out[2]}
 
     def legendre_flops(self, nf):
         return _lib.Trans_legendre_flops(self._h, nf)

@@ -672,6 +672,14 @@ def main():
             out["native_failed"] = bool(impl.startswith("torch (fallback)"))
             if impl_note is not None:
                 out["dist_impl_note"] = impl_note
+            if out["native_failed"]:
+                # a multi-GPU line measures csrc/dist_trans.hip or nothing: what the torch.distributed
+                # stand-in reached is kept beside it for diagnosis, never as `value`
+                out["fallback_value"], out["value"] = out["value"], None
+                out["fallback_ms_per_step"] = out["ms_per_step"]
+                out["error"] = ("the library's distributed driver (csrc/dist_trans.hip over RCCL) did not run or failed its "
+                                "cross-check; the timed region ran atlas_amd/dist_torch.py instead -- value withheld"
+                                + (": " + impl_note if impl_note else ""))
         if use_dist and sharded_note is not None:
             out["config"]["input_spectra"] = sharded_note
         if os.environ.get("BENCH_TEST_STANDIN") == "1":

@@ -34,7 +34,8 @@ typedef struct atlas_amd_StructuredColumns atlas_amd_StructuredColumns;
  * errors / library info
  * ------------------------------------------------------------------------------------------------------------- */
 const char* atlas_amd__last_error(void);
-/* thread-local diagnostics that are not errors, set by the last call that has any (empty otherwise): e.g. the TransLocal option
+/* thread-local diagnostics that are not errors, set (or cleared) by atlas_amd__Trans__new_config -- the only call that has any so
+ * far -- and left untouched by every other call: e.g. the TransLocal option
  * keys atlas_amd__Trans__new_config accepted and ignored (fft, matrix_multiply, precompute, warning, write_fft, ...;
  * src/atlas/option/TransOptions.cc:38-74, TransLocal.cc:61-110) */
 const char* atlas_amd__last_note(void);
@@ -293,6 +294,10 @@ int atlas_amd__Trans__nlat0(const atlas_amd_Trans* t, int nlat0_out[] /* T+1 */)
  * (0 run-time shaped, 1 specialised Bluestein, 2 specialised direct, 3 dense-stage experiment, 4 native mixed radix).  Parity tests
  * take one northern and one southern row of every (method, M, kernel) that is launched (TransLocal.cc:1155-1196 treats all rows alike) */
 int atlas_amd__Trans__fft_row_classes(const atlas_amd_Trans* t, int out[] /* 3 * nlats */);
+/* kernel launches of one Fourier stage: out = {launches (one per row class), of which: the fused launch of the coarse Bluestein
+ * classes (0 / 1), launches of native rows with two fields per workgroup}.  The A/B switches ATLAS_AMD_FFT_COARSE_FUSED /
+ * ATLAS_AMD_FFT_NATIVE_FPJ are read when the object is built; the bitwise tests assert through this that the other path ran */
+int atlas_amd__Trans__fourier_launch_plan(const atlas_amd_Trans* t, int out[3]);
 double atlas_amd__Trans__legendre_flops(const atlas_amd_Trans* t, int nb_fields);
 int64_t atlas_amd__Trans__legendre_table_bytes(const atlas_amd_Trans* t);
 /* accumulated kernel times from HIP events on the Trans stream (profile=1):
@@ -415,8 +420,9 @@ int atlas_amd__Trans__spectral_shard(const atlas_amd_Trans* t, long long moff_ou
 int atlas_amd__Trans__invtrans_distributed_many_halo(atlas_amd_Trans* t, atlas_amd_Comm* c, int ntransforms, int nb_fields,
                                                      const double* const* sp_dev, double* const* gp_dev,
                                                      atlas_amd_HaloExchange* hx, double* const* field_dev);
-/* largest message of the transposition (default 512 MiB).  MUST be set to the same value on every rank -- both ends of a
- * pair cut their runs alike; takes effect at the next transform. */
+/* largest message of the transposition (default 512 MiB).  COLLECTIVE over `comm`: every rank calls it, with the same value -- both
+ * ends of a pair cut their runs alike; the ranks compare the value inside the call (a mismatch is an error on every rank); takes effect
+ * at the next transform. */
 int atlas_amd__Trans__set_max_message_bytes(atlas_amd_Trans* t, atlas_amd_Comm* comm, long long bytes);
 /* [r3] the messages the distributed transform sends (test hook, host only): rank `part` packs, for every latitude row, the
  * wavenumbers m <= row_mmax[row] it owns (m % nparts == part) with `cols` = 2 * nb_fields doubles each -- no dead

@@ -47,7 +47,7 @@ def _bench_worker(rank, world, port, argv, grid, corrupt_mirror, outdir):
         sys.stdout.flush()
 
 
-def run_bench(tmp_path, world, argv, grid="O16", corrupt_mirror=False):
+def run_bench(tmp_path, world, argv, grid="O16", corrupt_mirror=False, expect_value=True):
     port = _free_port()
     ctx = mp.get_context("spawn")
     procs = [ctx.Process(target=_bench_worker, args=(r, world, port, argv, grid, corrupt_mirror, str(tmp_path)))
@@ -65,6 +65,8 @@ def run_bench(tmp_path, world, argv, grid="O16", corrupt_mirror=False):
         assert k in out, k
     assert out["n_gpus"] == world and out["scaling"] == "weak" and out["vs_baseline"] is None
     assert out["higher_is_better"] is True and out["dtype"] == "f64" and out["data"] == "synthetic"
+    if not expect_value:
+        return out
     assert out["value"] > 0 and out["ms_per_step"] > 0 and "workload" in out["config"]
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     return out
@@ -143,6 +145,16 @@ def test_all_to_all_decomposition_with_cross_check(tmp_path):
     out = run_bench(tmp_path, 3, ["--gpus", "3", "--steps", "2", "--warmup", "1", "--dist-mode", "alltoall"])
     assert out["config"]["parallelism"].startswith("m-sharded")
     assert out["multi_gpu_crosscheck"]["bitwise_equal_on_all_ranks"] is True
+
+
+def test_a_failed_native_driver_withholds_the_value(tmp_path):
+    """--gpus N > 1 must measure csrc/dist_trans.hip or nothing: here the library's driver cannot start
+    (no HIP device in this container), every rank falls back to the torch.distributed stand-in together -- the line keeps
+    that number under `fallback_value`, prints "value": null and says why"""
+    out = run_bench(tmp_path, 2, ["--gpus", "2", "--steps", "1", "--warmup", "0", "--dist-impl", "native", "--no-alt"],
+                    expect_value=False)
+    assert out["native_failed"] is True and out["dist_impl"].startswith("torch (fallback)")
+    assert out["value"] is None and out["fallback_value"] > 0 and "error" in out and "dist_trans.hip" in out["error"]
 
 
 def test_explicit_modes(tmp_path):

@@ -279,3 +279,33 @@ def test_a_failing_rank_releases_the_others_instead_of_hanging():
     rcs = run_ranks(2, rank)
     assert all(rc != 0 for rc in rcs), rcs
     assert any("matching send" in (e or "") for e in errors) and any("another rank" in (e or "") or "matching" in (e or "") for e in errors)
+
+
+def test_ranks_with_different_message_limits_get_an_error_not_a_hang():
+    """set_max_message_bytes is collective: the ranks compare the value inside the call (the check used to sit inside the
+    next transform, where only the ranks whose setting had changed entered it); a caller alternating between two field counts
+    pays the comparison once per (field count, limit) pair"""
+    g = atlas_amd.Grid("O32")
+    T, nparts = 31, 2
+    errors = [None] * nparts
+
+    def rank(comm):
+        d = DistributedTrans(g, T, comm=comm, mode="alltoall")
+        try:
+            d.set_max_message_bytes(4096 if comm.rank() == 0 else 8192)
+        except Exception as e:  # noqa: BLE001
+            errors[comm.rank()] = str(e)
+        d.set_max_message_bytes(1 << 14)               # agreed again: usable afterwards
+        n = d.trans.nb_gridpoints()
+        outs = []
+        for nf in (3, 1, 3, 1):                        # alternating field counts
+            sp = torch.from_numpy(red_spectra(T, nf, seed=5)).cuda()
+            gp = torch.zeros(nf * n, dtype=torch.float64, device="cuda")
+            d.invtrans(nf, sp, gp)
+            d.trans.synchronize()
+            outs.append(gp.cpu().numpy())
+        assert np.array_equal(outs[0], outs[2]) and np.array_equal(outs[1], outs[3])
+        return True
+
+    assert all(run_ranks(nparts, rank))
+    assert all(e is not None and "message limit" in e for e in errors), errors

@@ -274,8 +274,11 @@ def test_native_mixed_radix_rows_against_the_oracle(monkeypatch):
     tr.synchronize()
     assert bool(torch.isfinite(gp32).all())
     assert compute_rms(gp32.cpu().numpy().astype(np.float64), ref32) < 2e-6
+    assert tr.fourier_launch_plan()["native_two_fields"] == 0
     monkeypatch.setenv("ATLAS_AMD_FFT_NATIVE_FPJ", "2")                         # two fields per workgroup: same arithmetic per field
-    assert np.array_equal(run_device(atlas_amd.Trans(g, T), nf, sp), gp)
+    tr2 = atlas_amd.Trans(g, T)
+    assert tr2.fourier_launch_plan()["native_two_fields"] >= 1                  # read per object: the other path really ran
+    assert np.array_equal(run_device(tr2, nf, sp), gp)
     monkeypatch.delenv("ATLAS_AMD_FFT_NATIVE_FPJ")
     monkeypatch.delenv("ATLAS_AMD_FFT_NATIVE")
     assert (atlas_amd.Trans(g, T).fft_row_classes()[:, 2] != 4).all()          # opt-in: off by default
@@ -315,6 +318,8 @@ def test_coarse_row_classes_in_one_launch_are_bitwise_equal_to_one_launch_per_cl
         tr = atlas_amd.Trans(g, T)
         cls = tr.fft_row_classes()
         assert set(cls[:, 1]) <= {256, 512, 1024} and (cls[:, 2] == 1).all()
+        plan = tr.fourier_launch_plan()                # the switch is read per object: the other path really ran
+        assert plan["coarse_fused"] == int(fused) and (plan["launches"] == 1 if fused == "1" else plan["launches"] >= 3), plan
         gp32 = torch.full((nf * g.size(),), float("nan"), dtype=torch.float32, device="cuda")
         tr.invtrans(nf, sp32, gp32)
         tr.synchronize()
