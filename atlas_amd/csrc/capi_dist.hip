@@ -224,6 +224,18 @@ int atlas_amd__Trans__invtrans_distributed_many_halo(atlas_amd_Trans* t, atlas_a
     dist_of(t, c).invtrans_many_halo(ntransforms, nb_fields, sp_dev, gp_dev, hx->impl, field_dev);
     DX_CATCH
 }
+int atlas_amd__Trans__pack_probe(atlas_amd_Trans* t, int nb_fields, int reps, double* ms, long long* bytes) {
+    DX_TRY
+    if (!t || !t->impl || !ms || nb_fields < 1 || reps < 1) {
+        throw std::invalid_argument("pack_probe: bad arguments");
+    }
+    int64_t b = 0;
+    *ms       = atlas_amd::trans::pack_probe(*t->impl, nb_fields, reps, &b);
+    if (bytes) {
+        *bytes = b;
+    }
+    DX_CATCH
+}
 int atlas_amd__Trans__set_max_message_bytes(atlas_amd_Trans* t, atlas_amd_Comm* c, long long bytes) {
     DX_TRY
     if (bytes < 8) {

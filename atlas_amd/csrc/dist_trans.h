@@ -67,6 +67,9 @@ PackedTransposePlan make_packed_transpose_plan(const std::vector<int>& row_mmax,
 std::vector<TransposeMsg> packed_transpose_messages(const PackedTransposePlan& plan, const std::vector<int>& bands, int nparts,
                                                     int part, int64_t max_message_elems);
 
+// measurement aid: one rank's pack kernel alone on the device (ms per launch; bytes packed per launch)
+double pack_probe(Trans& trans, int nb_fields, int reps, int64_t* bytes);
+
 class DistributedTrans {
 public:
     DistributedTrans(Trans& trans, parallel::Comm& comm);

@@ -176,6 +176,59 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(const double* __restrict
     }
 }
 
+// Measurement aid (tools/scaling_model.py): the pack kernel of ONE rank of a P-rank transform, alone on the device -- the rank's
+// intermediate F (uninitialised: the kernel only copies) packed into its send buffer S `reps` times between two events on the
+// Trans stream.  No communicator: the plan is host arithmetic.  Returns ms per launch, *bytes = bytes written to S per launch.
+double pack_probe(Trans& trans, int nb_fields, int reps, int64_t* bytes) {
+    const TransGeometry& geo = trans.geometry();
+    std::vector<int> row_mmax(geo.nlats);
+    for (int j = 0; j < geo.nlats; ++j) {
+        const int jleg = j < geo.nlatsNH ? j : geo.nlats - 1 - j;
+        row_mmax[j]    = std::min(geo.mmax_leg[jleg], geo.T);
+    }
+    const int RP = trans.fourier_row_pitch(nb_fields);
+    const PackedTransposePlan plan = make_packed_transpose_plan(row_mmax, 2 * nb_fields, trans.bands(), trans.nparts(), trans.part());
+    std::vector<long long> src(plan.rowoff[trans.part()].begin(), plan.rowoff[trans.part()].end());
+    std::vector<int> kept(geo.nlats);
+    for (int j = 0; j < geo.nlats; ++j) {
+        kept[j] = (int)((src[j + 1] - src[j]) / plan.cols);
+    }
+    double *F = nullptr, *S = nullptr;
+    long long* d_src = nullptr;
+    int* d_kept      = nullptr;
+    HIP_CHECK(hipMalloc((void**)&F, std::max<size_t>(trans.fourier_doubles(nb_fields), 1) * sizeof(double)));
+    HIP_CHECK(hipMalloc((void**)&S, (size_t)std::max<int64_t>(plan.send_total, 1) * sizeof(double)));
+    HIP_CHECK(hipMalloc((void**)&d_src, src.size() * sizeof(long long)));
+    HIP_CHECK(hipMalloc((void**)&d_kept, kept.size() * sizeof(int)));
+    HIP_CHECK(hipMemcpy(d_src, src.data(), src.size() * sizeof(long long), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_kept, kept.data(), kept.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemset(F, 0, std::max<size_t>(trans.fourier_doubles(nb_fields), 1) * sizeof(double)));
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    float ms = 0;
+    for (int pass = 0; pass < 2; ++pass) {   // pass 0: warm-up
+        HIP_CHECK(hipEventRecord(e0, trans.stream()));
+        for (int i = 0; i < (pass ? reps : 1); ++i) {
+            hipLaunchKernelGGL(pack_rows_kernel, dim3(geo.nlats, 4), dim3(256), 0, trans.stream(), F, S, d_src, d_kept,
+                               trans.owned_wavenumbers(), RP, plan.cols);
+        }
+        HIP_CHECK(hipEventRecord(e1, trans.stream()));
+        HIP_CHECK(hipEventSynchronize(e1));
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(F);
+    (void)hipFree(S);
+    (void)hipFree(d_src);
+    (void)hipFree(d_kept);
+    if (bytes) {
+        *bytes = plan.send_total * (int64_t)sizeof(double);
+    }
+    return ms / std::max(reps, 1);
+}
+
 DistributedTrans::DistributedTrans(Trans& trans, parallel::Comm& comm) : trans_(trans), comm_(comm) {
     if (trans.nparts() != comm.size() || trans.part() != comm.rank()) {
         throw std::invalid_argument("DistributedTrans: the Trans must be made with (nparts, part) = (comm size, comm rank)");

@@ -420,6 +420,9 @@ int atlas_amd__Trans__spectral_shard(const atlas_amd_Trans* t, long long moff_ou
 int atlas_amd__Trans__invtrans_distributed_many_halo(atlas_amd_Trans* t, atlas_amd_Comm* c, int ntransforms, int nb_fields,
                                                      const double* const* sp_dev, double* const* gp_dev,
                                                      atlas_amd_HaloExchange* hx, double* const* field_dev);
+/* measurement aid (tools/scaling_model.py): the pack kernel of this rank of a wavenumber-sharded Trans (nparts, part, shard=m), alone on
+ * the device: ms per launch and bytes packed per launch.  No communicator involved. */
+int atlas_amd__Trans__pack_probe(atlas_amd_Trans* t, int nb_fields, int reps, double* ms, long long* bytes);
 /* largest message of the transposition (default 512 MiB).  COLLECTIVE over `comm`: every rank calls it, with the same value -- both
  * ends of a pair cut their runs alike; the ranks compare the value inside the call (a mismatch is an error on every rank); takes effect
  * at the next transform. */

@@ -253,6 +253,44 @@ def test_config_C3_TL639_O640_137_levels_on_four_ranks():
         assert same and halo_ok
 
 
+def test_config_C4_split_TL1279_O1280_137_levels_on_eight_ranks():
+    """BASELINE config C4's own split at full size: TL1279 -> O1280, 137 levels over EIGHT latitude-band
+    parts -- m-sharded Legendre stage (160 wavenumbers per rank), packed transposition (5.07 GB over 56 pair messages, the
+    largest 100 MB), band Fourier stage reading the packed runs -- the eight ranks emulated as threads on one GPU: every
+    band equals the single-device field bit for bit (sampled rows of which test_gpu_trans.py compares with the oracle), for
+    the replicated and for the m-sharded input, and for the second transform of a pipelined call."""
+    g = atlas_amd.Grid("O1280")
+    T, nf, nparts = 1279, 137, 8
+    sp_h = [red_spectra(T, nf, seed=s) for s in (5, 6)]
+    sps = [torch.from_numpy(a).cuda() for a in sp_h]
+    refs = []
+    tr = atlas_amd.Trans(g, T)
+    for sp in sps:
+        ref = torch.zeros(nf * g.size(), dtype=torch.float64, device="cuda")
+        tr.invtrans(nf, sp, ref)
+        tr.synchronize()
+        refs.append(ref.view(nf, -1))
+    del tr
+    off = np.concatenate([[0], np.cumsum(g.nx())])
+
+    def rank(comm):
+        d = DistributedTrans(g, T, comm=comm, mode="alltoall")
+        n = d.trans.nb_gridpoints()
+        b0, b1 = d.bands[comm.rank()], d.bands[comm.rank() + 1]
+        gps = [torch.full((nf * n,), float("nan"), dtype=torch.float64, device="cuda") for _ in sps]
+        d.invtrans_many(nf, sps, gps)
+        d.trans.synchronize()
+        ok = all(torch.equal(gp.view(nf, -1), ref[:, off[b0]:off[b1]]) for gp, ref in zip(gps, refs))
+        shard = torch.from_numpy(d.shard_spectra(nf, sp_h[1])).cuda()      # 1/8 of the coefficients
+        gp_s = torch.full((nf * n,), float("nan"), dtype=torch.float64, device="cuda")
+        d.invtrans_many_sharded(nf, [shard], [gp_s])
+        d.trans.synchronize()
+        return ok, torch.equal(gp_s.view(nf, -1), refs[1][:, off[b0]:off[b1]]), shard.numel() * 7 <= sps[1].numel()
+
+    for ok, ok_sharded, small in run_ranks(nparts, rank):
+        assert ok and ok_sharded and small
+
+
 def test_a_failing_rank_releases_the_others_instead_of_hanging():
     """a rank of the in-process communicator that throws between two meeting points (here: a receive whose size
     does not match the peer's send) marks the hub failed; the rank that waits at the meeting point throws too."""
