@@ -29,7 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 GRID, T, NF = "O1280", 1279, 137
 
 
-def measure_rank(g, sp, P, part, reps=5):
+def measure_rank(g, sp, P, part, reps=25):
     import torch
     import atlas_amd
     from atlas_amd import _lib
@@ -39,7 +39,7 @@ def measure_rank(g, sp, P, part, reps=5):
     tr = atlas_amd.Trans(g, T, profile=True, nparts=P, part=part, shard="m")
     tr.use_torch_stream()
     F = torch.zeros(tr.fourier_size(NF), dtype=torch.float64, device="cuda")
-    for _ in range(2):
+    for _ in range(5):   # (a 1 ms kernel timed over 5 launches after 2 read 15 % slow: the clocks were still ramping)
         tr.legendre_device(T, NF, sp, F)
     torch.cuda.synchronize()
     tr.timings(reset=True)
@@ -60,7 +60,7 @@ def measure_rank(g, sp, P, part, reps=5):
     tb = atlas_amd.Trans(g, T, profile=True, nparts=P, part=part, shard="band")
     tb.use_torch_stream()
     gp = torch.zeros(NF * tb.nb_gridpoints(), dtype=torch.float64, device="cuda")
-    for _ in range(2):
+    for _ in range(5):
         tb.invtrans(NF, sp, gp)
     torch.cuda.synchronize()
     tb.timings(reset=True)
