@@ -27,6 +27,7 @@
 #include "atlas/array.h"
 #include "atlas/array/ArrayView.h"
 #include "atlas/array/ArrayViewDefs.h"
+#include "atlas/array/ArrayViewUtil.h"   // array::get_parallel_dim (found missing by the front-end check of round 5)
 #include "atlas/array_fwd.h"
 #include "atlas/library/config.h"
 #include "atlas/parallel/mpi/mpi.h"
@@ -85,7 +86,8 @@ public:  // methods (HaloExchange.h:47-58)
         // the library's own transport: RCCL's unique id is created on rank 0 and broadcast over eckit::mpi -- the only MPI call
         // of this object; setup_comm runs the two collectives of HaloExchange.cc:118,156-159 over the RCCL communicator
         if (!rccl_) {
-            std::vector<char> id(size_t(atlas_amd__Comm__unique_id_bytes()));
+            const size_t id_bytes = size_t(atlas_amd__Comm__unique_id_bytes());   // (not `vector<char> id(size_t(f()))`: a function declaration)
+            std::vector<char> id(id_bytes);
             if (myproc == 0) {
                 check(atlas_amd__Comm__get_unique_id(id.data()));
             }
@@ -167,7 +169,7 @@ private:
         // and the message buffers live.  A host-resident field (on_device == false) is given device storage for the duration
         // of the call if it has none: the reference packs such a field on the host (HaloExchange.h:160-172), this backend has
         // no host kernels.
-        const bool device_msgs = on_device && ATLAS_HAVE_GPU_AWARE_MPI;
+        [[maybe_unused]] const bool device_msgs = on_device && ATLAS_HAVE_GPU_AWARE_MPI;   // (unused by the RCCL transport)
         bool allocated_here    = false;
         if (on_device) {
             ATLAS_ASSERT(field.deviceAllocated());

@@ -30,6 +30,7 @@
 #include "atlas/domain.h"
 #include "atlas/field/Field.h"
 #include "atlas/field/FieldSet.h"
+#include "atlas/grid/Iterator.h"   // IterateLonLat (Grid.h only forward-declares it): found by the front-end check of round 5
 #include "atlas/grid/StructuredGrid.h"
 #include "atlas/grid/UnstructuredGrid.h"
 #include "atlas/trans/detail/TransFactory.h"

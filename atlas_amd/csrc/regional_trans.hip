@@ -3,6 +3,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <limits>
 #include <stdexcept>
 #include <string>
 
@@ -93,6 +95,8 @@ __global__ void __launch_bounds__(256) points_dft_kernel(const double* __restric
 // inner object's Legendre stage covers the row range the target needs; rowsel_ maps target rows / points to its rows
 void RegionalTrans::make_inner(const std::vector<double>& lats_deg, bool clamp_scale) {
     std::vector<double> a;
+    const char* rp_env         = std::getenv("ATLAS_AMD_REFERENCE_POLES");   // read per object
+    const bool reference_poles = rp_env && atoi(rp_env) != 0;
     for (double y : lats_deg) {
         if (!(y >= -90. && y <= 90.)) {
             throw std::invalid_argument("RegionalTrans: latitude outside [-90, 90]");
@@ -127,6 +131,18 @@ void RegionalTrans::make_inner(const std::vector<double>& lats_deg, bool clamp_s
             }
         }
         const int k = lo;
+        if (reference_poles && y < 0) {
+            // ATLAS_AMD_REFERENCE_POLES=1 ("Deviations"): the reference's Legendre routine, called with the target's
+            // own latitudes on this branch, sets cos(colatitude) = +1 when sin(colatitude) <= sqrt(epsilon) -- within a metre of
+            // EITHER pole (LegendrePolynomials.cc:58-61,72-76) -- so a row at latitude -90 gets the NORTH-pole polynomials.  The
+            // switch reproduces that: such a row reads the northern row of the symmetric set instead of its mirror image.
+            const double zdlx1       = M_PI_2 - (-v) * (M_PI / 180.);
+            const double zdlx        = std::cos(zdlx1);
+            volatile double zdlsita  = std::sqrt(1. - zdlx * zdlx);
+            if (std::fabs(zdlsita) <= std::sqrt(std::numeric_limits<double>::epsilon())) {
+                return k;
+            }
+        }
         return y >= 0 || (equator && k == (int)a.size() - 1) ? k : (int)sym.y.size() - 1 - k;
     };
     std::vector<int> rows;

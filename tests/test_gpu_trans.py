@@ -877,6 +877,29 @@ def test_rectangular_domain_crop_is_the_window_of_the_global_transform(gridname,
     assert np.array_equal(crop.reshape(ns + 2 * nvd, -1), full.reshape(ns + 2 * nvd, -1)[:, idx])
 
 
+def test_reference_poles_switch_reproduces_the_reference_at_the_south_pole(monkeypatch):
+    """INTEGRATION.md "Deviations": by default a row at latitude -90 of a no_nest target is the mirror image of the north-pole
+    row; ATLAS_AMD_REFERENCE_POLES=1 reproduces what the reference computes there -- its Legendre routine sets cos(colatitude) =
+    +1 within a metre of either pole (LegendrePolynomials.cc:58-61,72-76), i.e. the north-pole polynomials -- which is what the
+    oracle's restatement of that routine returns unpatched."""
+    T, nf = 63, 4
+    sp = red_spectra(T, nf, seed=45)
+    lats, west, dlon, nlon = np.array([90.0, 30.0, -89.99999995, -90.0, -30.0]), 0.0, 11.25, 32
+    lons = west + dlon * np.arange(nlon)
+    want = oracle.invtrans_regional(T, lats, lons, nf, sp)          # the reference's arithmetic, wrong sign at -90 included
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ATLAS_AMD_REFERENCE_POLES", flag)
+        rt = atlas_amd.RegionalTrans(nlon, west, dlon, lats, T)
+        gp = torch.zeros(nf * nlon * len(lats), dtype=torch.float64, device="cuda")
+        rt.invtrans(nf, dev(sp), gp)
+        rt.synchronize()
+        outs[flag] = gp.cpu().numpy().reshape(nf, len(lats), nlon)
+    assert compute_rms(outs["1"].ravel(), want.ravel()) < 1e-13
+    assert np.array_equal(outs["1"][:, [0, 1, 4], :], outs["0"][:, [0, 1, 4], :])      # only the polar rows differ
+    assert compute_rms(outs["0"][:, 3, :].ravel(), want[:, 3, :].ravel()) > 1e-3          # the default is the mirror image
+
+
 @pytest.mark.parametrize("case", ["northern_box", "across_equator_unsorted", "with_equator_and_poles"])
 def test_regional_target_that_is_not_a_crop_of_a_global_grid(case):
     """TransLocal's no_nest branch (TransLocal.cc:394-406,535-557,719-738,1139-1148) through atlas_amd__RegionalTrans__*:
