@@ -223,14 +223,22 @@ void Trans::release() noexcept {
         (void)hipStreamDestroy(stream2_);
         stream2_ = nullptr;
     }
-    if (pin_[0]) {
+    if (hp_up_stream_) {
+        (void)hipStreamSynchronize(hp_up_stream_);
+        (void)hipStreamSynchronize(copy_stream_);
         for (int i = 0; i < 2; ++i) {
-            (void)hipHostFree(pin_[i]);
-            (void)hipEventDestroy(pin_ev_[i]);
-            pin_[i] = nullptr;
+            if (hp_up_[i]) {
+                (void)hipHostFree(hp_up_[i]);
+                (void)hipHostFree(hp_down_[i]);
+                (void)hipFree(hp_dsp_[i]);
+                (void)hipFree(hp_dgp_[i]);
+            }
+            (void)hipEventDestroy(hp_up_done_[i]);
+            (void)hipEventDestroy(hp_comp_done_[i]);
+            (void)hipEventDestroy(hp_down_done_[i]);
         }
+        (void)hipStreamDestroy(hp_up_stream_);
         (void)hipStreamDestroy(copy_stream_);
-        (void)hipEventDestroy(stage_ev_);
     }
     for (auto st : side_streams_) {
         (void)hipStreamDestroy(st);
@@ -1151,86 +1159,116 @@ void Trans::invtrans(int nb_scalar_fields, const double scalar_spectra[], double
     }
     const size_t nsp = nb_spectral_coefficients() * (size_t)nb_scalar_fields;
     const size_t ngp = (size_t)nb_gridpoints() * (size_t)nb_scalar_fields;  // all points, or the rows of a crop
-    ensure(d_sp_, sp_cap_, nsp);
-    ensure(d_gp_, gp_cap_, ngp);
-    // measured (tools/bench_host.py, gpurun_out/r02/bench_host.txt): 180.4 ms without and 180.7 ms with the staging pipeline at
-    // TL1279 / O1280 / 137 levels = 50 GB/s of the ~57 GB/s link either way -- the runtime's own pageable path already
-    // streams at the link rate and the 18 ms of compute are a tenth of the transfer; the pipeline stays opt-in.
-    static const bool pipe_env = std::getenv("ATLAS_AMD_HOST_PIPELINE") ? atoi(std::getenv("ATLAS_AMD_HOST_PIPELINE")) != 0 : false;
-    if (pipe_env && nb_scalar_fields >= 16 && ngp * sizeof(double) >= (size_t(256) << 20) && fourier_parts() == 1 && !windowed()) {
+    // large transfers go through the field-chunked full-duplex pipeline below (ATLAS_AMD_HOST_PIPELINE=0: one upload, one
+    // transform, one download, strictly serial -- 178 ms at TL1279 / O1280 / 137 levels; profiles/r05_bench_host.txt).  Read per
+    // call: round 4's bench toggled a process-wide static and measured the same path twice.
+    bool pipe = true;
+    if (const char* e = std::getenv("ATLAS_AMD_HOST_PIPELINE")) {
+        pipe = atoi(e) != 0;
+    }
+    if (pipe && nb_scalar_fields >= 32 && ngp * sizeof(double) >= (size_t(256) << 20) && fourier_parts() == 1 && !windowed()) {
         invtrans_host_pipelined(nb_scalar_fields, scalar_spectra, gp_fields);
         return;
     }
+    ensure(d_sp_, sp_cap_, nsp);
+    ensure(d_gp_, gp_cap_, ngp);
     HIP_CHECK(hipMemcpyAsync(d_sp_, scalar_spectra, nsp * sizeof(double), hipMemcpyHostToDevice, stream_));
     invtrans_uv_device(geo_.T, nb_scalar_fields, 0, d_sp_, d_gp_);
     HIP_CHECK(hipMemcpyAsync(gp_fields, d_gp_, ngp * sizeof(double), hipMemcpyDeviceToHost, stream_));
     synchronize();
 }
 
-// Host arrays in, host arrays out (what atlas__Trans__invtrans_scalar callers pass): 1.8 GB up and 7.2 GB down per 137
-// levels at TL1279 / O1280 against 18 ms of compute, i.e. bound by PCIe.  The transfers go through pinned staging buffers
-// in pieces so that (a) both directions run at the link rate instead of the pageable rate, (b) the caller-side copies
-// (multi-threaded) overlap the DMA, (c) the grid points of a group of fields leave the device while the Fourier stage of
-// the next group runs.
+// Host arrays in, host arrays out (what atlas__Trans__invtrans_scalar callers pass, TransInterface.h:74-79): 1.8 GB up and
+// 7.2 GB down per 137 levels at TL1279 / O1280 against 15 ms of compute -- bound by the link.  PCIe is full duplex: the transform
+// is cut into CHUNKS OF FIELDS (fields are independent in both stages) and run as a three-stream pipeline, so that the spectra of
+// chunk c+1 go up and chunk c is transformed while the grid points of chunk c-1 come down:
+//     host:           gather the chunk's columns of sp into a pinned buffer (threads) | drain a pinned buffer into gp (threads)
+//     upload stream:  H2D(c+1)
+//     Trans stream:   Legendre + Fourier stage of chunk c (nf = the chunk's fields: per-field arithmetic does not depend on the
+//                     other fields of a call -- bitwise equal to the one-call device path, tests/test_gpu_pipeline.py)
+//     copy stream:    D2H(c-1)
+// Exposed beside the 7.2 GB download: the upload and the transform of the FIRST chunk only.  Two pinned buffers per direction
+// (chunk x coefficients / chunk x points) and two device buffers per direction; a buffer is reused two chunks later, guarded by
+// events.  ATLAS_AMD_HOST_CHUNK=<fields> (multiple of 8; default 24).
+static void gather_field_columns(double* dst, const double* src, size_t nrows, int nf, int f0, int n) {
+    // dst[r * n + j] = src[r * nf + f0 + j]: the chunk's fields of every spectral coefficient (fields are the fastest index)
+    const long long rows = (long long)nrows;
+#pragma omp parallel for schedule(static)
+    for (long long r = 0; r < rows; ++r) {
+        std::memcpy(dst + (size_t)r * n, src + (size_t)r * nf + f0, (size_t)n * sizeof(double));
+    }
+}
+
 void Trans::invtrans_host_pipelined(int nf, const double* sp_host, double* gp_host) {
-    const size_t nsp  = nb_spectral_coefficients() * (size_t)nf;
-    const size_t npts = (size_t)nb_gridpoints();
-    const size_t piece = size_t(64) << 20;   // doubles per staging buffer (512 MiB)
-    if (!pin_[0]) {
-        for (int i = 0; i < 2; ++i) {
-            HIP_CHECK(hipHostMalloc((void**)&pin_[i], piece * sizeof(double), hipHostMallocDefault));
-            HIP_CHECK(hipEventCreateWithFlags(&pin_ev_[i], hipEventDisableTiming));
-        }
+    const size_t ncoef = nb_spectral_coefficients();   // doubles per field
+    const size_t npts  = (size_t)nb_gridpoints();
+    int C = 24;
+    if (const char* e = std::getenv("ATLAS_AMD_HOST_CHUNK")) {
+        C = std::max(8, atoi(e) / 8 * 8);
+    }
+    C = std::min(C, nf);
+    const int nchunks = (nf + C - 1) / C;
+    if (!hp_up_stream_) {
+        HIP_CHECK(hipStreamCreateWithFlags(&hp_up_stream_, hipStreamNonBlocking));
         HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
-        HIP_CHECK(hipEventCreateWithFlags(&stage_ev_, hipEventDisableTiming));
-    }
-    // ---- spectra up: caller -> pinned (threads) -> device, two buffers in flight
-    int k = 0;
-    for (size_t o = 0; o < nsp; o += piece, ++k) {
-        const size_t n = std::min(piece, nsp - o);
-        const int b    = k & 1;
-        if (k >= 2) {
-            HIP_CHECK(hipEventSynchronize(pin_ev_[b]));   // the DMA out of this buffer has finished
+        for (int i = 0; i < 2; ++i) {
+            HIP_CHECK(hipEventCreateWithFlags(&hp_up_done_[i], hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&hp_comp_done_[i], hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&hp_down_done_[i], hipEventDisableTiming));
         }
-        parallel_copy(pin_[b], sp_host + o, n * sizeof(double));
-        HIP_CHECK(hipMemcpyAsync(d_sp_ + o, pin_[b], n * sizeof(double), hipMemcpyHostToDevice, stream_));
-        HIP_CHECK(hipEventRecord(pin_ev_[b], stream_));
     }
-    // ---- Legendre stage for all fields, Fourier stage by groups of fields, grid points down group by group
-    double* F = fourier_buffer(nf);
-    legendre_device(geo_.T, nf, d_sp_, F);
-    const double* base[1] = {F};
-    const int cnt[1]      = {m_cnt_};
-    const int group       = std::max(8, (int)(piece / npts) / 8 * 8);   // fields per staging buffer, whole groups of 8
-    if ((size_t)group * npts > piece) {
-        throw std::logic_error("host pipeline: a group of 8 fields does not fit the staging buffer");
+    if ((size_t)C * ncoef > hp_up_cap_ || (size_t)C * npts > hp_down_cap_) {   // (re)allocate the staging buffers for this chunk size
+        synchronize();
+        HIP_CHECK(hipStreamSynchronize(hp_up_stream_));
+        HIP_CHECK(hipStreamSynchronize(copy_stream_));
+        hp_up_cap_   = std::max(hp_up_cap_, (size_t)C * ncoef);
+        hp_down_cap_ = std::max(hp_down_cap_, (size_t)C * npts);
+        for (int i = 0; i < 2; ++i) {
+            if (hp_up_[i]) {
+                (void)hipHostFree(hp_up_[i]);
+                (void)hipHostFree(hp_down_[i]);
+                (void)hipFree(hp_dsp_[i]);
+                (void)hipFree(hp_dgp_[i]);
+            }
+            HIP_CHECK(hipHostMalloc((void**)&hp_up_[i], hp_up_cap_ * sizeof(double), hipHostMallocDefault));
+            HIP_CHECK(hipHostMalloc((void**)&hp_down_[i], hp_down_cap_ * sizeof(double), hipHostMallocDefault));
+            HIP_CHECK(hipMalloc((void**)&hp_dsp_[i], hp_up_cap_ * sizeof(double)));
+            HIP_CHECK(hipMalloc((void**)&hp_dgp_[i], hp_down_cap_ * sizeof(double)));
+        }
     }
-    HIP_CHECK(hipStreamSynchronize(stream_));   // the staging buffers are free again (spectra uploaded)
-    struct Pending {
-        int f0, f1, buf;
+    (void)fourier_buffer(C);   // grown (with a synchronisation) before the pipeline starts, not inside it
+    auto drain = [&](int c) {   // pinned -> the caller's array, once the chunk's download has finished
+        const int f0 = c * C, n = std::min(C, nf - f0);
+        HIP_CHECK(hipEventSynchronize(hp_down_done_[c & 1]));
+        parallel_copy(gp_host + (size_t)f0 * npts, hp_down_[c & 1], (size_t)n * npts * sizeof(double));
     };
-    std::vector<Pending> pending;
-    k = 0;
-    for (int f0 = 0; f0 < nf; f0 += group, ++k) {
-        const int f1 = std::min(nf, f0 + group);
-        const int b  = k & 1;
-        fourier_fields(nf, 0, base, cnt, d_gp_, f0, f1, stream_);
-        HIP_CHECK(hipEventRecord(stage_ev_, stream_));
-        if (k >= 2) {   // the previous content of this buffer must have reached the caller's array
-            const Pending p = pending[k - 2];
-            HIP_CHECK(hipEventSynchronize(pin_ev_[p.buf]));
-            parallel_copy(gp_host + (size_t)p.f0 * npts, pin_[p.buf], (size_t)(p.f1 - p.f0) * npts * sizeof(double));
+    for (int c = 0; c < nchunks; ++c) {
+        const int b  = c & 1;
+        const int f0 = c * C, n = std::min(C, nf - f0);
+        if (c >= 2) {
+            HIP_CHECK(hipEventSynchronize(hp_up_done_[b]));       // the upload out of this pinned buffer (chunk c-2) has finished
         }
-        HIP_CHECK(hipStreamWaitEvent(copy_stream_, stage_ev_, 0));
-        HIP_CHECK(hipMemcpyAsync(pin_[b], d_gp_ + (size_t)f0 * npts, (size_t)(f1 - f0) * npts * sizeof(double),
-                                 hipMemcpyDeviceToHost, copy_stream_));
-        HIP_CHECK(hipEventRecord(pin_ev_[b], copy_stream_));
-        pending.push_back(Pending{f0, f1, b});
+        gather_field_columns(hp_up_[b], sp_host, ncoef, nf, f0, n);
+        if (c >= 2) {
+            HIP_CHECK(hipStreamWaitEvent(hp_up_stream_, hp_comp_done_[b], 0));   // chunk c-2 no longer reads this device buffer
+        }
+        HIP_CHECK(hipMemcpyAsync(hp_dsp_[b], hp_up_[b], (size_t)n * ncoef * sizeof(double), hipMemcpyHostToDevice, hp_up_stream_));
+        HIP_CHECK(hipEventRecord(hp_up_done_[b], hp_up_stream_));
+        HIP_CHECK(hipStreamWaitEvent(stream_, hp_up_done_[b], 0));
+        if (c >= 2) {
+            HIP_CHECK(hipStreamWaitEvent(stream_, hp_down_done_[b], 0));         // chunk c-2's grid points have left this device buffer
+        }
+        invtrans_uv_device(geo_.T, n, 0, hp_dsp_[b], hp_dgp_[b]);
+        HIP_CHECK(hipEventRecord(hp_comp_done_[b], stream_));
+        if (c >= 2) {
+            drain(c - 2);                                                        // frees the pinned download buffer b
+        }
+        HIP_CHECK(hipStreamWaitEvent(copy_stream_, hp_comp_done_[b], 0));
+        HIP_CHECK(hipMemcpyAsync(hp_down_[b], hp_dgp_[b], (size_t)n * npts * sizeof(double), hipMemcpyDeviceToHost, copy_stream_));
+        HIP_CHECK(hipEventRecord(hp_down_done_[b], copy_stream_));
     }
-    for (size_t i = pending.size() >= 2 ? pending.size() - 2 : 0; i < pending.size(); ++i) {
-        const Pending p = pending[i];
-        HIP_CHECK(hipEventSynchronize(pin_ev_[p.buf]));
-        parallel_copy(gp_host + (size_t)p.f0 * npts, pin_[p.buf], (size_t)(p.f1 - p.f0) * npts * sizeof(double));
+    for (int c = std::max(0, nchunks - 2); c < nchunks; ++c) {
+        drain(c);
     }
     synchronize();
 }

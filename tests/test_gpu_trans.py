@@ -877,6 +877,27 @@ def test_rectangular_domain_crop_is_the_window_of_the_global_transform(gridname,
     assert np.array_equal(crop.reshape(ns + 2 * nvd, -1), full.reshape(ns + 2 * nvd, -1)[:, idx])
 
 
+def test_host_pointer_pipeline_is_bitwise_equal_to_the_device_path(monkeypatch):
+    """the host-pointer entry point (what atlas__Trans__invtrans_scalar callers pass, TransInterface.h:74-79) runs large calls
+    as a full-duplex pipeline over chunks of fields (csrc/trans.hip: invtrans_host_pipelined): upload of chunk c+1, transform
+    of chunk c and download of chunk c-1 at the same time, pinned staging buffers reused two chunks later.  Same bits as the
+    one-call device path and as the serial host path, for chunk sizes that give 2, 3 and 5 chunks incl. a ragged last one."""
+    g, tr = get_trans("O640", 639)
+    T, nf = 639, 40                                   # 40 x 1.66 M points x 8 B = 531 MB: above the pipeline's threshold
+    sp = red_spectra(T, nf, seed=93)
+    ref = run_device(tr, nf, sp)
+    for env in ({"ATLAS_AMD_HOST_PIPELINE": "0"}, {}, {"ATLAS_AMD_HOST_CHUNK": "16"}, {"ATLAS_AMD_HOST_CHUNK": "8"},
+                {"ATLAS_AMD_HOST_CHUNK": "24"}):
+        for k2, v in env.items():
+            monkeypatch.setenv(k2, v)
+        for rep in range(2):                          # the second call reuses the staging buffers
+            gp = np.full(nf * g.size(), np.nan)
+            tr.invtrans(nf, sp, gp)
+            assert np.array_equal(gp, ref), (env, rep)
+        for k2 in env:
+            monkeypatch.delenv(k2)
+
+
 def test_reference_poles_switch_reproduces_the_reference_at_the_south_pole(monkeypatch):
     """INTEGRATION.md "Deviations": by default a row at latitude -90 of a no_nest target is the mirror image of the north-pole
     row; ATLAS_AMD_REFERENCE_POLES=1 reproduces what the reference computes there -- its Legendre routine sets cos(colatitude) =

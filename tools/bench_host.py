@@ -16,18 +16,19 @@ tr.synchronize()
 ref = ref.cpu().numpy()
 del tr
 nbytes = sp.nbytes + ref.nbytes
-for pipe in ("0", "1"):
-    os.environ["ATLAS_AMD_HOST_PIPELINE"] = pipe
+for pipe, chunk in (("0", "24"), ("1", "24"), ("1", "16"), ("1", "32"), ("1", "48")):
+    os.environ["ATLAS_AMD_HOST_PIPELINE"] = pipe      # (read per call by the library)
+    os.environ["ATLAS_AMD_HOST_CHUNK"] = chunk
     tr = atlas_amd.Trans(g, T)
     gp = np.zeros(nf * g.size())
     tr.invtrans(nf, sp, gp)
     ts = []
-    for _ in range(3):
+    for _ in range(4):
         gp[:] = 0
         t0 = time.perf_counter()
         tr.invtrans(nf, sp, gp)
         ts.append(time.perf_counter() - t0)
-    print(f"ATLAS_AMD_HOST_PIPELINE={pipe}: {min(ts) * 1e3:.1f} ms per transform (host arrays), "
+    print(f"ATLAS_AMD_HOST_PIPELINE={pipe} chunk={chunk if pipe == '1' else '-'}: {min(ts) * 1e3:.1f} ms per transform (host arrays; {sorted(round(t * 1e3, 1) for t in ts)}), "
           f"{nbytes / min(ts) / 1e9:.1f} GB/s over PCIe (1.8 GB up + 7.2 GB down), bitwise equal to the device path: "
           f"{np.array_equal(gp, ref)}", flush=True)
     del tr
