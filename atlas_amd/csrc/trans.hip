@@ -1,14 +1,16 @@
 // See trans.h.  Host code of the MI355X TransLocal replacement: builds the plan, uploads the tables once,
 // launches the two kernels per call on the object's HIP stream.
 #include "trans.h"
-#include "host_copy.h"
 #include "trace.h"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <sstream>
 #include <stdexcept>
 
@@ -225,20 +227,16 @@ void Trans::release() noexcept {
     }
     if (hp_up_stream_) {
         (void)hipStreamSynchronize(hp_up_stream_);
-        (void)hipStreamSynchronize(copy_stream_);
         for (int i = 0; i < 2; ++i) {
             if (hp_up_[i]) {
                 (void)hipHostFree(hp_up_[i]);
-                (void)hipHostFree(hp_down_[i]);
                 (void)hipFree(hp_dsp_[i]);
                 (void)hipFree(hp_dgp_[i]);
             }
             (void)hipEventDestroy(hp_up_done_[i]);
             (void)hipEventDestroy(hp_comp_done_[i]);
-            (void)hipEventDestroy(hp_down_done_[i]);
         }
         (void)hipStreamDestroy(hp_up_stream_);
-        (void)hipStreamDestroy(copy_stream_);
     }
     for (auto st : side_streams_) {
         (void)hipStreamDestroy(st);
@@ -1179,17 +1177,20 @@ void Trans::invtrans(int nb_scalar_fields, const double scalar_spectra[], double
 }
 
 // Host arrays in, host arrays out (what atlas__Trans__invtrans_scalar callers pass, TransInterface.h:74-79): 1.8 GB up and
-// 7.2 GB down per 137 levels at TL1279 / O1280 against 15 ms of compute -- bound by the link.  PCIe is full duplex: the transform
-// is cut into CHUNKS OF FIELDS (fields are independent in both stages) and run as a three-stream pipeline, so that the spectra of
-// chunk c+1 go up and chunk c is transformed while the grid points of chunk c-1 come down:
-//     host:           gather the chunk's columns of sp into a pinned buffer (threads) | drain a pinned buffer into gp (threads)
-//     upload stream:  H2D(c+1)
-//     Trans stream:   Legendre + Fourier stage of chunk c (nf = the chunk's fields: per-field arithmetic does not depend on the
-//                     other fields of a call -- bitwise equal to the one-call device path, tests/test_gpu_pipeline.py)
-//     copy stream:    D2H(c-1)
-// Exposed beside the 7.2 GB download: the upload and the transform of the FIRST chunk only.  Two pinned buffers per direction
-// (chunk x coefficients / chunk x points) and two device buffers per direction; a buffer is reused two chunks later, guarded by
-// events.  ATLAS_AMD_HOST_CHUNK=<fields> (multiple of 8; default 24).
+// 7.2 GB down per 137 levels at TL1279 / O1280 against 15 ms of compute -- bound by the link.  PCIe is full duplex (97 GB/s for
+// both directions at once against 57 for one, tools/probe/probe_host_link.hip): the transform is cut into CHUNKS OF FIELDS
+// (fields are independent in both stages) so that the spectra of later chunks go up, and later chunks are transformed, while
+// the grid points of earlier chunks come down:
+//     this thread:     gathers the chunk's columns of sp into a pinned buffer (OpenMP; 42 GB/s) and enqueues
+//     upload stream:   H2D(c+1) from the pinned buffer
+//     Trans stream:    Legendre + Fourier stage of chunk c (nf = the chunk's fields: per-field arithmetic does not depend on the
+//                      other fields of a call -- bitwise equal to the one-call device path, tests/test_gpu_trans.py)
+//     download thread: D2H(c-1) straight into the caller's pageable array (blocking hipMemcpy: the runtime's own pageable path
+//                      runs at 50 GB/s; staging through pinned buffers of our own is bound by the host copy, 19 - 29 GB/s on the
+//                      GPU box, and lost: 376 ms against 179 -- profiles/r05_bench_host.txt)
+// Exposed beside the 7.2 GB download: gather, upload and transform of the FIRST chunk only.  Two pinned upload buffers, two
+// device buffers per direction; a buffer is reused two chunks later (events for the device side, a counter for the downloads).
+// ATLAS_AMD_HOST_CHUNK=<fields> (multiple of 8; default 16).
 static void gather_field_columns(double* dst, const double* src, size_t nrows, int nf, int f0, int n) {
     // dst[r * n + j] = src[r * nf + f0 + j]: the chunk's fields of every spectral coefficient (fields are the fastest index)
     const long long rows = (long long)nrows;
@@ -1202,7 +1203,7 @@ static void gather_field_columns(double* dst, const double* src, size_t nrows, i
 void Trans::invtrans_host_pipelined(int nf, const double* sp_host, double* gp_host) {
     const size_t ncoef = nb_spectral_coefficients();   // doubles per field
     const size_t npts  = (size_t)nb_gridpoints();
-    int C = 24;
+    int C = 16;
     if (const char* e = std::getenv("ATLAS_AMD_HOST_CHUNK")) {
         C = std::max(8, atoi(e) / 8 * 8);
     }
@@ -1210,65 +1211,106 @@ void Trans::invtrans_host_pipelined(int nf, const double* sp_host, double* gp_ho
     const int nchunks = (nf + C - 1) / C;
     if (!hp_up_stream_) {
         HIP_CHECK(hipStreamCreateWithFlags(&hp_up_stream_, hipStreamNonBlocking));
-        HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
         for (int i = 0; i < 2; ++i) {
             HIP_CHECK(hipEventCreateWithFlags(&hp_up_done_[i], hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&hp_comp_done_[i], hipEventDisableTiming));
-            HIP_CHECK(hipEventCreateWithFlags(&hp_down_done_[i], hipEventDisableTiming));
         }
     }
-    if ((size_t)C * ncoef > hp_up_cap_ || (size_t)C * npts > hp_down_cap_) {   // (re)allocate the staging buffers for this chunk size
+    if ((size_t)C * ncoef > hp_up_cap_ || (size_t)C * npts > hp_down_cap_) {   // (re)allocate the buffers for this chunk size
         synchronize();
         HIP_CHECK(hipStreamSynchronize(hp_up_stream_));
-        HIP_CHECK(hipStreamSynchronize(copy_stream_));
         hp_up_cap_   = std::max(hp_up_cap_, (size_t)C * ncoef);
         hp_down_cap_ = std::max(hp_down_cap_, (size_t)C * npts);
         for (int i = 0; i < 2; ++i) {
             if (hp_up_[i]) {
                 (void)hipHostFree(hp_up_[i]);
-                (void)hipHostFree(hp_down_[i]);
                 (void)hipFree(hp_dsp_[i]);
                 (void)hipFree(hp_dgp_[i]);
             }
             HIP_CHECK(hipHostMalloc((void**)&hp_up_[i], hp_up_cap_ * sizeof(double), hipHostMallocDefault));
-            HIP_CHECK(hipHostMalloc((void**)&hp_down_[i], hp_down_cap_ * sizeof(double), hipHostMallocDefault));
             HIP_CHECK(hipMalloc((void**)&hp_dsp_[i], hp_up_cap_ * sizeof(double)));
             HIP_CHECK(hipMalloc((void**)&hp_dgp_[i], hp_down_cap_ * sizeof(double)));
         }
     }
     (void)fourier_buffer(C);   // grown (with a synchronisation) before the pipeline starts, not inside it
-    auto drain = [&](int c) {   // pinned -> the caller's array, once the chunk's download has finished
-        const int f0 = c * C, n = std::min(C, nf - f0);
-        HIP_CHECK(hipEventSynchronize(hp_down_done_[c & 1]));
-        parallel_copy(gp_host + (size_t)f0 * npts, hp_down_[c & 1], (size_t)n * npts * sizeof(double));
-    };
-    for (int c = 0; c < nchunks; ++c) {
-        const int b  = c & 1;
-        const int f0 = c * C, n = std::min(C, nf - f0);
-        if (c >= 2) {
-            HIP_CHECK(hipEventSynchronize(hp_up_done_[b]));       // the upload out of this pinned buffer (chunk c-2) has finished
+    int device = 0;
+    HIP_CHECK(hipGetDevice(&device));
+    // ---- the download thread: chunk c leaves the device as soon as its transform has finished
+    std::mutex mtx;
+    std::condition_variable cv;
+    int enqueued = 0, downloaded = 0;   // chunks whose transform is enqueued (event recorded) / whose grid points have arrived
+    bool abort = false;
+    std::string thread_error;
+    std::thread down([&]() {
+        try {
+            HIP_CHECK(hipSetDevice(device));
+            for (int c = 0; c < nchunks; ++c) {
+                {
+                    std::unique_lock<std::mutex> lk(mtx);
+                    cv.wait(lk, [&] { return enqueued > c || abort; });
+                    if (abort) {
+                        return;
+                    }
+                }
+                const int f0 = c * C, n = std::min(C, nf - f0);
+                HIP_CHECK(hipEventSynchronize(hp_comp_done_[c & 1]));
+                HIP_CHECK(hipMemcpy(gp_host + (size_t)f0 * npts, hp_dgp_[c & 1], (size_t)n * npts * sizeof(double), hipMemcpyDeviceToHost));
+                {
+                    std::lock_guard<std::mutex> lk(mtx);
+                    downloaded = c + 1;
+                }
+                cv.notify_all();
+            }
         }
-        gather_field_columns(hp_up_[b], sp_host, ncoef, nf, f0, n);
-        if (c >= 2) {
-            HIP_CHECK(hipStreamWaitEvent(hp_up_stream_, hp_comp_done_[b], 0));   // chunk c-2 no longer reads this device buffer
+        catch (const std::exception& e) {
+            std::lock_guard<std::mutex> lk(mtx);
+            thread_error = e.what();
+            abort        = true;
+            cv.notify_all();
         }
-        HIP_CHECK(hipMemcpyAsync(hp_dsp_[b], hp_up_[b], (size_t)n * ncoef * sizeof(double), hipMemcpyHostToDevice, hp_up_stream_));
-        HIP_CHECK(hipEventRecord(hp_up_done_[b], hp_up_stream_));
-        HIP_CHECK(hipStreamWaitEvent(stream_, hp_up_done_[b], 0));
-        if (c >= 2) {
-            HIP_CHECK(hipStreamWaitEvent(stream_, hp_down_done_[b], 0));         // chunk c-2's grid points have left this device buffer
+    });
+    try {
+        for (int c = 0; c < nchunks; ++c) {
+            const int b  = c & 1;
+            const int f0 = c * C, n = std::min(C, nf - f0);
+            if (c >= 2) {
+                HIP_CHECK(hipEventSynchronize(hp_up_done_[b]));       // the upload out of this pinned buffer (chunk c-2) has finished
+            }
+            gather_field_columns(hp_up_[b], sp_host, ncoef, nf, f0, n);
+            if (c >= 2) {
+                HIP_CHECK(hipStreamWaitEvent(hp_up_stream_, hp_comp_done_[b], 0));   // chunk c-2 no longer reads this device buffer
+            }
+            HIP_CHECK(hipMemcpyAsync(hp_dsp_[b], hp_up_[b], (size_t)n * ncoef * sizeof(double), hipMemcpyHostToDevice, hp_up_stream_));
+            HIP_CHECK(hipEventRecord(hp_up_done_[b], hp_up_stream_));
+            if (c >= 2) {   // the grid points of chunk c-2 must have left device buffer b (the event below is re-recorded, too)
+                std::unique_lock<std::mutex> lk(mtx);
+                cv.wait(lk, [&] { return downloaded > c - 2 || abort; });
+                if (abort) {
+                    break;
+                }
+            }
+            HIP_CHECK(hipStreamWaitEvent(stream_, hp_up_done_[b], 0));
+            invtrans_uv_device(geo_.T, n, 0, hp_dsp_[b], hp_dgp_[b]);
+            HIP_CHECK(hipEventRecord(hp_comp_done_[b], stream_));
+            {
+                std::lock_guard<std::mutex> lk(mtx);
+                enqueued = c + 1;
+            }
+            cv.notify_all();
         }
-        invtrans_uv_device(geo_.T, n, 0, hp_dsp_[b], hp_dgp_[b]);
-        HIP_CHECK(hipEventRecord(hp_comp_done_[b], stream_));
-        if (c >= 2) {
-            drain(c - 2);                                                        // frees the pinned download buffer b
-        }
-        HIP_CHECK(hipStreamWaitEvent(copy_stream_, hp_comp_done_[b], 0));
-        HIP_CHECK(hipMemcpyAsync(hp_down_[b], hp_dgp_[b], (size_t)n * npts * sizeof(double), hipMemcpyDeviceToHost, copy_stream_));
-        HIP_CHECK(hipEventRecord(hp_down_done_[b], copy_stream_));
     }
-    for (int c = std::max(0, nchunks - 2); c < nchunks; ++c) {
-        drain(c);
+    catch (...) {
+        {
+            std::lock_guard<std::mutex> lk(mtx);
+            abort = true;
+        }
+        cv.notify_all();
+        down.join();
+        throw;
+    }
+    down.join();
+    if (!thread_error.empty()) {
+        throw std::runtime_error("host pipeline, download thread: " + thread_error);
     }
     synchronize();
 }

@@ -312,19 +312,26 @@ def test_coarse_row_classes_in_one_launch_are_bitwise_equal_to_one_launch_per_cl
     T, nf = 159, 11
     sp = red_spectra(T, nf, seed=43)
     sp32 = torch.from_numpy(sp.astype(np.float32)).cuda()
-    outs = {}
+    outs, plans = {}, {}
     for fused in ("1", "0"):
         monkeypatch.setenv("ATLAS_AMD_FFT_COARSE_FUSED", fused)
         tr = atlas_amd.Trans(g, T)
         cls = tr.fft_row_classes()
         assert set(cls[:, 1]) <= {256, 512, 1024} and (cls[:, 2] == 1).all()
-        plan = tr.fourier_launch_plan()                # the switch is read per object: the other path really ran
-        assert plan["coarse_fused"] == int(fused) and (plan["launches"] == 1 if fused == "1" else plan["launches"] >= 3), plan
+        plans[fused] = tr.fourier_launch_plan()        # the switch is read per object: the other path really ran
+        assert plans[fused]["coarse_fused"] == int(fused), plans
         gp32 = torch.full((nf * g.size(),), float("nan"), dtype=torch.float32, device="cuda")
         tr.invtrans(nf, sp32, gp32)
         tr.synchronize()
         outs[fused] = (run_device(tr, nf, sp), gp32.cpu().numpy())
-    assert np.array_equal(outs["1"][0], outs["0"][0]) and np.array_equal(outs["1"][1], outs["0"][1])
+    assert plans["0"]["launches"] >= plans["1"]["launches"] + 2, plans      # three classes in one launch / one launch each
+    assert np.array_equal(outs["1"][0], outs["0"][0]), "fp64: fused and per-class launches differ"
+    # fp32: the same source instantiated in two kernels is contracted into FMAs differently by the compiler (1 ulp here and there;
+    # round 4's "bitwise" claim compared a setting with itself -- ADVICE r4): within 1e-6 of the largest value, and both within
+    # the fp32 tolerance of the fp64 result
+    assert np.abs(outs["1"][1] - outs["0"][1]).max() <= 1e-6 * np.abs(outs["1"][0]).max()
+    for k in ("1", "0"):
+        assert compute_rms(outs[k][1].astype(np.float64), outs["1"][0]) < 2e-6
     assert compute_rms(outs["1"][0], oracle.OraclePlan(T, g.nx(), g.y()).invtrans(nf, sp, use_fft=True)) < TOL
 
 

@@ -16,7 +16,7 @@ tr.synchronize()
 ref = ref.cpu().numpy()
 del tr
 nbytes = sp.nbytes + ref.nbytes
-for pipe, chunk in (("0", "24"), ("1", "24"), ("1", "16"), ("1", "32"), ("1", "48")):
+for pipe, chunk in (("0", "16"), ("1", "16"), ("1", "8"), ("1", "24"), ("1", "48")):
     os.environ["ATLAS_AMD_HOST_PIPELINE"] = pipe      # (read per call by the library)
     os.environ["ATLAS_AMD_HOST_CHUNK"] = chunk
     tr = atlas_amd.Trans(g, T)
