@@ -245,13 +245,16 @@ private:
     void ensure(double*& ptr, size_t& cap, size_t n);
     // host-pointer pipeline (pinned staging)
     void invtrans_host_pipelined(int nb_fields, const double* sp_host, double* gp_host);
-    double* hp_up_[2]   = {nullptr, nullptr};   // pinned: a chunk's spectra
-    double* hp_dsp_[2]  = {nullptr, nullptr};   // device: a chunk's spectra / grid points
+    double* hp_up_[2]   = {nullptr, nullptr};   // pinned: a chunk's spectra / grid points
+    double* hp_down_[2] = {nullptr, nullptr};
+    double* hp_dsp_[2]  = {nullptr, nullptr};   // device: the same
     double* hp_dgp_[2]  = {nullptr, nullptr};
     size_t hp_up_cap_ = 0, hp_down_cap_ = 0;    // doubles
     hipEvent_t hp_up_done_[2]   = {nullptr, nullptr};
     hipEvent_t hp_comp_done_[2] = {nullptr, nullptr};
+    hipEvent_t hp_down_done_[2] = {nullptr, nullptr};
     hipStream_t hp_up_stream_ = nullptr;
+    hipStream_t copy_stream_  = nullptr;
     std::vector<hipEvent_t> events_;  // pairs (begin, end)
     std::vector<int> ev_kind_;        // 0 legendre, 1 fourier, per pair
     size_t ev_used_ = 0;

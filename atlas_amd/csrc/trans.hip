@@ -1,6 +1,7 @@
 // See trans.h.  Host code of the MI355X TransLocal replacement: builds the plan, uploads the tables once,
 // launches the two kernels per call on the object's HIP stream.
 #include "trans.h"
+#include "host_copy.h"
 #include "trace.h"
 
 #include <algorithm>
@@ -227,16 +228,20 @@ void Trans::release() noexcept {
     }
     if (hp_up_stream_) {
         (void)hipStreamSynchronize(hp_up_stream_);
+        (void)hipStreamSynchronize(copy_stream_);
         for (int i = 0; i < 2; ++i) {
             if (hp_up_[i]) {
                 (void)hipHostFree(hp_up_[i]);
+                (void)hipHostFree(hp_down_[i]);
                 (void)hipFree(hp_dsp_[i]);
                 (void)hipFree(hp_dgp_[i]);
             }
             (void)hipEventDestroy(hp_up_done_[i]);
             (void)hipEventDestroy(hp_comp_done_[i]);
+            (void)hipEventDestroy(hp_down_done_[i]);
         }
         (void)hipStreamDestroy(hp_up_stream_);
+        (void)hipStreamDestroy(copy_stream_);
     }
     for (auto st : side_streams_) {
         (void)hipStreamDestroy(st);
@@ -1185,21 +1190,15 @@ void Trans::invtrans(int nb_scalar_fields, const double scalar_spectra[], double
 //     upload stream:   H2D(c+1) from the pinned buffer
 //     Trans stream:    Legendre + Fourier stage of chunk c (nf = the chunk's fields: per-field arithmetic does not depend on the
 //                      other fields of a call -- bitwise equal to the one-call device path, tests/test_gpu_trans.py)
-//     download thread: D2H(c-1) straight into the caller's pageable array (blocking hipMemcpy: the runtime's own pageable path
-//                      runs at 50 GB/s; staging through pinned buffers of our own is bound by the host copy, 19 - 29 GB/s on the
-//                      GPU box, and lost: 376 ms against 179 -- profiles/r05_bench_host.txt)
-// Exposed beside the 7.2 GB download: gather, upload and transform of the FIRST chunk only.  Two pinned upload buffers, two
-// device buffers per direction; a buffer is reused two chunks later (events for the device side, a counter for the downloads).
-// ATLAS_AMD_HOST_CHUNK=<fields> (multiple of 8; default 16).
-static void gather_field_columns(double* dst, const double* src, size_t nrows, int nf, int f0, int n) {
-    // dst[r * n + j] = src[r * nf + f0 + j]: the chunk's fields of every spectral coefficient (fields are the fastest index)
-    const long long rows = (long long)nrows;
-#pragma omp parallel for schedule(static)
-    for (long long r = 0; r < rows; ++r) {
-        std::memcpy(dst + (size_t)r * n, src + (size_t)r * nf + f0, (size_t)n * sizeof(double));
-    }
-}
-
+//     download thread: D2H(c) into a pinned buffer (copy stream, 57 GB/s) while it drains the pinned buffer of chunk c-1 into the
+//                      caller's array (OpenMP)
+// Exposed beside the 7.2 GB download: gather, upload and transform of the FIRST chunk and the drain of the last.  Two pinned and
+// two device buffers per direction; a buffer is reused two chunks later (events for the device side, a counter for the downloads).
+// What round 5 measured on the way (profiles/r05_bench_host.txt, r05_host_link_probe.txt): the host copies must run on a BOUNDED
+// team -- with the box's 256 hardware threads an OpenMP memcpy reaches 20 GB/s, with 16 - 32 threads 120 - 165 GB/s (first version
+// of this pipeline: 376 ms against 179 serial); the runtime's own pageable path (blocking hipMemcpy from a second thread, 50 GB/s)
+// does not overlap the two directions at all (53 GB/s for both together against 97 from pinned memory: 180 ms, no gain).
+// ATLAS_AMD_HOST_CHUNK=<fields> (multiple of 8; default 16), ATLAS_AMD_HOST_THREADS=<n> (default 16).
 void Trans::invtrans_host_pipelined(int nf, const double* sp_host, double* gp_host) {
     const size_t ncoef = nb_spectral_coefficients();   // doubles per field
     const size_t npts  = (size_t)nb_gridpoints();
@@ -1211,23 +1210,28 @@ void Trans::invtrans_host_pipelined(int nf, const double* sp_host, double* gp_ho
     const int nchunks = (nf + C - 1) / C;
     if (!hp_up_stream_) {
         HIP_CHECK(hipStreamCreateWithFlags(&hp_up_stream_, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
         for (int i = 0; i < 2; ++i) {
             HIP_CHECK(hipEventCreateWithFlags(&hp_up_done_[i], hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&hp_comp_done_[i], hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&hp_down_done_[i], hipEventDisableTiming));
         }
     }
     if ((size_t)C * ncoef > hp_up_cap_ || (size_t)C * npts > hp_down_cap_) {   // (re)allocate the buffers for this chunk size
         synchronize();
         HIP_CHECK(hipStreamSynchronize(hp_up_stream_));
+        HIP_CHECK(hipStreamSynchronize(copy_stream_));
         hp_up_cap_   = std::max(hp_up_cap_, (size_t)C * ncoef);
         hp_down_cap_ = std::max(hp_down_cap_, (size_t)C * npts);
         for (int i = 0; i < 2; ++i) {
             if (hp_up_[i]) {
                 (void)hipHostFree(hp_up_[i]);
+                (void)hipHostFree(hp_down_[i]);
                 (void)hipFree(hp_dsp_[i]);
                 (void)hipFree(hp_dgp_[i]);
             }
             HIP_CHECK(hipHostMalloc((void**)&hp_up_[i], hp_up_cap_ * sizeof(double), hipHostMallocDefault));
+            HIP_CHECK(hipHostMalloc((void**)&hp_down_[i], hp_down_cap_ * sizeof(double), hipHostMallocDefault));
             HIP_CHECK(hipMalloc((void**)&hp_dsp_[i], hp_up_cap_ * sizeof(double)));
             HIP_CHECK(hipMalloc((void**)&hp_dgp_[i], hp_down_cap_ * sizeof(double)));
         }
@@ -1244,6 +1248,16 @@ void Trans::invtrans_host_pipelined(int nf, const double* sp_host, double* gp_ho
     std::thread down([&]() {
         try {
             HIP_CHECK(hipSetDevice(device));
+            auto drain = [&](int c) {   // pinned -> the caller's array, once the chunk's download has finished
+                const int f0 = c * C, n = std::min(C, nf - f0);
+                HIP_CHECK(hipEventSynchronize(hp_down_done_[c & 1]));
+                {
+                    std::lock_guard<std::mutex> lk(mtx);
+                    downloaded = c + 1;      // the device buffer of chunk c is free
+                }
+                cv.notify_all();
+                bounded_copy(gp_host + (size_t)f0 * npts, hp_down_[c & 1], (size_t)n * npts * sizeof(double));
+            };
             for (int c = 0; c < nchunks; ++c) {
                 {
                     std::unique_lock<std::mutex> lk(mtx);
@@ -1252,15 +1266,17 @@ void Trans::invtrans_host_pipelined(int nf, const double* sp_host, double* gp_ho
                         return;
                     }
                 }
-                const int f0 = c * C, n = std::min(C, nf - f0);
-                HIP_CHECK(hipEventSynchronize(hp_comp_done_[c & 1]));
-                HIP_CHECK(hipMemcpy(gp_host + (size_t)f0 * npts, hp_dgp_[c & 1], (size_t)n * npts * sizeof(double), hipMemcpyDeviceToHost));
-                {
-                    std::lock_guard<std::mutex> lk(mtx);
-                    downloaded = c + 1;
+                const int n = std::min(C, nf - c * C);
+                // pinned buffer c & 1 was drained (chunk c - 2) in the previous iteration
+                HIP_CHECK(hipStreamWaitEvent(copy_stream_, hp_comp_done_[c & 1], 0));
+                HIP_CHECK(hipMemcpyAsync(hp_down_[c & 1], hp_dgp_[c & 1], (size_t)n * npts * sizeof(double), hipMemcpyDeviceToHost,
+                                         copy_stream_));
+                HIP_CHECK(hipEventRecord(hp_down_done_[c & 1], copy_stream_));
+                if (c >= 1) {
+                    drain(c - 1);            // beside the download of chunk c
                 }
-                cv.notify_all();
             }
+            drain(nchunks - 1);
         }
         catch (const std::exception& e) {
             std::lock_guard<std::mutex> lk(mtx);

@@ -48,6 +48,19 @@ int main() {
     rate("memcpy pageable -> pinned, OpenMP", [&] { pcopy(pin1, pg1, N); }, (double)N);
     rate("memcpy pinned -> pageable, OpenMP", [&] { pcopy(pg2, pin2, N); }, (double)N);
     rate("memcpy pageable -> pageable, OpenMP", [&] { pcopy(pg2, pg1, N); }, (double)N);
+    for (int nt : {2, 4, 8, 16, 32, 64}) {
+        omp_set_num_threads(nt);
+        char what[96];
+        std::snprintf(what, sizeof what, "memcpy pinned -> pageable, %d threads", nt);
+        rate(what, [&] { pcopy(pg2, pin2, N); }, (double)N);
+        std::snprintf(what, sizeof what, "D2H pinned + drain of the other pinned buffer, %d threads", nt);
+        rate(what, [&] {
+            CK(hipMemcpyAsync(pin2, d2, N, hipMemcpyDeviceToHost, s2));
+            pcopy(pg2, pin1, N);
+            CK(hipStreamSynchronize(s2));
+        }, (double)N);
+    }
+    omp_set_num_threads(omp_get_num_procs());
     {   // field gather: rows of 137 doubles, 24 of them taken
         const int nf = 137, n = 24;
         const size_t rows = N / (nf * 8);
