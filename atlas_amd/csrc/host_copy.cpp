@@ -7,7 +7,7 @@
 namespace atlas_amd {
 
 int host_copy_threads() {
-    int n = 16;
+    int n = 8;
     if (const char* e = std::getenv("ATLAS_AMD_HOST_THREADS")) {
         n = std::max(1, atoi(e));
     }

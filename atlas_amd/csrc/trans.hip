@@ -1198,7 +1198,7 @@ void Trans::invtrans(int nb_scalar_fields, const double scalar_spectra[], double
 // team -- with the box's 256 hardware threads an OpenMP memcpy reaches 20 GB/s, with 16 - 32 threads 120 - 165 GB/s (first version
 // of this pipeline: 376 ms against 179 serial); the runtime's own pageable path (blocking hipMemcpy from a second thread, 50 GB/s)
 // does not overlap the two directions at all (53 GB/s for both together against 97 from pinned memory: 180 ms, no gain).
-// ATLAS_AMD_HOST_CHUNK=<fields> (multiple of 8; default 16), ATLAS_AMD_HOST_THREADS=<n> (default 16).
+// ATLAS_AMD_HOST_CHUNK=<fields> (multiple of 8; default 16), ATLAS_AMD_HOST_THREADS=<n> (default 8).
 void Trans::invtrans_host_pipelined(int nf, const double* sp_host, double* gp_host) {
     const size_t ncoef = nb_spectral_coefficients();   // doubles per field
     const size_t npts  = (size_t)nb_gridpoints();

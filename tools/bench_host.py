@@ -16,9 +16,13 @@ tr.synchronize()
 ref = ref.cpu().numpy()
 del tr
 nbytes = sp.nbytes + ref.nbytes
-for pipe, chunk in (("0", "16"), ("1", "16"), ("1", "8"), ("1", "24"), ("1", "48")):
-    os.environ["ATLAS_AMD_HOST_PIPELINE"] = pipe      # (read per call by the library)
+SWEEP = [("0", "16", "8"), ("1", "16", "8")]
+if "--sweep" in sys.argv:
+    SWEEP += [("1", c, t) for t in ("8", "12", "16", "24") for c in ("16", "24", "32", "40")]
+for pipe, chunk, threads in SWEEP:
+    os.environ["ATLAS_AMD_HOST_PIPELINE"] = pipe      # (all three are read per call by the library)
     os.environ["ATLAS_AMD_HOST_CHUNK"] = chunk
+    os.environ["ATLAS_AMD_HOST_THREADS"] = threads
     tr = atlas_amd.Trans(g, T)
     gp = np.zeros(nf * g.size())
     tr.invtrans(nf, sp, gp)
@@ -28,7 +32,7 @@ for pipe, chunk in (("0", "16"), ("1", "16"), ("1", "8"), ("1", "24"), ("1", "48
         t0 = time.perf_counter()
         tr.invtrans(nf, sp, gp)
         ts.append(time.perf_counter() - t0)
-    print(f"ATLAS_AMD_HOST_PIPELINE={pipe} chunk={chunk if pipe == '1' else '-'}: {min(ts) * 1e3:.1f} ms per transform (host arrays; {sorted(round(t * 1e3, 1) for t in ts)}), "
+    print(f"ATLAS_AMD_HOST_PIPELINE={pipe} chunk={chunk if pipe == '1' else '-'} threads={threads if pipe == '1' else '-'}: {min(ts) * 1e3:.1f} ms per transform (host arrays; {sorted(round(t * 1e3, 1) for t in ts)}), "
           f"{nbytes / min(ts) / 1e9:.1f} GB/s over PCIe (1.8 GB up + 7.2 GB down), bitwise equal to the device path: "
           f"{np.array_equal(gp, ref)}", flush=True)
     del tr
