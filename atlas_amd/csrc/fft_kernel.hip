@@ -162,7 +162,9 @@ template <class S, bool F32, bool FAST>
 #ifndef AA_FFT_PLAIN_WPS
 #define AA_FFT_PLAIN_WPS 3   // wavefronts per SIMD the plain (not row_ct3) Bluestein rows are compiled for (dev builds: 4)
 #endif
-__global__ void AA_FFT_VGPR_CAP __launch_bounds__(S::NT, (FAST ? ((F32 && AA_FFT_F32_ARITH) ? AA_FFT_F32_FAST_WPS : S::WPS) : AA_FFT_PLAIN_WPS)) fft_rows_ct_kernel(FourierParams p) {
+// (plain rows whose first butterfly has 20 or 24 points -- M = 320, 384, 5120, 6144 -- get 256 registers as well: at 168 the butterfly's
+// 80 - 96 data registers beside its table values spilled 30 - 73 registers; M = 320 / 384 are rows of the headline grid)
+__global__ void AA_FFT_VGPR_CAP __launch_bounds__(S::NT, (FAST ? ((F32 && AA_FFT_F32_ARITH) ? AA_FFT_F32_FAST_WPS : S::WPS) : (S::radix(0) >= 20 && !(F32 && AA_FFT_F32_ARITH) ? 2 : AA_FFT_PLAIN_WPS))) fft_rows_ct_kernel(FourierParams p) {
     // the fp32 variant runs in fp32 arithmetic: float tables, 8-byte LDS elements, packed v_pk_*_f32 (-DAA_FFT_F32_FP64_ARITH:
     // float storage around fp64 arithmetic, the form of rounds 1 - 2)
     using C = std::conditional_t<(F32 && AA_FFT_F32_ARITH), fft::cplxf, cplx>;

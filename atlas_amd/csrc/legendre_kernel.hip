@@ -907,7 +907,12 @@ void legendre_tiling(int nf, int& rtw, int& nrg, int& nchunks) {
     rtw          = ((rt + nchunks - 1) / nchunks + nrg - 1) / nrg;
     if (const char* e = std::getenv("ATLAS_AMD_LEG_CFG")) {  // A/B: "rtw,nrg"
         int a = 0, b = 0;
-        if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && a <= 9 && b >= 1 && b <= 3 && (b < 3 || a <= 4)) {
+#if defined(ATLAS_AMD_EXPERIMENTS)
+        const int amax = 9, bmax = 3;   // the tilings that lost (round 1 sweep, {9x2, 9x1, 6x1, 5x2, 3x3, ...}): experiments build only
+#else
+        const int amax = 3, bmax = 2;   // the product library instantiates what legendre_tiling() can return by itself
+#endif
+        if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && a <= amax && b >= 1 && b <= bmax && (b < 3 || a <= 4)) {
             rtw     = a;
             nrg     = b;
             nchunks = (rt + a * b - 1) / (a * b);
@@ -924,6 +929,7 @@ static hipError_t launch_legendre_t(const LegendreParamsT<Real>& p, int nitems, 
         chunk0 = 0;
         nrun   = nchunks;
     }
+#if defined(ATLAS_AMD_EXPERIMENTS)
 #define LEG_CASE(R)                                                                                    \
     case R:                                                                                            \
         if (nrg == 1) return launch_cfg<R, 1, Real>(p, nitems, nchunks, chunk0, nrun, stream);         \
@@ -932,6 +938,17 @@ static hipError_t launch_legendre_t(const LegendreParamsT<Real>& p, int nitems, 
     switch (rtw) {
         LEG_CASE(1) LEG_CASE(2) LEG_CASE(3) LEG_CASE(4) LEG_CASE(5) LEG_CASE(6) LEG_CASE(7) LEG_CASE(8) LEG_CASE(9)
     }
+#else
+    // (round 4's library also carried the A/B tilings 4 .. 9 tiles per wavefront and three column groups: 42 kernels nothing launched,
+    // among them the only Legendre instances with register spills -- profiles/r05_kernel_resources.txt)
+#define LEG_CASE(R)                                                                                    \
+    case R:                                                                                            \
+        if (nrg == 1) return launch_cfg<R, 1, Real>(p, nitems, nchunks, chunk0, nrun, stream);         \
+        return launch_cfg<R, 2, Real>(p, nitems, nchunks, chunk0, nrun, stream);
+    switch (rtw) {
+        LEG_CASE(1) LEG_CASE(2) LEG_CASE(3)
+    }
+#endif
 #undef LEG_CASE
     return hipErrorInvalidValue;
 }

@@ -31,7 +31,7 @@ HEADLINE = [
     r"trans::legendre_kernel_lean_n<[12], (double|float)>$",
     r"trans::fft_rows_ct_kernel<fft::CtShape<(1, 12|15, 8|9, 9|5, 10|3, 11)>, (false|true), true>$",     # row_ct3
     r"trans::fft_rows_ct_pair_kernel<fft::CtShape<(1, 12|15, 8|9, 9|5, 10|3, 11)>, true>$",              # row_ct3, fp32 pairs
-    r"trans::fft_rows_ct_kernel<fft::CtShape<(3, 10|1, 11|5, 9|9, 8|5, 8|3, 9|1, 10|3, 8|1, 9|5, 7|1, 8)>, false, false>$",
+    r"trans::fft_rows_ct_kernel<fft::CtShape<(3, 10|1, 11|5, 9|9, 8|5, 8|3, 9|1, 10|3, 8|1, 9|5, 7|1, 8|3, 7|5, 6)>, false, false>$",
     r"trans::fft_rows_dct_kernel<fft::CtShape<(5, 9|1, 11|3, 9|1, 9|9, 8|3, 8|1, 10|1, 8|5, 7|5, 8)>, false, false>$",
     r"trans::fft_rows_dct_pair_kernel<.*>$",
     r"trans::fft_rows_coarse(_multi)?_kernel$",
