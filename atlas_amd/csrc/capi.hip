@@ -914,9 +914,11 @@ int atlas_amd__Trans__fft_row_classes(const atlas_amd_Trans* t, int out[]) {
         out[3 * j]     = pl.method;
         out[3 * j + 1] = pl.shape.M;
         out[3 * j + 2] = t->impl->fft_row_kernel(pl);
+#if defined(ATLAS_AMD_EXPERIMENTS)
         if (pl.method == fft::FFT_NATIVE) {   // every native half length is its own shape: the class is (first radix, stages)
             out[3 * j + 1] = pl.nat.radix[0] * 10 + pl.nat.ns;
         }
+#endif
     }
     AA_CATCH_INT
 }
@@ -1039,6 +1041,9 @@ int atlas_amd__fft_host_row_native(int n, const double* modes, int mmax, double*
     if (n < 1 || !modes || !out) {
         throw std::invalid_argument("fft_host_row_native: n >= 1 and non-null arrays are required");
     }
+#if !defined(ATLAS_AMD_EXPERIMENTS)
+    throw std::runtime_error("fft_host_row_native: the native mixed-radix rows live in tools/experiments (make -C atlas_amd/csrc experiments)");
+#endif
     fft::PlanOptions po;
     po.native = true;
     fft::FftPlanSet ps = fft::make_fft_plans({n}, po);
@@ -1065,7 +1070,13 @@ int atlas_amd__fft_plan_info(int n, int native, int out[16]) {
         throw std::invalid_argument("fft_plan_info: n >= 1 and a non-null array are required");
     }
     fft::PlanOptions po;
+#if defined(ATLAS_AMD_EXPERIMENTS)
     po.native                  = native != 0;
+#else
+    if (native != 0) {
+        throw std::runtime_error("fft_plan_info: the native mixed-radix rows live in tools/experiments (make -C atlas_amd/csrc experiments)");
+    }
+#endif
     fft::FftPlanSet ps         = fft::make_fft_plans({n}, po);
     const fft::FftRowPlan& pl = ps.plans.at(0);
     for (int i = 0; i < 16; ++i) {
@@ -1079,7 +1090,9 @@ int atlas_amd__fft_plan_info(int n, int native, int out[16]) {
         out[4 + i] = pl.shape.radix[i];
     }
     out[12] = pl.ct_k >= 0 ? 1 : 0;
+#if defined(ATLAS_AMD_EXPERIMENTS)
     out[13] = pl.method == fft::FFT_NATIVE ? pl.nat.pitch : 0;
+#endif
     out[14] = (int)ps.nat_table.size();
     AA_CATCH_INT
 }

@@ -61,7 +61,11 @@ struct alignas(64) FftRowDesc {
     long long off_tw, off_pre, off_chirp, off_bhat_t;   // into FourierParams::table
 };
 
-// The same for a native mixed-radix row (fft_native.h): the stage list in execution order and the offsets of its tables, 128 bytes
+// The same for a native mixed-radix row (tools/experiments/fft_native.h; experiments build): the stage list in execution order and
+// the offsets of its tables, 128 bytes
+#if !defined(ATLAS_AMD_EXPERIMENTS)
+struct FftNatDesc;   // (only ever a null pointer in the product library)
+#else
 struct alignas(128) FftNatDesc {
     int row;                 // latitude row (global index)
     int mmax;                // highest kept wavenumber, already clamped to h
@@ -76,6 +80,7 @@ struct alignas(128) FftNatDesc {
     int pad_;
 };
 static_assert(sizeof(FftNatDesc) == 128, "one 128-byte scalar load per workgroup");
+#endif
 
 struct FourierParts {
     const double* base[fft::MAX_PARTS];

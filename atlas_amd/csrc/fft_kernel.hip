@@ -689,6 +689,9 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR, (dct_waves_per_simd<S, F32A>()))
 hipError_t launch_fourier_hyb(const FourierParams&, int, int, hipStream_t) {
     return hipErrorNotSupported;   // hybrid rows are planned only in experiment builds (fft_plan.cpp)
 }
+hipError_t launch_fourier_nat(const FourierParams&, int, int, int, hipStream_t) {
+    return hipErrorNotSupported;   // native mixed-radix rows: likewise (tools/experiments/fft_native.hip)
+}
 #endif
 
 template <class S, bool F32, bool FAST>

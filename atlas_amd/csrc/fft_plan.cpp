@@ -182,158 +182,21 @@ int hybrid_dense_radix(int h) {
     return h;
 }
 
-// ---- native mixed-radix rows (fft_native.h) ------------------------------------------------------------------------
-namespace {
-// rough vector-ALU instructions per point of a twiddled stage of radix r (butterfly + twiddle products + power chain + addresses)
-double nat_stage_cost(int r) {
-    switch (r) {
-        case 2: return 6;   case 3: return 8;   case 4: return 9;   case 5: return 12;  case 6: return 13;  case 7: return 18;
-        case 8: return 16;  case 9: return 18;  case 10: return 19; case 11: return 22; case 12: return 20; case 13: return 24;
-        case 15: return 22; case 16: return 20;
-    }
-    return 1e9;
-}
-}  // namespace
-
-bool make_native_shape(int h, NatShape& s, std::vector<uint32_t>& table) {
-    if (h < 6 || h > NAT_MAX_H || h % 2 != 0) {
-        return false;
-    }
-    // prime factors
-    std::vector<int> pf;
-    {
-        int r = h;
-        for (int p = 2; p * p <= r; ++p) {
-            while (r % p == 0) {
-                pf.push_back(p);
-                r /= p;
-            }
-        }
-        if (r > 1) {
-            pf.push_back(r);
-        }
-    }
-    int nbig = 0, big = 0;
-    for (int p : pf) {
-        if (p > 13) {
-            ++nbig;
-            big = p;
-        }
-    }
-    if (nbig > 1 || big > NAT_MAX_PRIME) {
-        return false;
-    }
-    const int max_nb = NAT_MAX_ROUNDS * NAT_NT;
-    // first stage (no twiddles): the big prime, else the largest odd radix that divides h
-    int RL = big;
-    if (RL == 0) {
-        for (int r : {15, 13, 11, 9, 7, 5, 3}) {
-            if (h % r == 0) {
-                RL = r;
-                break;
-            }
-        }
-    }
-    if (RL == 0 || !nat_radix_first_ok(RL) || h / RL > max_nb) {
-        return false;
-    }
-    // the other stages: ordered factorisations of Q = h / RL into at most NAT_MAX_STAGES - 1 radices of the menu, every stage
-    // with at most max_nb butterflies; fewest stages first, then the cheapest by nat_stage_cost
-    const int Q = h / RL;
-    const int menu[] = {16, 15, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
-    std::vector<int> best, cur;
-    double best_cost = 1e18;
-    std::function<void(int, double)> rec = [&](int rem, double cost) {
-        if (rem == 1) {
-            if (!cur.empty() && (best.empty() || cur.size() < best.size() || (cur.size() == best.size() && cost < best_cost))) {
-                best      = cur;
-                best_cost = cost;
-            }
-            return;
-        }
-        if ((int)cur.size() >= NAT_MAX_STAGES - 1) {
-            return;
-        }
-        for (int r : menu) {
-            if (rem % r == 0 && h / r <= max_nb) {
-                cur.push_back(r);
-                rec(rem / r, cost + nat_stage_cost(r));
-                cur.pop_back();
-            }
-        }
-    };
-    rec(Q, 0.);
-    if (best.empty()) {
-        return false;
-    }
-    // DIF order: best[0] = r_0 (last executed, fused with the store) ... ; prefer the largest radix last executed?  Any order of
-    // the same multiset costs the same arithmetic; the store stage wants few butterflies per worker: largest radix as r_0.
-    std::sort(best.begin(), best.end(), [](int a, int b) { return a > b; });
-    std::vector<int> dif(best);
-    dif.push_back(RL);
-    const int ns = (int)dif.size();
-    s            = NatShape{};
-    s.h          = h;
-    s.ns         = ns;
-    const int Ls0 = h / dif[0];
-    s.pitch       = (Ls0 % 2 == 0) ? Ls0 + 1 : Ls0;
-    auto nat_pos  = [&](int pos) { return (pos / Ls0) * s.pitch + pos % Ls0; };
-    s.lds_elems   = std::max(h + 1, dif[0] * s.pitch);
-    s.lds_elems   = (s.lds_elems + 15) / 16 * 16;
-    if (s.lds_elems > 65535) {
-        return false;
-    }
-    // fold permutation: frequency k -> element of the digit-reversed position (fft_core.h: pos_of_freq)
-    FftShape fs{};
-    fs.M       = h;
-    fs.nstages = ns;
-    for (int i = 0; i < ns; ++i) {
-        fs.radix[i] = dif[i];
-        fs.lsh[i]   = -1;
-    }
-    s.perm = (int)table.size();
-    for (int k = 0; k < h; ++k) {
-        table.push_back((uint32_t)nat_pos(pos_of_freq(fs, k)));
-    }
-    for (int e = 0; e < ns; ++e) {
-        const int i = ns - 1 - e;   // DIF index of execution stage e
-        int L = h;
-        for (int q = 0; q < i; ++q) {
-            L /= dif[q];
-        }
-        const int R  = dif[i];
-        const int Ls = L / R;
-        s.radix[e]   = R;
-        s.nb[e]      = h / R;
-        s.stride[e]  = (i == 0) ? s.pitch : Ls;
-        s.tab[e]     = (int)table.size();
-        if ((e == 0 && !nat_radix_first_ok(R)) || (e > 0 && !nat_radix_tw_ok(R)) || s.nb[e] > max_nb) {
-            throw std::logic_error("make_native_shape: stage outside the kernel's menu");
-        }
-        for (int b = 0; b < s.nb[e]; ++b) {
-            const int blk = b / Ls, j = b - blk * Ls;
-            const int pos = blk * L + j;
-            const int base = nat_pos(pos);
-            for (int q = 0; q < R; ++q) {
-                if (nat_pos(pos + q * Ls) != base + q * s.stride[e]) {
-                    throw std::logic_error("make_native_shape: a butterfly is not an arithmetic progression in LDS");
-                }
-            }
-            const int twidx = j * (h / L);
-            if (twidx >= h || twidx > 0xffff || base > 0xffff) {
-                throw std::logic_error("make_native_shape: table entry out of range");
-            }
-            table.push_back((uint32_t)base | ((uint32_t)twidx << 16));
-        }
-    }
-    return true;
-}
+#if defined(ATLAS_AMD_EXPERIMENTS)
+#include "../../tools/experiments/fft_native_plan.inc"   // make_native_shape: the native mixed-radix rows [r4], out of the product since round 5
+#endif
 
 FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, bool specialised_shapes) {
     PlanOptions opt;
     opt.specialised_shapes = specialised_shapes;
-    if (const char* e = std::getenv("ATLAS_AMD_FFT_NATIVE")) {   // native mixed-radix rows: opt-in
+    if (const char* e = std::getenv("ATLAS_AMD_FFT_NATIVE")) {   // native mixed-radix rows: experiments build only
+#if defined(ATLAS_AMD_EXPERIMENTS)
         opt.native = atoi(e) != 0;
+#else
+        if (atoi(e) != 0) {
+            throw std::runtime_error("ATLAS_AMD_FFT_NATIVE=1 needs a library built with -DATLAS_AMD_EXPERIMENTS (make -C atlas_amd/csrc experiments)");
+        }
+#endif
     }
     if (const char* e = std::getenv("ATLAS_AMD_FFT_HYBRID")) {
 #if defined(ATLAS_AMD_EXPERIMENTS)
@@ -424,8 +287,9 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, const PlanOptions
                 }
             }
         }
-        // native mixed-radix rows [r4]: every half length with a stage list (fft_native.h) that is not a length of the
-        // specialised direct family (those kernels are compile-time shaped throughout)
+#if defined(ATLAS_AMD_EXPERIMENTS)
+        // native mixed-radix rows [r4] (tools/experiments/fft_native.h): every half length with a stage list that is not a length of
+        // the specialised direct family (those kernels are compile-time shaped throughout)
         bool family_direct = false;
         if (specialised_shapes) {
             for (int f : {1, 3, 5, 9, 15}) {
@@ -457,6 +321,7 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, const PlanOptions
             ps.plans.push_back(p);
             continue;
         }
+#endif
         if (smooth_direct) {
             p.method = FFT_DIRECT;
             // h itself a length of the specialised family?  (regular grids: every row)
@@ -633,6 +498,7 @@ void host_execute_row(const FftPlanSet& ps, int plan, const cplx* X, int mmax, d
         }
         return;
     }
+#if defined(ATLAS_AMD_EXPERIMENTS)
     if (p.method == FFT_NATIVE) {
         std::vector<cplx> Xh(p.h + 1, cplx{0., 0.});
         for (int m = 0; m <= std::min(mmax, p.h); ++m) {
@@ -642,7 +508,6 @@ void host_execute_row(const FftPlanSet& ps, int plan, const cplx* X, int mmax, d
                              std::min(mmax, p.h), y);
         return;
     }
-#if defined(ATLAS_AMD_EXPERIMENTS)
     if (p.method == FFT_HYBRID) {
         RowTablesHyb r;
         r.n = p.n, r.h = p.h, r.A = p.hyb_A, r.B = p.hyb_B, r.Kp = (p.hyb_A + 1) / 2;

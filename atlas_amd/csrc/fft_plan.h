@@ -10,9 +10,9 @@
 //   HYBRID    n even, h = A*B, B smooth, A = product of the primes > 5 of h, 7 <= A <= HYB_MAX_A :
 //                                          half-length complex FFT whose radix-A stage is a dense DFT on the matrix
 //                                          cores (fft_core.h: "HYBRID rows"), no Bluestein
-//   NATIVE    n even, h has only small prime factors -- any number of {2,...,13}, at most one prime 17..31 -- and is not a
-//             length of the specialised direct family : half-length complex mixed-radix DIT with the stage list chosen here and
-//             executed from tables by ONE kernel for every such shape (fft_native.h) [r4]
+//   NATIVE    (experiments build only since round 5: tools/experiments/fft_native.h) n even, h has only small prime factors -- any
+//             number of {2,...,13}, at most one prime 17..31 -- and is not a length of the specialised direct family : half-length
+//             complex mixed-radix DIT with the stage list chosen at plan time, executed from tables by ONE kernel [r4]
 //   BLUESTEIN n even otherwise            : half-length chirp-z with a {2,3,5}-smooth M >= 2h-1
 //   DFT       n odd                       : O(n*modes) direct sum (never hit by Gaussian grids)
 #pragma once
@@ -20,9 +20,9 @@
 #include <vector>
 
 #include "fft_core.h"
-#include "fft_native.h"
 #if defined(ATLAS_AMD_EXPERIMENTS)
 #include "../../tools/experiments/fft_hybrid_core.h"
+#include "../../tools/experiments/fft_native.h"
 #endif
 
 namespace atlas_amd {
@@ -46,7 +46,9 @@ struct FftRowPlan {
     int hyb_Mt, hyb_Ks; // HYBRID: tiles of the padded (A+1)/2 x (A+1)/2 cos / sin matrices (16 rows, 4 columns)
     int hyb_raw;        // HYBRID: entries of the LDS staging area for the row's modes (after the padded_size(h) work area)
     int64_t off_cs;     // HYBRID: [Mt][Ks][64] {cos, sin} operand fragments
+#if defined(ATLAS_AMD_EXPERIMENTS)
     NatShape nat;       // NATIVE: stage list and table offsets (into FftPlanSet::nat_table)
+#endif
 };
 struct PlanOptions {
     bool specialised_shapes = true;  // compile-time specialised kernel instances where they exist
@@ -60,10 +62,10 @@ struct PlanOptions {
     // a handful of launches.  Set by Trans for reduced grids of at most 704 points per row (a property of the GLOBAL grid, so
     // that every decomposition of one grid plans its rows alike); ATLAS_AMD_FFT_COARSE=0/1 overrides.
     bool coarse_classes     = false;
-    // native mixed-radix rows (fft_native.h) for every half length the planner finds a stage list for: opt-in
-    // (ATLAS_AMD_FFT_NATIVE=1) -- measured at parity with the Bluestein rows they replace (TL1279 -> O1280: 25 % of the points,
-    // 1.55 - 1.62 ms against 1.4 - 1.5 ms; the stage 6.60 - 6.65 against 6.61 - 6.67 ms; profiles/r04_fft_native.txt), so the
-    // default stays the kernels with three rounds of evidence behind them
+    // native mixed-radix rows (tools/experiments/fft_native.h; experiments build, ATLAS_AMD_FFT_NATIVE=1) for every half length the
+    // planner finds a stage list for -- measured at parity with the Bluestein rows they replace (TL1279 -> O1280: 25 % of the
+    // points, 1.55 - 1.62 ms against 1.4 - 1.5 ms; the stage 6.60 - 6.65 against 6.61 - 6.67 ms; profiles/r04_fft_native.txt): out
+    // of the product library since round 5
     bool native             = false;
     int native_min_h        = 24;
 };
@@ -83,9 +85,11 @@ FftShape make_shape(int M, int max_pow2_radix = 16);  // M must be {2,3,5}-smoot
 FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, const PlanOptions& opt);
 FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, bool specialised_shapes = true);
 int hybrid_dense_radix(int h);  // product of the prime factors > 5 of h
+#if defined(ATLAS_AMD_EXPERIMENTS)
 // stage list and tables of a native row of half length h (appended to `table`); false: h has no native plan (a prime factor
 // above NAT_MAX_PRIME, two primes above 13, a power of two, too long, or no stage list within the per-stage butterfly limit)
 bool make_native_shape(int h, NatShape& shape, std::vector<uint32_t>& table);
+#endif
 
 // Host execution of one row with exactly the kernel's algorithm (used by CPU tests; NOT a product fallback:
 // nothing in the invtrans path calls it).  X: h+1 (or n/2+1) complex modes (zero beyond mmax); y: n reals.

@@ -131,8 +131,13 @@ Trans::Trans(const grid::StructuredGrid& grid, int truncation, const TransConfig
             }
 #endif
         }
-        if (const char* e = std::getenv("ATLAS_AMD_FFT_NATIVE")) {      // 1: native mixed-radix rows where a stage list exists (opt-in)
+        if (const char* e = std::getenv("ATLAS_AMD_FFT_NATIVE")) {      // 1: native mixed-radix rows where a stage list exists
             po.native = atoi(e) != 0;
+#if !defined(ATLAS_AMD_EXPERIMENTS)
+            if (po.native) {   // kernel and planner live in tools/experiments since round 5 (at parity with Bluestein, never the default)
+                throw std::runtime_error("ATLAS_AMD_FFT_NATIVE=1 needs a library built with -DATLAS_AMD_EXPERIMENTS (make -C atlas_amd/csrc experiments)");
+            }
+#endif
         }
         if (const char* e = std::getenv("ATLAS_AMD_FFT_HYB_MAXA")) {    // largest dense radix
             po.hybrid_max_a = atoi(e);
@@ -329,10 +334,12 @@ void Trans::download_legendre_table(double* out, size_t size_doubles) const {
 
 // LDS elements of ONE work array of a native row (the staging area of the gathered modes aliases it: whole 64-lane granules); a
 // workgroup has one or two of them and the 64-element dump area of the L2 prefetch requests behind them (fft_native.hip)
+#if defined(ATLAS_AMD_EXPERIMENTS)
 static int native_lds_elems(const fft::FftRowPlan& pl, int row_mmax) {
     const int mmax = std::max(0, std::min(row_mmax, pl.h));
     return std::max(pl.nat.lds_elems, (mmax + 1 + 63) / 64 * 64);
 }
+#endif
 
 void Trans::upload() {
     // ---- Legendre table (tile-blocked), owned wavenumbers only ----
@@ -470,6 +477,7 @@ void Trans::upload() {
             by_class[{2, pl.shape.M}].push_back(j);  // specialised direct rows
             continue;
         }
+#if defined(ATLAS_AMD_EXPERIMENTS)
         if (pl.method == fft::FFT_NATIVE) {
             // native mixed-radix rows: one kernel for every shape.  Two register classes (first-stage radix 3 .. 15: four
             // workgroups per CU / prime 17 .. 31: three); launches bucketed by LDS footprint: 40 KiB (four per CU), 52 KiB (three),
@@ -493,6 +501,7 @@ void Trans::upload() {
             by_class[{10 + 2 * bigp + (fpj - 1), cls}].push_back(j);
             continue;
         }
+#endif
         if (pl.method == fft::FFT_HYBRID) {
             // dense-stage rows, bucketed by LDS footprint (workgroups per CU: 8, 6, 4, 3, 2, 1)
             const int fp = pl.lds_complex;
@@ -543,6 +552,7 @@ void Trans::upload() {
         c.native = it->first.first >= 10 && it->first.first <= 13;
         c.native_bigp = c.native && ((it->first.first - 10) & 2) != 0;
         c.native_fpj  = c.native ? ((it->first.first - 10) & 1) + 1 : 1;
+#if defined(ATLAS_AMD_EXPERIMENTS)
         if (c.native) {
             int lds = 0;
             for (int j : it->second) {
@@ -551,6 +561,7 @@ void Trans::upload() {
             c.lds_bytes = lds * 16;
             c.nthreads  = fft::NAT_NT;
         }
+#endif
         if (c.hybrid) {
             int lds = 0, nthr = 64;
             for (int j : it->second) {
@@ -608,6 +619,7 @@ void Trans::upload() {
             }
             c.d_desc = dev_upload(desc.data(), desc.size());
         }
+#if defined(ATLAS_AMD_EXPERIMENTS)
         if (c.native) {   // one 128-byte record per row (device_structs.h: FftNatDesc)
             std::vector<FftNatDesc> desc(it->second.size());
             for (size_t i = 0; i < desc.size(); ++i) {
@@ -635,6 +647,7 @@ void Trans::upload() {
             }
             c.d_desc = dev_upload(desc.data(), desc.size());
         }
+#endif
         classes_.push_back(c);
     }
 }

@@ -49,7 +49,7 @@ PARITY_TOL = 1e-12             # rel-RMS of the whole field against the CPU rest
                                # fields at T63; at T1279 the two fp64 summation orders differ by ~1e-15)
 
 
-KERNEL_SOURCES = ("legendre_kernel.hip", "fft_kernel.hip", "fft_kernel_pairs.hip", "fft_ct_rows.h", "fft_pair.h", "fft_device.h", "fft_core.h", "fft_native.h", "fft_native_impl.h", "fft_native.hip", "fft_plan.cpp",
+KERNEL_SOURCES = ("legendre_kernel.hip", "fft_kernel.hip", "fft_kernel_pairs.hip", "fft_ct_rows.h", "fft_pair.h", "fft_device.h", "fft_core.h", "fft_plan.cpp",
                   "trans.hip", "trans_plan.cpp", "Makefile")   # the Makefile carries per-file code-generation flags
 
 

@@ -6,6 +6,7 @@ wind: 2e-6 vs analytic (reference :538), 1e-12 vs oracle.  Full-size (TL1279 -> 
 sampled latitude rows against the oracle and through size-independent properties (linearity, zero input,
 dropped m=T wavenumber, host/device entry points agree bitwise)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -250,58 +251,14 @@ def test_every_bluestein_row_shape_fp64_and_fp32(f, k):
     assert compute_rms(gp32.cpu().numpy().astype(np.float64), ref32) < 2e-6
 
 
-def test_native_mixed_radix_rows_against_the_oracle(monkeypatch):
-    """[r4] ATLAS_AMD_FFT_NATIVE=1: rows whose half length has a native stage list take fft_rows_nat_kernel (one kernel for every
-    shape, csrc/fft_native_impl.h) instead of a Bluestein row.  The whole O320 / T319 field in fp64 against the oracle (19 fields:
-    two full field groups and one of three), repeated calls bit-identical (the kernel's L2 prefetch requests must not land in
-    anybody's registers), and the fp32 variant against the fp64 device result of the float-rounded spectra."""
+def test_native_rows_switch_fails_loudly_in_the_product_library(monkeypatch):
+    """ATLAS_AMD_FFT_NATIVE=1 (the native mixed-radix rows, tools/experiments/ since round 5) needs the experiments build:
+    the product library says so when the object is built instead of silently planning something else"""
+    if "exp" in os.environ.get("ATLAS_AMD_LIB", ""):
+        pytest.skip("experiments build")
     monkeypatch.setenv("ATLAS_AMD_FFT_NATIVE", "1")
-    g = atlas_amd.Grid("O320")
-    T, nf = 319, 19
-    tr = atlas_amd.Trans(g, T)
-    cls = tr.fft_row_classes()
-    assert (cls[:, 2] == 4).sum() >= 300                      # most rows of this grid have a native plan
-    sp = red_spectra(T, nf, seed=41)
-    gp = run_device(tr, nf, sp)
-    ref = oracle.OraclePlan(T, g.nx(), g.y()).invtrans(nf, sp, use_fft=True)
-    assert compute_rms(gp, ref) < TOL
-    for _ in range(4):
-        assert np.array_equal(run_device(tr, nf, sp), gp)
-    sp32 = sp.astype(np.float32)
-    ref32 = run_device(tr, nf, sp32.astype(np.float64))
-    gp32 = torch.full((nf * g.size(),), float("nan"), dtype=torch.float32, device="cuda")
-    tr.invtrans(nf, torch.from_numpy(sp32).cuda(), gp32)
-    tr.synchronize()
-    assert bool(torch.isfinite(gp32).all())
-    assert compute_rms(gp32.cpu().numpy().astype(np.float64), ref32) < 2e-6
-    assert tr.fourier_launch_plan()["native_two_fields"] == 0
-    monkeypatch.setenv("ATLAS_AMD_FFT_NATIVE_FPJ", "2")                         # two fields per workgroup: same arithmetic per field
-    tr2 = atlas_amd.Trans(g, T)
-    assert tr2.fourier_launch_plan()["native_two_fields"] >= 1                  # read per object: the other path really ran (ADVICE r4)
-    assert np.array_equal(run_device(tr2, nf, sp), gp)
-    monkeypatch.delenv("ATLAS_AMD_FFT_NATIVE_FPJ")
-    monkeypatch.delenv("ATLAS_AMD_FFT_NATIVE")
-    assert (atlas_amd.Trans(g, T).fft_row_classes()[:, 2] != 4).all()          # opt-in: off by default
-
-
-def test_native_mixed_radix_rows_at_full_size_one_row_pair_per_shape_class(monkeypatch):
-    """TL1279 -> O1280, 137 fields with the native rows on: a northern and a southern row of every (first radix, number of stages)
-    class of native rows -- dense radix-17 .. 31 first stages, two to four stages, one and two rounds of butterflies per stage --
-    and of every Bluestein class that remains, against the oracle"""
-    monkeypatch.setenv("ATLAS_AMD_FFT_NATIVE", "1")
-    g = atlas_amd.Grid("O1280")
-    T, nf = 1279, 137
-    tr = atlas_amd.Trans(g, T)
-    sp = red_spectra(T, nf)
-    gp = run_device(tr, nf, sp).reshape(nf, -1)
-    rows, classes = rows_of_every_fft_class(tr)
-    nat = [c for c in classes if c[2] == 4]
-    assert {c[1] // 10 for c in nat} == {3, 5, 7, 9, 11, 13, 15, 17, 19, 23, 29, 31} and {c[1] % 10 for c in nat} >= {3, 4}
-    op = oracle.OraclePlan(T, g.nx(), g.y(), with_tables=False)
-    off = np.concatenate([[0], np.cumsum(g.nx())])
-    for r, ref in zip(rows, op.invtrans_rows(nf, sp, rows, use_fft=True)):
-        err = compute_rms(gp[:, off[r]:off[r + 1]], ref)
-        assert err < 1e-12, (r, tuple(tr.fft_row_classes()[r]), err)
+    with pytest.raises(Exception, match="ATLAS_AMD_EXPERIMENTS"):
+        atlas_amd.Trans(atlas_amd.Grid("O320"), 319)
 
 
 def test_coarse_row_classes_in_one_launch_are_bitwise_equal_to_one_launch_per_class(monkeypatch):

@@ -209,58 +209,18 @@ def test_fft_phase_code_on_every_row_length_of_the_octahedral_grid(N):
     assert worst < 2e-15, worst
 
 
-def test_native_mixed_radix_rows_on_every_row_length_of_O1280_that_has_a_plan():
-    """[r4] the native mixed-radix rows (csrc/fft_native.h; opt-in on the device): every distinct row length of O1280 for which the
-    planner finds a stage list -- half lengths with any number of primes 2..13 and at most one prime 17..31 that are not a length
-    of the specialised direct family: 428 of the 1280 lengths, 25 % of the grid points -- through the host run of the kernel's own
-    tables (fold permutation, per-stage butterfly tables) and butterflies (dense odd-prime radices included), with the row's own
-    Fourier truncation, against pocketfft.  What FFTW / pocketfft do natively for the reference (linalg/fft/FFTW.cc:38-61)."""
-    g = atlas_amd.Grid("O1280")
-    T, N = 1279, 1280
-    rng = np.random.default_rng(4)
-    nx, y = g.nx(), g.y()
-    worst, nat, pts = 0.0, 0, 0
-    firsts = set()
-    for j in range(N):
-        n = int(nx[j])
-        info = np.zeros(16, dtype=np.int32)
-        _lib.check(_lib.fft_plan_info(n, 1, info.ctypes.data))
-        if info[0] != 5:                       # FFT_NATIVE
-            continue
-        ns, rad = int(info[3]), [int(v) for v in info[4:4 + int(info[3])]]
-        assert 2 <= ns <= 4 and int(np.prod(rad)) == n // 2 == info[1]
-        assert rad[-1] % 2 == 1 and rad[-1] <= 31 and all(r <= 16 for r in rad[:-1])     # DIF order: the first executed stage is last
-        assert info[13] % 2 == 1 and info[13] >= n // 2 // rad[0]                         # odd LDS pitch of the top-level blocks
-        assert info[2] >= n // 2 + 1
-        firsts.add(rad[-1])
-        nat += 1
-        pts += n
-        nc = n // 2 + 1
-        mmax = _lib.fourier_truncation(T, n, g.nxmax(), 2 * N, math.radians(y[j]), 0)
-        x = rng.standard_normal(nc) + 1j * rng.standard_normal(nc)
-        x[mmax + 1:] = 0
-        out = np.zeros(n)
-        _lib.check(_lib.fft_host_row_native(n, np.ascontiguousarray(x).ctypes.data, mmax, out.ctypes.data))
-        xx = x.copy()
-        xx[0] = xx[0].real
-        xx[-1] = xx[-1].real
-        worst = max(worst, compute_rms(out, np.fft.irfft(xx, n) * n))
-    assert nat == 428 and abs(pts / float(np.sum(nx[:N])) - 0.2523) < 1e-3
-    assert firsts == {3, 5, 7, 9, 11, 13, 15, 17, 19, 23, 29, 31}
-    assert worst < 1e-15, worst
-
-
-def test_native_plan_is_off_by_default_and_refuses_lengths_without_a_stage_list():
+def test_native_mixed_radix_rows_are_out_of_the_product_library():
+    """[r5] the native mixed-radix rows (25 % of O1280's points, at parity with the Bluestein rows they replace in rounds 4's
+    measurements, never the default) moved to tools/experiments/ with their planner, kernels and tests: the product library
+    plans Bluestein for those lengths and says so when asked for a native plan (VERDICT r4 item 3 iv / item 8)"""
     info = np.zeros(16, dtype=np.int32)
-    _lib.check(_lib.fft_plan_info(2 * 1190, 0, info.ctypes.data))          # h = 2 * 5 * 7 * 17
-    assert info[0] == 1                                                    # Bluestein unless asked for
-    _lib.check(_lib.fft_plan_info(2 * 1190, 1, info.ctypes.data))
-    assert info[0] == 5 and sorted(info[4:4 + info[3]]) == [7, 10, 17]
-    for n in (2 * 2 * 641, 2 * 17 * 19 * 4, 2 * 37 * 32, 2 * 1024, 2 * 2560):   # big prime, two primes > 13, prime > 31, family lengths
-        _lib.check(_lib.fft_plan_info(n, 1, info.ctypes.data))
-        assert info[0] != 5, n
-    out = np.zeros(2 * 1282)
-    assert _lib.fft_host_row_native(2 * 1282, np.zeros(1283, dtype=np.complex128).ctypes.data, 10, out.ctypes.data) != 0
+    _lib.check(_lib.fft_plan_info(2 * 1190, 0, info.ctypes.data))          # h = 2 * 5 * 7 * 17: a native length
+    assert info[0] == 1                                                    # Bluestein
+    if "exp" in os.environ.get("ATLAS_AMD_LIB", ""):
+        pytest.skip("experiments build: the native rows are in")
+    assert _lib.fft_plan_info(2 * 1190, 1, info.ctypes.data) != 0 and b"tools/experiments" in _lib.last_error()
+    out = np.zeros(2 * 1190)
+    assert _lib.fft_host_row_native(2 * 1190, np.zeros(1191, dtype=np.complex128).ctypes.data, 10, out.ctypes.data) != 0
 
 
 def test_fft_phase_code_with_the_coarse_row_classes_of_small_reduced_grids():

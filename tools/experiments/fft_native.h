@@ -27,7 +27,7 @@
 #include <cstdint>
 #include <utility>
 
-#include "fft_core.h"
+#include "../../atlas_amd/csrc/fft_core.h"
 
 namespace atlas_amd {
 namespace fft {

@@ -12,9 +12,9 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
-#include "device_structs.h"
-#include "dyn_lds.h"
-#include "fft_device.h"
+#include "../../atlas_amd/csrc/device_structs.h"
+#include "../../atlas_amd/csrc/dyn_lds.h"
+#include "../../atlas_amd/csrc/fft_device.h"
 #include "fft_native.h"
 
 namespace atlas_amd {

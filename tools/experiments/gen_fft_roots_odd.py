@@ -1,8 +1,8 @@
-"""Generator of atlas_amd/csrc/fft_roots_odd.inc: cos / sin (2 pi k / P), k = 0..P-1, correctly rounded (mpmath, 50 digits), for
-the odd prime radices of the native mixed-radix Fourier rows (csrc/fft_native.h: bfly_odd_stream).  The index is a compile-time
+"""Generator of tools/experiments/fft_roots_odd.inc: cos / sin (2 pi k / P), k = 0..P-1, correctly rounded (mpmath, 50 digits), for
+the odd prime radices of the native mixed-radix Fourier rows (tools/experiments/fft_native.h: bfly_odd_stream).  The index is a compile-time
 constant wherever the table is used, so the entries end up as literal operands of the butterflies.
 
-Usage: python tools/gen_fft_roots_odd.py > atlas_amd/csrc/fft_roots_odd.inc"""
+Usage: python tools/gen_fft_roots_odd.py > tools/experiments/fft_roots_odd.inc"""
 import mpmath
 
 mpmath.mp.dps = 50
