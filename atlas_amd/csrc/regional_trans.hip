@@ -97,9 +97,34 @@ void RegionalTrans::make_inner(const std::vector<double>& lats_deg, bool clamp_s
     std::vector<double> a;
     const char* rp_env         = std::getenv("ATLAS_AMD_REFERENCE_POLES");   // read per object
     const bool reference_poles = rp_env && atoi(rp_env) != 0;
+    // ATLAS_AMD_REFERENCE_POLES=1 ("Deviations"): on this branch the reference calls its Legendre routine with the
+    // target's own, unmirrored latitudes; within a metre of EITHER pole (sin(colatitude) <= sqrt(epsilon)) that routine sets
+    // cos(colatitude) = +1 and sin = 0 for its recurrences while the cos(j theta) / sin(j theta) of its series keep the true
+    // colatitude (LegendrePolynomials.cc:58-76): at the SOUTH pole the m = 0, 1 columns and the recurrences for m >= 2 disagree
+    // about the sign of cos(theta) and the row comes out as neither pole's polynomials.  The default here is the mirror image of the
+    // north-pole row; with the switch such a row becomes a Legendre row of its own whose table row is generated by the same routine
+    // (csrc/legendre_series.h, the bit-identical twin of the reference's) AT THE NEGATIVE LATITUDE -- the reference's numbers.
+    auto south_polar = [&](double y) {
+        if (!reference_poles || y >= 0) {
+            return false;
+        }
+        const double lat        = std::max(y, -kLatPole) * (M_PI / 180.);
+        const double zdlx       = std::cos(M_PI_2 - lat);
+        volatile double zdlsita = std::sqrt(1. - zdlx * zdlx);
+        return std::fabs(zdlsita) <= std::sqrt(std::numeric_limits<double>::epsilon());
+    };
+    const double pseudo = kLatPole - 1.e-10;   // |latitude| that stands for "south pole as the reference computes it" in the symmetric set
+    bool have_pseudo    = false;
     for (double y : lats_deg) {
         if (!(y >= -90. && y <= 90.)) {
             throw std::invalid_argument("RegionalTrans: latitude outside [-90, 90]");
+        }
+        if (south_polar(y)) {
+            if (!have_pseudo) {
+                a.push_back(pseudo);
+            }
+            have_pseudo = true;
+            continue;
         }
         a.push_back(std::min(std::fabs(y), kLatPole));
     }
@@ -118,7 +143,8 @@ void RegionalTrans::make_inner(const std::vector<double>& lats_deg, bool clamp_s
     sym.nx.assign(sym.y.size(), 4 * (T_ + 1));
     sym.regular = true;
     auto row_of = [&](double y) {
-        const double v = std::min(std::fabs(y), kLatPole);
+        const bool quirk = south_polar(y);
+        const double v   = quirk ? pseudo : std::min(std::fabs(y), kLatPole);
         // a is sorted descending: binary search for the entry within the merge tolerance
         int lo = 0, hi = (int)a.size() - 1;
         while (lo < hi) {
@@ -131,17 +157,8 @@ void RegionalTrans::make_inner(const std::vector<double>& lats_deg, bool clamp_s
             }
         }
         const int k = lo;
-        if (reference_poles && y < 0) {
-            // ATLAS_AMD_REFERENCE_POLES=1 ("Deviations"): the reference's Legendre routine, called with the target's
-            // own latitudes on this branch, sets cos(colatitude) = +1 when sin(colatitude) <= sqrt(epsilon) -- within a metre of
-            // EITHER pole (LegendrePolynomials.cc:58-61,72-76) -- so a row at latitude -90 gets the NORTH-pole polynomials.  The
-            // switch reproduces that: such a row reads the northern row of the symmetric set instead of its mirror image.
-            const double zdlx1       = M_PI_2 - (-v) * (M_PI / 180.);
-            const double zdlx        = std::cos(zdlx1);
-            volatile double zdlsita  = std::sqrt(1. - zdlx * zdlx);
-            if (std::fabs(zdlsita) <= std::sqrt(std::numeric_limits<double>::epsilon())) {
-                return k;
-            }
+        if (quirk) {
+            return k;   // the NORTHERN output of the pseudo row: sym + asym = the plain sum over n of the table row below
         }
         return y >= 0 || (equator && k == (int)a.size() - 1) ? k : (int)sym.y.size() - 1 - k;
     };
@@ -150,6 +167,9 @@ void RegionalTrans::make_inner(const std::vector<double>& lats_deg, bool clamp_s
         rows.push_back(row_of(y));
     }
     TransConfig cfg;
+    if (have_pseudo) {   // the pseudo row's polynomials: the routine evaluated at the clamped SOUTHERN latitude (TransLocal.cc:537-543)
+        cfg.leg_lat_override.push_back({row_of(-90.), -kLatPole * (M_PI / 180.)});
+    }
     cfg.row_begin = *std::min_element(rows.begin(), rows.end());
     cfg.row_end   = *std::max_element(rows.begin(), rows.end()) + 1;
     inner_.reset(new Trans(sym, T_, cfg));

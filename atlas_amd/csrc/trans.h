@@ -33,6 +33,9 @@ struct TransConfig {
     size_t legendre_cache_size = 0;
     int nparts                 = 1;  // m-sharding / latitude-band decomposition
     int part                   = 0;
+    // (Legendre row, latitude in radians): the table row is generated at this latitude instead of the grid's -- RegionalTrans with
+    // ATLAS_AMD_REFERENCE_POLES=1 only (the reference's south-pole row, csrc/regional_trans.hip)
+    std::vector<std::pair<int, double>> leg_lat_override;
     int row_begin = 0, row_end = 0;        // row_end > row_begin: transform only these latitude rows (a zonal-band
                                            // crop of the global grid, TransLocal.cc:394-470 "nested" case)
     bool by_band               = false;  // nparts > 1: false = wavenumber sharding (all-to-all transposition follows),

@@ -70,6 +70,12 @@ Trans::Trans(const grid::StructuredGrid& grid, int truncation, const TransConfig
     if (cfg.nparts < 1 || cfg.nparts > fft::MAX_PARTS || cfg.part < 0 || cfg.part >= cfg.nparts) {
         throw std::invalid_argument("Trans: invalid (nparts, part)");
     }
+    for (const auto& ov : cfg.leg_lat_override) {
+        if (ov.first < 0 || ov.first >= (int)geo_.lats_leg.size()) {
+            throw std::invalid_argument("Trans: leg_lat_override row out of range");
+        }
+        geo_.lats_leg[ov.first] = ov.second;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         throw std::runtime_error(

@@ -865,8 +865,9 @@ def test_host_pointer_pipeline_is_bitwise_equal_to_the_device_path(monkeypatch):
 def test_reference_poles_switch_reproduces_the_reference_at_the_south_pole(monkeypatch):
     """INTEGRATION.md "Deviations": by default a row at latitude -90 of a no_nest target is the mirror image of the north-pole
     row; ATLAS_AMD_REFERENCE_POLES=1 reproduces what the reference computes there -- its Legendre routine sets cos(colatitude) =
-    +1 within a metre of either pole (LegendrePolynomials.cc:58-61,72-76), i.e. the north-pole polynomials -- which is what the
-    oracle's restatement of that routine returns unpatched."""
+    +1, sin = 0 for its recurrences within a metre of either pole while its series keep the true colatitude
+    (LegendrePolynomials.cc:58-76): a row that is neither pole's polynomials -- which is what the oracle's restatement of that
+    routine returns unpatched."""
     T, nf = 63, 4
     sp = red_spectra(T, nf, seed=45)
     lats, west, dlon, nlon = np.array([90.0, 30.0, -89.99999995, -90.0, -30.0]), 0.0, 11.25, 32
