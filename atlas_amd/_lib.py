@@ -111,6 +111,8 @@ Trans_invtrans_device = _sig("atlas_amd__Trans__invtrans_device", C.c_int, c_voi
                              c_void_p, c_void_p, c_void_p)
 Trans_invtrans_scalar_device_f32 = _sig("atlas_amd__Trans__invtrans_scalar_device_f32", C.c_int, c_void_p, C.c_int,
                                         c_void_p, c_void_p)
+Trans_invtrans_device_f32 = _sig("atlas_amd__Trans__invtrans_device_f32", C.c_int, c_void_p, C.c_int, c_void_p, C.c_int,
+                                 c_void_p, c_void_p, c_void_p)
 Trans_invtrans_scalar_f32 = _sig("atlas_amd__Trans__invtrans_scalar_f32", C.c_int, c_void_p, C.c_int, c_void_p, c_void_p)
 Trans_dirtrans_scalar = _sig("atlas_amd__Trans__dirtrans_scalar", C.c_int, c_void_p, C.c_int, c_void_p, c_void_p)
 Trans_dirtrans_wind2vordiv = _sig("atlas_amd__Trans__dirtrans_wind2vordiv", C.c_int, c_void_p, C.c_int, c_void_p,

@@ -575,6 +575,18 @@ int atlas_amd__Trans__invtrans_scalar_device_f32(atlas_amd_Trans* t, int nb_fiel
     t->impl->invtrans_scalar_device_f32(nb_fields, scalar_spectra, gp_fields);
     AA_CATCH_INT
 }
+int atlas_amd__Trans__invtrans_device_f32(atlas_amd_Trans* t, int nb_scalar_fields, const float* scalar_spectra_dev,
+                                          int nb_vordiv_fields, const float* vorticity_spectra_dev,
+                                          const float* divergence_spectra_dev, float* gp_fields_dev) {
+    AA_TRY
+    if (!gp_fields_dev || (nb_scalar_fields > 0 && !scalar_spectra_dev) ||
+        (nb_vordiv_fields > 0 && (!vorticity_spectra_dev || !divergence_spectra_dev))) {
+        throw std::invalid_argument("invtrans_device_f32: null array");
+    }
+    t->impl->invtrans_device_f32(nb_scalar_fields, scalar_spectra_dev, nb_vordiv_fields, vorticity_spectra_dev,
+                                 divergence_spectra_dev, gp_fields_dev);
+    AA_CATCH_INT
+}
 int atlas_amd__Trans__invtrans_scalar_f32(atlas_amd_Trans* t, int nb_fields, const float scalar_spectra[],
                                           float gp_fields[]) {
     AA_TRY

@@ -91,6 +91,9 @@ public:
 
     // ---- device-pointer API (asynchronous on stream()) ----
     void invtrans_scalar_device_f32(int nb_fields, const float* sp_dev, float* gp_dev);  // fp32 variant
+    void invtrans_device_f32(int nb_scalar, const float* sp_dev, int nb_vordiv, const float* vor_dev, const float* div_dev,
+                             float* gp_dev);                                              // ... its vor/div call [r5]
+    void invtrans_uv_device_f32(int trc_in, int nb_fields, int nb_vordiv, const float* sp_dev, float* gp_dev);
     void invtrans_scalar_f32(int nb_fields, const float scalar_spectra[], float gp_fields[]);  // host pointers
     // TransLocal::invtrans_uv (TransLocal.cc:1409-1484); the first 2*nb_vordiv fields are scaled by 1/cos(lat)
     void invtrans_uv_device(int trc_in, int nb_fields, int nb_vordiv, const double* sp_dev, double* gp_dev);

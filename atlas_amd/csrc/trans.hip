@@ -40,6 +40,8 @@ hipError_t launch_fourier_dct(const FourierParams& p, int ctf, int ctk, int lds_
                               hipStream_t stream);
 hipError_t launch_spectra_prepare(const double* vor, const double* div, const double* sp, double* out, int T, int nvd,
                                   int ns, hipStream_t stream);
+hipError_t launch_spectra_prepare_f32(const float* vor, const float* div, const float* sp, float* out, int T, int nvd, int ns,
+                                      hipStream_t stream);
 
 namespace {
 void hip_check(hipError_t e, const char* what, const char* file, int line) {
@@ -1074,6 +1076,29 @@ void Trans::invtrans_uv_device(int trc_in, int nb_fields, int nb_vordiv, const d
 // ---- fp32 variant (BASELINE config C5): fp32 spectra / table / intermediate / grid points, v_mfma_f32_16x16x4_f32 in the
 // Legendre stage; the Fourier stage converts on load and store and keeps its arithmetic in fp64.
 void Trans::invtrans_scalar_device_f32(int nb_fields, const float* sp_dev, float* gp_dev) {
+    invtrans_uv_device_f32(geo_.T, nb_fields, 0, sp_dev, gp_dev);
+}
+
+// the vor/div call of the fp32 variant (an extension, like the variant itself): spectra_prepare with float storage (double
+// arithmetic), Legendre + Fourier stage at truncation T + 1, 1 / cos(lat) in the Fourier store epilogue -- TransLocal.cc:1523-1597
+void Trans::invtrans_device_f32(int nb_scalar, const float* sp_dev, int nb_vordiv, const float* vor_dev, const float* div_dev,
+                                float* gp_dev) {
+    if (nb_vordiv <= 0) {
+        invtrans_uv_device_f32(geo_.T, std::max(nb_scalar, 0), 0, sp_dev, gp_dev);
+        return;
+    }
+    nb_scalar         = std::max(nb_scalar, 0);
+    const int T       = geo_.T;
+    const int nall    = 2 * nb_vordiv + nb_scalar;
+    const size_t nout = size_t(T + 2) * size_t(T + 3) * size_t(nall);
+    ensure(d_all_, all_cap_, (nout + 1) / 2);   // (the double buffer of the fp64 path, used as floats)
+    timed_begin(2);
+    HIP_CHECK(launch_spectra_prepare_f32(vor_dev, div_dev, sp_dev, reinterpret_cast<float*>(d_all_), T, nb_vordiv, nb_scalar, stream_));
+    timed_end();
+    invtrans_uv_device_f32(T + 1, nall, nb_vordiv, reinterpret_cast<const float*>(d_all_), gp_dev);
+}
+
+void Trans::invtrans_uv_device_f32(int trc_in, int nb_fields, int nb_vordiv, const float* sp_dev, float* gp_dev) {
     if (nb_fields <= 0) {
         return;
     }
@@ -1108,7 +1133,7 @@ void Trans::invtrans_scalar_device_f32(int nb_fields, const float* sp_dev, float
     p.nlat0     = d_nlat0_;
     p.zero      = d_zero32_;
     p.T         = geo_.T;
-    p.trc_in    = geo_.T;
+    p.trc_in    = trc_in;
     p.nf        = nb_fields;
     p.RP        = fourier_row_pitch(nb_fields);
     p.nlats     = geo_.nlats;
@@ -1123,7 +1148,7 @@ void Trans::invtrans_scalar_device_f32(int nb_fields, const float* sp_dev, float
     timed_end();
     const double* base[1] = {reinterpret_cast<const double*>(d_fourier32_)};
     const int cnt[1]      = {m_cnt_};
-    fourier_fields(nb_fields, 0, base, cnt, reinterpret_cast<double*>(gp_dev), 0, nb_fields, stream_, true);
+    fourier_fields(nb_fields, nb_vordiv, base, cnt, reinterpret_cast<double*>(gp_dev), 0, nb_fields, stream_, true);
 }
 
 void Trans::invtrans_scalar_f32(int nb_fields, const float scalar_spectra[], float gp_fields[]) {

@@ -22,11 +22,14 @@ namespace trans {
 
 constexpr double kEarthRadius = 6371229.;  // util::Earth::radius(), src/atlas/util/Earth.h:23
 
-struct PrepareParams {
-    const double* vor;  // [(T+1)(T+2)] x nvd, truncation T layout
-    const double* div;
-    const double* sp;   // scalars, truncation T layout, ns fields (may be null if ns == 0)
-    double* out;        // [(T+2)(T+3)] x (2*nvd + ns), truncation T+1 layout
+// Real: storage type of the spectra (double; float for the fp32 variant -- the arithmetic is double either way: the factors
+// a^2 / (n (n + 1)) and 1 / a span thirteen decades)
+template <class Real>
+struct PrepareParamsT {
+    const Real* vor;  // [(T+1)(T+2)] x nvd, truncation T layout
+    const Real* div;
+    const Real* sp;   // scalars, truncation T layout, ns fields (may be null if ns == 0)
+    Real* out;        // [(T+2)(T+3)] x (2*nvd + ns), truncation T+1 layout
     int T;
     int nvd;
     int ns;
@@ -45,7 +48,8 @@ __device__ __forceinline__ double dev_lap(int n) {
     return -kEarthRadius * kEarthRadius / (n * (n + 1.));
 }
 
-__global__ void __launch_bounds__(256) spectra_prepare_kernel(PrepareParams p) {
+template <class Real>
+__global__ void __launch_bounds__(256) spectra_prepare_kernel(PrepareParamsT<Real> p) {
     const int m    = blockIdx.y;
     const int T    = p.T;
     const int TE   = T + 1;
@@ -69,17 +73,17 @@ __global__ void __launch_bounds__(256) spectra_prepare_kernel(PrepareParams p) {
         else if (m <= T || n <= T) {
             const bool isV = fld >= p.nvd;
             const int f    = isV ? fld - p.nvd : fld;
-            auto get = [&](const double* a, int nn, int im) -> double {
+            auto get = [&](const Real* a, int nn, int im) -> double {
                 if (nn < m || nn > T || m > T) {
                     return 0.;
                 }
-                return a[(ibase + 2 * (nn - m) + im) * p.nvd + f];
+                return (double)a[(ibase + 2 * (nn - m) + im) * p.nvd + f];
             };
             const double chi  = m * dev_lap(n);
             const double psiM = (n - 1) * dev_eps(m, n) * dev_lap(n - 1);
             const double psiP = (n + 2) * dev_eps(m, n + 1) * dev_lap(n + 1);
-            const double* A   = isV ? p.div : p.vor;  // the field the psi terms act on
-            const double* B   = isV ? p.vor : p.div;  // the field the chi term acts on
+            const Real* A     = isV ? p.div : p.vor;  // the field the psi terms act on
+            const Real* B     = isV ? p.vor : p.div;  // the field the chi term acts on
             const double sg   = isV ? -1. : 1.;
             double r;
             if (m == 0) {
@@ -93,7 +97,7 @@ __global__ void __launch_bounds__(256) spectra_prepare_kernel(PrepareParams p) {
             }
             v = r * (1. / kEarthRadius);
         }
-        p.out[obase + e] = v;
+        p.out[obase + e] = (Real)v;
     }
 }
 
@@ -167,17 +171,26 @@ hipError_t launch_convert_f64_f32(const double* src, float* dst, size_t n, hipSt
     return hipGetLastError();
 }
 
-hipError_t launch_spectra_prepare(const double* vor, const double* div, const double* sp, double* out, int T, int nvd,
-                                  int ns, hipStream_t stream) {
-    PrepareParams p{vor, div, sp, out, T, nvd, ns};
+template <class Real>
+static hipError_t launch_spectra_prepare_t(const Real* vor, const Real* div, const Real* sp, Real* out, int T, int nvd, int ns,
+                                           hipStream_t stream) {
+    PrepareParamsT<Real> p{vor, div, sp, out, T, nvd, ns};
     const int nall = 2 * nvd + ns;
     const int len0 = (T + 2) * 2 * nall;
     dim3 grid((len0 + 255) / 256, T + 2);
     if (grid.x > 64) {
         grid.x = 64;
     }
-    hipLaunchKernelGGL(spectra_prepare_kernel, grid, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(spectra_prepare_kernel<Real>, grid, dim3(256), 0, stream, p);
     return hipGetLastError();
+}
+hipError_t launch_spectra_prepare(const double* vor, const double* div, const double* sp, double* out, int T, int nvd,
+                                  int ns, hipStream_t stream) {
+    return launch_spectra_prepare_t<double>(vor, div, sp, out, T, nvd, ns, stream);
+}
+hipError_t launch_spectra_prepare_f32(const float* vor, const float* div, const float* sp, float* out, int T, int nvd, int ns,
+                                      hipStream_t stream) {
+    return launch_spectra_prepare_t<float>(vor, div, sp, out, T, nvd, ns, stream);
 }
 
 // ---- longitude-window crop (RectangularDomain): out[f][win_off[r] + i] = full[f][rowoff[r] - rowoff[0] + (win_i0[r] + i) mod n_r]

@@ -141,6 +141,19 @@ class Trans:
             nvd, vor, div, gp = args
             ns, nvd = int(nb_scalar_fields), int(nvd)
             dev = _is_device(gp)
+            if dev:
+                import torch
+                if gp.dtype == torch.float32:   # fp32 variant (an extension): all arrays float32 on the device
+                    arrs = [a for a in (scalar_spectra if ns > 0 else None, vor, div) if a is not None]
+                    if not all(_is_device(a) and a.dtype == torch.float32 and a.is_contiguous() for a in arrs) or not gp.is_contiguous():
+                        raise TypeError("fp32 vor/div call: contiguous float32 device tensors throughout")
+                    if (ns > 0 and scalar_spectra.numel() < ncoef * ns) or vor.numel() < ncoef * nvd or div.numel() < ncoef * nvd \
+                            or gp.numel() < npts * (ns + 2 * nvd):
+                        raise ValueError("float32 arrays too small")
+                    with _lib.torch_stream_order(self.stream()):
+                        _lib.check(_lib.Trans_invtrans_device_f32(self._h, ns, scalar_spectra.data_ptr() if ns > 0 else None, nvd,
+                                                                   vor.data_ptr(), div.data_ptr(), gp.data_ptr()))
+                    return gp
             sp_p = _ptr(scalar_spectra, ncoef * ns, "scalar_spectra") if ns > 0 else None
             vor_p = _ptr(vor, ncoef * nvd, "vorticity_spectra") if nvd > 0 else None
             div_p = _ptr(div, ncoef * nvd, "divergence_spectra") if nvd > 0 else None

@@ -177,6 +177,11 @@ int atlas_amd__Trans__invtrans_scalar_device_f32(atlas_amd_Trans* t, int nb_fiel
                                                  float* gp_fields);
 int atlas_amd__Trans__invtrans_scalar_f32(atlas_amd_Trans* t, int nb_fields, const float scalar_spectra[],
                                           float gp_fields[]); /* host pointers */
+/* [r5] the vor/div call of the fp32 variant on device arrays: atlas__Trans__invtrans (TransInterface.h:74-79; TransLocal.cc:1523-1597)
+ * with float spectra and grid points; U, V spectra formed in double and stored as float; gp = [u fields][v fields][scalar fields] */
+int atlas_amd__Trans__invtrans_device_f32(atlas_amd_Trans* t, int nb_scalar_fields, const float* scalar_spectra_dev,
+                                          int nb_vordiv_fields, const float* vorticity_spectra_dev,
+                                          const float* divergence_spectra_dev, float* gp_fields_dev);
 
 /* direct transforms and adjoints: not implemented by TransLocal either (TransLocal.cc:848-857,899-927,1599-1685);
  * these return an error whose message starts with "Not implemented" */

@@ -131,3 +131,48 @@ def test_vordiv_full_size_field_independence_and_host_entry():
         got = full[:, off[r]:off[r + 1]].cpu().numpy()
         for f in range(ns + 2 * nvd):
             assert compute_rms(got[f], rr[f]) < 1e-12, (r, f)
+
+
+@pytest.mark.parametrize("gridname,T", [("O160", 159), ("F96", 191)])
+def test_vordiv_fp32_variant_on_reduced_and_regular_grids(gridname, T):
+    """the vor/div call of the fp32 variant (atlas_amd__Trans__invtrans_device_f32; an extension -- TransLocal is double only):
+    whole field against the fp64 oracle on the float-rounded spectra, per field kind, rel-RMS 2e-6 (the fp32 tolerance of the
+    scalar path, tests/test_gpu_trans.py: C5)"""
+    g = atlas_amd.Grid(gridname)
+    tr = atlas_amd.Trans(g, T)
+    ns, nvd = 3, 5                                     # 13 fields: an odd count, the u / v / scalar boundaries inside field pairs
+    sp, vor, div = (red_spectra(T, n, s).astype(np.float32) for n, s in ((ns, 11), (nvd, 12), (nvd, 13)))
+    gp = torch.full(((ns + 2 * nvd) * g.size(),), float("nan"), dtype=torch.float32, device="cuda")
+    tr.invtrans(ns, torch.from_numpy(sp).cuda(), nvd, torch.from_numpy(vor).cuda(), torch.from_numpy(div).cuda(), gp)
+    tr.synchronize()
+    assert bool(torch.isfinite(gp).all())
+    ref = oracle.OraclePlan(T, g.nx(), g.y()).invtrans_vordiv(ns, sp.astype(np.float64), nvd, vor.astype(np.float64),
+                                                              div.astype(np.float64), use_fft=True)
+    a, b = gp.cpu().numpy().astype(np.float64).reshape(ns + 2 * nvd, -1), ref.reshape(ns + 2 * nvd, -1)
+    for f in range(ns + 2 * nvd):
+        assert compute_rms(a[f], b[f]) < 2e-6, (gridname, "u" if f < nvd else "v" if f < 2 * nvd else "scalar", f)
+
+
+def test_vordiv_fp32_full_size_every_fft_class():
+    """TL1279 -> O1280, nb_scalar = nb_vordiv = 137 in fp32: rows of every Fourier class (the two-field fp32
+    rows with the 1 / cos(lat) epilogue, the u/v boundary at field 137 -- odd -- inside a pair), sampled fields, 2e-6"""
+    T, ns, nvd = 1279, 137, 137
+    g = atlas_amd.Grid("O1280")
+    tr = atlas_amd.Trans(g, T)
+    sp, vor, div = (red_spectra(T, n, s).astype(np.float32) for n, s in ((ns, 31), (nvd, 32), (nvd, 33)))
+    gp = torch.full(((ns + 2 * nvd) * g.size(),), float("nan"), dtype=torch.float32, device="cuda")
+    tr.invtrans(ns, torch.from_numpy(sp).cuda(), nvd, torch.from_numpy(vor).cuda(), torch.from_numpy(div).cuda(), gp)
+    tr.synchronize()
+    assert bool(torch.isfinite(gp).all())
+    v = gp.view(ns + 2 * nvd, -1)
+    rows, classes = rows_of_every_fft_class(tr, extra=[0, 639, 1279, 1280, 2559])
+    pick = [0, 68, 136]
+    cols = lambda a, n: np.ascontiguousarray(a.astype(np.float64).reshape(-1, n)[:, pick]).reshape(-1)
+    op = oracle.OraclePlan(T, g.nx(), g.y(), with_tables=False)
+    ref = op.invtrans_vordiv_rows(3, cols(sp, ns), 3, cols(vor, nvd), cols(div, nvd), rows, use_fft=True)
+    fields = pick + [nvd + k for k in pick] + [2 * nvd + k for k in pick]
+    off = np.concatenate([[0], np.cumsum(g.nx())])
+    for r, rr in zip(rows, ref):
+        got = v[fields][:, off[r]:off[r + 1]].cpu().numpy().astype(np.float64)
+        for kind, sl in (("u", slice(0, 3)), ("v", slice(3, 6)), ("scalar", slice(6, 9))):
+            assert compute_rms(got[sl], rr[sl]) < 2e-6, (r, kind, tuple(tr.fft_row_classes()[r]))
