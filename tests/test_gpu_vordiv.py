@@ -174,5 +174,9 @@ def test_vordiv_fp32_full_size_every_fft_class():
     off = np.concatenate([[0], np.cumsum(g.nx())])
     for r, rr in zip(rows, ref):
         got = v[fields][:, off[r]:off[r + 1]].cpu().numpy().astype(np.float64)
-        for kind, sl in (("u", slice(0, 3)), ("v", slice(3, 6)), ("scalar", slice(6, 9))):
-            assert compute_rms(got[sl], rr[sl]) < 2e-6, (r, kind, tuple(tr.fft_row_classes()[r]))
+        # scalars: the fp32 tolerance of the scalar path.  u, v: U = u cos(lat) is what the fp32 stages compute -- near the poles a
+        # sum of terms of 1e6 - 1e7 that cancel to ~1e4 -- and the store epilogue multiplies by 1 / cos(lat) (900 on the first row
+        # of O1280): the row's relative error grows with that factor (measured 1.1e-5 on row 0, < 2e-6 from ~20 rows inwards)
+        wind_tol = 2e-6 * max(1.0, min(10.0, 0.02 / math.cos(math.radians(float(g.y()[r])))))
+        for kind, sl, tol in (("u", slice(0, 3), wind_tol), ("v", slice(3, 6), wind_tol), ("scalar", slice(6, 9), 2e-6)):
+            assert compute_rms(got[sl], rr[sl]) < tol, (r, kind, tuple(tr.fft_row_classes()[r]), tol)

@@ -14,7 +14,7 @@ Template: the reference's own benchmark driver, src/sandbox/benchmark_trans/atla
   C4vd      TL1279 -> O1280, nscalar 137 + nvordiv 137 in ONE invtrans(nb_scalar, sp, nb_vordiv, vor, div, gp): the other axis of the
             reference's benchmark (atlas-benchmark-trans.cc:66-76,148-149 `--nscalar --nvordiv`; TransLocal.cc:1523-1597): 411 output
             fields (137 u, 137 v, 137 scalars); stage times incl. the spectra_prepare kernel (extend_truncation + vd2uv + interleave)
-  C2vd      TL159 -> O160, nscalar 60 + nvordiv 60
+  C2vd      TL159 -> O160, nscalar 60 + nvordiv 60;  C4vdf32: C4vd in the fp32 variant
 """
 import argparse
 import json
@@ -38,6 +38,7 @@ CONFIGS = {
     "C4f32": ("O1280", 1279, 137, True, 10, 3),
     "C4vd": ("O1280", 1279, 137, False, 8, 2, 137),
     "C2vd": ("O160", 159, 60, False, 200, 20, 60),
+    "C4vdf32": ("O1280", 1279, 137, True, 8, 2, 137),
 }
 
 
@@ -63,8 +64,8 @@ def run(name, grid, T, nf, f32, steps, warmup, nvd=0):
     if f32:
         sp = sp.to(torch.float32)
     if nvd:
-        vor = torch.from_numpy(red_spectra(T, nvd, seed=2)).cuda()
-        div = torch.from_numpy(red_spectra(T, nvd, seed=3)).cuda()
+        vor = torch.from_numpy(red_spectra(T, nvd, seed=2)).cuda().to(dt_t)
+        div = torch.from_numpy(red_spectra(T, nvd, seed=3)).cuda().to(dt_t)
         call = lambda: tr.invtrans(ns, sp, nvd, vor, div, gp)
     else:
         call = lambda: tr.invtrans(nf, sp, gp)
@@ -120,7 +121,7 @@ def run(name, grid, T, nf, f32, steps, warmup, nvd=0):
     if nvd:
         prep_ms = tm["prepare_ms"] / max(tm["prepare_calls"], 1)
         ncoef = (T + 1) * (T + 2)
-        prep_bytes = (2 * nvd + ns) * ncoef * 8 + (2 * nvd + ns) * (T + 2) * (T + 3) * 8   # vor, div, sp read; merged spectra written
+        prep_bytes = (2 * nvd + ns) * ncoef * esz + (2 * nvd + ns) * (T + 2) * (T + 3) * esz   # vor, div, sp read; merged spectra written
         out["metric"] = f"inverse SH transforms/sec (T{T}, {grid}, nscalar {ns} + nvordiv {nvd})"
         out["value"] = steps * (nf / 137.0 if nf % 137 == 0 else 1.0) / dt
         out["config"]["workload"] = (f"TransLocal invtrans(nb_scalar={ns}, sp, nb_vordiv={nvd}, vor, div, gp) T{T} -> {grid}: {nf} output "
