@@ -250,7 +250,9 @@ private:
     size_t vd_cap_      = 0;
     void ensure(double*& ptr, size_t& cap, size_t n);
     // host-pointer pipeline (pinned staging)
-    void invtrans_host_pipelined(int nb_fields, const double* sp_host, double* gp_host);
+    void invtrans_host_pipelined(int nb_scalar, const double* sp_host, int nb_vordiv, const double* vor_host, const double* div_host,
+                                 double* gp_host);
+    void invtrans_scalars_extended_device(int nb_scalar, const double* sp_dev, double* gp_dev);
     double* hp_up_[2]   = {nullptr, nullptr};   // pinned: a chunk's spectra / grid points
     double* hp_down_[2] = {nullptr, nullptr};
     double* hp_dsp_[2]  = {nullptr, nullptr};   // device: the same

@@ -1214,7 +1214,7 @@ void Trans::invtrans(int nb_scalar_fields, const double scalar_spectra[], double
         pipe = atoi(e) != 0;
     }
     if (pipe && nb_scalar_fields >= 32 && ngp * sizeof(double) >= (size_t(256) << 20) && fourier_parts() == 1 && !windowed()) {
-        invtrans_host_pipelined(nb_scalar_fields, scalar_spectra, gp_fields);
+        invtrans_host_pipelined(nb_scalar_fields, scalar_spectra, 0, nullptr, nullptr, gp_fields);
         return;
     }
     ensure(d_sp_, sp_cap_, nsp);
@@ -1243,15 +1243,28 @@ void Trans::invtrans(int nb_scalar_fields, const double scalar_spectra[], double
 // of this pipeline: 376 ms against 179 serial); the runtime's own pageable path (blocking hipMemcpy from a second thread, 50 GB/s)
 // does not overlap the two directions at all (53 GB/s for both together against 97 from pinned memory: 180 ms, no gain).
 // ATLAS_AMD_HOST_CHUNK=<fields> (multiple of 8; default 16), ATLAS_AMD_HOST_THREADS=<n> (default 8).
-void Trans::invtrans_host_pipelined(int nf, const double* sp_host, double* gp_host) {
+void Trans::invtrans_host_pipelined(int nb_scalar, const double* sp_host, int nb_vordiv, const double* vor_host,
+                                    const double* div_host, double* gp_host) {
     const size_t ncoef = nb_spectral_coefficients();   // doubles per field
     const size_t npts  = (size_t)nb_gridpoints();
     int C = 16;
     if (const char* e = std::getenv("ATLAS_AMD_HOST_CHUNK")) {
         C = std::max(8, atoi(e) / 8 * 8);
     }
-    C = std::min(C, nf);
-    const int nchunks = (nf + C - 1) / C;
+    // the chunks: groups of C / 2 vor/div pairs (C output fields: u then v), then groups of C scalar fields; output field order
+    // of the call: [u 0 .. nvd) [v 0 .. nvd) [scalars] (TransLocal.cc:1555-1581)
+    struct Job {
+        bool vd;
+        int f0, n;
+    };
+    std::vector<Job> jobs;
+    for (int f0 = 0; f0 < nb_vordiv; f0 += C / 2) {
+        jobs.push_back(Job{true, f0, std::min(C / 2, nb_vordiv - f0)});
+    }
+    for (int f0 = 0; f0 < nb_scalar; f0 += C) {
+        jobs.push_back(Job{false, f0, std::min(C, nb_scalar - f0)});
+    }
+    const int nchunks = (int)jobs.size();
     if (!hp_up_stream_) {
         HIP_CHECK(hipStreamCreateWithFlags(&hp_up_stream_, hipStreamNonBlocking));
         HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
@@ -1280,27 +1293,38 @@ void Trans::invtrans_host_pipelined(int nf, const double* sp_host, double* gp_ho
             HIP_CHECK(hipMalloc((void**)&hp_dgp_[i], hp_down_cap_ * sizeof(double)));
         }
     }
-    (void)fourier_buffer(C);   // grown (with a synchronisation) before the pipeline starts, not inside it
+    // buffers the stages grow on demand (with a synchronisation): before the pipeline starts, not inside it
+    (void)fourier_buffer(C);
+    if (nb_vordiv > 0) {
+        ensure(d_all_, all_cap_, size_t(geo_.T + 2) * size_t(geo_.T + 3) * size_t(C));
+    }
     int device = 0;
     HIP_CHECK(hipGetDevice(&device));
     // ---- the download thread: chunk c leaves the device as soon as its transform has finished
     std::mutex mtx;
     std::condition_variable cv;
-    int enqueued = 0, downloaded = 0;   // chunks whose transform is enqueued (event recorded) / whose grid points have arrived
+    int enqueued = 0, downloaded = 0;   // chunks whose transform is enqueued (event recorded) / whose grid points have left the device
     bool abort = false;
     std::string thread_error;
     std::thread down([&]() {
         try {
             HIP_CHECK(hipSetDevice(device));
             auto drain = [&](int c) {   // pinned -> the caller's array, once the chunk's download has finished
-                const int f0 = c * C, n = std::min(C, nf - f0);
+                const Job& j = jobs[c];
                 HIP_CHECK(hipEventSynchronize(hp_down_done_[c & 1]));
                 {
                     std::lock_guard<std::mutex> lk(mtx);
                     downloaded = c + 1;      // the device buffer of chunk c is free
                 }
                 cv.notify_all();
-                bounded_copy(gp_host + (size_t)f0 * npts, hp_down_[c & 1], (size_t)n * npts * sizeof(double));
+                const size_t blk = (size_t)j.n * npts;
+                if (j.vd) {
+                    bounded_copy(gp_host + (size_t)j.f0 * npts, hp_down_[c & 1], blk * sizeof(double));
+                    bounded_copy(gp_host + (size_t)(nb_vordiv + j.f0) * npts, hp_down_[c & 1] + blk, blk * sizeof(double));
+                }
+                else {
+                    bounded_copy(gp_host + (size_t)(2 * nb_vordiv + j.f0) * npts, hp_down_[c & 1], blk * sizeof(double));
+                }
             };
             for (int c = 0; c < nchunks; ++c) {
                 {
@@ -1310,11 +1334,10 @@ void Trans::invtrans_host_pipelined(int nf, const double* sp_host, double* gp_ho
                         return;
                     }
                 }
-                const int n = std::min(C, nf - c * C);
+                const size_t out = (size_t)(jobs[c].vd ? 2 : 1) * jobs[c].n * npts;
                 // pinned buffer c & 1 was drained (chunk c - 2) in the previous iteration
                 HIP_CHECK(hipStreamWaitEvent(copy_stream_, hp_comp_done_[c & 1], 0));
-                HIP_CHECK(hipMemcpyAsync(hp_down_[c & 1], hp_dgp_[c & 1], (size_t)n * npts * sizeof(double), hipMemcpyDeviceToHost,
-                                         copy_stream_));
+                HIP_CHECK(hipMemcpyAsync(hp_down_[c & 1], hp_dgp_[c & 1], out * sizeof(double), hipMemcpyDeviceToHost, copy_stream_));
                 HIP_CHECK(hipEventRecord(hp_down_done_[c & 1], copy_stream_));
                 if (c >= 1) {
                     drain(c - 1);            // beside the download of chunk c
@@ -1332,15 +1355,23 @@ void Trans::invtrans_host_pipelined(int nf, const double* sp_host, double* gp_ho
     try {
         for (int c = 0; c < nchunks; ++c) {
             const int b  = c & 1;
-            const int f0 = c * C, n = std::min(C, nf - f0);
+            const Job& j = jobs[c];
             if (c >= 2) {
                 HIP_CHECK(hipEventSynchronize(hp_up_done_[b]));       // the upload out of this pinned buffer (chunk c-2) has finished
             }
-            gather_field_columns(hp_up_[b], sp_host, ncoef, nf, f0, n);
+            size_t up = (size_t)j.n * ncoef;
+            if (j.vd) {
+                gather_field_columns(hp_up_[b], vor_host, ncoef, nb_vordiv, j.f0, j.n);
+                gather_field_columns(hp_up_[b] + up, div_host, ncoef, nb_vordiv, j.f0, j.n);
+                up *= 2;
+            }
+            else {
+                gather_field_columns(hp_up_[b], sp_host, ncoef, nb_scalar, j.f0, j.n);
+            }
             if (c >= 2) {
                 HIP_CHECK(hipStreamWaitEvent(hp_up_stream_, hp_comp_done_[b], 0));   // chunk c-2 no longer reads this device buffer
             }
-            HIP_CHECK(hipMemcpyAsync(hp_dsp_[b], hp_up_[b], (size_t)n * ncoef * sizeof(double), hipMemcpyHostToDevice, hp_up_stream_));
+            HIP_CHECK(hipMemcpyAsync(hp_dsp_[b], hp_up_[b], up * sizeof(double), hipMemcpyHostToDevice, hp_up_stream_));
             HIP_CHECK(hipEventRecord(hp_up_done_[b], hp_up_stream_));
             if (c >= 2) {   // the grid points of chunk c-2 must have left device buffer b (the event below is re-recorded, too)
                 std::unique_lock<std::mutex> lk(mtx);
@@ -1350,7 +1381,19 @@ void Trans::invtrans_host_pipelined(int nf, const double* sp_host, double* gp_ho
                 }
             }
             HIP_CHECK(hipStreamWaitEvent(stream_, hp_up_done_[b], 0));
-            invtrans_uv_device(geo_.T, n, 0, hp_dsp_[b], hp_dgp_[b]);
+            if (j.vd) {
+                invtrans_device(0, nullptr, j.n, hp_dsp_[b], hp_dsp_[b] + (size_t)j.n * ncoef, hp_dgp_[b]);
+            }
+            else {
+                // inside a vor/div call the scalars are transformed at truncation T + 1 like the wind fields (TransLocal.cc:1590): the
+                // m = T wavenumber, dropped by the scalar-only call, survives -- keep that by going through the same entry point
+                if (nb_vordiv > 0) {
+                    invtrans_scalars_extended_device(j.n, hp_dsp_[b], hp_dgp_[b]);
+                }
+                else {
+                    invtrans_uv_device(geo_.T, j.n, 0, hp_dsp_[b], hp_dgp_[b]);
+                }
+            }
             HIP_CHECK(hipEventRecord(hp_comp_done_[b], stream_));
             {
                 std::lock_guard<std::mutex> lk(mtx);
@@ -1450,6 +1493,17 @@ void Trans::invtrans_device(int nb_scalar, const double* sp_dev, int nb_vordiv, 
     }
 }
 
+// the scalar fields of a vor/div call on their own: zero-extended to truncation T + 1 and transformed there, as inside the combined
+// call (TransLocal.cc:1496-1519,1590) -- same bits per field (the host pipeline transforms a call chunk by chunk)
+void Trans::invtrans_scalars_extended_device(int nb_scalar, const double* sp_dev, double* gp_dev) {
+    const int T = geo_.T;
+    ensure(d_all_, all_cap_, size_t(T + 2) * size_t(T + 3) * size_t(nb_scalar));
+    timed_begin(2);
+    HIP_CHECK(launch_spectra_prepare(nullptr, nullptr, sp_dev, d_all_, T, 0, nb_scalar, stream_));
+    timed_end();
+    invtrans_uv_device(T + 1, nb_scalar, 0, d_all_, gp_dev);
+}
+
 void Trans::invtrans(int nb_scalar, const double sp[], int nb_vordiv, const double vor[], const double div[],
                      double gp[]) {
     if (nb_vordiv <= 0) {
@@ -1461,6 +1515,16 @@ void Trans::invtrans(int nb_scalar, const double sp[], int nb_vordiv, const doub
     const size_t nvd   = ncoef * (size_t)nb_vordiv;
     const size_t nsp   = ncoef * (size_t)nb_scalar;
     const size_t ngp   = (size_t)nb_gridpoints() * (size_t)(2 * nb_vordiv + nb_scalar);
+    {   // large calls: the field-chunked full-duplex pipeline (invtrans_host_pipelined), as for the scalar call
+        bool pipe = true;
+        if (const char* e = std::getenv("ATLAS_AMD_HOST_PIPELINE")) {
+            pipe = atoi(e) != 0;
+        }
+        if (pipe && 2 * nb_vordiv + nb_scalar >= 32 && ngp * sizeof(double) >= (size_t(256) << 20) && fourier_parts() == 1 && !windowed()) {
+            invtrans_host_pipelined(nb_scalar, sp, nb_vordiv, vor, div, gp);
+            return;
+        }
+    }
     ensure(d_vd_, vd_cap_, 2 * nvd);
     ensure(d_sp_, sp_cap_, std::max<size_t>(nsp, 1));
     ensure(d_gp_, gp_cap_, ngp);

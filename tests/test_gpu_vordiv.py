@@ -180,3 +180,26 @@ def test_vordiv_fp32_full_size_every_fft_class():
         wind_tol = 2e-6 * max(1.0, min(10.0, 0.02 / math.cos(math.radians(float(g.y()[r])))))
         for kind, sl, tol in (("u", slice(0, 3), wind_tol), ("v", slice(3, 6), wind_tol), ("scalar", slice(6, 9), 2e-6)):
             assert compute_rms(got[sl], rr[sl]) < tol, (r, kind, tuple(tr.fft_row_classes()[r]), tol)
+
+
+def test_vordiv_host_pointer_pipeline_is_bitwise_equal_to_the_device_path(monkeypatch):
+    """atlas__Trans__invtrans with host arrays (TransInterface.h:74-79): large calls run as the full-duplex field-chunk pipeline
+    (csrc/trans.hip: invtrans_host_pipelined) -- groups of vor/div pairs, then groups of scalars, each transformed on its own
+    at truncation T + 1 as inside the combined call.  Same bits as the one-call device path and as the serial host path."""
+    T, ns, nvd = 639, 9, 17                              # 43 output fields x 1.66 M points x 8 B = 571 MB: above the threshold
+    g = atlas_amd.Grid("O640")
+    tr = atlas_amd.Trans(g, T)
+    sp, vor, div = red_spectra(T, ns, 51), red_spectra(T, nvd, 52), red_spectra(T, nvd, 53)
+    ref = vordiv_device(tr, ns, sp, nvd, vor, div).cpu().numpy()
+    for env in ({"ATLAS_AMD_HOST_PIPELINE": "0"}, {}, {"ATLAS_AMD_HOST_CHUNK": "8"}, {"ATLAS_AMD_HOST_CHUNK": "32"}):
+        for k2, v in env.items():
+            monkeypatch.setenv(k2, v)
+        for rep in range(2):
+            gp = np.full(ref.size, np.nan)
+            tr.invtrans(ns, sp, nvd, vor, div, gp)
+            assert np.array_equal(gp, ref), (env, rep)
+        for k2 in env:
+            monkeypatch.delenv(k2)
+    w = np.full(2 * nvd * g.size(), np.nan)                # no scalars
+    tr.invtrans(0, None, nvd, vor, div, w)
+    assert np.array_equal(w, ref[:w.size])

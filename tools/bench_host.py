@@ -36,3 +36,22 @@ for pipe, chunk, threads in SWEEP:
           f"{nbytes / min(ts) / 1e9:.1f} GB/s over PCIe (1.8 GB up + 7.2 GB down), bitwise equal to the device path: "
           f"{np.array_equal(gp, ref)}", flush=True)
     del tr
+
+# the vor/div call shape (atlas__Trans__invtrans: nb_scalar + nb_vordiv, TransInterface.h:74-79) through host arrays
+if "--vordiv" in sys.argv:
+    ns = nvd = 137
+    vor, div = red_spectra(T, nvd, seed=2), red_spectra(T, nvd, seed=3)
+    nb = sp.nbytes + vor.nbytes + div.nbytes + (ns + 2 * nvd) * g.size() * 8
+    for pipe in ("0", "1"):
+        os.environ.update({"ATLAS_AMD_HOST_PIPELINE": pipe, "ATLAS_AMD_HOST_CHUNK": "16", "ATLAS_AMD_HOST_THREADS": "8"})
+        tr = atlas_amd.Trans(g, T)
+        gpv = np.zeros((ns + 2 * nvd) * g.size())
+        tr.invtrans(ns, sp, nvd, vor, div, gpv)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            tr.invtrans(ns, sp, nvd, vor, div, gpv)
+            ts.append(time.perf_counter() - t0)
+        print(f"vor/div call, nscalar 137 + nvordiv 137 (411 output fields), ATLAS_AMD_HOST_PIPELINE={pipe}: {min(ts) * 1e3:.1f} ms "
+              f"({sorted(round(t * 1e3, 1) for t in ts)}), {nb / min(ts) / 1e9:.1f} GB/s over PCIe (5.4 GB up + 21.7 GB down)", flush=True)
+        del tr
