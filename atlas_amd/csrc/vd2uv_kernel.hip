@@ -33,6 +33,7 @@ struct PrepareParamsT {
     int T;
     int nvd;
     int ns;
+    int fshift;       // log2 of the threads that run over the fields (the launcher: smallest power of two >= the field count, at most 256)
 };
 
 __device__ __forceinline__ double dev_eps(int m, int n) {
@@ -48,56 +49,78 @@ __device__ __forceinline__ double dev_lap(int n) {
     return -kEarthRadius * kEarthRadius / (n * (n + 1.));
 }
 
+// One workgroup per (m, chunk of PREP_NB total wavenumbers n); the three factors of a coefficient (m, n) -- chi, psi-, psi+: two square
+// roots and five divisions in fp64 -- are the same for every field: computed once per (m, n) into LDS, then the fields (fastest index
+// of input and output: coalesced) stream through.  Round 4's form computed them per ELEMENT, with an integer division by the field
+// count on top: 3.76 ms for 137 + 137 + 137 fields at TL1279 (0.36 of HBM) -- see profiles/r05_configs.jsonl for the figure now.
+constexpr int PREP_NB = 32;
 template <class Real>
 __global__ void __launch_bounds__(256) spectra_prepare_kernel(PrepareParamsT<Real> p) {
+    __shared__ double s_chi[PREP_NB], s_psiM[PREP_NB], s_psiP[PREP_NB];
     const int m    = blockIdx.y;
     const int T    = p.T;
     const int TE   = T + 1;
     const int nall = 2 * p.nvd + p.ns;
-    const int len  = (TE - m + 1) * 2 * nall;  // (n - m, imag, fld) for this m
+    const int nn   = TE - m + 1;               // total wavenumbers n = m .. TE of this m
     const long long obase = (long long)(2 * TE + 3 - m) * m / 2 * 2 * nall;
     const long long ibase = (long long)(2 * T + 3 - m) * m / 2 * 2;  // x nf of the respective input
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < len; e += gridDim.x * blockDim.x) {
-        const int fld  = e % nall;
-        const int rest = e / nall;
-        const int imag = rest & 1;
-        const int n    = m + (rest >> 1);
-        double v       = 0.;
-        if (fld >= 2 * p.nvd) {
-            // scalar field, zero-extended (TransLocal.cc:1507-1513)
-            const int f = fld - 2 * p.nvd;
-            if (n <= T && m <= T) {
-                v = p.sp[(ibase + 2 * (n - m) + imag) * p.ns + f];
-            }
+    for (int n0 = blockIdx.x * PREP_NB; n0 < nn; n0 += gridDim.x * PREP_NB) {
+        __syncthreads();
+        if (threadIdx.x < PREP_NB && n0 + (int)threadIdx.x < nn) {
+            const int n         = m + n0 + threadIdx.x;
+            s_chi[threadIdx.x]  = m * dev_lap(n);
+            s_psiM[threadIdx.x] = (n - 1) * dev_eps(m, n) * dev_lap(n - 1);
+            s_psiP[threadIdx.x] = (n + 2) * dev_eps(m, n + 1) * dev_lap(n + 1);
         }
-        else if (m <= T || n <= T) {
-            const bool isV = fld >= p.nvd;
-            const int f    = isV ? fld - p.nvd : fld;
-            auto get = [&](const Real* a, int nn, int im) -> double {
-                if (nn < m || nn > T || m > T) {
-                    return 0.;
+        __syncthreads();
+        const int cnt = nn - n0 < PREP_NB ? nn - n0 : PREP_NB;
+        // threads: the low fshift bits run over the fields, the others over the (n, imag) rows of the chunk (few fields: several rows
+        // at once; more than 256 fields: one row at a time, the fields in strides of 256)
+        const int fstep = 1 << p.fshift;
+        for (int rr = threadIdx.x >> p.fshift; rr < 2 * cnt; rr += (int)blockDim.x >> p.fshift) {
+            const int k       = rr >> 1;
+            const int imag    = rr & 1;
+            const int n       = m + n0 + k;
+            const double chi  = s_chi[k];
+            const double psiM = s_psiM[k];
+            const double psiP = s_psiP[k];
+            Real* out         = p.out + obase + (long long)(2 * (n - m) + imag) * nall;
+            for (int fld = threadIdx.x & (fstep - 1); fld < nall; fld += fstep) {
+                double v = 0.;
+                if (fld >= 2 * p.nvd) {
+                    // scalar field, zero-extended (TransLocal.cc:1507-1513)
+                    const int f = fld - 2 * p.nvd;
+                    if (n <= T && m <= T) {
+                        v = p.sp[(ibase + 2 * (n - m) + imag) * p.ns + f];
+                    }
                 }
-                return (double)a[(ibase + 2 * (nn - m) + im) * p.nvd + f];
-            };
-            const double chi  = m * dev_lap(n);
-            const double psiM = (n - 1) * dev_eps(m, n) * dev_lap(n - 1);
-            const double psiP = (n + 2) * dev_eps(m, n + 1) * dev_lap(n + 1);
-            const Real* A     = isV ? p.div : p.vor;  // the field the psi terms act on
-            const Real* B     = isV ? p.vor : p.div;  // the field the chi term acts on
-            const double sg   = isV ? -1. : 1.;
-            double r;
-            if (m == 0) {
-                r = imag ? 0. : sg * (psiM * get(A, n - 1, 0) - psiP * get(A, n + 1, 0));
+                else if (m <= T || n <= T) {
+                    const bool isV = fld >= p.nvd;
+                    const int f    = isV ? fld - p.nvd : fld;
+                    auto get = [&](const Real* a, int nn_, int im) -> double {
+                        if (nn_ < m || nn_ > T || m > T) {
+                            return 0.;
+                        }
+                        return (double)a[(ibase + 2 * (nn_ - m) + im) * p.nvd + f];
+                    };
+                    const Real* A   = isV ? p.div : p.vor;  // the field the psi terms act on
+                    const Real* B   = isV ? p.vor : p.div;  // the field the chi term acts on
+                    const double sg = isV ? -1. : 1.;
+                    double r;
+                    if (m == 0) {
+                        r = imag ? 0. : sg * (psiM * get(A, n - 1, 0) - psiP * get(A, n + 1, 0));
+                    }
+                    else if (imag == 0) {
+                        r = -chi * get(B, n, 1) + sg * (psiM * get(A, n - 1, 0) - psiP * get(A, n + 1, 0));
+                    }
+                    else {
+                        r = +chi * get(B, n, 0) + sg * (psiM * get(A, n - 1, 1) - psiP * get(A, n + 1, 1));
+                    }
+                    v = r * (1. / kEarthRadius);
+                }
+                out[fld] = (Real)v;
             }
-            else if (imag == 0) {
-                r = -chi * get(B, n, 1) + sg * (psiM * get(A, n - 1, 0) - psiP * get(A, n + 1, 0));
-            }
-            else {
-                r = +chi * get(B, n, 0) + sg * (psiM * get(A, n - 1, 1) - psiP * get(A, n + 1, 1));
-            }
-            v = r * (1. / kEarthRadius);
         }
-        p.out[obase + e] = (Real)v;
     }
 }
 
@@ -174,13 +197,12 @@ hipError_t launch_convert_f64_f32(const double* src, float* dst, size_t n, hipSt
 template <class Real>
 static hipError_t launch_spectra_prepare_t(const Real* vor, const Real* div, const Real* sp, Real* out, int T, int nvd, int ns,
                                            hipStream_t stream) {
-    PrepareParamsT<Real> p{vor, div, sp, out, T, nvd, ns};
-    const int nall = 2 * nvd + ns;
-    const int len0 = (T + 2) * 2 * nall;
-    dim3 grid((len0 + 255) / 256, T + 2);
-    if (grid.x > 64) {
-        grid.x = 64;
+    int fshift = 0;
+    while ((1 << fshift) < 2 * nvd + ns && fshift < 8) {
+        ++fshift;
     }
+    PrepareParamsT<Real> p{vor, div, sp, out, T, nvd, ns, fshift};
+    dim3 grid((T + 2 + PREP_NB - 1) / PREP_NB, T + 2);   // (chunks of total wavenumbers of m = 0, zonal wavenumbers 0 .. T + 1)
     hipLaunchKernelGGL(spectra_prepare_kernel<Real>, grid, dim3(256), 0, stream, p);
     return hipGetLastError();
 }
