@@ -34,6 +34,7 @@ struct PrepareParamsT {
     int nvd;
     int ns;
     int fshift;       // log2 of the threads that run over the fields (the launcher: smallest power of two >= the field count, at most 256)
+    int nb;           // total wavenumbers per workgroup chunk, <= PREP_NB
 };
 
 __device__ __forceinline__ double dev_eps(int m, int n) {
@@ -64,16 +65,17 @@ __global__ void __launch_bounds__(256) spectra_prepare_kernel(PrepareParamsT<Rea
     const int nn   = TE - m + 1;               // total wavenumbers n = m .. TE of this m
     const long long obase = (long long)(2 * TE + 3 - m) * m / 2 * 2 * nall;
     const long long ibase = (long long)(2 * T + 3 - m) * m / 2 * 2;  // x nf of the respective input
-    for (int n0 = blockIdx.x * PREP_NB; n0 < nn; n0 += gridDim.x * PREP_NB) {
+    const int NB = p.nb;   // total wavenumbers per chunk (<= PREP_NB; fewer for small truncations: enough workgroups to fill the device)
+    for (int n0 = blockIdx.x * NB; n0 < nn; n0 += gridDim.x * NB) {
         __syncthreads();
-        if (threadIdx.x < PREP_NB && n0 + (int)threadIdx.x < nn) {
+        if ((int)threadIdx.x < NB && n0 + (int)threadIdx.x < nn) {
             const int n         = m + n0 + threadIdx.x;
             s_chi[threadIdx.x]  = m * dev_lap(n);
             s_psiM[threadIdx.x] = (n - 1) * dev_eps(m, n) * dev_lap(n - 1);
             s_psiP[threadIdx.x] = (n + 2) * dev_eps(m, n + 1) * dev_lap(n + 1);
         }
         __syncthreads();
-        const int cnt = nn - n0 < PREP_NB ? nn - n0 : PREP_NB;
+        const int cnt = nn - n0 < NB ? nn - n0 : NB;
         // threads: the low fshift bits run over the fields, the others over the (n, imag) rows of the chunk (few fields: several rows
         // at once; more than 256 fields: one row at a time, the fields in strides of 256)
         const int fstep = 1 << p.fshift;
@@ -201,8 +203,10 @@ static hipError_t launch_spectra_prepare_t(const Real* vor, const Real* div, con
     while ((1 << fshift) < 2 * nvd + ns && fshift < 8) {
         ++fshift;
     }
-    PrepareParamsT<Real> p{vor, div, sp, out, T, nvd, ns, fshift};
-    dim3 grid((T + 2 + PREP_NB - 1) / PREP_NB, T + 2);   // (chunks of total wavenumbers of m = 0, zonal wavenumbers 0 .. T + 1)
+    const long long total_n = (long long)(T + 2) * (T + 3) / 2;
+    const int nb            = (int)std::max<long long>(2, std::min<long long>(PREP_NB, total_n / 4096));
+    PrepareParamsT<Real> p{vor, div, sp, out, T, nvd, ns, fshift, nb};
+    dim3 grid((T + 2 + nb - 1) / nb, T + 2);   // (chunks of total wavenumbers of m = 0, zonal wavenumbers 0 .. T + 1)
     hipLaunchKernelGGL(spectra_prepare_kernel<Real>, grid, dim3(256), 0, stream, p);
     return hipGetLastError();
 }
