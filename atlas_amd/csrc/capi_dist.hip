@@ -236,6 +236,14 @@ int atlas_amd__Trans__pack_probe(atlas_amd_Trans* t, int nb_fields, int reps, do
     }
     DX_CATCH
 }
+int atlas_amd__Trans__fourier_packed_probe(atlas_amd_Trans* t, int nb_fields, int reps, double* ms) {
+    DX_TRY
+    if (!t || !t->impl || !ms || nb_fields < 1 || reps < 1) {
+        throw std::invalid_argument("fourier_packed_probe: bad arguments");
+    }
+    *ms = atlas_amd::trans::fourier_packed_probe(*t->impl, nb_fields, reps);
+    DX_CATCH
+}
 int atlas_amd__Trans__set_max_message_bytes(atlas_amd_Trans* t, atlas_amd_Comm* c, long long bytes) {
     DX_TRY
     if (bytes < 8) {

@@ -69,6 +69,8 @@ std::vector<TransposeMsg> packed_transpose_messages(const PackedTransposePlan& p
 
 // measurement aid: one rank's pack kernel alone on the device (ms per launch; bytes packed per launch)
 double pack_probe(Trans& trans, int nb_fields, int reps, int64_t* bytes);
+// ... and its Fourier stage as the distributed transform runs it (packed runs of P sources, per-row offsets), ms per stage
+double fourier_packed_probe(Trans& trans, int nb_fields, int reps);
 
 class DistributedTrans {
 public:

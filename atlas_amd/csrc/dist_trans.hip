@@ -229,6 +229,65 @@ double pack_probe(Trans& trans, int nb_fields, int reps, int64_t* bytes) {
     return ms / std::max(reps, 1);
 }
 
+// Measurement aid (tools/scaling_model.py): the Fourier stage of ONE rank of a P-rank transform as the distributed transform runs it
+// -- on the rank's latitude band, reading the P packed runs of the receive buffer through the per-row offsets and the piece table --
+// alone on the device.  The receive buffer holds zeros (the stage's time does not depend on the values).  ms per stage.
+double fourier_packed_probe(Trans& trans, int nb_fields, int reps) {
+    const TransGeometry& geo = trans.geometry();
+    std::vector<int> row_mmax(geo.nlats);
+    for (int j = 0; j < geo.nlats; ++j) {
+        const int jleg = j < geo.nlatsNH ? j : geo.nlats - 1 - j;
+        row_mmax[j]    = std::min(geo.mmax_leg[jleg], geo.T);
+    }
+    const int P = trans.nparts(), part = trans.part();
+    const PackedTransposePlan plan = make_packed_transpose_plan(row_mmax, 2 * nb_fields, trans.bands(), P, part);
+    const int b0 = trans.bands()[part], b1 = trans.bands()[part + 1];
+    const int rows = std::max(b1 - b0, 1);
+    std::vector<long long> dst((size_t)P * rows, 0);
+    for (int p = 0; p < P; ++p) {
+        for (int r = 0; r < b1 - b0; ++r) {
+            dst[(size_t)p * rows + r] = plan.rowoff[p][b0 + r] - plan.rowoff[p][b0];
+        }
+    }
+    double *Rbuf = nullptr, *gp = nullptr;
+    long long* d_dst = nullptr;
+    const size_t nR  = (size_t)std::max<int64_t>(plan.out_total, 1);
+    const size_t ngp = (size_t)std::max<int64_t>((int64_t)nb_fields * trans.nb_gridpoints(), 1);
+    HIP_CHECK(hipMalloc((void**)&Rbuf, nR * sizeof(double)));
+    HIP_CHECK(hipMalloc((void**)&gp, ngp * sizeof(double)));
+    HIP_CHECK(hipMalloc((void**)&d_dst, dst.size() * sizeof(long long)));
+    HIP_CHECK(hipMemset(Rbuf, 0, nR * sizeof(double)));
+    HIP_CHECK(hipMemcpy(d_dst, dst.data(), dst.size() * sizeof(long long), hipMemcpyHostToDevice));
+    std::vector<const double*> base(P);
+    std::vector<const long long*> rowoff(P);
+    for (int p = 0; p < P; ++p) {
+        base[p]   = Rbuf + plan.out_offsets[p];
+        rowoff[p] = d_dst + (size_t)p * rows;
+    }
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    float ms = 0;
+    for (int pass = 0; pass < 2; ++pass) {   // pass 0: warm-up
+        const int n = pass ? reps : 3;
+        HIP_CHECK(hipEventRecord(e0, trans.stream()));
+        for (int i = 0; i < n; ++i) {
+            trans.fourier_device_packed(nb_fields, 0, base.data(), rowoff.data(), plan.cols, gp);
+        }
+        HIP_CHECK(hipEventRecord(e1, trans.stream()));
+        HIP_CHECK(hipEventSynchronize(e1));
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    trans.synchronize();
+    trans.clear_fourier_parts_cache();   // keyed by the buffers freed below
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(Rbuf);
+    (void)hipFree(gp);
+    (void)hipFree(d_dst);
+    return ms / std::max(reps, 1);
+}
+
 DistributedTrans::DistributedTrans(Trans& trans, parallel::Comm& comm) : trans_(trans), comm_(comm) {
     if (trans.nparts() != comm.size() || trans.part() != comm.rank()) {
         throw std::invalid_argument("DistributedTrans: the Trans must be made with (nparts, part) = (comm size, comm rank)");

@@ -37,6 +37,7 @@ Trans_invtrans_distributed_sharded = _sig("atlas_amd__Trans__invtrans_distribute
                                           c_int, c_void_p, c_void_p)
 Trans_spectral_shard = _sig("atlas_amd__Trans__spectral_shard", c_int, c_void_p, c_void_p, c_void_p)
 Trans_pack_probe = _sig("atlas_amd__Trans__pack_probe", c_int, c_void_p, c_int, c_int, c_void_p, c_void_p)
+Trans_fourier_packed_probe = _sig("atlas_amd__Trans__fourier_packed_probe", c_int, c_void_p, c_int, c_int, c_void_p)
 Trans_set_max_message_bytes = _sig("atlas_amd__Trans__set_max_message_bytes", c_int, c_void_p, c_void_p, C.c_longlong)
 _transpose_messages = _sig("atlas_amd__transpose_messages", c_int, c_int, c_int, c_int, c_int, c_void_p, C.c_longlong,
                            c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p)

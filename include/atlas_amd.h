@@ -428,6 +428,9 @@ int atlas_amd__Trans__invtrans_distributed_many_halo(atlas_amd_Trans* t, atlas_a
 /* measurement aid (tools/scaling_model.py): the pack kernel of this rank of a wavenumber-sharded Trans (nparts, part, shard=m), alone on
  * the device: ms per launch and bytes packed per launch.  No communicator involved. */
 int atlas_amd__Trans__pack_probe(atlas_amd_Trans* t, int nb_fields, int reps, double* ms, long long* bytes);
+/* ... and the rank's Fourier stage as the distributed transform runs it: on its latitude band, reading the packed runs of all
+ * `nparts` sources (zeros) through per-row offsets and the piece table; ms per stage */
+int atlas_amd__Trans__fourier_packed_probe(atlas_amd_Trans* t, int nb_fields, int reps, double* ms);
 /* largest message of the transposition (default 512 MiB).  COLLECTIVE over `comm`: every rank calls it, with the same value -- both
  * ends of a pair cut their runs alike; the ranks compare the value inside the call (a mismatch is an error on every rank); takes effect
  * at the next transform. */

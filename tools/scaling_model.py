@@ -5,8 +5,9 @@
 For P = 2, 4, 8 and EVERY rank p of P, alone on the device (the rank's own share, nothing beside it):
   * Legendre stage of the wavenumbers m % P == p              (Trans(nparts=P, part=p, shard="m").legendre_device, HIP events)
   * pack kernel of that rank's intermediate                   (atlas_amd__Trans__pack_probe: kept wavenumbers x 2 nf columns)
-  * Fourier stage of latitude band p                          (Trans(nparts=P, part=p, shard="band"), HIP events; the transposed
-                                                               transform runs the same kernels on the band, reading packed runs)
+  * Fourier stage of latitude band p as the transposed transform runs it: modes read from the P packed runs of the receive buffer
+                                                              (atlas_amd__Trans__fourier_packed_probe; beside it the same rows from
+                                                               a rank-local intermediate, Trans(shard="band"): `fourier_band_ms`)
 and from the library's own message plan (host code, no device): bytes every pair exchanges.  The model of the pipelined call
 (csrc/dist_trans.hip: L(i+1) and F(i-1) on the Trans stream beside pack + exchange of i on the communication stream):
     ms per transform = max( max_p L_p + max_p F_p ,  max_p pack_p + X )        X = largest pair message / link rate
@@ -33,7 +34,7 @@ def measure_rank(g, sp, P, part, reps=25):
     import torch
     import atlas_amd
     from atlas_amd import _lib
-    from atlas_amd.dist import Trans_pack_probe
+    from atlas_amd.dist import Trans_fourier_packed_probe, Trans_pack_probe
     out = {"part": part}
     # Legendre stage, m-sharded
     tr = atlas_amd.Trans(g, T, profile=True, nparts=P, part=part, shard="m")
@@ -54,6 +55,10 @@ def measure_rank(g, sp, P, part, reps=25):
     _lib.check(Trans_pack_probe(tr._h, NF, 10, C.byref(ms), C.byref(nbytes)))
     out["pack_ms"], out["pack_bytes"] = ms.value, int(nbytes.value)
     out["pack_GBs_read_plus_write"] = 2 * nbytes.value / (ms.value * 1e-3) / 1e9 if ms.value > 0 else None
+    # the rank's Fourier stage as the distributed transform runs it: band rows, modes read from the P packed runs
+    fms = C.c_double(0.0)
+    _lib.check(Trans_fourier_packed_probe(tr._h, NF, reps, C.byref(fms)))
+    out["fourier_packed_ms"] = fms.value
     del tr, F
     torch.cuda.empty_cache()
     # Fourier stage of the rank's latitude band
@@ -68,7 +73,8 @@ def measure_rank(g, sp, P, part, reps=25):
         tb.invtrans(NF, sp, gp)
     torch.cuda.synchronize()
     tm = tb.timings()
-    out["fourier_ms"] = tm["fourier_ms"] / max(tm["fourier_calls"], 1)
+    out["fourier_band_ms"] = tm["fourier_ms"] / max(tm["fourier_calls"], 1)   # the same rows from a rank-local intermediate (mode "band")
+    out["fourier_ms"] = out["fourier_packed_ms"]
     out["band_points"] = int(tb.nb_gridpoints())
     del tb, gp
     torch.cuda.empty_cache()
