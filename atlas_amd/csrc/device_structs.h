@@ -99,6 +99,10 @@ struct FourierParams {
     const long long* part_rowoff0;                 // packed form: offset (doubles) of every local row inside the piece; else unused
     int part_cnt0;
     int packed_cols;                               // packed form: doubles per (row, wavenumber) = 2 * nb_fields; 0: classic layout
+    const long long* packed_rowbase;               // packed form, optional: [local row][nparts] offset (doubles, relative to part_base0) of
+                                                   // the row's run inside piece `part` -- ONE table read per mode instead of the piece
+                                                   // table's base + row-offset pointer + row offset (three dependent reads) [r5]
+    int parts_shift;                               // log2(nparts) if nparts is a power of two (m -> piece, index by shift / mask), else -1
     const FourierParts* parts;                     // [nparts > 1] all pieces
     int nparts;
     int lat0;                         // first row of the local latitude band

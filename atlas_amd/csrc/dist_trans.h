@@ -131,6 +131,8 @@ private:
     std::vector<TransposeMsg> msgs_;
     long long* d_rowoff_src_ = nullptr;   // [nlats + 1]: rowoff of this rank as a source (pack kernel)
     long long* d_rowoff_dst_ = nullptr;   // [nparts][rows of my band]: row offsets inside each received run (Fourier kernels)
+    long long* d_rowbase_    = nullptr;   // [rows of my band][nparts]: the same combined with the runs' offsets inside R: one read per mode [r5]
+    bool use_rowbase_        = true;      // ATLAS_AMD_DIST_ROWBASE=0: the piece-table walk (A/B)
     int* d_kept_             = nullptr;   // [nlats]: kept(part, lat)
     Slot slot_[2];
 };

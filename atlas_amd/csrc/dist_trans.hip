@@ -264,6 +264,17 @@ double fourier_packed_probe(Trans& trans, int nb_fields, int reps) {
         base[p]   = Rbuf + plan.out_offsets[p];
         rowoff[p] = d_dst + (size_t)p * rows;
     }
+    std::vector<long long> rowbase((size_t)rows * P, 0);
+    for (int r = 0; r < b1 - b0; ++r) {
+        for (int p = 0; p < P; ++p) {
+            rowbase[(size_t)r * P + p] = (plan.out_offsets[p] - plan.out_offsets[0]) + dst[(size_t)p * rows + r];
+        }
+    }
+    long long* d_rowbase = nullptr;
+    HIP_CHECK(hipMalloc((void**)&d_rowbase, rowbase.size() * sizeof(long long)));
+    HIP_CHECK(hipMemcpy(d_rowbase, rowbase.data(), rowbase.size() * sizeof(long long), hipMemcpyHostToDevice));
+    const char* rb_env    = std::getenv("ATLAS_AMD_DIST_ROWBASE");
+    const bool use_rowbase = !(rb_env && atoi(rb_env) == 0);
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0));
     HIP_CHECK(hipEventCreate(&e1));
@@ -272,7 +283,7 @@ double fourier_packed_probe(Trans& trans, int nb_fields, int reps) {
         const int n = pass ? reps : 3;
         HIP_CHECK(hipEventRecord(e0, trans.stream()));
         for (int i = 0; i < n; ++i) {
-            trans.fourier_device_packed(nb_fields, 0, base.data(), rowoff.data(), plan.cols, gp);
+            trans.fourier_device_packed(nb_fields, 0, base.data(), rowoff.data(), plan.cols, gp, use_rowbase ? d_rowbase : nullptr);
         }
         HIP_CHECK(hipEventRecord(e1, trans.stream()));
         HIP_CHECK(hipEventSynchronize(e1));
@@ -285,6 +296,7 @@ double fourier_packed_probe(Trans& trans, int nb_fields, int reps) {
     (void)hipFree(Rbuf);
     (void)hipFree(gp);
     (void)hipFree(d_dst);
+    (void)hipFree(d_rowbase);
     return ms / std::max(reps, 1);
 }
 
@@ -297,6 +309,9 @@ DistributedTrans::DistributedTrans(Trans& trans, parallel::Comm& comm) : trans_(
     }
     if (const char* e = std::getenv("ATLAS_AMD_DIST_POISON")) {
         poison_ = atoi(e) != 0;
+    }
+    if (const char* e = std::getenv("ATLAS_AMD_DIST_ROWBASE")) {   // A/B: 0 = the piece-table walk of round 3
+        use_rowbase_ = atoi(e) != 0;
     }
     HIP_CHECK(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));
     for (Slot& s : slot_) {
@@ -326,6 +341,7 @@ DistributedTrans::~DistributedTrans() {
     (void)hipStreamDestroy(comm_stream_);
     (void)hipFree(d_rowoff_src_);
     (void)hipFree(d_rowoff_dst_);
+    (void)hipFree(d_rowbase_);
     (void)hipFree(d_kept_);
 }
 
@@ -392,11 +408,21 @@ void DistributedTrans::ensure(int nb_fields) {
                 dst[(size_t)p * (b1 - b0) + r] = pplan_.rowoff[p][b0 + r] - pplan_.rowoff[p][b0];
             }
         }
+        // [local row][source rank]: where the row's run of that source starts, relative to the run of source 0 (all P runs live in one
+        // receive buffer): what the Fourier kernels read once per mode
+        std::vector<long long> rowbase((size_t)std::max(b1 - b0, 1) * P, 0);
+        for (int r = 0; r < b1 - b0; ++r) {
+            for (int p = 0; p < P; ++p) {
+                rowbase[(size_t)r * P + p] = (pplan_.out_offsets[p] - pplan_.out_offsets[0]) + dst[(size_t)p * (b1 - b0) + r];
+            }
+        }
         if (!d_rowoff_src_) {
             HIP_CHECK(hipMalloc((void**)&d_rowoff_src_, src.size() * sizeof(long long)));
             HIP_CHECK(hipMalloc((void**)&d_rowoff_dst_, dst.size() * sizeof(long long)));
+            HIP_CHECK(hipMalloc((void**)&d_rowbase_, rowbase.size() * sizeof(long long)));
             HIP_CHECK(hipMalloc((void**)&d_kept_, kept.size() * sizeof(int)));
         }
+        HIP_CHECK(hipMemcpy(d_rowbase_, rowbase.data(), rowbase.size() * sizeof(long long), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(d_rowoff_src_, src.data(), src.size() * sizeof(long long), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(d_rowoff_dst_, dst.data(), dst.size() * sizeof(long long), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(d_kept_, kept.data(), kept.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -508,7 +534,7 @@ void DistributedTrans::fourier(int nb_fields, Slot& s, double* gp_dev) {
         base[p]   = s.R + pplan_.out_offsets[p];
         rowoff[p] = d_rowoff_dst_ + (size_t)p * rows;
     }
-    trans_.fourier_device_packed(nb_fields, 0, base.data(), rowoff.data(), pplan_.cols, gp_dev);
+    trans_.fourier_device_packed(nb_fields, 0, base.data(), rowoff.data(), pplan_.cols, gp_dev, use_rowbase_ ? d_rowbase_ : nullptr);
     HIP_CHECK(hipEventRecord(s.fourier_done, trans_.stream()));
     s.used = true;
 }

@@ -116,8 +116,29 @@ struct ModeReaderT {
         glong_ptr ro     = (glong_ptr)(uintptr_t)p.part_rowoff0;
         int cnt          = p.part_cnt0;
         int ml           = m;
+        if (p.packed_rowbase) {   // packed runs with the combined row table (the distributed transform): one table read per mode
+            int part = 0;
+            if (p.nparts > 1) {
+                if (p.parts_shift >= 0) {
+                    ml   = m >> p.parts_shift;
+                    part = m & (p.nparts - 1);
+                }
+                else {
+                    ml   = m / p.nparts;
+                    part = m - ml * p.nparts;
+                }
+            }
+            glong_ptr rb = (glong_ptr)(uintptr_t)p.packed_rowbase;
+            o = rb[lat_local * p.nparts + part] + (long long)__umul24((unsigned)ml, (unsigned)p.packed_cols) + f2;
+            return base;
+        }
         if (p.nparts > 1) {   // the piece of wavenumber m: a (cached) table lookup per lane
-            ml             = m / p.nparts;
+            if (p.parts_shift >= 0) {
+                ml = m >> p.parts_shift;
+            }
+            else {
+                ml = m / p.nparts;
+            }
             const int part = m - ml * p.nparts;
             const FourierParts* tb = p.parts;
             uintptr_t b    = (uintptr_t)tb->base[part];

@@ -108,8 +108,11 @@ public:
     void fourier_device(int nb_fields, int nb_vordiv, const double* const* part_base, const int* part_cnt,
                         double* gp_dev);
     // packed pieces (dist_trans.h: PackedTransposePlan): part_rowoff_dev[i][r] = offset in doubles of local row r inside piece i
+    // rowbase_dev (optional): [local row][nparts] = (part_base[i] - part_base[0]) + part_rowoff_dev[i][r], the combined table the
+    // kernels read once per mode instead of walking the piece table
     void fourier_device_packed(int nb_fields, int nb_vordiv, const double* const* part_base,
-                               const long long* const* part_rowoff_dev, int cols, double* gp_dev);
+                               const long long* const* part_rowoff_dev, int cols, double* gp_dev,
+                               const long long* rowbase_dev = nullptr);
     size_t fourier_doubles(int nb_fields) const;  // local Fourier intermediate: nlats * owned m * RP
     int fourier_row_pitch(int nb_fields) const;   // RP = 16*ceil(2*nb_fields/16)
     double* fourier_buffer(int nb_fields);        // scratch intermediate owned by the object (grown on demand)
@@ -151,7 +154,8 @@ private:
                          bool sharded_input = false);
     void fourier_fields(int nb_fields, int nb_vordiv, const double* const* part_base, const int* part_cnt,
                         double* gp_dev, int f_begin, int f_end, hipStream_t stream, bool f32 = false,
-                        const long long* const* part_rowoff_dev = nullptr, int packed_cols = 0);
+                        const long long* const* part_rowoff_dev = nullptr, int packed_cols = 0,
+                        const long long* packed_rowbase_dev = nullptr);
     void timed_end();
 
     TransGeometry geo_;

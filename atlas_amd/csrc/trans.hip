@@ -794,11 +794,12 @@ void Trans::fourier_device(int nb_fields, int nb_vordiv, const double* const* pa
 }
 
 void Trans::fourier_device_packed(int nb_fields, int nb_vordiv, const double* const* part_base,
-                                  const long long* const* part_rowoff_dev, int cols, double* gp_dev) {
+                                  const long long* const* part_rowoff_dev, int cols, double* gp_dev,
+                                  const long long* rowbase_dev) {
     if (!part_rowoff_dev || cols != 2 * nb_fields) {
         throw std::invalid_argument("fourier_device_packed: row offsets / cols == 2 * nb_fields");
     }
-    fourier_fields(nb_fields, nb_vordiv, part_base, nullptr, gp_dev, 0, nb_fields, stream_, false, part_rowoff_dev, cols);
+    fourier_fields(nb_fields, nb_vordiv, part_base, nullptr, gp_dev, 0, nb_fields, stream_, false, part_rowoff_dev, cols, rowbase_dev);
 }
 
 // device copy of a piece table: the callers alternate between a few buffer sets (dist_trans.h slots), so a handful of tables
@@ -838,7 +839,7 @@ const FourierParts* Trans::device_parts(const FourierParts& hp) {
 
 void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* part_base, const int* part_cnt,
                            double* gp_dev, int f_begin, int f_end, hipStream_t stream, bool f32,
-                           const long long* const* part_rowoff_dev, int packed_cols) {
+                           const long long* const* part_rowoff_dev, int packed_cols, const long long* packed_rowbase_dev) {
     if (nb_fields <= 0 || f_end <= f_begin) {
         return;
     }
@@ -855,7 +856,14 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
     p.part_rowoff0 = hp.rowoff[0];
     p.parts        = fourier_parts() > 1 ? device_parts(hp) : nullptr;
     p.packed_cols = part_rowoff_dev ? packed_cols : 0;
+    p.packed_rowbase  = part_rowoff_dev ? packed_rowbase_dev : nullptr;
     p.nparts          = fourier_parts();
+    p.parts_shift     = -1;
+    for (int s = 0; s < 8; ++s) {
+        if ((1 << s) == p.nparts) {
+            p.parts_shift = s;
+        }
+    }
     p.lat0            = band_begin();
     p.gp              = gp_dev;
     if (windowed()) {
