@@ -157,6 +157,18 @@ std::vector<TransposeMsg> packed_transpose_messages(const PackedTransposePlan& p
     return msgs;
 }
 
+// Doubles per packed (row, wavenumber) record.  The live columns are 2 nf; padded to the intermediate's own pitch (a multiple of 16
+// doubles = 128 bytes) every record starts on a line boundary and the 16-byte pieces of 8 neighbouring fields share ONE line, as in
+// the single-device layout -- with 2 nf = 274 a field group's 128 bytes straddle two lines for most wavenumbers and the gather of
+// the Fourier rows, which is bound by line fills, pays for it.  ATLAS_AMD_DIST_PACK_PAD=0: unpadded records (5 % fewer bytes on the wire).
+static int packed_cols_for(const Trans& trans, int nb_fields) {
+    bool pad = true;
+    if (const char* e = std::getenv("ATLAS_AMD_DIST_PACK_PAD")) {
+        pad = atoi(e) != 0;
+    }
+    return pad ? trans.fourier_row_pitch(nb_fields) : 2 * nb_fields;
+}
+
 // S[rowoff[lat] + ml * cols + c] = F[(lat * cnt + ml) * RP + c]: one workgroup per row, 16-byte pieces (cols, RP and the
 // row offsets are even)
 __global__ void __launch_bounds__(256) pack_rows_kernel(const double* __restrict__ F, double* __restrict__ S,
@@ -187,7 +199,7 @@ double pack_probe(Trans& trans, int nb_fields, int reps, int64_t* bytes) {
         row_mmax[j]    = std::min(geo.mmax_leg[jleg], geo.T);
     }
     const int RP = trans.fourier_row_pitch(nb_fields);
-    const PackedTransposePlan plan = make_packed_transpose_plan(row_mmax, 2 * nb_fields, trans.bands(), trans.nparts(), trans.part());
+    const PackedTransposePlan plan = make_packed_transpose_plan(row_mmax, packed_cols_for(trans, nb_fields), trans.bands(), trans.nparts(), trans.part());
     std::vector<long long> src(plan.rowoff[trans.part()].begin(), plan.rowoff[trans.part()].end());
     std::vector<int> kept(geo.nlats);
     for (int j = 0; j < geo.nlats; ++j) {
@@ -240,7 +252,7 @@ double fourier_packed_probe(Trans& trans, int nb_fields, int reps) {
         row_mmax[j]    = std::min(geo.mmax_leg[jleg], geo.T);
     }
     const int P = trans.nparts(), part = trans.part();
-    const PackedTransposePlan plan = make_packed_transpose_plan(row_mmax, 2 * nb_fields, trans.bands(), P, part);
+    const PackedTransposePlan plan = make_packed_transpose_plan(row_mmax, packed_cols_for(trans, nb_fields), trans.bands(), P, part);
     const int b0 = trans.bands()[part], b1 = trans.bands()[part + 1];
     const int rows = std::max(b1 - b0, 1);
     std::vector<long long> dst((size_t)P * rows, 0);
@@ -390,7 +402,7 @@ void DistributedTrans::ensure(int nb_fields) {
             row_mmax[j]    = std::min(geo.mmax_leg[jleg], geo.T);
         }
         RP_    = trans_.fourier_row_pitch(nb_fields);
-        pplan_ = make_packed_transpose_plan(row_mmax, 2 * nb_fields, trans_.bands(), trans_.nparts(), trans_.part());
+        pplan_ = make_packed_transpose_plan(row_mmax, packed_cols_for(trans_, nb_fields), trans_.bands(), trans_.nparts(), trans_.part());
         // device copies of the offsets: source side (pack kernel), destination side (Fourier kernels).  Their sizes do not
         // depend on the field count: allocated once, rewritten in place (both streams are idle here), so that the pointers the
         // Fourier stage's piece table is keyed by stay the same for every field count (a caller alternating between

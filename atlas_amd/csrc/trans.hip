@@ -796,8 +796,8 @@ void Trans::fourier_device(int nb_fields, int nb_vordiv, const double* const* pa
 void Trans::fourier_device_packed(int nb_fields, int nb_vordiv, const double* const* part_base,
                                   const long long* const* part_rowoff_dev, int cols, double* gp_dev,
                                   const long long* rowbase_dev) {
-    if (!part_rowoff_dev || cols != 2 * nb_fields) {
-        throw std::invalid_argument("fourier_device_packed: row offsets / cols == 2 * nb_fields");
+    if (!part_rowoff_dev || (cols != 2 * nb_fields && cols != fourier_row_pitch(nb_fields))) {
+        throw std::invalid_argument("fourier_device_packed: row offsets / cols == 2 * nb_fields or the intermediate's pitch");
     }
     fourier_fields(nb_fields, nb_vordiv, part_base, nullptr, gp_dev, 0, nb_fields, stream_, false, part_rowoff_dev, cols, rowbase_dev);
 }
