@@ -160,9 +160,11 @@ std::vector<TransposeMsg> packed_transpose_messages(const PackedTransposePlan& p
 // Doubles per packed (row, wavenumber) record.  The live columns are 2 nf; padded to the intermediate's own pitch (a multiple of 16
 // doubles = 128 bytes) every record starts on a line boundary and the 16-byte pieces of 8 neighbouring fields share ONE line, as in
 // the single-device layout -- with 2 nf = 274 a field group's 128 bytes straddle two lines for most wavenumbers and the gather of
-// the Fourier rows, which is bound by line fills, pays for it.  ATLAS_AMD_DIST_PACK_PAD=0: unpadded records (5 % fewer bytes on the wire).
+// the Fourier rows, which is bound by line fills, pays for it.  Measured per rank (tools/scaling_model.py, round 5): padded records take
+// 2 % off the Fourier stage at P = 2 (3.66 -> 3.58 ms), nothing at P = 8, and put 5 % more bytes on the wire -- where P = 2 and 4 are
+// bound: the default stays the unpadded record; ATLAS_AMD_DIST_PACK_PAD=1 pads.
 static int packed_cols_for(const Trans& trans, int nb_fields) {
-    bool pad = true;
+    bool pad = false;
     if (const char* e = std::getenv("ATLAS_AMD_DIST_PACK_PAD")) {
         pad = atoi(e) != 0;
     }
