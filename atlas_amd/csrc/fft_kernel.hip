@@ -600,19 +600,29 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR, (dct_waves_per_simd<S, F32A>()))
         constexpr int NMIDS = SR::NS > 2 ? SR::NS - 2 : 0;
         C wmid[NMIDS > 0 ? NMIDS : 1];
         int mbase[NMIDS > 0 ? NMIDS : 1];
-        dct_for_each_mid<SR, 1>([&](auto ic) {
-            constexpr int I  = decltype(ic)::value;
-            constexpr int R  = SR::radix(I);
-            constexpr int L  = SR::L(I);
-            const int b      = tid < SR::M / R ? tid : 0;
-            int blk, j;
-            fft::split_index(b, L / R, SR::lsh(I), blk, j);
-            mbase[I - 1] = blk * L + j;
-            wmid[I - 1]  = r.tw[j * (SR::M / L)];
-        });
         constexpr int R0   = SR::radix(0);
         constexpr int Ls0  = SR::M / R0;
-        const C wlast      = r.tw[tid < Ls0 ? tid : 0];
+        // (first butterflies of 20 / 24 points in 16-byte elements -- h = 320, 384, 5120, 6144: F160, F192, F2560, F3072 -- fill the
+        // register file by themselves: there the later stages' twiddles are requested BEHIND the first butterfly; requested ahead of it
+        // they went to scratch, 16 - 62 spilled registers in the round-4 binary)
+        constexpr bool LATE_TW = RL * sizeof(C) >= 320;
+        C wlast{};
+        auto request_stage_twiddles = [&]() {
+            dct_for_each_mid<SR, 1>([&](auto ic) {
+                constexpr int I  = decltype(ic)::value;
+                constexpr int R  = SR::radix(I);
+                constexpr int L  = SR::L(I);
+                const int b      = tid < SR::M / R ? tid : 0;
+                int blk, j;
+                fft::split_index(b, L / R, SR::lsh(I), blk, j);
+                mbase[I - 1] = blk * L + j;
+                wmid[I - 1]  = r.tw[j * (SR::M / L)];
+            });
+            wlast = r.tw[tid < Ls0 ? tid : 0];
+        };
+        if constexpr (!LATE_TW) {
+            request_stage_twiddles();
+        }
         AA_SCHED_FENCE();
         __syncthreads();
         const int h = r.h;
@@ -637,6 +647,10 @@ __global__ void __launch_bounds__(FFT_MAX_NTHR, (dct_waves_per_simd<S, F32A>()))
             const int b = fft::dct_first_butterfly<S>(bp);
 #pragma unroll
             for (int q = 0; q < RL; ++q) work[fft::PAD(b * RL + q)] = x[q];
+        }
+        if constexpr (LATE_TW) {
+            AA_SCHED_FENCE();
+            request_stage_twiddles();
         }
         __syncthreads();
         if (prof) {
