@@ -301,6 +301,18 @@ public:
     void invtrans_device(int nb_scalar_fields, const float* scalar_spectra, float* gp_fields) const {
         detail::check(atlas_amd__Trans__invtrans_scalar_device_f32(h_, nb_scalar_fields, scalar_spectra, gp_fields));
     }
+    // the vor/div call of the fp32 variant [r5]
+    void invtrans_device(int nb_scalar_fields, const float* scalar_spectra, int nb_vordiv_fields, const float* vorticity_spectra,
+                         const float* divergence_spectra, float* gp_fields) const {
+        detail::check(atlas_amd__Trans__invtrans_device_f32(h_, nb_scalar_fields, scalar_spectra, nb_vordiv_fields,
+                                                            vorticity_spectra, divergence_spectra, gp_fields));
+    }
+    // HIP-event stage times (profile=1): {legendre_ms, legendre_calls, fourier_ms, fourier_calls}, and for vor/div calls the
+    // spectra_prepare stage {prepare_ms, prepare_calls}
+    void timings(double out[4], bool reset = false) const { detail::check(atlas_amd__Trans__timings(h_, out, reset ? 1 : 0)); }
+    void timings_vordiv(double out[2], bool reset = false) const {
+        detail::check(atlas_amd__Trans__timings_vordiv(h_, out, reset ? 1 : 0));
+    }
     // ---- not implemented by TransLocal: these throw NotImplemented ----
     void dirtrans(int nb_fields, const double scalar_fields[], double scalar_spectra[]) const {
         detail::check(atlas_amd__Trans__dirtrans_scalar(h_, nb_fields, scalar_fields, scalar_spectra));
