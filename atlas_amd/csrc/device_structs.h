@@ -119,6 +119,7 @@ struct FourierParams {
     int jobs;                         // tools/experiments/fft_kernel_p.hip only (field groups a workgroup walks through); 1
     int pf_dist;                      // L2 prefetch of the modes of the job 8 * pf_dist further on (same XCD); 0: off
     int pf_sectors;                   // requests per 128-byte line of that prefetch (1, 2 or 4)
+    int seq_ok;                       // experiments build: every row of this launch keeps at most 1280 wavenumbers (fft_ct_rows_seq.inc)
     int mid_rot;                      // row_ct3 rows with more than 256 middle butterflies: the wavefront that takes the second round rotates
                                       // with the job (0: always the first wavefront -- on the SIMD that holds the first wavefront of both jobs of a CU)
     int row_affinity;                 // FftRowDesc kernels: a row's field groups all on one XCD (fft_device.h: fft_unit_to_job)

@@ -746,6 +746,9 @@ static hipError_t launch_ct_t(FourierParams p, int lds_bytes, unsigned nblk, hip
     hipLaunchKernelGGL((fft_rows_ct_kernel<S, F32, FAST>), dim3(grid), dim3(S::NT), lds_bytes, stream, p);
     return hipGetLastError();
 }
+#if defined(ATLAS_AMD_EXPERIMENTS)
+#include "../../tools/experiments/fft_ct_rows_seq.inc"
+#endif
 // dev switch ATLAS_AMD_FFT_FAST_M=<M>,<M>,...: only these lengths take the row_ct3 form (A/B runs); unset: every shape that has it
 static bool ct3_enabled_for(int M) {
     static const char* e = std::getenv("ATLAS_AMD_FFT_FAST_M");
@@ -768,6 +771,13 @@ static hipError_t launch_ct(const FourierParams& p, int lds_bytes, unsigned nblk
         static const bool halfwin = std::getenv("ATLAS_AMD_FFT_HALFWIN") && atoi(std::getenv("ATLAS_AMD_FFT_HALFWIN")) != 0;
         if (halfwin && !p.f32) {   // LDS as a half-row window: three workgroups per CU (tools/experiments/fft_halfwin_rows.inc)
             return launch_cth<S>(p, nblk, stream);
+        }
+#endif
+#if defined(ATLAS_AMD_EXPERIMENTS)
+        // two jobs per workgroup in sequence, the second gather behind the first job's tail (tools/experiments/fft_ct_rows_seq.inc)
+        const char* sq = std::getenv("ATLAS_AMD_FFT_SEQ");
+        if (sq && atoi(sq) != 0 && !p.f32 && p.nparts <= 1 && !p.packed_cols && p.seq_ok) {
+            return launch_ct_seq<S>(p, lds_bytes, stream);
         }
 #endif
         if (ct3_enabled_for(S::M)) {

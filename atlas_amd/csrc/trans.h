@@ -205,6 +205,7 @@ private:
         int ct_f, ct_k;  // specialised kernel instance, or ct_k < 0
         bool direct;     // specialised instance is the direct (no Bluestein) kernel
         bool hybrid = false;  // dense-stage rows (fft_rows_hyb_kernel)
+        int max_mmax = -1;    // highest kept wavenumber of any row of the class (specialised Bluestein rows)
         bool coarse_fused = false;   // the coarse Bluestein classes 256 / 512 / 1024 of a small reduced grid in one launch
         int coarse_n[3]   = {0, 0, 0};   // ... rows of Bluestein length 1024 / 512 / 256 in the (sorted) list
         bool native = false;  // native mixed-radix rows (fft_rows_nat_kernel): d_desc holds FftNatDesc records

@@ -616,6 +616,7 @@ void Trans::upload() {
                 FftRowDesc& d             = desc[i];
                 d.row        = j;
                 d.mmax       = std::min(row_mmax[j], pl.h);
+                c.max_mmax   = std::max(c.max_mmax, d.mmax);
                 d.h          = pl.h;
                 d.n          = pl.n;
                 d.goff_rel   = (long long)(geo_.rowoff[j] - geo_.rowoff[band_begin()]);
@@ -970,6 +971,7 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
         p.coarse_n[0] = c.coarse_n[0];
         p.coarse_n[1] = c.coarse_n[1];
         p.coarse_n[2] = c.coarse_n[2];
+        p.seq_ok = c.max_mmax + 1 <= 1280 ? 1 : 0;
         p.desc  = c.native ? nullptr : (const FftRowDesc*)c.d_desc;
         p.ndesc = c.native ? (const FftNatDesc*)c.d_desc : nullptr;
         if (only_m && c.lds_bytes != fft::padded_size(only_m) * 16) {  // dev tool (tools/fft_phase_prof.py): one class

@@ -229,3 +229,17 @@ def test_native_mixed_radix_rows_at_full_size_one_row_pair_per_shape_class(monke
         assert err < 1e-12, (r, tuple(tr.fft_row_classes()[r]), err)
 
 
+
+
+def test_two_jobs_in_sequence_rows_are_bitwise_equal_to_the_product_rows(monkeypatch):
+    """[r5] tools/experiments/fft_ct_rows_seq.inc (ATLAS_AMD_FFT_SEQ=1): a workgroup transforms two fields of a row one after the
+    other, the second job's modes requested into registers behind the first job's last phases -- same arithmetic, same bits;
+    an odd number of field groups leaves the last workgroup of a row with one job"""
+    g = atlas_amd.Grid("O1280")
+    T, nf = 1279, 21                                   # three field groups: pairs (0, 1) and a single (2), the last group with 5 fields
+    tr = atlas_amd.Trans(g, T)
+    sp = red_spectra(T, nf, seed=97)
+    ref = run_device(tr, nf, sp)
+    monkeypatch.setenv("ATLAS_AMD_FFT_SEQ", "1")
+    got = run_device(atlas_amd.Trans(g, T), nf, sp)
+    assert np.array_equal(got, ref)
