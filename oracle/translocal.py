@@ -10,7 +10,7 @@ _SO = os.path.join(_HERE, "liboracle.so")
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("translocal_oracle.c", "halo_oracle.c")]
+    src = [os.path.join(_HERE, f) for f in ("translocal_oracle.c",)]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
