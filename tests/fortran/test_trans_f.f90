@@ -2,7 +2,8 @@
 ! bind(C), handles as type(c_ptr): src/atlas_f/trans/atlas_Trans_module.F90:156-177 for the constructor, the pointer calls of
 ! src/atlas/trans/detail/TransInterface.h:74-79 for the transforms).  Checks, as src/tests/trans/test_transgeneral.cc:829-839 does
 ! (rel-RMS 1e-13): unit spectral coefficients -> closed-form spherical harmonics on every point of F32 and O32; the IFS-style call
-! invtrans(nb_scalar, sp, nb_vordiv, vor, div, gp) on a solid-body rotation with a scalar beside it.
+! invtrans(nb_scalar, sp, nb_vordiv, vor, div, gp) on a solid-body rotation with a scalar beside it; atlas_HaloExchange's
+! setup / execute / execute_adjoint with the strides and extents atlas_f passes for field(nvar, nnodes).
 !   test_trans_f --host-only    sizes, grids, error reporting (no GPU)
 !   test_trans_f                + the transforms on the MI355X
 ! Built and run by tests/test_fortran_api.py (amdflang).
@@ -112,6 +113,40 @@ module atlas_amd_c_binding
       real(c_double), dimension(*) :: wind_fields
       integer(c_int) :: rc
     end function
+    function atlas_amd__HaloExchange__new() bind(C, name="atlas_amd__HaloExchange__new") result(hx)
+      import :: c_ptr
+      type(c_ptr) :: hx
+    end function
+    subroutine atlas_amd__HaloExchange__delete(hx) bind(C, name="atlas_amd__HaloExchange__delete")
+      import :: c_ptr
+      type(c_ptr), value :: hx
+    end subroutine
+    function atlas_amd__HaloExchange__setup(hx, part, remote_idx, base, parsize) &
+        & bind(C, name="atlas_amd__HaloExchange__setup") result(rc)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: hx
+      integer(c_int), dimension(*), intent(in) :: part, remote_idx
+      integer(c_int), value :: base, parsize
+      integer(c_int) :: rc
+    end function
+    function atlas_amd__HaloExchange__execute_strided_double(hx, field, var_strides, var_extents, var_rank) &
+        & bind(C, name="atlas_amd__HaloExchange__execute_strided_double") result(rc)
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: hx
+      real(c_double), dimension(*) :: field
+      integer(c_int), dimension(*), intent(in) :: var_strides, var_extents
+      integer(c_int), value :: var_rank
+      integer(c_int) :: rc
+    end function
+    function atlas_amd__HaloExchange__execute_adjoint_strided_double(hx, field, var_strides, var_extents, var_rank) &
+        & bind(C, name="atlas_amd__HaloExchange__execute_adjoint_strided_double") result(rc)
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: hx
+      real(c_double), dimension(*) :: field
+      integer(c_int), dimension(*), intent(in) :: var_strides, var_extents
+      integer(c_int), value :: var_rank
+      integer(c_int) :: rc
+    end function
   end interface
 contains
   function c_str(s) result(z)   ! null-terminated copy, as fckit's c_str
@@ -161,6 +196,9 @@ program test_trans_f
     before = failures
     call case_invtrans_vordiv_with_scalar()
     call report("invtrans_vordiv_with_scalar", before)
+    before = failures
+    call case_halo_exchange()
+    call report("halo_exchange", before)
   end if
   print '(i0,a)', failures, " failure(s)"
   if (failures /= 0) stop 1
@@ -375,6 +413,56 @@ contains
     call expect(err_w == 0, "invtrans_vordiv2wind gives the same winds")
     call atlas_amd__Trans__delete(trans)
     call atlas_amd__Grid__delete(grid)
+  end subroutine
+
+  ! atlas_HaloExchange as atlas_f drives it (src/atlas_f/parallel/atlas_HaloExchange_module.fypp:88-120): setup(part, remote_idx)
+  ! with base 1; execute on field(nvar, nnodes) with strides (stride of dim 2, stride of dim 1), extents (1, nvar), rank 2
+  ! (HaloExchange.cc:195-209 builds the shape [parsize, 1, nvar] from that).  One process: ghost nodes are duplicates of owned
+  ! nodes of the same process (periodic points).  The adjoint adds the halo values onto their owners and zeroes the halo.
+  subroutine case_halo_exchange()
+    integer, parameter :: nnodes = 12, nowned = 8, nvar = 3
+    integer(c_int) :: part(nnodes), remote_idx(nnodes), rc
+    real(c_double) :: field(nvar, nnodes), scalar(nnodes), expected(nvar, nnodes)
+    type(c_ptr) :: hx
+    integer :: i, v
+    part = 0
+    do i = 1, nnodes
+      remote_idx(i) = i
+    end do
+    remote_idx(nowned + 1:nnodes) = [3, 1, 8, 5]
+    hx = atlas_amd__HaloExchange__new()
+    call expect(c_associated(hx), "HaloExchange handle")
+    rc = atlas_amd__HaloExchange__setup(hx, part, remote_idx, 1_c_int, int(nnodes, c_int))
+    call expect(rc == 0, "HaloExchange setup")
+    do i = 1, nnodes
+      do v = 1, nvar
+        field(v, i) = merge(100._c_double * i + v, -1._c_double, i <= nowned)
+      end do
+      scalar(i) = merge(real(i, c_double), -1._c_double, i <= nowned)
+    end do
+    rc = atlas_amd__HaloExchange__execute_strided_double(hx, field, [int(nvar, c_int), 1_c_int], &
+      & [1_c_int, int(nvar, c_int)], 2_c_int)
+    call expect(rc == 0, "execute rank 2")
+    rc = atlas_amd__HaloExchange__execute_strided_double(hx, scalar, [1_c_int], [1_c_int], 1_c_int)
+    call expect(rc == 0, "execute rank 1")
+    do i = 1, nnodes
+      do v = 1, nvar
+        call expect(field(v, i) == 100._c_double * remote_idx(i) + v, "halo values of field(nvar, nnodes)")
+      end do
+      call expect(scalar(i) == real(remote_idx(i), c_double), "halo values of a scalar field")
+    end do
+    ! adjoint: owners collect their duplicates, halo zeroed (HaloExchange.h:227-306)
+    field = 1
+    expected = 1
+    expected(:, nowned + 1:nnodes) = 0
+    do i = nowned + 1, nnodes
+      expected(:, remote_idx(i)) = expected(:, remote_idx(i)) + 1
+    end do
+    rc = atlas_amd__HaloExchange__execute_adjoint_strided_double(hx, field, [int(nvar, c_int), 1_c_int], &
+      & [1_c_int, int(nvar, c_int)], 2_c_int)
+    call expect(rc == 0, "execute_adjoint rank 2")
+    call expect(all(field == expected), "adjoint: owners collect, halo zeroed")
+    call atlas_amd__HaloExchange__delete(hx)
   end subroutine
 
 end program test_trans_f

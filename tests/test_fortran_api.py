@@ -2,7 +2,8 @@
 atlas_f binds atlas__Trans__* (src/atlas_f/trans/atlas_Trans_module.F90:156-177; TransInterface.h:74-79), is compiled with
 amdflang against the shared library and run -- sizes, grids and error reporting on CPU; on the GPU the analytic spherical
 harmonics at 1e-13 (src/tests/trans/test_transgeneral.cc:829-839) on F32 and O32 and the IFS-style call
-invtrans(nb_scalar, sp, nb_vordiv, vor, div, gp) on a solid-body rotation."""
+invtrans(nb_scalar, sp, nb_vordiv, vor, div, gp) on a solid-body rotation, and atlas_HaloExchange's setup / execute /
+execute_adjoint with atlas_f's strides and extents (src/atlas_f/parallel/atlas_HaloExchange_module.fypp:88-120)."""
 import os
 import shutil
 import subprocess
@@ -46,5 +47,5 @@ def test_fortran_binding_host_cases(fortran_binary):
 def test_fortran_caller_on_device(fortran_binary):
     out = _run(fortran_binary)
     assert "0 failure(s)" in out, out
-    for case in ("invtrans_analytic_F32", "invtrans_analytic_O32", "invtrans_vordiv_with_scalar"):
+    for case in ("invtrans_analytic_F32", "invtrans_analytic_O32", "invtrans_vordiv_with_scalar", "halo_exchange"):
         assert f"ok     {case}" in out
