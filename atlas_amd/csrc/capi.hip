@@ -29,6 +29,9 @@ thread_local std::string g_last_note;    // diagnostics that are not errors (e.g
 thread_local std::string g_last_error;
 void set_last_error(const std::string& s) {
     g_last_error = s;
+    // a HIP call that failed inside the library leaves the runtime's per-thread "last error" set; the launch checks of the NEXT call
+    // (hipGetLastError behind a kernel launch) would report it as theirs.  The failure is reported here, once.
+    (void)hipGetLastError();
 }
 }  // namespace atlas_amd
 
