@@ -430,10 +430,18 @@ void atlas_amd__Trans__delete(atlas_amd_Trans* t) {
         delete t;
     }
 }
+// getters on a null handle (the reference: ATLAS_ASSERT(This != nullptr), TransInterface.cc:43-283): -1 and a message
+#define AA_NULL_HANDLE(t, what, ret)                                            \
+    if (!(t) || !(t)->impl) {                                                   \
+        atlas_amd::set_last_error(std::string(what) + ": null Trans handle");   \
+        return ret;                                                             \
+    }
 int atlas_amd__Trans__truncation(const atlas_amd_Trans* t) {
+    AA_NULL_HANDLE(t, "Trans::truncation", -1)
     return t->impl->truncation();
 }
 int64_t atlas_amd__Trans__nb_gridpoints(const atlas_amd_Trans* t) {
+    AA_NULL_HANDLE(t, "Trans::nb_gridpoints", -1)
     return t->impl->nb_gridpoints();
 }
 // ---------------------------------------------------------------- regional (non-nested) targets
@@ -537,63 +545,83 @@ int atlas_amd__Grid__crop_to_domain(const atlas_amd_Grid* grid, double west, dou
     AA_CATCH_INT
 }
 int64_t atlas_amd__Trans__nb_gridpoints_global(const atlas_amd_Trans* t) {
+    AA_NULL_HANDLE(t, "Trans::nb_gridpoints_global", -1)
     return t->impl->nb_gridpoints_global();
 }
 int64_t atlas_amd__Trans__nb_spectral_coefficients(const atlas_amd_Trans* t) {
+    AA_NULL_HANDLE(t, "Trans::nb_spectral_coefficients", -1)
     return (int64_t)t->impl->nb_spectral_coefficients();
 }
 
+// The reference asserts its arguments (ATLAS_ASSERT -> eckit::Exception); across a C ABI a null handle, a negative field count or a
+// missing array of a call that announces fields is an error code, not a crash.  Zero fields of a kind need no array of that kind.
+static atlas_amd::trans::Trans& checked_call(atlas_amd_Trans* t, const char* what, int nb_scalar, const void* sp, int nb_vordiv,
+                                             const void* vor, const void* div, const void* gp) {
+    if (!t || !t->impl) {
+        throw std::invalid_argument(std::string(what) + ": null Trans handle");
+    }
+    if (nb_scalar < 0 || nb_vordiv < 0) {
+        throw std::invalid_argument(std::string(what) + ": negative number of fields");
+    }
+    if ((nb_scalar > 0 && !sp) || (nb_vordiv > 0 && (!vor || !div)) || (nb_scalar + nb_vordiv > 0 && !gp)) {
+        throw std::invalid_argument(std::string(what) + ": null array for a call with " + std::to_string(nb_scalar) +
+                                    " scalar and " + std::to_string(nb_vordiv) + " vor/div fields");
+    }
+    return *t->impl;
+}
 int atlas_amd__Trans__invtrans_scalar(atlas_amd_Trans* t, int nb_fields, const double sp[], double gp[]) {
     AA_TRY
-    t->impl->invtrans(nb_fields, sp, gp);
+    checked_call(t, "invtrans_scalar", nb_fields, sp, 0, nullptr, nullptr, gp).invtrans(nb_fields, sp, gp);
     AA_CATCH_INT
 }
 int atlas_amd__Trans__invtrans_scalar_device(atlas_amd_Trans* t, int nb_fields, const double* sp, double* gp) {
     AA_TRY
-    t->impl->invtrans_uv_device(t->impl->truncation(), nb_fields, 0, sp, gp);
+    auto& tr = checked_call(t, "invtrans_scalar_device", nb_fields, sp, 0, nullptr, nullptr, gp);
+    tr.invtrans_uv_device(tr.truncation(), nb_fields, 0, sp, gp);
     AA_CATCH_INT
 }
 int atlas_amd__Trans__invtrans(atlas_amd_Trans* t, int nb_scalar, const double sp[], int nb_vordiv,
                                const double vor[], const double div[], double gp[]) {
     AA_TRY
-    t->impl->invtrans(nb_scalar, sp, nb_vordiv, vor, div, gp);
+    checked_call(t, "invtrans", nb_scalar, sp, nb_vordiv, vor, div, gp).invtrans(nb_scalar, sp, nb_vordiv, vor, div, gp);
     AA_CATCH_INT
 }
 int atlas_amd__Trans__invtrans_device(atlas_amd_Trans* t, int nb_scalar, const double* sp, int nb_vordiv,
                                       const double* vor, const double* div, double* gp) {
     AA_TRY
-    t->impl->invtrans_device(nb_scalar, sp, nb_vordiv, vor, div, gp);
+    checked_call(t, "invtrans_device", nb_scalar, sp, nb_vordiv, vor, div, gp)
+        .invtrans_device(nb_scalar, sp, nb_vordiv, vor, div, gp);
     AA_CATCH_INT
 }
 int atlas_amd__Trans__invtrans_vordiv2wind(atlas_amd_Trans* t, int nb_fields, const double vor[],
                                            const double div[], double wind[]) {
     AA_TRY
     // TransLocal.cc:1486-1490: invtrans(0, nullptr, nb_vordiv, vor, div, gp)
-    t->impl->invtrans(0, nullptr, nb_fields, vor, div, wind);
+    checked_call(t, "invtrans_vordiv2wind", 0, nullptr, nb_fields, vor, div, wind).invtrans(0, nullptr, nb_fields, vor, div, wind);
     AA_CATCH_INT
 }
 int atlas_amd__Trans__invtrans_scalar_device_f32(atlas_amd_Trans* t, int nb_fields, const float* scalar_spectra,
                                                  float* gp_fields) {
     AA_TRY
-    t->impl->invtrans_scalar_device_f32(nb_fields, scalar_spectra, gp_fields);
+    checked_call(t, "invtrans_scalar_device_f32", nb_fields, scalar_spectra, 0, nullptr, nullptr, gp_fields)
+        .invtrans_scalar_device_f32(nb_fields, scalar_spectra, gp_fields);
     AA_CATCH_INT
 }
 int atlas_amd__Trans__invtrans_device_f32(atlas_amd_Trans* t, int nb_scalar_fields, const float* scalar_spectra_dev,
                                           int nb_vordiv_fields, const float* vorticity_spectra_dev,
                                           const float* divergence_spectra_dev, float* gp_fields_dev) {
     AA_TRY
-    if (!gp_fields_dev || (nb_scalar_fields > 0 && !scalar_spectra_dev) ||
-        (nb_vordiv_fields > 0 && (!vorticity_spectra_dev || !divergence_spectra_dev))) {
-        throw std::invalid_argument("invtrans_device_f32: null array");
-    }
-    t->impl->invtrans_device_f32(nb_scalar_fields, scalar_spectra_dev, nb_vordiv_fields, vorticity_spectra_dev,
-                                 divergence_spectra_dev, gp_fields_dev);
+    checked_call(t, "invtrans_device_f32", nb_scalar_fields, scalar_spectra_dev, nb_vordiv_fields, vorticity_spectra_dev,
+                 divergence_spectra_dev, gp_fields_dev)
+        .invtrans_device_f32(nb_scalar_fields, scalar_spectra_dev, nb_vordiv_fields, vorticity_spectra_dev, divergence_spectra_dev,
+                             gp_fields_dev);
     AA_CATCH_INT
 }
 int atlas_amd__Trans__invtrans_scalar_f32(atlas_amd_Trans* t, int nb_fields, const float scalar_spectra[],
                                           float gp_fields[]) {
     AA_TRY
-    t->impl->invtrans_scalar_f32(nb_fields, scalar_spectra, gp_fields);
+    checked_call(t, "invtrans_scalar_f32", nb_fields, scalar_spectra, 0, nullptr, nullptr, gp_fields)
+        .invtrans_scalar_f32(nb_fields, scalar_spectra, gp_fields);
     AA_CATCH_INT
 }
 static int not_implemented(const char* what) {
@@ -814,14 +842,17 @@ int atlas_amd__VorDivToUV__execute(int truncation, int nb_coeff, int nb_fields, 
 }
 
 void* atlas_amd__Trans__stream(atlas_amd_Trans* t) {
+    AA_NULL_HANDLE(t, "Trans::stream", nullptr)
     return (void*)t->impl->stream();
 }
 int atlas_amd__Trans__set_stream(atlas_amd_Trans* t, void* s) {
+    AA_NULL_HANDLE(t, "Trans::set_stream", 1)
     AA_TRY
     t->impl->set_stream((hipStream_t)s);
     AA_CATCH_INT
 }
 int atlas_amd__Trans__synchronize(atlas_amd_Trans* t) {
+    AA_NULL_HANDLE(t, "Trans::synchronize", 1)
     AA_TRY
     t->impl->synchronize();
     AA_CATCH_INT

@@ -37,8 +37,14 @@ namespace {
 int strided(atlas_amd_HaloExchange* h, int dtype, void* field, const int var_strides[], const int var_shape[],
             int var_rank, bool adjoint) {
     HX_TRY
+    if (!h) {
+        throw std::invalid_argument("HaloExchange::execute: null handle");
+    }
     if (var_rank < 0 || var_rank > 3) {
         throw std::invalid_argument("Rank not supported in halo exchange");
+    }
+    if (!field || (var_rank > 0 && (!var_strides || !var_shape))) {
+        throw std::invalid_argument("HaloExchange::execute: null array");
     }
     int shape[4];
     long long strides[4];
