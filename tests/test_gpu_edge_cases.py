@@ -99,3 +99,46 @@ def test_field_counts_around_the_column_chunk(nf):
     ref = oracle.OraclePlan(T, g.nx(), g.y()).invtrans(nf, sp, use_fft=False).reshape(nf, -1)
     worst = max(compute_rms(got[f], ref[f]) for f in range(nf))
     assert worst < TOL, worst
+
+
+def test_twenty_thousand_fields_in_one_call():
+    """far more fields than any launch dimension was sized for by the benchmark configurations (1370): 20 000 fields on O32 in one
+    call, seven distinct spectra repeated -- every copy equals the seven-field call bit for bit (fields are independent columns of
+    the two GEMMs, TransLocal.cc:1040-1070, and independent transforms of the FFT)"""
+    T, ndist, nf = 31, 7, 20000
+    g = atlas_amd.Grid("O32")
+    tr = atlas_amd.Trans(g, T)
+    base = red_spectra(T, ndist, seed=77).reshape(-1, ndist)
+    want = _device_field(tr, ndist, base.reshape(-1).copy(), g.size()).reshape(ndist, -1)
+    ref = oracle.OraclePlan(T, g.nx(), g.y()).invtrans(ndist, base.reshape(-1).copy(), use_fft=False).reshape(ndist, -1)
+    assert compute_rms(want, ref) < TOL
+    sp = torch.from_numpy(base).cuda()[:, torch.arange(nf, device="cuda") % ndist].contiguous()
+    gp = torch.full((nf * g.size(),), float("nan"), dtype=torch.float64, device="cuda")
+    tr.invtrans(nf, sp.view(-1), gp)
+    tr.synchronize()
+    gp = gp.view(nf, -1)
+    wd = torch.from_numpy(want).cuda()
+    for k in range(ndist):
+        assert bool((gp[k::ndist] == wd[k]).all()), k
+
+
+def test_creating_and_destroying_transforms_does_not_leak_device_memory():
+    g = atlas_amd.Grid("O64")
+    sp = torch.from_numpy(red_spectra(63, 3)).cuda()
+    gp = torch.zeros(3 * g.size(), dtype=torch.float64, device="cuda")
+
+    def cycle():
+        tr = atlas_amd.Trans(g, 63)
+        tr.invtrans(3, sp, gp)
+        tr.synchronize()
+        del tr
+
+    for _ in range(3):
+        cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(40):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < (8 << 20), (free0, free1)     # 40 objects of ~10 MB each would show
