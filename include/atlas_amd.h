@@ -8,7 +8,9 @@
  * Conventions
  *   - functions returning int return 0 on success, non-zero on error; atlas_amd__last_error() gives the message
  *     (the reference throws eckit::Exception through its extern "C" layer, TransInterface.cc:43-283; a C ABI
- *     cannot, so the adapter re-throws).
+ *     cannot, so the adapter re-throws).  What the reference asserts (ATLAS_ASSERT: null handles, negative field counts, an
+ *     array missing for a call that announces fields of its kind) is such an error here, never a crash; getters on a null
+ *     handle return -1 / NULL.  Zero fields of a kind need no array of that kind (TransLocal.cc:1486-1490 passes nullptr).
  *   - "_device" variants take device pointers and are asynchronous on the object's HIP stream;
  *     the others take host pointers and are synchronous.
  *   - layouts are exactly those of the reference (SURVEY.md section 8 "Layout cheat-sheet"):
