@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
+#include <string>
 
 #include "device_structs.h"
 
@@ -48,6 +50,25 @@ __device__ __forceinline__ double dev_lap(int n) {
         return 0.;
     }
     return -kEarthRadius * kEarthRadius / (n * (n + 1.));
+}
+
+// One coefficient of U (sg = +1: A = vor, B = div) or V (sg = -1: A = div, B = vor): b_other = B(n) of the OTHER complex part,
+// a_minus / a_plus = A(n - 1) / A(n + 1) of the same part.  Written with explicit roundings so that both kernels below (and any
+// field count, which selects between them) give the same bits.
+__device__ __forceinline__ double wind_coefficient(bool m_is_zero, int imag, double sg, double chi, double psiM, double psiP,
+                                                   double b_other, double a_minus, double a_plus) {
+    const double t = __dmul_rn(sg, __fma_rn(psiM, a_minus, -__dmul_rn(psiP, a_plus)));
+    double r;
+    if (m_is_zero) {
+        r = imag ? 0. : t;
+    }
+    else if (imag == 0) {
+        r = __fma_rn(-chi, b_other, t);
+    }
+    else {
+        r = __fma_rn(chi, b_other, t);
+    }
+    return __dmul_rn(r, 1. / kEarthRadius);
 }
 
 // One workgroup per (m, chunk of PREP_NB total wavenumbers n); the three factors of a coefficient (m, n) -- chi, psi-, psi+: two square
@@ -108,17 +129,8 @@ __global__ void __launch_bounds__(256) spectra_prepare_kernel(PrepareParamsT<Rea
                     const Real* A   = isV ? p.div : p.vor;  // the field the psi terms act on
                     const Real* B   = isV ? p.vor : p.div;  // the field the chi term acts on
                     const double sg = isV ? -1. : 1.;
-                    double r;
-                    if (m == 0) {
-                        r = imag ? 0. : sg * (psiM * get(A, n - 1, 0) - psiP * get(A, n + 1, 0));
-                    }
-                    else if (imag == 0) {
-                        r = -chi * get(B, n, 1) + sg * (psiM * get(A, n - 1, 0) - psiP * get(A, n + 1, 0));
-                    }
-                    else {
-                        r = +chi * get(B, n, 0) + sg * (psiM * get(A, n - 1, 1) - psiP * get(A, n + 1, 1));
-                    }
-                    v = r * (1. / kEarthRadius);
+                    v = wind_coefficient(m == 0, imag, sg, chi, psiM, psiP, m == 0 ? 0. : get(B, n, 1 - imag), get(A, n - 1, imag),
+                                         get(A, n + 1, imag));
                 }
                 out[fld] = (Real)v;
             }
@@ -196,6 +208,88 @@ hipError_t launch_convert_f64_f32(const double* src, float* dst, size_t n, hipSt
     return hipGetLastError();
 }
 
+// Streaming form for many vor/div fields [r5]: a lane owns a FIELD and walks the wavenumbers n of its sub-chunk upwards with
+// vor / div of n - 1, n, n + 1 (both complex parts) in registers -- every input value is requested once per sub-chunk (the form above
+// requests it three times: as A(n - 1), B(n) and A(n + 1) of three output rows), and the four outputs of a step are four coalesced
+// stores.  One workgroup per (m, chunk of PREP_SNB total wavenumbers); wavefront w takes the w-th quarter of the chunk for every
+// group of 64 fields; the scalar fields are copied row by row as above.  Same arithmetic (wind_coefficient): same bits.
+constexpr int PREP_SNB = 64;
+template <class Real>
+__global__ void __launch_bounds__(256) spectra_prepare_stream_kernel(PrepareParamsT<Real> p) {
+    __shared__ double s_chi[PREP_SNB], s_psiM[PREP_SNB], s_psiP[PREP_SNB];
+    const int m    = blockIdx.y;
+    const int T    = p.T;
+    const int TE   = T + 1;
+    const int nvd  = p.nvd;
+    const int nall = 2 * nvd + p.ns;
+    const int nn   = TE - m + 1;               // total wavenumbers n = m .. TE of this m
+    const int n0   = blockIdx.x * PREP_SNB;    // first one of this chunk, as n - m
+    if (n0 >= nn) {
+        return;
+    }
+    const int cnt = nn - n0 < PREP_SNB ? nn - n0 : PREP_SNB;
+    if ((int)threadIdx.x < cnt) {
+        const int n         = m + n0 + threadIdx.x;
+        s_chi[threadIdx.x]  = m * dev_lap(n);
+        s_psiM[threadIdx.x] = (n - 1) * dev_eps(m, n) * dev_lap(n - 1);
+        s_psiP[threadIdx.x] = (n + 2) * dev_eps(m, n + 1) * dev_lap(n + 1);
+    }
+    __syncthreads();
+    const long long obase = (long long)(2 * TE + 3 - m) * m / 2 * 2 * nall;
+    const long long ibase = (long long)(2 * T + 3 - m) * m / 2 * 2;  // x nf of the respective input
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sl   = (cnt + 3) >> 2;
+    const int ka   = wave * sl;
+    const int kb   = ka + sl < cnt ? ka + sl : cnt;
+    const bool m_in = m <= T;
+    for (int f = lane; f < nvd && ka < kb; f += 64) {
+        const Real* __restrict__ vor = p.vor + f;
+        const Real* __restrict__ div = p.div + f;
+        // value (n, im) of a vor/div field; 0 outside m <= n <= T (the reference pads its work arrays)
+        auto ld = [&](const Real* a, int n, int im) -> double {
+            return (m_in && n >= m && n <= T) ? (double)a[(ibase + 2 * (n - m) + im) * nvd] : 0.;
+        };
+        int n = m + n0 + ka;
+        double vm[2] = {ld(vor, n - 1, 0), ld(vor, n - 1, 1)}, dm[2] = {ld(div, n - 1, 0), ld(div, n - 1, 1)};
+        double v0[2] = {ld(vor, n, 0), ld(vor, n, 1)}, d0[2] = {ld(div, n, 0), ld(div, n, 1)};
+        Real* __restrict__ o = p.out + obase + (long long)(2 * (n - m)) * nall + f;
+        for (int k = ka; k < kb; ++k, ++n, o += 2 * nall) {
+            const double vp[2] = {ld(vor, n + 1, 0), ld(vor, n + 1, 1)}, dp[2] = {ld(div, n + 1, 0), ld(div, n + 1, 1)};
+            const double chi = s_chi[k], psiM = s_psiM[k], psiP = s_psiP[k];
+#pragma unroll
+            for (int imag = 0; imag < 2; ++imag) {
+                double u = 0., v = 0.;
+                if (m_in || n <= T) {
+                    u = wind_coefficient(m == 0, imag, 1., chi, psiM, psiP, m == 0 ? 0. : d0[1 - imag], vm[imag], vp[imag]);
+                    v = wind_coefficient(m == 0, imag, -1., chi, psiM, psiP, m == 0 ? 0. : v0[1 - imag], dm[imag], dp[imag]);
+                }
+                o[imag * nall]       = (Real)u;
+                o[imag * nall + nvd] = (Real)v;
+            }
+#pragma unroll
+            for (int im = 0; im < 2; ++im) {
+                vm[im] = v0[im];
+                dm[im] = d0[im];
+                v0[im] = vp[im];
+                d0[im] = dp[im];
+            }
+        }
+    }
+    // scalar fields, zero-extended (TransLocal.cc:1507-1513): rows (n, imag) over the wavefronts, fields over the lanes
+    if (p.ns > 0) {
+        for (int rr = wave; rr < 2 * cnt; rr += 4) {
+            const int n    = m + n0 + (rr >> 1);
+            const int imag = rr & 1;
+            Real* out      = p.out + obase + (long long)(2 * (n - m) + imag) * nall + 2 * nvd;
+            const bool in  = n <= T && m_in;
+            const Real* src = p.sp + (ibase + 2 * (n - m) + imag) * p.ns;
+            for (int f = lane; f < p.ns; f += 64) {
+                out[f] = in ? src[f] : (Real)0;
+            }
+        }
+    }
+}
+
 template <class Real>
 static hipError_t launch_spectra_prepare_t(const Real* vor, const Real* div, const Real* sp, Real* out, int T, int nvd, int ns,
                                            hipStream_t stream) {
@@ -206,6 +300,15 @@ static hipError_t launch_spectra_prepare_t(const Real* vor, const Real* div, con
     const long long total_n = (long long)(T + 2) * (T + 3) / 2;
     const int nb            = (int)std::max<long long>(2, std::min<long long>(PREP_NB, total_n / 4096));
     PrepareParamsT<Real> p{vor, div, sp, out, T, nvd, ns, fshift, nb};
+    // many vor/div fields and enough coefficients to fill the device with 64-wavenumber chunks: the streaming form (a lane per field);
+    // ATLAS_AMD_PREPARE=rows / stream forces one of the two (same bits either way: tests/test_gpu_vordiv.py)
+    const char* e     = std::getenv("ATLAS_AMD_PREPARE");
+    const bool stream_form = e && *e ? std::string(e) == "stream" : (nvd >= 48 && total_n >= 64 * 2048);
+    if (stream_form) {
+        dim3 grid((T + 2 + PREP_SNB - 1) / PREP_SNB, T + 2);
+        hipLaunchKernelGGL(spectra_prepare_stream_kernel<Real>, grid, dim3(256), 0, stream, p);
+        return hipGetLastError();
+    }
     dim3 grid((T + 2 + nb - 1) / nb, T + 2);   // (chunks of total wavenumbers of m = 0, zonal wavenumbers 0 .. T + 1)
     hipLaunchKernelGGL(spectra_prepare_kernel<Real>, grid, dim3(256), 0, stream, p);
     return hipGetLastError();

@@ -203,3 +203,27 @@ def test_vordiv_host_pointer_pipeline_is_bitwise_equal_to_the_device_path(monkey
     w = np.full(2 * nvd * g.size(), np.nan)                # no scalars
     tr.invtrans(0, None, nvd, vor, div, w)
     assert np.array_equal(w, ref[:w.size])
+
+
+@pytest.mark.parametrize("fp32", [False, True])
+def test_the_two_forms_of_the_spectral_preparation_give_the_same_bits(fp32, monkeypatch):
+    """csrc/vd2uv_kernel.hip: spectra_prepare_kernel (threads over the elements of a row: few fields, small truncations) and
+    spectra_prepare_stream_kernel (a lane per field walking the wavenumbers: the 137 + 137-field calls at T >= 511) share their
+    arithmetic; which one runs depends on the field count, so a field's result must not depend on it.  64- and 65-field calls: full and
+    one-lane groups of the streaming form; T = 159 has chunk ends inside and at the end of the 64-wavenumber chunks."""
+    g = atlas_amd.Grid("O160")
+    T = 159
+    tr = atlas_amd.Trans(g, T)
+    dt = torch.float32 if fp32 else torch.float64
+    for ns, nvd in ((3, 64), (0, 65), (70, 5)):
+        sp, vor, div = red_spectra(T, max(ns, 1), 1), red_spectra(T, nvd, 2), red_spectra(T, nvd, 3)
+        got = {}
+        for form in ("rows", "stream"):
+            monkeypatch.setenv("ATLAS_AMD_PREPARE", form)
+            gp = torch.full(((ns + 2 * nvd) * g.size(),), float("nan"), dtype=dt, device="cuda")
+            tr.invtrans(ns, dev(sp).to(dt) if ns else None, nvd, dev(vor).to(dt), dev(div).to(dt), gp)
+            tr.synchronize()
+            got[form] = gp
+        assert bool(torch.isfinite(got["rows"]).all())
+        assert torch.equal(got["rows"], got["stream"]), (ns, nvd)
+    monkeypatch.delenv("ATLAS_AMD_PREPARE")
