@@ -208,15 +208,22 @@ hipError_t launch_convert_f64_f32(const double* src, float* dst, size_t n, hipSt
     return hipGetLastError();
 }
 
-// Streaming form for many vor/div fields [r5]: a lane owns a FIELD and walks the wavenumbers n of its sub-chunk upwards with
-// vor / div of n - 1, n, n + 1 (both complex parts) in registers -- every input value is requested once per sub-chunk (the form above
-// requests it three times: as A(n - 1), B(n) and A(n + 1) of three output rows), and the four outputs of a step are four coalesced
-// stores.  One workgroup per (m, chunk of PREP_SNB total wavenumbers); wavefront w takes the w-th quarter of the chunk for every
-// group of 64 fields; the scalar fields are copied row by row as above.  Same arithmetic (wind_coefficient): same bits.
-constexpr int PREP_SNB = 64;
+// Streaming form for many vor/div fields [r5]: a lane owns a FIELD and walks the wavenumbers n of its chunk upwards with vor / div of
+// n - 1, n, n + 1 (both complex parts) in registers and those of n + 2 on their way -- every input value is requested once per chunk
+// (the form above requests it three times: as A(n - 1), B(n) and A(n + 1) of three output rows), and the four outputs of a step are
+// four coalesced stores.  One workgroup per (m, chunk of PREP_SNB total wavenumbers); the groups of 64 fields of a row go to
+// different wavefronts (see below); the scalar fields are copied row by row.  Same arithmetic (wind_coefficient): same bits.
+// TL1279, 137 + 137 + 137 fields, ms (fp64 | fp32; profiles/r05_prepare_ab.txt): row form 3.2 - 3.45 | 3.6; a wavefront taking the
+// groups one after the other, chunks of 64: 3.1 - 3.3 | 2.15; groups side by side: 2.8 | 1.6; chunks of 128 / 32 / 16 / 8:
+// 2.85 / 2.55 / 2.37 / 2.25 | 1.7 / 1.55 / 1.55 / 1.77.
+constexpr int PREP_SNB = 16;
 template <class Real>
 __global__ void __launch_bounds__(256) spectra_prepare_stream_kernel(PrepareParamsT<Real> p) {
     __shared__ double s_chi[PREP_SNB], s_psiM[PREP_SNB], s_psiP[PREP_SNB];
+    __shared__ int s_next_row;
+    if (threadIdx.x == 0) {
+        s_next_row = 0;
+    }
     const int m    = blockIdx.y;
     const int T    = p.T;
     const int TE   = T + 1;
@@ -238,11 +245,20 @@ __global__ void __launch_bounds__(256) spectra_prepare_stream_kernel(PreparePara
     const long long obase = (long long)(2 * TE + 3 - m) * m / 2 * 2 * nall;
     const long long ibase = (long long)(2 * T + 3 - m) * m / 2 * 2;  // x nf of the respective input
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int sl   = (cnt + 3) >> 2;
-    const int ka   = wave * sl;
-    const int kb   = ka + sl < cnt ? ka + sl : cnt;
     const bool m_in = m <= T;
-    for (int f = lane; f < nvd && ka < kb; f += 64) {
+    // tasks (group of 64 fields, sub-chunk of the wavenumbers): the groups of a row go to DIFFERENT wavefronts, which walk the chunk side
+    // by side -- the 128-byte lines at the seams of the groups are then touched by all their users within a few steps (one wavefront
+    // taking the groups one after the other re-fetches them, and writes the seam lines of the output twice, partially)
+    const int G    = (nvd + 63) >> 6;
+    const int nsub = G >= 4 ? 1 : 4 / G;       // 1 group: 4 sub-chunks, 2: 2, 3 and more: the whole chunk
+    const int sl   = (cnt + nsub - 1) / nsub;
+    for (int task = wave; task < G * nsub; task += 4) {
+        const int f  = (task % G) * 64 + lane;
+        const int ka = (task / G) * sl;
+        const int kb = ka + sl < cnt ? ka + sl : cnt;
+        if (f >= nvd || ka >= kb) {
+            continue;
+        }
         const Real* __restrict__ vor = p.vor + f;
         const Real* __restrict__ div = p.div + f;
         // value (n, im) of a vor/div field; 0 outside m <= n <= T (the reference pads its work arrays)
@@ -252,9 +268,12 @@ __global__ void __launch_bounds__(256) spectra_prepare_stream_kernel(PreparePara
         int n = m + n0 + ka;
         double vm[2] = {ld(vor, n - 1, 0), ld(vor, n - 1, 1)}, dm[2] = {ld(div, n - 1, 0), ld(div, n - 1, 1)};
         double v0[2] = {ld(vor, n, 0), ld(vor, n, 1)}, d0[2] = {ld(div, n, 0), ld(div, n, 1)};
+        double vp[2] = {ld(vor, n + 1, 0), ld(vor, n + 1, 1)}, dp[2] = {ld(div, n + 1, 0), ld(div, n + 1, 1)};
         Real* __restrict__ o = p.out + obase + (long long)(2 * (n - m)) * nall + f;
         for (int k = ka; k < kb; ++k, ++n, o += 2 * nall) {
-            const double vp[2] = {ld(vor, n + 1, 0), ld(vor, n + 1, 1)}, dp[2] = {ld(div, n + 1, 0), ld(div, n + 1, 1)};
+            // the values of n + 2 are requested a step before they are used (the step's own arithmetic waits for nothing new)
+            const int nq = k + 1 < kb ? n + 2 : -1;   // (the last step of the sub-chunk has nothing to request)
+            const double vq[2] = {ld(vor, nq, 0), ld(vor, nq, 1)}, dq[2] = {ld(div, nq, 0), ld(div, nq, 1)};
             const double chi = s_chi[k], psiM = s_psiM[k], psiP = s_psiP[k];
 #pragma unroll
             for (int imag = 0; imag < 2; ++imag) {
@@ -272,12 +291,23 @@ __global__ void __launch_bounds__(256) spectra_prepare_stream_kernel(PreparePara
                 dm[im] = d0[im];
                 v0[im] = vp[im];
                 d0[im] = dp[im];
+                vp[im] = vq[im];
+                dp[im] = dq[im];
             }
         }
     }
-    // scalar fields, zero-extended (TransLocal.cc:1507-1513): rows (n, imag) over the wavefronts, fields over the lanes
+    // scalar fields, zero-extended (TransLocal.cc:1507-1513): fields over the lanes, rows (n, imag) handed out to whichever wavefront
+    // is free (with three groups of wind fields the fourth wavefront starts here at once)
     if (p.ns > 0) {
-        for (int rr = wave; rr < 2 * cnt; rr += 4) {
+        for (;;) {
+            int rr = 0;
+            if (lane == 0) {
+                rr = atomicAdd(&s_next_row, 1);
+            }
+            rr = __builtin_amdgcn_readfirstlane(rr);
+            if (rr >= 2 * cnt) {
+                break;
+            }
             const int n    = m + n0 + (rr >> 1);
             const int imag = rr & 1;
             Real* out      = p.out + obase + (long long)(2 * (n - m) + imag) * nall + 2 * nvd;
@@ -300,10 +330,10 @@ static hipError_t launch_spectra_prepare_t(const Real* vor, const Real* div, con
     const long long total_n = (long long)(T + 2) * (T + 3) / 2;
     const int nb            = (int)std::max<long long>(2, std::min<long long>(PREP_NB, total_n / 4096));
     PrepareParamsT<Real> p{vor, div, sp, out, T, nvd, ns, fshift, nb};
-    // many vor/div fields and enough coefficients to fill the device with 64-wavenumber chunks: the streaming form (a lane per field);
+    // many vor/div fields and enough coefficients to fill the device with its chunks (T >= 255): the streaming form (a lane per field);
     // ATLAS_AMD_PREPARE=rows / stream forces one of the two (same bits either way: tests/test_gpu_vordiv.py)
     const char* e     = std::getenv("ATLAS_AMD_PREPARE");
-    const bool stream_form = e && *e ? std::string(e) == "stream" : (nvd >= 48 && total_n >= 64 * 2048);
+    const bool stream_form = e && *e ? std::string(e) == "stream" : (nvd >= 48 && total_n >= PREP_SNB * 2048);
     if (stream_form) {
         dim3 grid((T + 2 + PREP_SNB - 1) / PREP_SNB, T + 2);
         hipLaunchKernelGGL(spectra_prepare_stream_kernel<Real>, grid, dim3(256), 0, stream, p);
