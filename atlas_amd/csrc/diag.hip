@@ -148,6 +148,40 @@ static int diag_mfma_rate(void (*kernel)(double*, int), double cycles_per_mfma, 
 extern "C" int atlas_amd__diag_mfma_f64_rate(double target_ms, int repeats, double* tflops_out) {
     return diag_mfma_rate(atlas_amd::diag::mfma_f64_rate_kernel, 64.0, "diag_mfma_f64_rate", target_ms, repeats, tflops_out);
 }
+namespace atlas_amd {
+namespace trans {
+hipError_t launch_gp_to_field(const double* gp, double* field, long long npts, int nf, hipStream_t stream);
+}
+}  // namespace atlas_amd
+// average milliseconds of the [nf][npts] -> [npts][nf] transposition of the distributed transform's halo path (csrc/vd2uv_kernel.hip)
+extern "C" int atlas_amd__diag_gp_to_field(const double* gp_dev, double* field_dev, long long npts, int nb_fields, int repeats,
+                                            double* ms_out) {
+    try {
+        if (!gp_dev || !field_dev || !ms_out || repeats < 1) {
+            throw std::invalid_argument("diag_gp_to_field: null argument");
+        }
+        hipEvent_t e0, e1;
+        DG_CHECK(hipEventCreate(&e0));
+        DG_CHECK(hipEventCreate(&e1));
+        DG_CHECK(atlas_amd::trans::launch_gp_to_field(gp_dev, field_dev, npts, nb_fields, nullptr));
+        DG_CHECK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < repeats; ++i) {
+            DG_CHECK(atlas_amd::trans::launch_gp_to_field(gp_dev, field_dev, npts, nb_fields, nullptr));
+        }
+        DG_CHECK(hipEventRecord(e1, nullptr));
+        DG_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        DG_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        *ms_out = (double)ms / repeats;
+        DG_CHECK(hipEventDestroy(e0));
+        DG_CHECK(hipEventDestroy(e1));
+        return 0;
+    }
+    catch (const std::exception& e) {
+        atlas_amd::set_last_error(e.what());
+        return 1;
+    }
+}
 extern "C" int atlas_amd__diag_mfma_f32_rate(double target_ms, int repeats, double* tflops_out) {
     return diag_mfma_rate(atlas_amd::diag::mfma_f32_rate_kernel, 32.0, "diag_mfma_f32_rate", target_ms, repeats, tflops_out);
 }

@@ -395,12 +395,52 @@ __global__ void __launch_bounds__(256) gp_to_field_kernel(const double* __restri
     }
 }
 
+// The same transposition with whole output rows per workgroup [r5]: 64 points x ALL fields, the fields in blocks of 64 through a
+// [64][65] LDS tile -- a wavefront reads 512 contiguous bytes of one field and writes 512 contiguous bytes of one point, and the
+// 64 x nf doubles a workgroup writes are ONE contiguous range of `field`, its 512-byte pieces written within a few iterations of
+// each other.  (The 32 x 32 tiles above write 256-byte pieces of rows whose neighbours belong to workgroups scheduled far away:
+// with rows of 137 doubles = 1096 bytes nearly every 128-byte line is written in two parts, at two times.)
+__global__ void __launch_bounds__(256) gp_to_field_rows_kernel(const double* __restrict__ gp, double* __restrict__ field, long long npts,
+                                                               int nf) {
+    __shared__ double tile[64][65];
+    const long long p0 = (long long)blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int np = npts - p0 < 64 ? (int)(npts - p0) : 64;
+    for (int f0 = 0; f0 < nf; f0 += 64) {
+        const int nfb = nf - f0 < 64 ? nf - f0 : 64;
+        if (f0 > 0) {
+            __syncthreads();
+        }
+        for (int r = wave; r < nfb; r += 4) {   // a field of the block: 64 points, contiguous in gp
+            if (lane < np) {
+                tile[lane][r] = gp[(long long)(f0 + r) * npts + p0 + lane];
+            }
+        }
+        __syncthreads();
+        for (int r = wave; r < np; r += 4) {    // a point: the block's fields, contiguous in field
+            if (lane < nfb) {
+                field[(p0 + r) * nf + f0 + lane] = tile[r][lane];
+            }
+        }
+    }
+}
+
+// Whole rows where there are enough points for a workgroup per 64 of them to fill the device and enough fields for 512-byte pieces
+// (a rank's band of O640 / 4, 137 levels: 264 -> 248 us; of O1280 / 8: 605 -> 470 us = 3.85 TB/s read + write); the tiles otherwise
+// (20 000 points x 1370 fields: 114 against 245 us).  ATLAS_AMD_GP_TO_FIELD=tiles|rows forces one (tools/probe/gp_to_field_probe.py).
 hipError_t launch_gp_to_field(const double* gp, double* field, long long npts, int nf, hipStream_t stream) {
     if (npts <= 0 || nf <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(gp_to_field_kernel, dim3((unsigned)((npts + 31) / 32), (unsigned)((nf + 31) / 32)), dim3(256), 0, stream, gp,
-                       field, npts, nf);
+    const char* e   = std::getenv("ATLAS_AMD_GP_TO_FIELD");
+    const bool rows = e && *e ? std::string(e) == "rows" : (nf >= 32 && (npts + 63) / 64 >= 1024);
+    if (!rows) {
+        hipLaunchKernelGGL(gp_to_field_kernel, dim3((unsigned)((npts + 31) / 32), (unsigned)((nf + 31) / 32)), dim3(256), 0, stream,
+                           gp, field, npts, nf);
+    }
+    else {
+        hipLaunchKernelGGL(gp_to_field_rows_kernel, dim3((unsigned)((npts + 63) / 64)), dim3(256), 0, stream, gp, field, npts, nf);
+    }
     return hipGetLastError();
 }
 

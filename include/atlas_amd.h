@@ -62,6 +62,10 @@ int atlas_amd__set_device(int device);
 int atlas_amd__diag_mfma_f64_rate(double target_ms, int repeats, double* tflops_out);
 /* the same for v_mfma_f32_16x16x4_f32, the instruction of the fp32 variant's Legendre stage [r4] */
 int atlas_amd__diag_mfma_f32_rate(double target_ms, int repeats, double* tflops_out);
+/* measurement aid: average milliseconds of the field-major [nb_fields][npts] -> point-major [npts][nb_fields] transposition that
+ * atlas_amd__Trans__invtrans_distributed_many_halo runs in front of the halo exchange (device pointers; default stream) */
+int atlas_amd__diag_gp_to_field(const double* gp_dev, double* field_dev, long long npts, int nb_fields, int repeats,
+                                double* ms_out);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Grid description.  Replaces the `const Grid::Implementation*` argument of atlas__Trans__new

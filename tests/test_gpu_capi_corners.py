@@ -108,3 +108,21 @@ def test_device_helpers_for_callers_without_hip_headers():
     assert np.array_equal(gp, ref)
     _lib.check(free(d_sp))
     _lib.check(free(d_gp))
+
+
+@pytest.mark.parametrize("form", ["tiles", "rows", ""])
+def test_both_forms_of_the_field_transposition_of_the_halo_path(form, monkeypatch):
+    """csrc/vd2uv_kernel.hip: grid points of a band [nf][npts] -> StructuredColumns field [npts][nf] (in front of the halo exchange
+    of atlas_amd__Trans__invtrans_distributed_many_halo), 32 x 32 tiles or whole rows: a pure permutation, bitwise against torch;
+    ragged point and field counts either side of the 64-blocks"""
+    import torch
+    if form:
+        monkeypatch.setenv("ATLAS_AMD_GP_TO_FIELD", form)
+    fn = _sig("atlas_amd__diag_gp_to_field", C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_double))
+    for npts, nf in ((70001, 137), (64, 64), (65, 63), (1, 1), (4099, 200), (100000, 33)):
+        gp = torch.randn(nf, npts, dtype=torch.float64, device="cuda")
+        out = torch.full((npts, nf), float("nan"), dtype=torch.float64, device="cuda")
+        ms = C.c_double(0.0)
+        _lib.check(fn(gp.data_ptr(), out.data_ptr(), npts, nf, 1, C.byref(ms)))
+        torch.cuda.synchronize()
+        assert torch.equal(out, gp.t().contiguous()), (form, npts, nf)
