@@ -47,8 +47,11 @@ double gamma_series(double x) {
 }
 
 double cap_area(double colat) {
+    // 4 pi * (sin^2), the square formed FIRST as in the reference's 4.0 * M_PI * std::pow(std::sin(0.5 * s_cap), 2)
+    // (EqualRegionsPartitioner.cc:125): the zones' shares of the regions are rounded from differences of these areas, and where a
+    // share is x.5 up to the last bit (N = 9, 31, ...) the other association, (4 pi s) s, moved a region to the neighbouring zone
     const double s = std::sin(0.5 * colat);
-    return 4. * kPi * s * s;
+    return 4. * kPi * (s * s);
 }
 double cap_colat(double area) {
     return 2. * std::asin(0.5 * std::sqrt(area / kPi));

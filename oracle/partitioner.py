@@ -38,7 +38,10 @@ def _c_round(v):
 
 
 def _area_of_cap(s_cap):
-    return 4.0 * math.pi * math.sin(0.5 * s_cap) ** 2
+    # EqualRegionsPartitioner.cc:125: 4.0 * M_PI * std::pow(std::sin(0.5 * s_cap), 2) -- the square first (g++ compiles the pow to a
+    # multiplication), then times 4 pi; the order matters: zone shares of x.5 are rounded from differences of these areas
+    s = math.sin(0.5 * s_cap)
+    return 4.0 * math.pi * (s * s)
 
 
 def _sradius_of_cap(area):

@@ -222,6 +222,21 @@ def test_equal_regions_partitioner_goldens_and_structuredcolumns():
             assert fss[pp[n]].global_index()[ridx[n]] == gi[n]
 
 
+def test_eq_caps_of_the_library_and_the_oracle_agree_for_every_count_incl_the_ties():
+    """eq_caps rounds the zones' ideal shares of the N regions (round_to_naturals, EqualRegionsPartitioner.cc:229-245); where a share
+    is x.5 up to the last bit (N = 9: 3.5 + 3.5; N = 31) the result hangs on the order of the floating-point operations in
+    area_of_cap (:125).  Round 5 found the library forming (4 pi s) s instead of 4 pi (s s): N = 9 gave [1, 4, 3, 1].  Library
+    (csrc/equal_regions.cpp) and oracle (oracle/partitioner.py) are two restatements of the same source lines: equal for every N,
+    region counts and cap colatitudes to the bit."""
+    from atlas_amd.partitioner import eq_caps
+    from oracle.partitioner import eq_caps as eq_caps_oracle
+    assert eq_caps(9)[0] == [1, 3, 4, 1] and eq_caps(31)[0] == [1, 6, 8, 9, 6, 1]
+    for N in list(range(1, 1025)) + [1280, 2047, 4096, 10000]:
+        a, b = eq_caps(N), eq_caps_oracle(N)
+        assert a[0] == list(b[0]) and a[1] == list(b[1]), N
+        assert sum(a[0]) == N
+
+
 def test_equal_regions_partition_of_O8_over_five_parts_is_the_reference_vector():
     """the expected array of src/tests/functionspace/test_structuredcolumns.cc:87-106 (partition of every point of O8 with
     the default partitioner on 5 MPI tasks; tests/golden/equal_regions_O8_5.json), from the library (C++) and from the
