@@ -28,10 +28,10 @@ namespace atlas_amd {
 thread_local std::string g_last_note;    // diagnostics that are not errors (e.g. accepted-and-ignored option keys)
 thread_local std::string g_last_error;
 void set_last_error(const std::string& s) {
+    // (a HIP call that failed inside the library clears the runtime's per-thread "last error" where it is caught -- hip_check --,
+    // not here: an argument error must not swallow a sticky error of the application's own preceding HIP calls, nor touch the
+    // HIP runtime from host-only paths)
     g_last_error = s;
-    // a HIP call that failed inside the library leaves the runtime's per-thread "last error" set; the launch checks of the NEXT call
-    // (hipGetLastError behind a kernel launch) would report it as theirs.  The failure is reported here, once.
-    (void)hipGetLastError();
 }
 }  // namespace atlas_amd
 
@@ -255,22 +255,46 @@ void atlas_amd__Grid__delete(atlas_amd_Grid* g) {
     delete g;
 }
 int atlas_amd__Grid__ny(const atlas_amd_Grid* g) {
+    if (!g) {
+        atlas_amd::set_last_error("Grid::ny: null handle");
+        return -1;
+    }
     return g->g.ny();
 }
 int atlas_amd__Grid__nxmax(const atlas_amd_Grid* g) {
+    if (!g) {
+        atlas_amd::set_last_error("Grid::nxmax: null handle");
+        return -1;
+    }
     return g->g.nxmax();
 }
 int64_t atlas_amd__Grid__size(const atlas_amd_Grid* g) {
+    if (!g) {
+        atlas_amd::set_last_error("Grid::size: null handle");
+        return -1;
+    }
     return g->g.size();
 }
 int atlas_amd__Grid__regular(const atlas_amd_Grid* g) {
+    if (!g) {
+        atlas_amd::set_last_error("Grid::regular: null handle");
+        return -1;
+    }
     return g->g.regular ? 1 : 0;
 }
 int atlas_amd__Grid__nx(const atlas_amd_Grid* g, int nx_out[]) {
+    if (!g) {
+        atlas_amd::set_last_error("Grid::nx: null handle");
+        return -1;
+    }
     std::memcpy(nx_out, g->g.nx.data(), sizeof(int) * g->g.nx.size());
     return 0;
 }
 int atlas_amd__Grid__y(const atlas_amd_Grid* g, double y_out[]) {
+    if (!g) {
+        atlas_amd::set_last_error("Grid::y: null handle");
+        return -1;
+    }
     std::memcpy(y_out, g->g.y.data(), sizeof(double) * g->g.y.size());
     return 0;
 }
@@ -492,11 +516,18 @@ static void need(const atlas_amd_RegionalTrans* t) {
     }
 }
 int64_t atlas_amd__RegionalTrans__nb_gridpoints(const atlas_amd_RegionalTrans* t) {
+    if (!t) {
+        atlas_amd::set_last_error("RegionalTrans::nb_gridpoints: null handle");
+        return -1;
+    }
     return t && t->impl ? t->impl->nb_gridpoints() : -1;
 }
 int atlas_amd__RegionalTrans__invtrans_scalar(atlas_amd_RegionalTrans* t, int nb_fields, const double scalar_spectra[],
                                               double gp_fields[]) {
     AA_TRY
+    if (!t) {
+        throw std::invalid_argument("RegionalTrans::invtrans_scalar: null handle");
+    }
     need(t);
     t->impl->invtrans(nb_fields, scalar_spectra, gp_fields);
     AA_CATCH_INT
@@ -504,6 +535,9 @@ int atlas_amd__RegionalTrans__invtrans_scalar(atlas_amd_RegionalTrans* t, int nb
 int atlas_amd__RegionalTrans__invtrans_scalar_device(atlas_amd_RegionalTrans* t, int nb_fields, const double* sp_dev,
                                                      double* gp_dev) {
     AA_TRY
+    if (!t) {
+        throw std::invalid_argument("RegionalTrans::invtrans_scalar_device: null handle");
+    }
     need(t);
     t->impl->invtrans_scalar_device(nb_fields, sp_dev, gp_dev);
     AA_CATCH_INT
@@ -512,17 +546,27 @@ int atlas_amd__RegionalTrans__invtrans_vordiv(atlas_amd_RegionalTrans* t, int nb
                                               int nb_vordiv_fields, const double vorticity_spectra[],
                                               const double divergence_spectra[], double gp_fields[]) {
     AA_TRY
+    if (!t) {
+        throw std::invalid_argument("RegionalTrans::invtrans_vordiv: null handle");
+    }
     need(t);
     t->impl->invtrans(nb_scalar_fields, scalar_spectra, nb_vordiv_fields, vorticity_spectra, divergence_spectra, gp_fields);
     AA_CATCH_INT
 }
 int atlas_amd__RegionalTrans__synchronize(atlas_amd_RegionalTrans* t) {
     AA_TRY
+    if (!t) {
+        throw std::invalid_argument("RegionalTrans::synchronize: null handle");
+    }
     need(t);
     t->impl->synchronize();
     AA_CATCH_INT
 }
 void* atlas_amd__RegionalTrans__stream(const atlas_amd_RegionalTrans* t) {
+    if (!t) {
+        atlas_amd::set_last_error("RegionalTrans::stream: null handle");
+        return nullptr;
+    }
     return t && t->impl ? (void*)t->impl->stream() : nullptr;
 }
 
@@ -684,15 +728,27 @@ const atlas_amd_Spectral* atlas_amd__Trans__spectral(const atlas_amd_Trans* t) {
     return &t->spectral;
 }
 int atlas_amd__Spectral__truncation(const atlas_amd_Spectral* s) {
+    if (!s) {
+        atlas_amd::set_last_error("Spectral::truncation: null handle");
+        return -1;
+    }
     return s ? s->truncation : -1;
 }
 int64_t atlas_amd__Spectral__nb_spectral_coefficients(const atlas_amd_Spectral* s) {
+    if (!s) {
+        atlas_amd::set_last_error("Spectral::nb_spectral_coefficients: null handle");
+        return -1;
+    }
     return s ? (int64_t)(s->truncation + 1) * (s->truncation + 2) : 0;
 }
 int64_t atlas_amd__Spectral__nb_spectral_coefficients_global(const atlas_amd_Spectral* s) {
     return atlas_amd__Spectral__nb_spectral_coefficients(s);
 }
 const atlas_amd_Grid* atlas_amd__Trans__grid(const atlas_amd_Trans* t) {
+    if (!t || !t->impl) {
+        atlas_amd::set_last_error("Trans::grid: null handle");
+        return nullptr;
+    }
     return t ? t->grid : nullptr;
 }
 
@@ -707,6 +763,9 @@ static void require_rank1(const atlas_amd_Field* f, const char* what) {
 }
 int atlas_amd__Trans__invtrans_field(atlas_amd_Trans* t, const atlas_amd_Field* spfield, atlas_amd_Field* gpfield) {
     AA_TRY
+    if (!t || !t->impl || !spfield || !gpfield) {
+        throw std::invalid_argument("Trans::invtrans_field: null handle");
+    }
     require_rank1(spfield, "spfield");
     require_rank1(gpfield, "gpfield");
     // TransLocal.cc:826-831 only prints debug output when the grid-point field is shorter than the grid; the call
@@ -720,6 +779,10 @@ int atlas_amd__Trans__invtrans_field(atlas_amd_Trans* t, const atlas_amd_Field* 
 }
 int atlas_amd__Trans__invtrans_fieldset(atlas_amd_Trans* t, const atlas_amd_Field* spfields, int nb_spfields,
                                         atlas_amd_Field* gpfields, int nb_gpfields) {
+    if (!t || !t->impl) {
+        atlas_amd::set_last_error("Trans::invtrans_fieldset: null handle");
+        return 1;
+    }
     if (nb_spfields != nb_gpfields) {  // ATLAS_ASSERT(spfields.size() == gpfields.size()), :840
         atlas_amd::set_last_error("invtrans(FieldSet, FieldSet): spfields.size() != gpfields.size()");
         return 1;
@@ -735,6 +798,9 @@ int atlas_amd__Trans__invtrans_fieldset(atlas_amd_Trans* t, const atlas_amd_Fiel
 int atlas_amd__Trans__invtrans_vordiv2wind_field(atlas_amd_Trans* t, const atlas_amd_Field* spvor,
                                                  const atlas_amd_Field* spdiv, atlas_amd_Field* gpwind) {
     AA_TRY
+    if (!t || !t->impl || !spvor || !spdiv) {
+        throw std::invalid_argument("Trans::invtrans_vordiv2wind_field: null handle");
+    }
     require_rank1(spvor, "spvor");
     require_rank1(spdiv, "spdiv");
     if (!gpwind || !gpwind->data || gpwind->rank != 2) {
@@ -858,10 +924,17 @@ int atlas_amd__Trans__synchronize(atlas_amd_Trans* t) {
     AA_CATCH_INT
 }
 size_t atlas_amd__Trans__legendre_cache_size(const atlas_amd_Trans* t) {
+    if (!t || !t->impl) {
+        atlas_amd::set_last_error("Trans::legendre_cache_size: null handle");
+        return -1;
+    }
     return t->impl->legendre_cache_bytes();
 }
 int atlas_amd__Trans__legendre_cache_export(const atlas_amd_Trans* t, void* buffer, size_t size) {
     AA_TRY
+    if (!t || !t->impl) {
+        throw std::invalid_argument("Trans::legendre_cache_export: null handle");
+    }
     if (size != t->impl->legendre_cache_bytes()) {
         throw std::invalid_argument("legendre_cache_export: wrong buffer size");
     }
@@ -870,6 +943,9 @@ int atlas_amd__Trans__legendre_cache_export(const atlas_amd_Trans* t, void* buff
 }
 int atlas_amd__Trans__mirror_rows(const atlas_amd_Trans* t, int out[2]) {
     AA_TRY
+    if (!t || !t->impl) {
+        throw std::invalid_argument("Trans::mirror_rows: null handle");
+    }
     if (t->mirror_b0 < 0) {
         throw std::invalid_argument("Trans__mirror_rows: the object was not built with shard=mirror");
     }
@@ -879,6 +955,9 @@ int atlas_amd__Trans__mirror_rows(const atlas_amd_Trans* t, int out[2]) {
 }
 int atlas_amd__mirror_bands(const atlas_amd_Grid* grid, int nparts, int bands_out[]) {
     AA_TRY
+    if (!grid) {
+        throw std::invalid_argument("mirror_bands: null handle");
+    }
     const std::vector<int> b = trans::mirror_bands(grid->g, nparts);
     std::memcpy(bands_out, b.data(), sizeof(int) * b.size());
     AA_CATCH_INT
@@ -895,6 +974,9 @@ int atlas_amd__latitude_bands(const atlas_amd_Grid* grid, int truncation, int np
 int atlas_amd__trans_geometry_probe(const atlas_amd_Grid* grid, int truncation, int caps_rows, int nlat0_out[],
                                     int row_mmax_out[]) {
     AA_TRY
+    if (!grid) {
+        throw std::invalid_argument("trans_geometry_probe: null handle");
+    }
     // geometry of the grid itself (caps_rows == 0) or of its two polar caps of caps_rows latitudes each, seen as part
     // of the full grid (what shard=mirror builds)
     const trans::TransGeometry geo =
@@ -910,19 +992,38 @@ int atlas_amd__trans_geometry_probe(const atlas_amd_Grid* grid, int truncation, 
 }
 int atlas_amd__Trans__legendre_table_download(const atlas_amd_Trans* t, double* out, size_t size) {
     AA_TRY
+    if (!t || !t->impl) {
+        throw std::invalid_argument("Trans::legendre_table_download: null handle");
+    }
     t->impl->download_legendre_table(out, size);
     AA_CATCH_INT
 }
 int atlas_amd__Trans__fourier_row_pitch(const atlas_amd_Trans* t, int nb_fields) {
+    if (!t || !t->impl) {
+        atlas_amd::set_last_error("Trans::fourier_row_pitch: null handle");
+        return -1;
+    }
     return t->impl->fourier_row_pitch(nb_fields);
 }
 int64_t atlas_amd__Trans__fourier_size(const atlas_amd_Trans* t, int nb_fields) {
+    if (!t || !t->impl) {
+        atlas_amd::set_last_error("Trans::fourier_size: null handle");
+        return -1;
+    }
     return (int64_t)t->impl->fourier_doubles(nb_fields);
 }
 int atlas_amd__Trans__owned_wavenumbers(const atlas_amd_Trans* t) {
+    if (!t || !t->impl) {
+        atlas_amd::set_last_error("Trans::owned_wavenumbers: null handle");
+        return -1;
+    }
     return t->impl->owned_wavenumbers();
 }
 int atlas_amd__Trans__bands(const atlas_amd_Trans* t, int out[]) {
+    if (!t || !t->impl) {
+        atlas_amd::set_last_error("Trans::bands: null handle");
+        return -1;
+    }
     const auto& b = t->impl->bands();
     std::memcpy(out, b.data(), sizeof(int) * b.size());
     return 0;
@@ -930,16 +1031,26 @@ int atlas_amd__Trans__bands(const atlas_amd_Trans* t, int out[]) {
 int atlas_amd__Trans__legendre_device(atlas_amd_Trans* t, int trc_in, int nb_fields, const double* sp,
                                       double* fourier) {
     AA_TRY
+    if (!t || !t->impl) {
+        throw std::invalid_argument("Trans::legendre_device: null handle");
+    }
     t->impl->legendre_device(trc_in, nb_fields, sp, fourier);
     AA_CATCH_INT
 }
 int atlas_amd__Trans__fourier_device(atlas_amd_Trans* t, int nb_fields, int nb_vordiv,
                                      const double* const part_base[], const int part_cnt[], double* gp) {
     AA_TRY
+    if (!t || !t->impl) {
+        throw std::invalid_argument("Trans::fourier_device: null handle");
+    }
     t->impl->fourier_device(nb_fields, nb_vordiv, part_base, part_cnt, gp);
     AA_CATCH_INT
 }
 int atlas_amd__Trans__nlat0(const atlas_amd_Trans* t, int out[]) {
+    if (!t || !t->impl) {
+        atlas_amd::set_last_error("Trans::nlat0: null handle");
+        return -1;
+    }
     const auto& v = t->impl->geometry().nlat0;
     std::memcpy(out, v.data(), sizeof(int) * v.size());
     return 0;
@@ -969,13 +1080,24 @@ int atlas_amd__Trans__fft_row_classes(const atlas_amd_Trans* t, int out[]) {
     AA_CATCH_INT
 }
 double atlas_amd__Trans__legendre_flops(const atlas_amd_Trans* t, int nb_fields) {
+    if (!t || !t->impl) {
+        atlas_amd::set_last_error("Trans::legendre_flops: null handle");
+        return -1.0;
+    }
     return trans::legendre_flops(t->impl->geometry(), nb_fields);
 }
 int64_t atlas_amd__Trans__legendre_table_bytes(const atlas_amd_Trans* t) {
+    if (!t || !t->impl) {
+        atlas_amd::set_last_error("Trans::legendre_table_bytes: null handle");
+        return -1;
+    }
     return t->impl->legendre_work().table_doubles * 8;
 }
 int atlas_amd__Trans__timings(atlas_amd_Trans* t, double out[4], int reset) {
     AA_TRY
+    if (!t || !t->impl) {
+        throw std::invalid_argument("Trans::timings: null handle");
+    }
     trans::StageTimings s = t->impl->timings();
     out[0]                = s.legendre_ms;
     out[1]                = s.legendre_calls;
@@ -996,6 +1118,9 @@ int atlas_amd__Trans__fourier_launch_plan(const atlas_amd_Trans* t, int out[3]) 
 }
 int atlas_amd__Trans__timings_vordiv(atlas_amd_Trans* t, double out[2], int reset) {
     AA_TRY
+    if (!t || !t->impl) {
+        throw std::invalid_argument("Trans::timings_vordiv: null handle");
+    }
     trans::StageTimings s = t->impl->timings();
     out[0]                = s.prepare_ms;
     out[1]                = s.prepare_calls;
@@ -1006,6 +1131,9 @@ int atlas_amd__Trans__timings_vordiv(atlas_amd_Trans* t, double out[2], int rese
 }
 int atlas_amd__Trans__set_profile(atlas_amd_Trans* t, int on) {
     AA_TRY
+    if (!t || !t->impl) {
+        throw std::invalid_argument("Trans::set_profile: null handle");
+    }
     t->impl->synchronize();
     t->impl->set_profile(on != 0);
     AA_CATCH_INT
@@ -1013,6 +1141,9 @@ int atlas_amd__Trans__set_profile(atlas_amd_Trans* t, int on) {
 
 int atlas_amd__Trans__fft_phase_profile(atlas_amd_Trans* t, int enable, unsigned long long out[64]) {
     AA_TRY
+    if (!t || !t->impl) {
+        throw std::invalid_argument("Trans::fft_phase_profile: null handle");
+    }
     if (out) {
         t->impl->read_phase_profile(out);
     }
@@ -1036,6 +1167,9 @@ int atlas_amd__fourier_truncation(int truncation, int nx, int nxmax, int ndgl, d
 int atlas_amd__legendre_reference_sizes(const atlas_amd_Grid* grid, int truncation, size_t* size_sym,
                                         size_t* size_asym) {
     AA_TRY
+    if (!grid) {
+        throw std::invalid_argument("legendre_reference_sizes: null handle");
+    }
     trans::TransGeometry geo = trans::make_geometry(grid->g, truncation);
     *size_sym                = geo.size_sym();
     *size_asym               = geo.size_asym();
@@ -1044,6 +1178,9 @@ int atlas_amd__legendre_reference_sizes(const atlas_amd_Grid* grid, int truncati
 int atlas_amd__legendre_reference_tables(const atlas_amd_Grid* grid, int truncation, double* leg_sym,
                                          size_t size_sym, double* leg_asym, size_t size_asym) {
     AA_TRY
+    if (!grid) {
+        throw std::invalid_argument("legendre_reference_tables: null handle");
+    }
     trans::TransGeometry geo = trans::make_geometry(grid->g, truncation);
     if (size_sym != geo.size_sym() || size_asym != geo.size_asym()) {
         throw std::invalid_argument("legendre_reference_tables: wrong sizes");
@@ -1056,6 +1193,9 @@ int atlas_amd__legendre_reference_tables(const atlas_amd_Grid* grid, int truncat
 int atlas_amd__legendre_gen_host_selfcheck(const atlas_amd_Grid* grid, int truncation, int nparts, int part,
                                            int by_band, long long* table_doubles, long long* mismatches) {
     AA_TRY
+    if (!grid) {
+        throw std::invalid_argument("legendre_gen_host_selfcheck: null handle");
+    }
     if (nparts < 1 || part < 0 || part >= nparts) {
         throw std::invalid_argument("legendre_gen_host_selfcheck: bad nparts / part");
     }

@@ -116,12 +116,24 @@ void atlas_amd__Comm__delete(atlas_amd_Comm* c) {
     delete c;
 }
 int atlas_amd__Comm__size(const atlas_amd_Comm* c) {
+    if (!c) {
+        atlas_amd::set_last_error("Comm::size: null handle");
+        return -1;
+    }
     return c && c->impl ? c->impl->size() : 0;
 }
 int atlas_amd__Comm__rank(const atlas_amd_Comm* c) {
+    if (!c) {
+        atlas_amd::set_last_error("Comm::rank: null handle");
+        return -1;
+    }
     return c && c->impl ? c->impl->rank() : -1;
 }
 const char* atlas_amd__Comm__kind(const atlas_amd_Comm* c) {
+    if (!c) {
+        atlas_amd::set_last_error("Comm::kind: null handle");
+        return nullptr;
+    }
     return c && c->impl ? c->impl->kind() : "";
 }
 int atlas_amd__Comm__barrier(atlas_amd_Comm* c) {
@@ -246,10 +258,8 @@ int atlas_amd__Trans__fourier_packed_probe(atlas_amd_Trans* t, int nb_fields, in
 }
 int atlas_amd__Trans__set_max_message_bytes(atlas_amd_Trans* t, atlas_amd_Comm* c, long long bytes) {
     DX_TRY
-    if (bytes < 8) {
-        throw std::invalid_argument("set_max_message_bytes: at least 8");
-    }
-    dist_of(t, c).set_max_message_elems(bytes / 8);
+    // collective: an invalid value (< 8 bytes = 0 elements) is refused INSIDE, after every rank has taken part in the comparison
+    dist_of(t, c).set_max_message_elems(bytes < 8 ? 0 : bytes / 8);
     DX_CATCH
 }
 int atlas_amd__transpose_messages(int truncation, int RP, int nparts, int part, const int bands[], long long max_message_elems,

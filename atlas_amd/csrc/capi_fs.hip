@@ -109,12 +109,24 @@ void atlas_amd__StructuredColumns__delete(atlas_amd_StructuredColumns* fs) {
     delete fs;
 }
 int atlas_amd__StructuredColumns__size_owned(const atlas_amd_StructuredColumns* fs) {
+    if (!fs) {
+        atlas_amd::set_last_error("StructuredColumns::size_owned: null handle");
+        return -1;
+    }
     return fs->impl.size_owned();
 }
 int atlas_amd__StructuredColumns__size_halo(const atlas_amd_StructuredColumns* fs) {
+    if (!fs) {
+        atlas_amd::set_last_error("StructuredColumns::size_halo: null handle");
+        return -1;
+    }
     return fs->impl.size_halo();
 }
 int atlas_amd__StructuredColumns__bounds(const atlas_amd_StructuredColumns* fs, int out[4]) {
+    if (!fs) {
+        atlas_amd::set_last_error("StructuredColumns::bounds: null handle");
+        return -1;
+    }
     out[0] = fs->impl.j_begin();
     out[1] = fs->impl.j_end();
     out[2] = fs->impl.j_begin_halo();
@@ -123,6 +135,9 @@ int atlas_amd__StructuredColumns__bounds(const atlas_amd_StructuredColumns* fs, 
 }
 int atlas_amd__StructuredColumns__row_bounds(const atlas_amd_StructuredColumns* fs, int j, int out[4]) {
     FS_TRY
+    if (!fs) {
+        throw std::invalid_argument("StructuredColumns::row_bounds: null handle");
+    }
     const auto& f = fs->impl;
     if (j < f.j_begin_halo() || j >= f.j_end_halo()) {
         throw std::out_of_range("row_bounds: j outside the halo");
@@ -136,11 +151,17 @@ int atlas_amd__StructuredColumns__row_bounds(const atlas_amd_StructuredColumns* 
 }
 int atlas_amd__StructuredColumns__index(const atlas_amd_StructuredColumns* fs, int i, int j, int* out) {
     FS_TRY
+    if (!fs) {
+        throw std::invalid_argument("StructuredColumns::index: null handle");
+    }
     *out = fs->impl.index(i, j);
     FS_CATCH
 }
 int atlas_amd__StructuredColumns__get_int(const atlas_amd_StructuredColumns* fs, const char* what, int out[]) {
     FS_TRY
+    if (!fs) {
+        throw std::invalid_argument("StructuredColumns::get_int: null handle");
+    }
     const std::string w       = what ? what : "";
     const std::vector<int>* v = nullptr;
     std::vector<int> tmp;
@@ -160,13 +181,25 @@ int atlas_amd__StructuredColumns__get_int(const atlas_amd_StructuredColumns* fs,
     FS_CATCH
 }
 int atlas_amd__StructuredColumns__nb_pole_row_nodes(const atlas_amd_StructuredColumns* fs) {
+    if (!fs) {
+        atlas_amd::set_last_error("StructuredColumns::nb_pole_row_nodes: null handle");
+        return -1;
+    }
     return (int)fs->impl.pole_row_nodes().size();
 }
 int atlas_amd__StructuredColumns__global_index(const atlas_amd_StructuredColumns* fs, int64_t out[]) {
+    if (!fs) {
+        atlas_amd::set_last_error("StructuredColumns::global_index: null handle");
+        return -1;
+    }
     std::memcpy(out, fs->impl.global_index().data(), fs->impl.global_index().size() * sizeof(int64_t));
     return 0;
 }
 int atlas_amd__StructuredColumns__xy(const atlas_amd_StructuredColumns* fs, double out[]) {
+    if (!fs) {
+        atlas_amd::set_last_error("StructuredColumns::xy: null handle");
+        return -1;
+    }
     std::memcpy(out, fs->impl.xy().data(), fs->impl.xy().size() * sizeof(double));
     return 0;
 }
@@ -175,6 +208,9 @@ int atlas_amd__StructuredColumns__xy(const atlas_amd_StructuredColumns* fs, doub
 int atlas_amd__StructuredColumns__setup_halo_exchange(const atlas_amd_StructuredColumns* fs,
                                                       atlas_amd_HaloExchange* hx, int nparts, int part) {
     FS_TRY
+    if (!fs || !hx) {
+        throw std::invalid_argument("StructuredColumns::setup_halo_exchange: null handle");
+    }
     const auto& f = fs->impl;
     if (nparts == 1) {
         hx->impl.setup(f.partition().data(), f.remote_index().data(), 0, f.size_halo(), f.size_owned());
@@ -189,6 +225,9 @@ int atlas_amd__StructuredColumns__fixup_halo_for_vectors(atlas_amd_StructuredCol
                                                          int levels, long long stride_n, long long stride_k,
                                                          long long stride_v, void* hip_stream) {
     FS_TRY
+    if (!fs) {
+        throw std::invalid_argument("StructuredColumns::fixup_halo_for_vectors: null handle");
+    }
     if (!fs->d_pole_nodes) {
         std::vector<int> nodes = fs->impl.pole_row_nodes();
         fs->npole              = (int)nodes.size();

@@ -76,18 +76,27 @@ void atlas_amd__HaloExchange__delete(atlas_amd_HaloExchange* h) {
 int atlas_amd__HaloExchange__setup(atlas_amd_HaloExchange* h, const int part[], const int remote_idx[], int base,
                                    int size) {
     HX_TRY
+    if (!h) {
+        throw std::invalid_argument("HaloExchange::setup: null handle");
+    }
     h->impl.setup(part, remote_idx, base, size, 0);
     HX_CATCH
 }
 int atlas_amd__HaloExchange__setup_halo_begin(atlas_amd_HaloExchange* h, const int part[], const int remote_idx[],
                                               int base, int size, int halo_begin) {
     HX_TRY
+    if (!h) {
+        throw std::invalid_argument("HaloExchange::setup_halo_begin: null handle");
+    }
     h->impl.setup(part, remote_idx, base, size, halo_begin);
     HX_CATCH
 }
 int atlas_amd__HaloExchange__setup_begin(atlas_amd_HaloExchange* h, int nproc, int myproc, const int part[],
                                          const int remote_idx[], int base, int size, int halo_begin) {
     HX_TRY
+    if (!h) {
+        throw std::invalid_argument("HaloExchange::setup_begin: null handle");
+    }
     h->impl.setup_begin(nproc, myproc, part, remote_idx, base, size, halo_begin);
     HX_CATCH
 }
@@ -95,26 +104,47 @@ int atlas_amd__HaloExchange__setup_begin_device(atlas_amd_HaloExchange* h, int n
                                                 const int* part_dev, const int* remote_idx_dev, int base, int size,
                                                 int halo_begin) {
     HX_TRY
+    if (!h) {
+        throw std::invalid_argument("HaloExchange::setup_begin_device: null handle");
+    }
     h->impl.setup_begin_device(nproc, myproc, part_dev, remote_idx_dev, base, size, halo_begin);
     HX_CATCH
 }
 int atlas_amd__HaloExchange__setup_finish(atlas_amd_HaloExchange* h, const int sendcounts[],
                                           const int recv_requests[]) {
     HX_TRY
+    if (!h) {
+        throw std::invalid_argument("HaloExchange::setup_finish: null handle");
+    }
     h->impl.setup_finish(sendcounts, recv_requests);
     HX_CATCH
 }
 int atlas_amd__HaloExchange__nproc(const atlas_amd_HaloExchange* h) {
+    if (!h) {
+        atlas_amd::set_last_error("HaloExchange::nproc: null handle");
+        return -1;
+    }
     return h->impl.plan().nproc;
 }
 int atlas_amd__HaloExchange__sendcnt(const atlas_amd_HaloExchange* h) {
+    if (!h) {
+        atlas_amd::set_last_error("HaloExchange::sendcnt: null handle");
+        return -1;
+    }
     return h->impl.plan().sendcnt;
 }
 int atlas_amd__HaloExchange__recvcnt(const atlas_amd_HaloExchange* h) {
+    if (!h) {
+        atlas_amd::set_last_error("HaloExchange::recvcnt: null handle");
+        return -1;
+    }
     return h->impl.plan().recvcnt;
 }
 int atlas_amd__HaloExchange__get(const atlas_amd_HaloExchange* h, const char* what, int out[]) {
     HX_TRY
+    if (!h) {
+        throw std::invalid_argument("HaloExchange::get: null handle");
+    }
     const auto& p           = h->impl.plan();
     const std::string w     = what ? what : "";
     const std::vector<int>* v = nullptr;
@@ -206,6 +236,9 @@ int atlas_amd__HaloExchange__field_op(atlas_amd_HaloExchange* h, int op, int dty
                                       const int shape[], const long long strides[], int parallel_dim, void* buffer,
                                       int on_device) {
     HX_TRY
+    if (!h) {
+        throw std::invalid_argument("HaloExchange::field_op: null handle");
+    }
     if (!on_device) {
         if (op != 0 && op != 1) {
             throw std::invalid_argument("host pointers are only supported for execute / execute_adjoint");
@@ -227,15 +260,25 @@ int atlas_amd__HaloExchange__field_op(atlas_amd_HaloExchange* h, int op, int dty
     HX_CATCH
 }
 void* atlas_amd__HaloExchange__stream(atlas_amd_HaloExchange* h) {
+    if (!h) {
+        atlas_amd::set_last_error("HaloExchange::stream: null handle");
+        return nullptr;
+    }
     return (void*)h->impl.stream();
 }
 int atlas_amd__HaloExchange__set_stream(atlas_amd_HaloExchange* h, void* s) {
     HX_TRY
+    if (!h) {
+        throw std::invalid_argument("HaloExchange::set_stream: null handle");
+    }
     h->impl.set_stream((hipStream_t)s);
     HX_CATCH
 }
 int atlas_amd__HaloExchange__synchronize(atlas_amd_HaloExchange* h) {
     HX_TRY
+    if (!h) {
+        throw std::invalid_argument("HaloExchange::synchronize: null handle");
+    }
     h->impl.synchronize();
     HX_CATCH
 }

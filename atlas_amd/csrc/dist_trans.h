@@ -110,6 +110,7 @@ private:
     };
     void ensure(int nb_fields);
     void check_ranks_agree(int nb_fields);
+    bool check_every_call_ = false;               // ATLAS_AMD_DIST_CHECK=always
     std::set<std::pair<int, int64_t>> checked_;   // (field count, message limit) pairs the ranks have compared
     void legendre(int nb_fields, const double* sp_dev, Slot& s);
     bool sharded_input_ = false;   // set for the duration of invtrans_many_sharded

@@ -14,6 +14,7 @@ void hip_check(hipError_t e, const char* what, const char* file, int line) {
     if (e != hipSuccess) {
         std::ostringstream ss;
         ss << "HIP error '" << hipGetErrorString(e) << "' in " << what << " (" << file << ":" << line << ")";
+        (void)hipGetLastError();   // the failure is reported here, once: not left sticky for the launch checks of the next call
         throw std::runtime_error(ss.str());
     }
 }
@@ -324,6 +325,12 @@ DistributedTrans::DistributedTrans(Trans& trans, parallel::Comm& comm) : trans_(
     if (const char* e = std::getenv("ATLAS_AMD_DIST_POISON")) {
         poison_ = atoi(e) != 0;
     }
+    // ATLAS_AMD_DIST_CHECK=always (debugging a hang or misplaced rows): the ranks compare (field count, message limit) on EVERY
+    // call, not only the first time a pair is used -- ranks that later call with different, individually already-compared field
+    // counts are then caught as well; costs a blocking 3-int all-to-all per call, hence not the default
+    if (const char* e = std::getenv("ATLAS_AMD_DIST_CHECK")) {
+        check_every_call_ = std::string(e) == "always";
+    }
     if (const char* e = std::getenv("ATLAS_AMD_DIST_ROWBASE")) {   // A/B: 0 = the piece-table walk of round 3
         use_rowbase_ = atoi(e) != 0;
     }
@@ -360,14 +367,26 @@ DistributedTrans::~DistributedTrans() {
 }
 
 void DistributedTrans::set_max_message_elems(int64_t elems) {
-    if (elems < 1) {
-        throw std::invalid_argument("DistributedTrans: the message limit must be at least one element");
-    }
-    max_message_elems_ = elems;   // ensure() rebuilds the message list when it differs from the one in use
     // COLLECTIVE: every rank of the communicator calls this, with the same value -- compared here, where all of them are, and not
     // inside the next transform (a check that only the ranks with a changed setting enter pairs its all-to-all with
-    // the other ranks' data messages)
-    check_ranks_agree(0);
+    // the other ranks' data messages).  An invalid value takes part in the comparison too and is refused AFTER it (a
+    // rank that throws before the collective leaves the others waiting in it): the ranks that passed a valid value get the
+    // "another message limit" error, this one the argument error, nobody hangs and nobody's limit changes.
+    const int64_t previous = max_message_elems_;
+    max_message_elems_     = elems;   // ensure() rebuilds the message list when it differs from the one in use
+    try {
+        check_ranks_agree(0);
+    }
+    catch (...) {
+        max_message_elems_ = previous;
+        if (elems >= 1) {
+            throw;
+        }
+    }
+    if (elems < 1) {
+        max_message_elems_ = previous;
+        throw std::invalid_argument("DistributedTrans: the message limit must be at least one element");
+    }
 }
 
 // the ranks compare (message limit, field count): an all-to-all of three ints; every rank takes part or none
@@ -390,6 +409,9 @@ void DistributedTrans::check_ranks_agree(int nb_fields) {
 }
 
 void DistributedTrans::ensure(int nb_fields) {
+    if (check_every_call_) {
+        check_ranks_agree(nb_fields);
+    }
     const bool same_plan = nb_fields == nf_plan_;
     if (same_plan && msgs_limit_ == max_message_elems_) {
         return;

@@ -15,6 +15,7 @@ void hip_check(hipError_t e, const char* what, const char* file, int line) {
     if (e != hipSuccess) {
         std::ostringstream ss;
         ss << "HIP error '" << hipGetErrorString(e) << "' in " << what << " (" << file << ":" << line << ")";
+        (void)hipGetLastError();   // the failure is reported here, once: not left sticky for the launch checks of the next call
         throw std::runtime_error(ss.str());
     }
 }

@@ -255,8 +255,10 @@ private:
     size_t vd_cap_      = 0;
     void ensure(double*& ptr, size_t& cap, size_t n);
     // host-pointer pipeline (pinned staging)
-    void invtrans_host_pipelined(int nb_scalar, const double* sp_host, int nb_vordiv, const double* vor_host, const double* div_host,
+    // false: the staging buffers could not be allocated, nothing was done -- the caller runs the serial path
+    bool invtrans_host_pipelined(int nb_scalar, const double* sp_host, int nb_vordiv, const double* vor_host, const double* div_host,
                                  double* gp_host);
+    bool ensure_host_pipeline_buffers(size_t up_doubles, size_t down_doubles);
     void invtrans_scalars_extended_device(int nb_scalar, const double* sp_dev, double* gp_dev);
     double* hp_up_[2]   = {nullptr, nullptr};   // pinned: a chunk's spectra / grid points
     double* hp_down_[2] = {nullptr, nullptr};

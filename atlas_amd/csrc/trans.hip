@@ -48,6 +48,7 @@ void hip_check(hipError_t e, const char* what, const char* file, int line) {
     if (e != hipSuccess) {
         std::ostringstream ss;
         ss << "HIP error '" << hipGetErrorString(e) << "' in " << what << " (" << file << ":" << line << ")";
+        (void)hipGetLastError();   // the failure is reported here, once: not left sticky for the launch checks of the next call
         throw std::runtime_error(ss.str());
     }
 }
@@ -243,12 +244,11 @@ void Trans::release() noexcept {
         (void)hipStreamSynchronize(hp_up_stream_);
         (void)hipStreamSynchronize(copy_stream_);
         for (int i = 0; i < 2; ++i) {
-            if (hp_up_[i]) {
-                (void)hipHostFree(hp_up_[i]);
-                (void)hipHostFree(hp_down_[i]);
-                (void)hipFree(hp_dsp_[i]);
-                (void)hipFree(hp_dgp_[i]);
-            }
+            if (hp_up_[i]) (void)hipHostFree(hp_up_[i]);
+            if (hp_down_[i]) (void)hipHostFree(hp_down_[i]);
+            if (hp_dsp_[i]) (void)hipFree(hp_dsp_[i]);
+            if (hp_dgp_[i]) (void)hipFree(hp_dgp_[i]);
+            hp_up_[i] = hp_down_[i] = hp_dsp_[i] = hp_dgp_[i] = nullptr;
             (void)hipEventDestroy(hp_up_done_[i]);
             (void)hipEventDestroy(hp_comp_done_[i]);
             (void)hipEventDestroy(hp_down_done_[i]);
@@ -1224,8 +1224,9 @@ void Trans::invtrans(int nb_scalar_fields, const double scalar_spectra[], double
         pipe = atoi(e) != 0;
     }
     if (pipe && nb_scalar_fields >= 32 && ngp * sizeof(double) >= (size_t(256) << 20) && fourier_parts() == 1 && !windowed()) {
-        invtrans_host_pipelined(nb_scalar_fields, scalar_spectra, 0, nullptr, nullptr, gp_fields);
-        return;
+        if (invtrans_host_pipelined(nb_scalar_fields, scalar_spectra, 0, nullptr, nullptr, gp_fields)) {
+            return;
+        }   // staging buffers unavailable: the serial path below
     }
     ensure(d_sp_, sp_cap_, nsp);
     ensure(d_gp_, gp_cap_, ngp);
@@ -1253,7 +1254,57 @@ void Trans::invtrans(int nb_scalar_fields, const double scalar_spectra[], double
 // of this pipeline: 376 ms against 179 serial); the runtime's own pageable path (blocking hipMemcpy from a second thread, 50 GB/s)
 // does not overlap the two directions at all (53 GB/s for both together against 97 from pinned memory: 180 ms, no gain).
 // ATLAS_AMD_HOST_CHUNK=<fields> (multiple of 8; default 16), ATLAS_AMD_HOST_THREADS=<n> (default 8).
-void Trans::invtrans_host_pipelined(int nb_scalar, const double* sp_host, int nb_vordiv, const double* vor_host,
+// The staging buffers of the pipeline: two pinned and two device buffers per direction, grown together.  A multi-GB hipHostMalloc
+// can fail (memlock limit, memory pressure): the new set is allocated into temporaries and committed only when all eight
+// allocations succeeded; on failure the temporaries are freed, the old set is dropped with its pointers nulled and capacities
+// zeroed (release() and the next call see a consistent "no buffers" state), the sticky allocation error is cleared and the
+// caller falls back to the serial path (ATLAS_AMD_HOST_PIPELINE_FAIL_ALLOC=1 forces this branch: tests).
+bool Trans::ensure_host_pipeline_buffers(size_t up_doubles, size_t down_doubles) {
+    if (up_doubles <= hp_up_cap_ && down_doubles <= hp_down_cap_ && hp_up_[0]) {
+        return true;
+    }
+    synchronize();
+    HIP_CHECK(hipStreamSynchronize(hp_up_stream_));
+    HIP_CHECK(hipStreamSynchronize(copy_stream_));
+    const size_t up_cap   = std::max(hp_up_cap_, up_doubles);
+    const size_t down_cap = std::max(hp_down_cap_, down_doubles);
+    auto drop = [](double* (&pin_up)[2], double* (&pin_down)[2], double* (&dev_sp)[2], double* (&dev_gp)[2]) {
+        for (int i = 0; i < 2; ++i) {
+            if (pin_up[i]) (void)hipHostFree(pin_up[i]);
+            if (pin_down[i]) (void)hipHostFree(pin_down[i]);
+            if (dev_sp[i]) (void)hipFree(dev_sp[i]);
+            if (dev_gp[i]) (void)hipFree(dev_gp[i]);
+            pin_up[i] = pin_down[i] = dev_sp[i] = dev_gp[i] = nullptr;
+        }
+    };
+    // the old set goes first: both sets together may not fit where the new one alone does
+    drop(hp_up_, hp_down_, hp_dsp_, hp_dgp_);
+    hp_up_cap_ = hp_down_cap_ = 0;
+    double *nu[2] = {nullptr, nullptr}, *nd[2] = {nullptr, nullptr}, *ns[2] = {nullptr, nullptr}, *ng[2] = {nullptr, nullptr};
+    bool ok = std::getenv("ATLAS_AMD_HOST_PIPELINE_FAIL_ALLOC") == nullptr;
+    for (int i = 0; i < 2 && ok; ++i) {
+        ok = hipHostMalloc((void**)&nu[i], up_cap * sizeof(double), hipHostMallocDefault) == hipSuccess &&
+             hipHostMalloc((void**)&nd[i], down_cap * sizeof(double), hipHostMallocDefault) == hipSuccess &&
+             hipMalloc((void**)&ns[i], up_cap * sizeof(double)) == hipSuccess &&
+             hipMalloc((void**)&ng[i], down_cap * sizeof(double)) == hipSuccess;
+    }
+    if (!ok) {
+        drop(nu, nd, ns, ng);
+        (void)hipGetLastError();   // the failed allocation's error code is ours: do not leave it sticky for the caller
+        return false;
+    }
+    for (int i = 0; i < 2; ++i) {
+        hp_up_[i]   = nu[i];
+        hp_down_[i] = nd[i];
+        hp_dsp_[i]  = ns[i];
+        hp_dgp_[i]  = ng[i];
+    }
+    hp_up_cap_   = up_cap;
+    hp_down_cap_ = down_cap;
+    return true;
+}
+
+bool Trans::invtrans_host_pipelined(int nb_scalar, const double* sp_host, int nb_vordiv, const double* vor_host,
                                     const double* div_host, double* gp_host) {
     const size_t ncoef = nb_spectral_coefficients();   // doubles per field
     const size_t npts  = (size_t)nb_gridpoints();
@@ -1284,24 +1335,8 @@ void Trans::invtrans_host_pipelined(int nb_scalar, const double* sp_host, int nb
             HIP_CHECK(hipEventCreateWithFlags(&hp_down_done_[i], hipEventDisableTiming));
         }
     }
-    if ((size_t)C * ncoef > hp_up_cap_ || (size_t)C * npts > hp_down_cap_) {   // (re)allocate the buffers for this chunk size
-        synchronize();
-        HIP_CHECK(hipStreamSynchronize(hp_up_stream_));
-        HIP_CHECK(hipStreamSynchronize(copy_stream_));
-        hp_up_cap_   = std::max(hp_up_cap_, (size_t)C * ncoef);
-        hp_down_cap_ = std::max(hp_down_cap_, (size_t)C * npts);
-        for (int i = 0; i < 2; ++i) {
-            if (hp_up_[i]) {
-                (void)hipHostFree(hp_up_[i]);
-                (void)hipHostFree(hp_down_[i]);
-                (void)hipFree(hp_dsp_[i]);
-                (void)hipFree(hp_dgp_[i]);
-            }
-            HIP_CHECK(hipHostMalloc((void**)&hp_up_[i], hp_up_cap_ * sizeof(double), hipHostMallocDefault));
-            HIP_CHECK(hipHostMalloc((void**)&hp_down_[i], hp_down_cap_ * sizeof(double), hipHostMallocDefault));
-            HIP_CHECK(hipMalloc((void**)&hp_dsp_[i], hp_up_cap_ * sizeof(double)));
-            HIP_CHECK(hipMalloc((void**)&hp_dgp_[i], hp_down_cap_ * sizeof(double)));
-        }
+    if (!ensure_host_pipeline_buffers((size_t)C * ncoef, (size_t)C * npts)) {
+        return false;   // nothing was enqueued: the caller takes the serial pageable path
     }
     // buffers the stages grow on demand (with a synchronisation): before the pipeline starts, not inside it
     (void)fourier_buffer(C);
@@ -1426,6 +1461,7 @@ void Trans::invtrans_host_pipelined(int nb_scalar, const double* sp_host, int nb
         throw std::runtime_error("host pipeline, download thread: " + thread_error);
     }
     synchronize();
+    return true;
 }
 
 void Trans::enable_phase_profile(bool on) {
@@ -1531,8 +1567,9 @@ void Trans::invtrans(int nb_scalar, const double sp[], int nb_vordiv, const doub
             pipe = atoi(e) != 0;
         }
         if (pipe && 2 * nb_vordiv + nb_scalar >= 32 && ngp * sizeof(double) >= (size_t(256) << 20) && fourier_parts() == 1 && !windowed()) {
-            invtrans_host_pipelined(nb_scalar, sp, nb_vordiv, vor, div, gp);
-            return;
+            if (invtrans_host_pipelined(nb_scalar, sp, nb_vordiv, vor, div, gp)) {
+                return;
+            }   // staging buffers unavailable: the serial path below
         }
     }
     ensure(d_vd_, vd_cap_, 2 * nvd);

@@ -333,7 +333,9 @@ static hipError_t launch_spectra_prepare_t(const Real* vor, const Real* div, con
     // many vor/div fields and enough coefficients to fill the device with its chunks (T >= 255): the streaming form (a lane per field);
     // ATLAS_AMD_PREPARE=rows / stream forces one of the two (same bits either way: tests/test_gpu_vordiv.py)
     const char* e     = std::getenv("ATLAS_AMD_PREPARE");
-    const bool stream_form = e && *e ? std::string(e) == "stream" : (nvd >= 48 && total_n >= PREP_SNB * 2048);
+    // (the streaming form walks groups of 64 vor/div fields: it has nothing to do -- and divides by the group count -- without any,
+    // e.g. the scalar chunks of a pipelined vor/div call, whatever the override says)
+    const bool stream_form = nvd > 0 && (e && *e ? std::string(e) == "stream" : (nvd >= 48 && total_n >= PREP_SNB * 2048));
     if (stream_form) {
         dim3 grid((T + 2 + PREP_SNB - 1) / PREP_SNB, T + 2);
         hipLaunchKernelGGL(spectra_prepare_stream_kernel<Real>, grid, dim3(256), 0, stream, p);

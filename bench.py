@@ -323,11 +323,144 @@ class Watchdog:
             self.timer = None
 
 
+class DeviceSampler:
+    """Clocks / power / temperature of the device WHILE the timed blocks run (a bench line must let a reader
+    tell a slow box from a slow build).  A thread polls amdsmi's gpu_metrics (0.2 ms per call, no subprocess) every few
+    milliseconds: shader clock per XCD, memory clock, socket power, hot-spot temperature, and the firmware's throttle-residency
+    accumulators (power / thermal / PROCHOT), whose increase over the timed region divided by the increase of the accumulation
+    counter is the share of the time the part was held back.  Fallback: the hwmon files of the card; neither: every field null.
+    A measurement aid: it never fails the bench."""
+    FIELDS = ("prochot_residency_acc", "ppt_residency_acc", "socket_thm_residency_acc", "vr_thm_residency_acc", "hbm_thm_residency_acc")
+
+    def __init__(self, device_index=0, period_s=0.004):
+        self.period, self.samples, self.thread, self.stop_flag = period_s, [], None, False
+        self.read, self.source, self.static = None, None, {}
+        try:
+            import amdsmi
+            amdsmi.amdsmi_init()
+            h = amdsmi.amdsmi_get_processor_handles()[device_index]
+            amdsmi.amdsmi_get_gpu_metrics_info(h)
+            self.read, self.source = (lambda: amdsmi.amdsmi_get_gpu_metrics_info(h)), "amdsmi gpu_metrics"
+            try:
+                cap = amdsmi.amdsmi_get_power_cap_info(h)
+                self.static["power_cap_w"] = float(cap["power_cap"]) / 1e6
+                clk = amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX)
+                self.static["sclk_max_mhz"] = clk.get("max_clk")
+            except Exception:
+                pass
+        except Exception:
+            import glob
+            hw = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))
+            if hw:
+                d = os.path.dirname(hw[min(device_index, len(hw) - 1)])
+
+                def rd(name, scale):
+                    try:
+                        with open(os.path.join(d, name)) as f:
+                            return float(f.read()) / scale
+                    except Exception:
+                        return None
+                self.read = lambda: {"current_gfxclk": rd("freq1_input", 1e6), "current_uclk": rd("freq2_input", 1e6),
+                                     "current_socket_power": rd("power1_input", 1e6), "temperature_hotspot": rd("temp2_input", 1e3),
+                                     "temperature_mem": rd("temp3_input", 1e3)}
+                self.source = "hwmon sysfs"
+                self.static["power_cap_w"] = rd("power1_cap", 1e6)
+
+    @staticmethod
+    def _num(v):
+        return float(v) if isinstance(v, (int, float)) else None
+
+    def snapshot(self):
+        if self.read is None:
+            return None
+        try:
+            m = self.read()
+        except Exception:
+            return None
+        clks = [c for c in (m.get("current_gfxclks") or []) if isinstance(c, (int, float))] or \
+               [c for c in [m.get("current_gfxclk")] if isinstance(c, (int, float))]
+        out = {"t": time.perf_counter(), "sclk": (sum(clks) / len(clks)) if clks else None, "sclk_min_xcd": min(clks) if clks else None,
+               "mclk": self._num(m.get("current_uclk")), "power": self._num(m.get("current_socket_power")),
+               "temp_hotspot": self._num(m.get("temperature_hotspot")), "temp_mem": self._num(m.get("temperature_mem")),
+               "acc": self._num(m.get("accumulation_counter"))}
+        for k in self.FIELDS:
+            out[k] = self._num(m.get(k))
+        return out
+
+    def start(self):
+        if self.read is None:
+            return
+        import threading
+        self.samples, self.stop_flag = [], False
+
+        def loop():
+            while not self.stop_flag:
+                s_ = self.snapshot()
+                if s_ is not None:
+                    self.samples.append(s_)
+                time.sleep(self.period)
+        self.thread = threading.Thread(target=loop, daemon=True)
+        self.thread.start()
+
+    def stop(self):
+        if self.thread is not None:
+            self.stop_flag = True
+            self.thread.join()
+            self.thread = None
+
+    def summary(self, before, after):
+        """before / after: snapshots taken outside the timed blocks (idle device); samples: inside them"""
+        if self.read is None:
+            return {"source": None, "note": "neither amdsmi nor the card's hwmon files are readable here"}
+
+        def stat(key):
+            v = [s_[key] for s_ in self.samples if s_.get(key) is not None]
+            return {"mean": sum(v) / len(v), "min": min(v), "max": max(v)} if v else None
+        out = {"source": self.source, "samples_in_timed_blocks": len(self.samples), "period_ms": self.period * 1e3,
+               "sclk_mhz": stat("sclk"), "sclk_slowest_xcd_mhz": stat("sclk_min_xcd"), "mclk_mhz": stat("mclk"),
+               "socket_power_w": stat("power"),
+               "temp_hotspot_c": {"before": (before or {}).get("temp_hotspot"), "after": (after or {}).get("temp_hotspot")},
+               "temp_mem_c": {"before": (before or {}).get("temp_mem"), "after": (after or {}).get("temp_mem")}}
+        out.update(self.static)
+        if before and after and before.get("acc") is not None and after.get("acc") is not None and after["acc"] > before["acc"]:
+            span = after["acc"] - before["acc"]
+            out["throttle_residency"] = {k.replace("_residency_acc", ""): ((after[k] - before[k]) / span
+                                                                          if before.get(k) is not None and after.get(k) is not None else None)
+                                         for k in self.FIELDS}
+            out["throttle_residency"]["note"] = ("share of the firmware's accumulation ticks between the snapshot before the first and "
+                                                 "after the last timed block in which the limiter was active (ppt = socket power)")
+        return out
+
+
+def measured_hbm_copy_rate(device, nbytes=2 << 30, repeats=5):
+    """what this box's HBM delivers on a plain device-to-device copy (read + write bytes per second), measured with the same
+    events as the stages right after the timed blocks: a box-speed reference for the bandwidth side, like
+    peak_sustained_measured for the matrix side"""
+    import torch
+    a = torch.empty(nbytes // 8, dtype=torch.float64, device=device).normal_()
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 0.0
+    for _ in range(repeats):
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        best = max(best, 2.0 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--blocks", type=int, default=3,
+                    help="timed blocks of exactly --steps steps each (barrier + synchronize on both sides of every block); `value` is "
+                         "the MEDIAN block, min / max are reported beside it under `repeats`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-fields", type=int, default=NLEV,
                     help="levels of the transform the CPU baseline runs (default: all 137 -- the dgemm shapes of the real call)")
@@ -514,19 +647,33 @@ def main():
         step()
     barrier()
     wd.phase("timed steps")
-    tr.timings(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        import torch.distributed as dist
-        tmax = torch.tensor([dt], dtype=torch.float64, device=DEVICE)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    # `--blocks` blocks of exactly `--steps` steps, each bracketed by barrier + synchronize; the block with the MEDIAN time is
+    # the one `value`, `ms_per_step` and the per-stage times describe (reference benchmark: min / max / iterations,
+    # atlas-benchmark-trans.cc:257-289).  The device state is sampled while the blocks run.
+    sampler = DeviceSampler(local_rank) if (on_gpu and rank == 0) else None
+    state_before = sampler.snapshot() if sampler else None
+    blocks = []
+    if sampler:
+        sampler.start()
+    for _ in range(max(1, args.blocks)):
+        tr.timings(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        bdt = time.perf_counter() - t0
+        if use_dist:
+            import torch.distributed as dist
+            tmax = torch.tensor([bdt], dtype=torch.float64, device=DEVICE)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            bdt = float(tmax.item())
+        blocks.append((bdt, tr.timings()))
+    if sampler:
+        sampler.stop()
+    state_after = sampler.snapshot() if sampler else None
+    order = sorted(range(len(blocks)), key=lambda i: blocks[i][0])
+    dt, tm = blocks[order[(len(blocks) - 1) // 2]]   # the median block (the lower one of an even count)
     wd.phase("after the timed region (alternative decomposition, report)")
-    tm = tr.timings()
     transforms = args.steps * world
     ms_per_step = dt / args.steps * 1e3
 
@@ -618,6 +765,12 @@ def main():
                 kernels[0]["frac_of_sustained"] = leg_tf / sustained if sustained > 0 else None
             except Exception as e:   # a measurement aid: never fails the bench
                 sys.stderr.write(f"[bench] sustained MFMA rate not measured: {type(e).__name__}: {e}\n")
+            if on_gpu:
+                try:
+                    kernels[1]["hbm_copy_measured"] = measured_hbm_copy_rate(DEVICE)
+                    kernels[1]["frac_of_hbm_copy_measured"] = fft_gbs / kernels[1]["hbm_copy_measured"]
+                except Exception as e:
+                    sys.stderr.write(f"[bench] HBM copy rate not measured: {type(e).__name__}: {e}\n")
         # the bound that actually applies to the Fourier stage is its own vector-ALU instruction stream (counter traffic
         # 1.04 x algorithmic, VALU the busiest unit): floor = wave-instructions x 4 cycles / 1024 SIMDs / 2.4 GHz
         valu = measured_valu_instructions() if world == 1 and not use_dist else {}
@@ -649,11 +802,22 @@ def main():
                            f"band are computed without their mirror hemisphere: 2/P of the single-GPU Legendre work)")},
             "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")},
             "roofline_kernels": kernels,
+            "repeats": {"blocks": len(blocks), "steps_per_block": args.steps, "value_is": "median block",
+                        "values": [transforms / b[0] for b in blocks],
+                        "ms_per_step": [b[0] / args.steps * 1e3 for b in blocks],
+                        "min": transforms / max(b[0] for b in blocks), "max": transforms / min(b[0] for b in blocks),
+                        "legendre_ms": [b[1]["legendre_ms"] / max(b[1]["legendre_calls"], 1) for b in blocks],
+                        "fourier_ms": [b[1]["fourier_ms"] / max(b[1]["fourier_calls"], 1) for b in blocks]},
+            "clocks": sampler.summary(state_before, state_after) if sampler else None,
         }
+        # what THIS box delivers on the two bare resources, measured in this run (boxes of the pool differ by up to 10 % on the
+        # same build: profiles/r06_ab_r4_vs_head.txt, r06_ab_prefetch.txt)
+        out["box"] = {"mfma_f64_sustained_tflops": kernels[0].get("peak_sustained_measured"),
+                      "hbm_copy_gbs": kernels[1].get("hbm_copy_measured")}
         out["roofline"]["kernel"] = dominant["kernel"]
         out["roofline"]["avg_ms"] = dominant["avg_ms"]
         for k in ("peak_sustained_measured", "frac_of_sustained", "valu_issue_floor_ms", "frac_of_valu_issue_floor",
-                  "valu_wave_instructions"):
+                  "valu_wave_instructions", "hbm_copy_measured", "frac_of_hbm_copy_measured"):
             if k in dominant:
                 out["roofline"][k] = dominant[k]
         out["roofline"]["traffic_source"] = (f"profiles/{traffic['_profile']} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same "

@@ -347,3 +347,59 @@ def test_ranks_with_different_message_limits_get_an_error_not_a_hang():
 
     assert all(run_ranks(nparts, rank))
     assert all(e is not None and "message limit" in e for e in errors), errors
+
+
+def test_one_rank_with_an_invalid_message_limit_is_an_error_on_every_rank_not_a_hang():
+    """the argument check of set_max_message_bytes used to run rank-locally BEFORE the collective comparison, so a rank
+    passing < 8 bytes threw and left the others waiting in the all-to-all.  Now every rank takes part and then fails: the rank with
+    the bad value with the argument error, the others because the limits differ; the previous limit stays in force."""
+    g = atlas_amd.Grid("O32")
+    T, nparts = 31, 2
+    errors = [None] * nparts
+
+    def rank(comm):
+        d = DistributedTrans(g, T, comm=comm, mode="alltoall")
+        d.set_max_message_bytes(1 << 14)
+        try:
+            d.set_max_message_bytes(4 if comm.rank() == 0 else 8192)
+        except Exception as e:  # noqa: BLE001
+            errors[comm.rank()] = str(e)
+        nf = 2
+        sp = torch.from_numpy(red_spectra(T, nf, seed=5)).cuda()
+        gp = torch.zeros(nf * d.trans.nb_gridpoints(), dtype=torch.float64, device="cuda")
+        d.invtrans(nf, sp, gp)                         # still usable, with the limit agreed before
+        d.trans.synchronize()
+        return bool(torch.isfinite(gp).all())
+
+    assert all(run_ranks(nparts, rank))
+    assert errors[0] is not None and "at least one element" in errors[0], errors
+    assert errors[1] is not None and "message limit" in errors[1], errors
+
+
+def test_field_counts_are_compared_on_every_call_in_debug_mode(monkeypatch):
+    """ATLAS_AMD_DIST_CHECK=always: ranks calling with different, individually already-compared field counts get an error
+    (by default a (field count, limit) pair is compared only the first time it is used: ADVICE r4 / r5)"""
+    monkeypatch.setenv("ATLAS_AMD_DIST_CHECK", "always")
+    g = atlas_amd.Grid("O32")
+    T, nparts = 31, 2
+    errors = [None] * nparts
+
+    def rank(comm):
+        d = DistributedTrans(g, T, comm=comm, mode="alltoall")
+        n = d.trans.nb_gridpoints()
+        for nf in (1, 2):                              # both counts compared once, on all ranks
+            sp = torch.from_numpy(red_spectra(T, nf, seed=5)).cuda()
+            gp = torch.zeros(nf * n, dtype=torch.float64, device="cuda")
+            d.invtrans(nf, sp, gp)
+            d.trans.synchronize()
+        nf = 1 if comm.rank() == 0 else 2              # now the ranks disagree
+        sp = torch.from_numpy(red_spectra(T, nf, seed=5)).cuda()
+        gp = torch.zeros(nf * n, dtype=torch.float64, device="cuda")
+        try:
+            d.invtrans(nf, sp, gp)
+        except Exception as e:  # noqa: BLE001
+            errors[comm.rank()] = str(e)
+        return True
+
+    assert all(run_ranks(nparts, rank))
+    assert all(e is not None and "field count" in e for e in errors), errors

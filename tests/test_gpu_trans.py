@@ -862,6 +862,28 @@ def test_host_pointer_pipeline_is_bitwise_equal_to_the_device_path(monkeypatch):
             monkeypatch.delenv(k2)
 
 
+def test_host_pointer_pipeline_falls_back_to_the_serial_path_when_its_buffers_cannot_be_allocated(monkeypatch):
+    """a failed hipHostMalloc of the pipeline's pinned staging buffers (memlock limit, memory pressure) used
+    to leave raised capacities beside freed pointers -- the next call would have copied into freed memory, release() freed them
+    twice.  Now the set is committed only when all eight allocations succeeded; on failure the object holds no staging buffers, the
+    call runs the serial pageable path (same bits), and a later call allocates again."""
+    g, tr = get_trans("O640", 639)
+    T, nf = 639, 40
+    sp = red_spectra(T, nf, seed=94)
+    ref = run_device(tr, nf, sp)
+    # fail with no buffers; succeed (chunks of 16); fail while growing to chunks of 32 (the old set is dropped); succeed again
+    for fail, chunk in (("1", "16"), (None, "16"), ("1", "32"), (None, "32")):
+        monkeypatch.setenv("ATLAS_AMD_HOST_CHUNK", chunk)
+        if fail:
+            monkeypatch.setenv("ATLAS_AMD_HOST_PIPELINE_FAIL_ALLOC", fail)
+        else:
+            monkeypatch.delenv("ATLAS_AMD_HOST_PIPELINE_FAIL_ALLOC", raising=False)
+        gp = np.full(nf * g.size(), np.nan)
+        tr.invtrans(nf, sp, gp)
+        assert np.array_equal(gp, ref), (fail, chunk)
+    monkeypatch.delenv("ATLAS_AMD_HOST_CHUNK", raising=False)
+
+
 def test_reference_poles_switch_reproduces_the_reference_at_the_south_pole(monkeypatch):
     """INTEGRATION.md "Deviations": by default a row at latitude -90 of a no_nest target is the mirror image of the north-pole
     row; ATLAS_AMD_REFERENCE_POLES=1 reproduces what the reference computes there -- its Legendre routine sets cos(colatitude) =
