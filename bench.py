@@ -117,10 +117,12 @@ def cpu_baseline(sample_fields=8):
                       f"built beforehand); scaled by {NLEV}/{sample_fields}"}
 
 
-def cpu_baseline_blas(sample_fields=8, keep_field=False):
+def cpu_baseline_blas(sample_fields=8, keep_field=False, one_thread_fields=4):
     """CPU baseline: the reference's algorithm with library kernels, BLAS dgemm (numpy) and pocketfft (scipy.fft) -- the
-    reference's eckit "lapack" + pocketfft configuration (oracle/translocal_blas.py).  keep_field: also return the grid-point
-    field it computed and its spectra (the checker of the bench line's `parity` block)."""
+    reference's eckit "lapack" + pocketfft configuration (oracle/translocal_blas.py) -- on a pool of threads over wavenumbers /
+    row groups, with the wall-clock split SURVEY 8(d) asks for (legendre_s / fourier_s / layout_s) and a one-thread figure from
+    a `one_thread_fields`-level sample scaled to 137 levels.  keep_field: also return the grid-point field it computed and its
+    spectra (the checker of the bench line's `parity` block)."""
     import numpy as np
     import atlas_amd
     import oracle
@@ -129,21 +131,34 @@ def cpu_baseline_blas(sample_fields=8, keep_field=False):
     g = atlas_amd.Grid(GRID)
     op = oracle.OraclePlan(TRUNC, g.nx(), g.y(), with_tables=True)
     sp = red_spectra(TRUNC, sample_fields)
-    workers = os.cpu_count() or 1
-    invtrans_blas(op, 1, np.ascontiguousarray(sp.reshape(-1, sample_fields)[:, :1]).reshape(-1), workers=workers)   # warm-up
-    t0 = time.perf_counter()
-    field = invtrans_blas(op, sample_fields, sp, workers=workers)
-    dt = time.perf_counter() - t0
     try:
-        from threadpoolctl import threadpool_info
-        blas_threads = max([int(i.get("num_threads", 1)) for i in threadpool_info() if i.get("user_api") == "blas"] or [1])
+        avail = len(os.sched_getaffinity(0))
     except Exception:
-        blas_threads = os.cpu_count() or 1
-    line = {"value": (sample_fields / NLEV) / dt, "unit": "transforms/s", "cores": blas_threads, "kind": "port",
-            "sample": f"{sample_fields} of {NLEV} levels of one TL{TRUNC}->{GRID} transform in {dt:.2f} s: the reference's "
-                      f"algorithm with library kernels -- per-m dgemm pairs (numpy/OpenBLAS, {blas_threads} threads) + per-row "
-                      f"pocketfft c2r (scipy.fft, {workers} workers) -- i.e. TransLocal with eckit 'lapack' + pocketfft "
-                      f"(oracle/translocal_blas.py; tables built beforehand); scaled by {NLEV}/{sample_fields}"}
+        avail = os.cpu_count() or 1
+    workers = max(1, min(avail, 64))   # one thread per core of a 64-core host; more threads than that only fight over memory
+    invtrans_blas(op, 1, np.ascontiguousarray(sp.reshape(-1, sample_fields)[:, :1]).reshape(-1), workers=workers)   # warm-up
+    tm = {}
+    t0 = time.perf_counter()
+    field = invtrans_blas(op, sample_fields, sp, workers=workers, timings=tm)
+    dt = time.perf_counter() - t0
+    line = {"value": (sample_fields / NLEV) / dt, "unit": "transforms/s", "cores": workers, "kind": "port",
+            "legendre_s": tm.get("legendre_s"), "fourier_s": tm.get("fourier_s"), "layout_s": tm.get("layout_s"),
+            "sample": f"{sample_fields} of {NLEV} levels of one TL{TRUNC}->{GRID} transform in {dt:.2f} s on {workers} threads "
+                      f"(of {avail} available): the reference's algorithm with library kernels -- per-m dgemm pairs (numpy/OpenBLAS, "
+                      f"one wavenumber per thread) + pocketfft c2r batched per row length (scipy.fft) -- i.e. TransLocal with eckit "
+                      f"'lapack' + pocketfft (oracle/translocal_blas.py; tables built beforehand); legendre_s / fourier_s: wall clock "
+                      f"of the two stages, layout_s: the part of it spent in the split / merge / transpose copies (thread-time / "
+                      f"threads); scaled by {NLEV}/{sample_fields}"}
+    if one_thread_fields and one_thread_fields > 0:
+        k = int(min(one_thread_fields, sample_fields))
+        sp1 = np.ascontiguousarray(sp.reshape(-1, sample_fields)[:, :k]).reshape(-1)
+        tm1 = {}
+        t0 = time.perf_counter()
+        invtrans_blas(op, k, sp1, workers=1, timings=tm1)
+        dt1 = time.perf_counter() - t0
+        line["one_thread"] = {"value": (k / NLEV) / dt1, "unit": "transforms/s", "cores": 1,
+                              "legendre_s": tm1.get("legendre_s"), "fourier_s": tm1.get("fourier_s"), "layout_s": tm1.get("layout_s"),
+                              "sample": f"{k} of {NLEV} levels in {dt1:.2f} s on one thread (BLAS limited to one thread), scaled by {NLEV}/{k}"}
     return (line, field, sp) if keep_field else line
 
 

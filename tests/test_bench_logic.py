@@ -78,6 +78,15 @@ def test_single_gpu_line_has_roofline_and_cpu_baseline(tmp_path):
     assert out["config"]["parallelism"] == "single GPU"
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "transforms/s"
+    # the per-stage split and the one-thread figure beside the all-core one
+    assert cb["legendre_s"] > 0 and cb["fourier_s"] > 0 and cb["layout_s"] >= 0
+    assert cb["one_thread"]["cores"] == 1 and cb["one_thread"]["value"] > 0 and cb["one_thread"]["legendre_s"] > 0
+    # three timed blocks of exactly --steps steps; value = the median block; device state (null fields off the GPU)
+    rp = out["repeats"]
+    assert rp["blocks"] == 3 and rp["steps_per_block"] == 2 and len(rp["values"]) == 3
+    assert rp["min"] <= out["value"] <= rp["max"] and sorted(rp["values"])[1] == pytest.approx(out["value"])
+    assert out["ms_per_step"] == pytest.approx(sorted(rp["ms_per_step"])[1])
+    assert "clocks" in out
     assert "multi_gpu_crosscheck" not in out and "alt_decomposition" not in out
     # the full-field parity block: every grid point of the CPU baseline's transform against the device result
     # of the same spectra (here the stand-in "device" computes something else: only the bookkeeping is checked)

@@ -83,7 +83,13 @@ def test_blas_pocketfft_variant_equals_plain_oracle(gridname, T, nf):
     g, nx, lat = grid_arrays(gridname)
     op = oracle.OraclePlan(T, nx, lat)
     sp = red_spectra(T, nf, seed=4)
-    assert compute_rms(invtrans_blas(op, nf, sp), op.invtrans(nf, sp, use_fft=True)) < 1e-15
+    ref = op.invtrans(nf, sp, use_fft=True)
+    assert compute_rms(invtrans_blas(op, nf, sp), ref) < 1e-15
+    # the threaded form (bench.py's cpu_baseline: a pool over wavenumbers / row groups) computes the same numbers and reports
+    # where its wall clock went
+    tm = {}
+    assert np.array_equal(invtrans_blas(op, nf, sp, workers=4, timings=tm), invtrans_blas(op, nf, sp))
+    assert tm["threads"] == 4 and tm["legendre_s"] > 0 and tm["fourier_s"] > 0 and 0 <= tm["layout_s"] <= tm["legendre_s"] + tm["fourier_s"]
 
 
 def test_oracle_rows_equals_table_path():
