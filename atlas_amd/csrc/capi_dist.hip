@@ -262,6 +262,22 @@ int atlas_amd__Trans__set_max_message_bytes(atlas_amd_Trans* t, atlas_amd_Comm* 
     dist_of(t, c).set_max_message_elems(bytes < 8 ? 0 : bytes / 8);
     DX_CATCH
 }
+int atlas_amd__Trans__timings_distributed(atlas_amd_Trans* t, atlas_amd_Comm* c, double out[8], int reset) {
+    DX_TRY
+    if (!out) {
+        throw std::invalid_argument("timings_distributed: null array");
+    }
+    const auto x = dist_of(t, c).exchange_timings(reset != 0);
+    out[0] = x.pack_ms;
+    out[1] = x.exchange_ms;
+    out[2] = x.calls;
+    out[3] = (double)x.bytes_sent_off_device;
+    out[4] = (double)x.bytes_received_off_device;
+    out[5] = (double)x.bytes_largest_peer;
+    out[6] = x.peers;
+    out[7] = 0;
+    DX_CATCH
+}
 int atlas_amd__transpose_messages(int truncation, int RP, int nparts, int part, const int bands[], long long max_message_elems,
                                   int capacity, int* peer, long long* send_begin, long long* send_end, long long* recv_begin,
                                   long long* recv_end, int* count) {

@@ -99,6 +99,16 @@ public:
     void set_max_message_elems(int64_t elems);
     int64_t max_message_elems() const { return max_message_elems_; }
     const PackedTransposePlan& packed_plan() const { return pplan_; }
+    // with Trans profiling on: HIP events on the communication stream around the pack kernel and around the send / receive group of
+    // every transform (a multi-GPU bench line shows where the curve bends).  The exchange time of a rank includes
+    // waiting for its peers to post their side.  bytes_*: per transform, this rank.
+    struct ExchangeTimings {
+        double pack_ms = 0, exchange_ms = 0;
+        int calls = 0;
+        int64_t bytes_sent_off_device = 0, bytes_received_off_device = 0, bytes_largest_peer = 0;
+        int peers = 0;
+    };
+    ExchangeTimings exchange_timings(bool reset);
 
 private:
     struct Slot {
@@ -118,6 +128,10 @@ private:
     void exchange(Slot& s);
     void fourier(int nb_fields, Slot& s, double* gp_dev);
     void halo(int nb_fields, Slot& s, const double* gp_dev, parallel::HaloExchange& hx, double* field_dev);
+
+    std::vector<hipEvent_t> xev_;   // triples (before pack, after pack, after the exchange) of the transforms since the last reset
+    size_t xev_used_ = 0;
+    ExchangeTimings xt_;
 
     Trans& trans_;
     parallel::Comm& comm_;

@@ -359,6 +359,9 @@ DistributedTrans::~DistributedTrans() {
         (void)hipEventDestroy(s.exchange_done);
         (void)hipEventDestroy(s.fourier_done);
     }
+    for (hipEvent_t e : xev_) {
+        (void)hipEventDestroy(e);
+    }
     (void)hipStreamDestroy(comm_stream_);
     (void)hipFree(d_rowoff_src_);
     (void)hipFree(d_rowoff_dst_);
@@ -540,12 +543,24 @@ void DistributedTrans::exchange(Slot& s) {
     if (s.used) {
         HIP_CHECK(hipStreamWaitEvent(comm_stream_, s.fourier_done, 0));   // R of this slot is still being read
     }
+    const bool prof = trans_.profile();
+    if (prof) {
+        while (xev_.size() < xev_used_ + 3) {
+            hipEvent_t e;
+            HIP_CHECK(hipEventCreate(&e));
+            xev_.push_back(e);
+        }
+        HIP_CHECK(hipEventRecord(xev_[xev_used_], comm_stream_));
+    }
     // pack: the kept wavenumbers and live columns of every row, contiguous per destination band
     if (pplan_.send_total > 0) {
         const int nlats = trans_.geometry().nlats;
         hipLaunchKernelGGL(pack_rows_kernel, dim3(nlats, 4), dim3(256), 0, comm_stream_, s.F, s.S, d_rowoff_src_, d_kept_,
                            trans_.owned_wavenumbers(), RP_, pplan_.cols);
         HIP_CHECK(hipGetLastError());
+    }
+    if (prof) {
+        HIP_CHECK(hipEventRecord(xev_[xev_used_ + 1], comm_stream_));
     }
     std::vector<parallel::Msg> sends, recvs;
     for (const TransposeMsg& m : msgs_) {
@@ -558,6 +573,41 @@ void DistributedTrans::exchange(Slot& s) {
     }
     comm_.exchange(sends, recvs, comm_stream_);
     HIP_CHECK(hipEventRecord(s.exchange_done, comm_stream_));
+    if (prof) {
+        HIP_CHECK(hipEventRecord(xev_[xev_used_ + 2], comm_stream_));
+        xev_used_ += 3;
+    }
+}
+
+DistributedTrans::ExchangeTimings DistributedTrans::exchange_timings(bool reset) {
+    HIP_CHECK(hipStreamSynchronize(comm_stream_));
+    for (size_t i = 0; i + 3 <= xev_used_; i += 3) {
+        float a = 0, b = 0;
+        HIP_CHECK(hipEventElapsedTime(&a, xev_[i], xev_[i + 1]));
+        HIP_CHECK(hipEventElapsedTime(&b, xev_[i + 1], xev_[i + 2]));
+        xt_.pack_ms += a;
+        xt_.exchange_ms += b;
+        xt_.calls += 1;
+    }
+    xev_used_ = 0;
+    ExchangeTimings out = xt_;
+    // what one transform moves between this rank and its peers (the message list in use)
+    std::vector<int64_t> to_peer(comm_.size(), 0);
+    for (const TransposeMsg& m : msgs_) {
+        if (m.peer != comm_.rank()) {
+            to_peer[m.peer] += (m.send_end - m.send_begin) * (int64_t)sizeof(double);
+            out.bytes_received_off_device += (m.recv_end - m.recv_begin) * (int64_t)sizeof(double);
+        }
+    }
+    for (int64_t b : to_peer) {
+        out.bytes_sent_off_device += b;
+        out.bytes_largest_peer = std::max(out.bytes_largest_peer, b);
+        out.peers += b > 0;
+    }
+    if (reset) {
+        xt_ = ExchangeTimings();
+    }
+    return out;
 }
 
 void DistributedTrans::fourier(int nb_fields, Slot& s, double* gp_dev) {

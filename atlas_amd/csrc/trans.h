@@ -139,6 +139,7 @@ public:
         timings_ = StageTimings();
     }
     void set_profile(bool on) { profile_ = on; }
+    bool profile() const { return profile_; }
     // dev profiling: per-phase shader-clock totals of the FFT kernel (thread 0 of every workgroup)
     void enable_phase_profile(bool on);
     void read_phase_profile(unsigned long long out[64]);

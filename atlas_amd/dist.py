@@ -38,6 +38,7 @@ Trans_invtrans_distributed_sharded = _sig("atlas_amd__Trans__invtrans_distribute
 Trans_spectral_shard = _sig("atlas_amd__Trans__spectral_shard", c_int, c_void_p, c_void_p, c_void_p)
 Trans_pack_probe = _sig("atlas_amd__Trans__pack_probe", c_int, c_void_p, c_int, c_int, c_void_p, c_void_p)
 Trans_fourier_packed_probe = _sig("atlas_amd__Trans__fourier_packed_probe", c_int, c_void_p, c_int, c_int, c_void_p)
+Trans_timings_distributed = _sig("atlas_amd__Trans__timings_distributed", c_int, c_void_p, c_void_p, c_void_p, c_int)
 Trans_set_max_message_bytes = _sig("atlas_amd__Trans__set_max_message_bytes", c_int, c_void_p, c_void_p, C.c_longlong)
 _transpose_messages = _sig("atlas_amd__transpose_messages", c_int, c_int, c_int, c_int, c_int, c_void_p, C.c_longlong,
                            c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p)
@@ -145,6 +146,17 @@ class DistributedTrans:
         with _lib.torch_stream_order(self.trans.stream()):
             _lib.check(Trans_invtrans_distributed_sharded(self.trans._h, self.comm._h, n, int(nf), a, b))
         return gps
+
+    def exchange_timings(self, reset=False):
+        """per-transform averages of this rank's transposition since the last reset (Trans made with profile=True): pack kernel and
+        send / receive group on the communication stream, bytes per transform to / from other ranks and to the busiest peer"""
+        if self.mode != "alltoall":
+            return None
+        out = (C.c_double * 8)()
+        _lib.check(Trans_timings_distributed(self.trans._h, self.comm._h, out, int(reset)))
+        n = max(int(out[2]), 1)
+        return {"pack_ms": out[0] / n, "exchange_ms": out[1] / n, "transforms": int(out[2]), "bytes_sent": int(out[3]),
+                "bytes_received": int(out[4]), "bytes_to_busiest_peer": int(out[5]), "peers": int(out[6])}
 
     def set_max_message_bytes(self, nbytes):
         _lib.check(Trans_set_max_message_bytes(self.trans._h, self.comm._h, int(nbytes)))

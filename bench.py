@@ -239,6 +239,7 @@ def dry_run(args):
         problems.append("the messages do not add up to the kept part of the intermediate")
     worst_link = int(off_dev.max()) if P > 1 else 0
     per_gpu_out = off_dev.sum(axis=1)
+    args.xgmi_gbs = 50.0 if args.xgmi_gbs is None else args.xgmi_gbs
     rate = args.xgmi_gbs * 1e9
     rows = [int(bands[q + 1] - bands[q]) for q in range(P)]
     pts = np.concatenate([[0], np.cumsum(np.asarray(g.nx(), dtype=np.int64))])
@@ -262,6 +263,20 @@ def dry_run(args):
                         "total_equals_kept_intermediate": not any("add up" in p for p in problems)},
         "problems": problems,
     }
+    # what `--dist-mode auto` would be expected to pick at this link rate, from the newest committed per-rank cost record
+    # (tools/scaling_model.py: every rank's share alone on one device); a live run decides by an untimed trial of both
+    import glob
+    models = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_scaling_model.json")))
+    if models and P > 1:
+        with open(models[-1]) as f:
+            sm = json.load(f)
+        ranks = (sm.get("P", {}).get(str(P)) or {}).get("ranks")
+        if ranks:
+            slow = max(ranks, key=lambda r: r["legendre_ms"] + r["fourier_ms"])
+            out["auto_choice_predicted"] = predict_decomposition(
+                P, slow["legendre_ms"], slow["fourier_ms"], max(r["pack_ms"] for r in ranks), worst_link, args.xgmi_gbs,
+                single_ms=sm["single_gpu"]["ms_per_transform"])
+            out["auto_choice_predicted"]["costs_from"] = "profiles/" + os.path.basename(models[-1])
     sys.stdout.write(json.dumps(out) + "\n")
     if problems:
         raise SystemExit(1)
@@ -468,6 +483,57 @@ def measured_hbm_copy_rate(device, nbytes=2 << 30, repeats=5):
     return best
 
 
+def predict_decomposition(world, leg_ms, fft_ms, pack_ms, busiest_pair_bytes, link_gbs, mirror_ms=None, single_ms=None):
+    """The model behind `--dist-mode auto` (also what --dry-run prints): per transform and rank, in the
+    pipelined driver the Trans stream carries L + F and the communication stream pack + exchange, the exchange bound by the busiest
+    pair's bytes over one xGMI link; the period is the larger of the two.  The exchange-free mirror bands cost (L1 + F1) / P plus
+    the polar-band penalty (measured when available).  Returns the prediction and which decomposition it favours and why."""
+    exch_ms = busiest_pair_bytes / (link_gbs * 1e9) * 1e3 if link_gbs and link_gbs > 0 else float("inf")
+    compute = leg_ms + fft_ms
+    comm = pack_ms + exch_ms
+    a2a = max(compute, comm)
+    if mirror_ms is None and single_ms is not None:
+        mirror_ms = 1.10 * single_ms / world          # polar bands cost 10 % more in the Fourier stage (profiles/r05_scaling_model.json)
+    out = {"alltoall_period_ms": a2a, "alltoall_compute_ms": compute, "alltoall_comm_ms": comm, "exchange_ms_at_link_rate": exch_ms,
+           "link_gbs": link_gbs, "busiest_pair_bytes": int(busiest_pair_bytes), "exchange_hidden": bool(comm <= compute),
+           "mirror_period_ms": mirror_ms}
+    if mirror_ms is None or a2a <= mirror_ms:
+        out["favours"] = "alltoall"
+        out["why"] = (f"the exchange hides: pack + exchange {comm:.2f} ms <= Legendre + Fourier {compute:.2f} ms per transform and rank"
+                      if comm <= compute else
+                      f"the exchange is exposed ({comm:.2f} ms against {compute:.2f} ms of compute) but still beats the mirror bands")
+    else:
+        out["favours"] = "mirror"
+        out["why"] = (f"the exchange does not hide at {link_gbs:.0f} GB/s per link: pack + exchange {comm:.2f} ms against Legendre + "
+                      f"Fourier {compute:.2f} ms per transform and rank; mirror bands need no exchange ({mirror_ms:.2f} ms)")
+    return out
+
+
+def link_probe(world, device, mib_per_pair=32, reps=3):
+    """what a pair of GPUs moves while ALL pairs exchange at once (the pattern of the transposition): torch.distributed
+    all_to_all_single over RCCL, `mib_per_pair` MiB per pair and direction; GB/s per pair and direction"""
+    import torch
+    import torch.distributed as dist
+    n = (mib_per_pair << 20) // 8
+    a = torch.ones(world * n, dtype=torch.float64, device=device)
+    b = torch.empty_like(a)
+    dist.all_to_all_single(b, a)
+    torch.cuda.synchronize()
+    best = float("inf")
+    for _ in range(reps):
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dist.all_to_all_single(b, a)
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        best = min(best, float(t.item()))
+    del a, b
+    return {"pattern": f"all_to_all_single, {mib_per_pair} MiB per pair and direction, all pairs at once (RCCL via torch.distributed)",
+            "gbs_per_pair_and_direction": (mib_per_pair << 20) / best / 1e9, "seconds": best}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -488,12 +554,15 @@ def main():
                          "decompositions (see atlas_amd/dist.py)")
     ap.add_argument("--dist-impl", default="auto", choices=["auto", "native", "torch"],
                     help="N > 1: driver inside the library (RCCL from C++) or the torch.distributed one (auto: native on GPUs)")
-    ap.add_argument("--no-alt", action="store_true", help="N > 1: do not time the alternative (mirror-band) decomposition")
+    ap.add_argument("--no-alt", action="store_true", help="N > 1: do not time the alternative decomposition (auto then times the "
+                                                         "wavenumber-sharded one without a trial)")
+    ap.add_argument("--trial-steps", type=int, default=3,
+                    help="N > 1, --dist-mode auto: steps of the untimed trial of each decomposition that decides which one is timed")
     ap.add_argument("--dry-run", action="store_true",
                     help="no device work: build the message plan of the distributed transform for --gpus N ranks (host code of "
                          "the library), check that it covers the send and receive buffers exactly once and that both ends of "
                          "every pair agree, print per-link bytes and the expected exchange time; one JSON line")
-    ap.add_argument("--xgmi-gbs", type=float, default=50.0,
+    ap.add_argument("--xgmi-gbs", type=float, default=None,
                     help="--dry-run: assumed one-directional rate of one xGMI link in GB/s (MI355X: 7 links x ~153 GB/s "
                          "aggregate per GPU on paper; RCCL send/recv between two GPUs has been seen at ~50 GB/s)")
     args = ap.parse_args()
@@ -531,6 +600,7 @@ def main():
     wd = Watchdog(rank, world, enabled=world > 1)
     wd.phase("set-up (process group, tables, communicator)")
     crosscheck = None
+    dm = None
     if not use_dist:
         tr = atlas_amd.Trans(g, TRUNC, profile=True)
         tr.use_torch_stream()
@@ -644,7 +714,7 @@ def main():
             else:
                 sharded_note = "input spectra scattered by m (1/P of the coefficients per rank), bitwise equal to the replicated call"
 
-        def step():
+        def step_alltoall():
             # `world` transforms per step, software-pipelined: the exchange of transform i overlaps the Legendre
             # stage of transform i+1 and the Fourier stage of transform i-1
             if shards is not None:
@@ -656,6 +726,95 @@ def main():
             sync()
             dist.barrier()
             sync()
+
+        def timed_steps(fn, n):
+            """n steps of fn between barriers; seconds, MAX over ranks"""
+            barrier()
+            t_ = time.perf_counter()
+            for _ in range(n):
+                fn()
+            barrier()
+            t_ = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=DEVICE)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            return float(t_.item())
+
+        # ---- the exchange-free mirror bands (a northern band of rows and its mirror image per GPU), usable only if every
+        # rank reproduces, bit for bit, the same rows through the GPU-tested zonal-band crop path
+        dm, gp_m, mirror_ok = None, None, False
+        if world > 1 and dtr.mode == "alltoall" and not args.no_alt:
+            wd.phase("mirror-band decomposition: set-up and bitwise self-check")
+            ok = 0
+            try:
+                dm = DistributedTrans(g, TRUNC, profile=True, mode="mirror")
+                b0, b1 = dm.trans.mirror_rows()
+                gp_m = torch.empty(nf * dm.trans.nb_gridpoints(), dtype=torch.float64, device=DEVICE)
+                dm.invtrans(nf, sps[0], gp_m)
+                ok, first = 1, 0
+                for j0, j1 in ((b0, b1), (g.ny() - b1, g.ny() - b0)):
+                    tc = atlas_amd.Trans(g, TRUNC, rows=(j0, j1))
+                    n = tc.nb_gridpoints()
+                    gp_c = torch.empty(nf * n, dtype=torch.float64, device=DEVICE)
+                    tc.invtrans(nf, sps[0], gp_c)
+                    tc.synchronize()
+                    sync()
+                    same = torch.equal(gp_m.view(nf, -1)[:, first:first + n], gp_c.view(nf, -1))
+                    ok = ok if (same and bool(torch.isfinite(gp_c).all()) and float(gp_c.abs().max()) > 0.0) else 0
+                    first += n
+                    del tc, gp_c
+                ok = ok if first * nf == gp_m.numel() else 0
+            except Exception as e:   # any failure means: not used, not reported
+                sys.stderr.write(f"[bench] rank {rank}: mirror-band self-check failed: {type(e).__name__}: {e}\n")
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=DEVICE)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            mirror_ok = bool(int(flag.item()))
+
+        def step_mirror():
+            dm.invtrans_many(nf, [sps[i % len(sps)] for i in range(world)], [gp_m] * world)
+
+        # ---- `--dist-mode auto` (VERDICT r5 item 5a): which decomposition is TIMED is decided by an untimed trial of both on this
+        # node -- the wavenumber-sharded one where its exchange hides behind the two stages, the mirror bands where it does not
+        # -- and the line says which and why; the other one is reported as `alt_decomposition`.  The model (per-rank stage costs
+        # measured in the trial, busiest pair's bytes, link rate from --xgmi-gbs or the all-pairs probe) is printed beside it.
+        timed_mode, auto_choice, links = dtr.mode, None, None
+        if on_gpu and world > 1:
+            try:
+                wd.phase("link probe (all pairs at once)")
+                links = link_probe(world, DEVICE)
+            except Exception as e:
+                sys.stderr.write(f"[bench] rank {rank}: link probe failed: {type(e).__name__}: {e}\n")
+        if args.dist_mode == "auto" and world > 1 and dtr.mode == "alltoall" and mirror_ok:
+            wd.phase("trial of the two decompositions")
+            nt = max(1, args.trial_steps)
+            step_alltoall()
+            step_mirror()
+            tr.timings(reset=True)
+            if hasattr(dtr, "exchange_timings"):
+                dtr.exchange_timings(reset=True)
+            t_a2a = timed_steps(step_alltoall, nt) / nt * 1e3
+            tma = tr.timings()
+            xta = dtr.exchange_timings(reset=True) if hasattr(dtr, "exchange_timings") else None
+            t_mir = timed_steps(step_mirror, nt) / nt * 1e3
+            # per transform and rank, slowest rank (a step is `world` transforms)
+            mine = torch.tensor([tma["legendre_ms"] / max(tma["legendre_calls"], 1), tma["fourier_ms"] / max(tma["fourier_calls"], 1),
+                                 (xta or {}).get("pack_ms", 0.0), float((xta or {}).get("bytes_to_busiest_peer", 0))],
+                                dtype=torch.float64, device=DEVICE)
+            dist.all_reduce(mine, op=dist.ReduceOp.MAX)
+            rate = args.xgmi_gbs if args.xgmi_gbs is not None else ((links or {}).get("gbs_per_pair_and_direction") or 50.0)
+            model = predict_decomposition(world, float(mine[0]), float(mine[1]), float(mine[2]), float(mine[3]), rate,
+                                          mirror_ms=t_mir / world)
+            timed_mode = "alltoall" if t_a2a <= t_mir else "mirror"
+            auto_choice = {"timed": timed_mode, "decided_by": f"untimed trial, {nt} steps of each decomposition after one warm-up step",
+                           "trial_ms_per_step": {"alltoall": t_a2a, "mirror": t_mir},
+                           "why": (f"trial: m-sharded Legendre + RCCL transposition {t_a2a:.2f} ms per step, mirror bands {t_mir:.2f} ms; "
+                                   f"model: {model['why']}"),
+                           "model": model,
+                           "link_rate_source": "--xgmi-gbs" if args.xgmi_gbs is not None else "all-pairs probe of this run"}
+        if auto_choice is not None and timed_mode == "mirror":
+            tr, gp = dm.trans, gp_m
+            step = step_mirror
+        else:
+            step = step_alltoall
 
     wd.phase("warm-up steps")
     for _ in range(args.warmup):
@@ -670,8 +829,11 @@ def main():
     blocks = []
     if sampler:
         sampler.start()
+    xt_blocks = []
     for _ in range(max(1, args.blocks)):
         tr.timings(reset=True)
+        if use_dist and timed_mode == "alltoall" and hasattr(dtr, "exchange_timings"):
+            dtr.exchange_timings(reset=True)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
@@ -683,60 +845,52 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             bdt = float(tmax.item())
         blocks.append((bdt, tr.timings()))
+        xt_blocks.append(dtr.exchange_timings(reset=True) if (use_dist and timed_mode == "alltoall" and hasattr(dtr, "exchange_timings"))
+                         else None)
     if sampler:
         sampler.stop()
     state_after = sampler.snapshot() if sampler else None
     order = sorted(range(len(blocks)), key=lambda i: blocks[i][0])
     dt, tm = blocks[order[(len(blocks) - 1) // 2]]   # the median block (the lower one of an even count)
+    xt = xt_blocks[order[(len(blocks) - 1) // 2]]
     wd.phase("after the timed region (alternative decomposition, report)")
     transforms = args.steps * world
     ms_per_step = dt / args.steps * 1e3
 
     alt = None
-    # the alternative decomposition, timed for comparison: mirror bands (no exchange, hemisphere symmetry kept), adopted
-    # only if every rank reproduces, bit for bit, the same rows through the GPU-tested zonal-band crop path
-    if use_dist and world > 1 and dtr.mode == "alltoall" and not args.no_alt:
+    per_rank = None
+    if use_dist and world > 1:
         import torch.distributed as dist
-        ok, dm = 0, None
-        try:
-            dm = DistributedTrans(g, TRUNC, profile=True, mode="mirror")
-            b0, b1 = dm.trans.mirror_rows()
-            gp_m = torch.empty(nf * dm.trans.nb_gridpoints(), dtype=torch.float64, device=DEVICE)
-            dm.invtrans(nf, sps[0], gp_m)
-            ok, first = 1, 0
-            for j0, j1 in ((b0, b1), (g.ny() - b1, g.ny() - b0)):
-                tc = atlas_amd.Trans(g, TRUNC, rows=(j0, j1))
-                n = tc.nb_gridpoints()
-                gp_c = torch.empty(nf * n, dtype=torch.float64, device=DEVICE)
-                tc.invtrans(nf, sps[0], gp_c)
-                tc.synchronize()
-                sync()
-                same = torch.equal(gp_m.view(nf, -1)[:, first:first + n], gp_c.view(nf, -1))
-                ok = ok if (same and bool(torch.isfinite(gp_c).all()) and float(gp_c.abs().max()) > 0.0) else 0
-                first += n
-                del tc, gp_c
-            ok = ok if first * nf == gp_m.numel() else 0
-        except Exception as e:   # any failure means: not reported
-            sys.stderr.write(f"[bench] rank {rank}: mirror-band self-check failed: {type(e).__name__}: {e}\n")
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=DEVICE)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        alt = {"mode": "mirror", "selfcheck_bitwise_equal_on_all_ranks": bool(int(flag.item()))}
-        if int(flag.item()) == 1:
-            asteps = max(1, min(args.steps, 5))
-            for _ in range(1):
-                dm.invtrans_many(nf, [sps[i % len(sps)] for i in range(world)], [gp_m] * world)
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(asteps):
-                dm.invtrans_many(nf, [sps[i % len(sps)] for i in range(world)], [gp_m] * world)
-            barrier()
-            adt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=DEVICE)
-            dist.all_reduce(adt, op=dist.ReduceOp.MAX)
-            alt.update({"value": asteps * world / float(adt.item()), "unit": "transforms/s", "steps": asteps,
-                        "ms_per_step": float(adt.item()) / asteps * 1e3,
-                        "note": "exchange-free: every GPU transforms a northern band of rows and its mirror image; output "
-                                "is two row ranges per GPU, not Atlas's contiguous bands"})
+        # the decomposition that was NOT timed, for comparison (same steps, barriers, MAX over ranks), in a short run
+        if dtr.mode == "alltoall" and not args.no_alt:
+            other = "mirror" if timed_mode == "alltoall" else "alltoall"
+            alt = {"mode": other}
+            if other == "mirror":
+                alt["selfcheck_bitwise_equal_on_all_ranks"] = mirror_ok
+            if other == "alltoall" or mirror_ok:
+                asteps = max(1, min(args.steps, 5))
+                fn = step_mirror if other == "mirror" else step_alltoall
+                fn()
+                adt = timed_steps(fn, asteps)
+                alt.update({"value": asteps * world / adt, "unit": "transforms/s", "steps": asteps, "ms_per_step": adt / asteps * 1e3,
+                            "note": ("exchange-free: every GPU transforms a northern band of rows and its mirror image; output "
+                                     "is two row ranges per GPU, not Atlas's contiguous bands") if other == "mirror" else
+                                    "m-sharded Legendre + RCCL m -> latitude transposition + latitude-band FFT: output in Atlas's bands"})
+        # where the curve bends: every rank's stage times of the median block, per transform
+        mine = {"rank": rank, "legendre_ms": tm["legendre_ms"] / max(tm["legendre_calls"], 1),
+                "fourier_ms": tm["fourier_ms"] / max(tm["fourier_calls"], 1)}
+        if xt:
+            mine.update({"pack_ms": xt["pack_ms"], "exchange_ms": xt["exchange_ms"], "bytes_sent": xt["bytes_sent"],
+                         "bytes_received": xt["bytes_received"], "bytes_to_busiest_peer": xt["bytes_to_busiest_peer"],
+                         "peers": xt["peers"],
+                         "achieved_gbs_busiest_link": (xt["bytes_to_busiest_peer"] / (xt["exchange_ms"] * 1e-3) / 1e9
+                                                       if xt["exchange_ms"] > 0 else None),
+                         "achieved_gbs_all_links_out": (xt["bytes_sent"] / (xt["exchange_ms"] * 1e-3) / 1e9
+                                                        if xt["exchange_ms"] > 0 else None)})
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
+    if dm is not None:
         del dm
 
     if rank == 0:
@@ -744,7 +898,7 @@ def main():
         fft_ms = tm["fourier_ms"] / max(tm["fourier_calls"], 1)
         # algorithmic work per launch (DESIGN.md "Kernels"): Legendre flops of SURVEY 8(d) / world (m-sharding);
         # Fourier bytes = kept part of the intermediate read once + grid-point output written once
-        if use_dist and dtr.mode == "mirror":
+        if use_dist and timed_mode == "mirror":
             # rank 0 owns rows [0, b1) and their mirror images: the geometry of its object is exactly its share
             b1 = tr.mirror_rows()[1]
             leg_flops = tr.legendre_flops(nf)
@@ -810,9 +964,9 @@ def main():
                        "grid": GRID, "truncation": TRUNC, "levels": NLEV,
                        "parallelism": "single GPU" if not use_dist else (
                            f"m-sharded Legendre + RCCL m->latitude transposition + latitude-band FFT over {world} GPUs"
-                           if dtr.mode == "alltoall" else
+                           if timed_mode == "alltoall" else
                            f"mirror-band sharding of both stages over {world} GPUs (a northern band of rows and its mirror "
-                           f"image per GPU: no exchange, hemisphere symmetry kept)" if dtr.mode == "mirror" else
+                           f"image per GPU: no exchange, hemisphere symmetry kept)" if timed_mode == "mirror" else
                            f"latitude-band sharding of both stages over {world} GPUs (no exchange; Legendre rows of a "
                            f"band are computed without their mirror hemisphere: 2/P of the single-GPU Legendre work)")},
             "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")},
@@ -840,6 +994,15 @@ def main():
                                              ("none: the committed PMC passes profile the single-GPU workload, not the distributed one"
                                               if (world > 1 or use_dist) else
                                               "none: no committed PMC profile matches these kernel sources"))
+        if use_dist and world > 1:
+            out["per_rank"] = per_rank
+            out["per_rank_note"] = ("stage times per transform of the median block on every rank: legendre / fourier on the Trans "
+                                    "stream, pack / exchange on the communication stream (exchange = the send / receive group incl. "
+                                    "waiting for the peers); achieved_gbs_busiest_link = bytes to the busiest peer / exchange_ms")
+            out["link_probe"] = links
+            if auto_choice is not None:
+                out["auto_choice"] = auto_choice
+                out["config"]["parallelism"] += "; chosen by --dist-mode auto: " + auto_choice["why"]
         if crosscheck is not None:
             out["multi_gpu_crosscheck"] = crosscheck
         if alt is not None:

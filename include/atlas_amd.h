@@ -441,6 +441,12 @@ int atlas_amd__Trans__fourier_packed_probe(atlas_amd_Trans* t, int nb_fields, in
  * ends of a pair cut their runs alike; the ranks compare the value inside the call (a mismatch is an error on every rank); takes effect
  * at the next transform. */
 int atlas_amd__Trans__set_max_message_bytes(atlas_amd_Trans* t, atlas_amd_Comm* comm, long long bytes);
+/* measurement aid of the distributed transform (Trans made with profile=1): accumulated since the last reset, this rank:
+ * out[0] pack kernel ms, out[1] exchange ms (send / receive group on the communication stream, incl. waiting for the peers),
+ * out[2] transforms counted; per transform: out[3] bytes sent to other ranks, out[4] bytes received from other ranks,
+ * out[5] bytes to the busiest peer, out[6] peers with data; out[7] reserved.  (No reference counterpart: TransLocal is
+ * single-process, TransLocal.cc:338-340.) */
+int atlas_amd__Trans__timings_distributed(atlas_amd_Trans* t, atlas_amd_Comm* comm, double out[8], int reset);
 /* [r3] the messages the distributed transform sends (test hook, host only): rank `part` packs, for every latitude row, the
  * wavenumbers m <= row_mmax[row] it owns (m % nparts == part) with `cols` = 2 * nb_fields doubles each -- no dead
  * wavenumbers above the row's Fourier truncation, no pitch padding -- and the rows of band q, one contiguous run, go to

@@ -7,6 +7,7 @@
 //     38-60: fields filled with the global index);
 //   * the same calls over a real RCCL communicator with one rank (what a one-GPU box can host).
 // Usage: test_dist_cxx [nranks=2] [grid=O32] [truncation=31] [nfields=3]
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -254,6 +255,38 @@ int main(int argc, char** argv) {
             run_rank(c, grid, T, nf, sp_a, sp_b, ref_a, ref_b, &res[0]);
             check_bands(res, "distributed transform + halo exchange, 1 rank over RCCL");
             atlas_amd__Comm__delete(c);
+        }
+    }
+    // ---- min(P, visible devices) ranks over a real RCCL communicator, ONE DEVICE EACH: only where >= 2 devices are visible
+    // (the grouped ncclSend / ncclRecv of csrc/comm.hip with a real peer; the one-GPU boxes of the pool skip it)
+    {
+        const int ndev = atlas_amd__device_count();
+        const int R    = std::min(P, ndev);
+        if (R >= 2) {
+            std::vector<char> id(atlas_amd__Comm__unique_id_bytes());
+            EXPECT(atlas_amd__Comm__get_unique_id(id.data()) == 0);
+            std::vector<RankResult> res(R);
+            std::vector<std::thread> th;
+            for (int r = 0; r < R; ++r) {
+                th.emplace_back([&, r]() {
+                    EXPECT(atlas_amd__set_device(r) == 0);
+                    atlas_amd_Comm* c = atlas_amd__Comm__new_rccl(id.data(), R, r);   // collective: every rank's thread enters
+                    EXPECT(c != nullptr);
+                    if (c) {
+                        EXPECT(std::string(atlas_amd__Comm__kind(c)) == "rccl" && atlas_amd__Comm__size(c) == R);
+                        run_rank(c, grid, T, nf, sp_a, sp_b, ref_a, ref_b, &res[r]);
+                        atlas_amd__Comm__delete(c);
+                    }
+                });
+            }
+            for (auto& t : th) {
+                t.join();
+            }
+            EXPECT(atlas_amd__set_device(0) == 0);
+            check_bands(res, ("distributed transform + halo exchange, " + std::to_string(R) + " ranks over RCCL, one device each").c_str());
+        }
+        else {
+            std::printf("skipped     ranks over RCCL on devices of their own: %d visible device(s)\n", ndev);
         }
     }
     atlas_amd__Grid__delete(grid);

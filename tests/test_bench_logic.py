@@ -115,7 +115,7 @@ def test_gpus_n_without_a_launcher_starts_its_own_ranks(tmp_path):
         assert k in out, k
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["test_standin"] is True
     assert out["metric"].startswith("STAND-IN")
-    assert out["config"]["parallelism"].startswith("m-sharded")
+    assert out["config"]["parallelism"].startswith(("m-sharded", "mirror-band"))       # --dist-mode auto: the trial's winner
     assert out["multi_gpu_crosscheck"]["bitwise_equal_on_all_ranks"] is True
 
 
@@ -128,17 +128,59 @@ def test_a_launcher_with_the_wrong_rank_count_is_an_error(tmp_path):
     assert r.returncode != 0 and "--nproc-per-node 4" in (r.stderr + r.stdout)
 
 
-def test_two_ranks_time_the_named_decomposition_and_report_the_mirror_bands_beside_it(tmp_path):
-    """N > 1 default: the m-sharded decomposition with the transposition (BASELINE C3 / C4) is the timed one, checked
-    against the band decomposition; the exchange-free mirror-band decomposition is timed as `alt_decomposition` after
-    its bitwise self-check"""
-    out = run_bench(tmp_path, 2, ["--gpus", "2", "--steps", "2", "--warmup", "1"])
-    assert out["config"]["parallelism"].startswith("m-sharded")
-    assert out["multi_gpu_crosscheck"]["bitwise_equal_on_all_ranks"] is True
+PREFIX = {"alltoall": "m-sharded", "mirror": "mirror-band"}
+
+
+def check_auto_line(out, world):
+    """--dist-mode auto: both decompositions pass their bitwise checks, an untimed trial of both decides which
+    one is timed, the line says which and why, the other one is `alt_decomposition`, and every rank's stage times are listed"""
+    ac = out["auto_choice"]
+    assert ac["timed"] in PREFIX and set(ac["trial_ms_per_step"]) == {"alltoall", "mirror"}
+    faster = min(ac["trial_ms_per_step"], key=ac["trial_ms_per_step"].get)
+    assert ac["timed"] == faster
+    assert out["config"]["parallelism"].startswith(PREFIX[ac["timed"]]) and "chosen by --dist-mode auto" in out["config"]["parallelism"]
+    assert {"alltoall_period_ms", "mirror_period_ms", "exchange_hidden", "favours", "why"} <= set(ac["model"])
     alt = out["alt_decomposition"]
-    assert alt["mode"] == "mirror" and alt["selfcheck_bitwise_equal_on_all_ranks"] is True and alt["value"] > 0
+    assert alt["mode"] == ({"alltoall", "mirror"} - {ac["timed"]}).pop() and alt["value"] > 0
+    assert out["multi_gpu_crosscheck"]["bitwise_equal_on_all_ranks"] is True
+    pr = out["per_rank"]
+    assert [r["rank"] for r in pr] == list(range(world)) and all(r["legendre_ms"] >= 0 and r["fourier_ms"] >= 0 for r in pr)
+
+
+def test_two_ranks_auto_times_the_winner_of_a_trial_and_reports_the_other_beside_it(tmp_path):
+    out = run_bench(tmp_path, 2, ["--gpus", "2", "--steps", "2", "--warmup", "1"])
+    check_auto_line(out, 2)
     assert out["dist_impl"].startswith("torch")                           # off the GPU; "native" on MI355X
     assert "cpu_baseline" not in out                                      # rank 0 at N = 1 only
+    assert out["repeats"]["blocks"] == 3 and len(out["repeats"]["values"]) == 3
+
+
+def test_the_model_of_auto_picks_mirror_bands_where_the_exchange_does_not_hide():
+    """the committed per-rank cost record (profiles/r05_scaling_model.json) through bench.predict_decomposition: at 50 GB/s per
+    link the transposition is exposed at P = 2 and 4; at 150 GB/s it hides from P = 4 on (where the two decompositions are within
+    a few per cent of each other and the live trial decides)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    with open(os.path.join(ROOT, "profiles", "r05_scaling_model.json")) as f:
+        sm = json.load(f)
+    single = sm["single_gpu"]["ms_per_transform"]
+    pair_bytes = {2: 1268e6, 4: 370e6, 8: 100e6}
+    picks = {}
+    for P in (2, 4, 8):
+        ranks = sm["P"][str(P)]["ranks"]
+        slow = max(ranks, key=lambda r: r["legendre_ms"] + r["fourier_ms"])
+        for rate in (50.0, 150.0):
+            m = bench.predict_decomposition(P, slow["legendre_ms"], slow["fourier_ms"], max(r["pack_ms"] for r in ranks),
+                                            pair_bytes[P], rate, single_ms=single)
+            picks[(P, rate)] = (m["favours"], m["exchange_hidden"])
+            assert m["exchange_hidden"] == (m["alltoall_comm_ms"] <= m["alltoall_compute_ms"])
+            want = "alltoall" if m["alltoall_period_ms"] <= m["mirror_period_ms"] else "mirror"
+            assert m["favours"] == want and (str(int(rate)) in m["why"] or m["exchange_hidden"])
+    # exposed at 50 GB/s for P = 2 and 4 (1.27 / 0.37 GB over one link per transform): mirror bands; hidden at 150 GB/s from P = 4 on
+    assert picks[(2, 50.0)] == ("mirror", False) and picks[(4, 50.0)] == ("mirror", False)
+    assert picks[(4, 150.0)][1] is True and picks[(8, 150.0)][1] is True
 
 
 def test_mirror_bands_are_not_reported_when_their_self_check_fails(tmp_path):
@@ -175,10 +217,10 @@ def test_explicit_modes(tmp_path):
     assert out["config"]["parallelism"].startswith("m-sharded") and "alt_decomposition" not in out
 
 
-def test_eight_ranks_auto_is_the_all_to_all_decomposition(tmp_path):
+def test_eight_ranks_auto(tmp_path):
     out = run_bench(tmp_path, 8, ["--gpus", "8", "--steps", "1", "--warmup", "1"], grid="O32")
-    assert out["n_gpus"] == 8 and out["config"]["parallelism"].startswith("m-sharded")
-    assert out["multi_gpu_crosscheck"]["bitwise_equal_on_all_ranks"] is True
+    assert out["n_gpus"] == 8
+    check_auto_line(out, 8)
     assert "8 transform(s) per step" in out["config"]["workload"]
 
 
