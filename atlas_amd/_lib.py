@@ -40,6 +40,21 @@ def _sig(name, restype, *argtypes):
 last_error = _sig("atlas_amd__last_error", C.c_char_p)
 last_note = _sig("atlas_amd__last_note", C.c_char_p)
 version = _sig("atlas_amd__version", C.c_char_p)
+set_ignore_env = _sig("atlas_amd__set_ignore_env", C.c_int, C.c_int)
+_effective_config = _sig("atlas_amd__effective_config", C.c_longlong, C.c_char_p, C.c_longlong)
+
+
+def effective_config():
+    """every environment switch of the library with the value in effect: {name: {"class", "value", "source", "default", "what"}}
+    (source: default | env | ignored | compiled out) -- csrc/env.cpp, include/atlas_amd.h"""
+    n = _effective_config(None, 0)
+    buf = C.create_string_buffer(int(n))
+    _effective_config(buf, n)
+    out = {}
+    for ln in buf.value.decode().splitlines():
+        name, cls, value, source, default, what = ln.split("\t")
+        out[name] = {"class": cls, "value": value, "source": source, "default": default, "what": what}
+    return out
 device_count = _sig("atlas_amd__device_count", C.c_int)
 stream_wait_stream = _sig("atlas_amd__stream_wait_stream", C.c_int, c_void_p, c_void_p)
 _diag_mfma_f64_rate = _sig("atlas_amd__diag_mfma_f64_rate", C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double))

@@ -17,6 +17,7 @@
 #include "fft_plan.h"
 #include "gaussian.h"
 #include "legendre_host.h"
+#include "env.h"
 #include "regional_trans.h"
 #include "trans.h"
 #include "trans_plan.h"
@@ -35,6 +36,15 @@ void set_last_error(const std::string& s) {
 }
 }  // namespace atlas_amd
 
+// a HIP call that failed is reported once, here: its error code must not stay in the runtime's per-thread "last error", where the
+// launch check of the NEXT call would pick it up as its own
+static inline bool hip_failed(hipError_t e) {
+    if (e == hipSuccess) {
+        return false;
+    }
+    (void)hipGetLastError();
+    return true;
+}
 #define AA_TRY try {
 #define AA_CATCH_INT                                 \
     }                                                \
@@ -96,9 +106,31 @@ const char* atlas_amd__last_error(void) {
 const char* atlas_amd__version(void) {
     return "atlas_amd 0.1.0 (gfx950; TransLocal invtrans + HaloExchange of ecmwf/atlas 0.44.1)";
 }
+int atlas_amd__set_ignore_env(int on) {
+    atlas_amd::env_set_ignore(on != 0);
+    return 0;
+}
+long long atlas_amd__effective_config(char* buf, long long capacity) {
+    std::string text;
+    int n                      = 0;
+    const atlas_amd::EnvSwitch* sw = atlas_amd::env_switches(&n);
+    for (int i = 0; i < n; ++i) {
+        const bool dev_out = sw[i].cls == atlas_amd::EnvClass::dev && !atlas_amd::env_dev_switches_compiled_in();
+        const char* v      = atlas_amd::env_get(sw[i].name);   // (a dev switch set in a product build: one line on stderr, once)
+        const char* source = v ? "env" : (dev_out ? "compiled out" : (atlas_amd::env_ignored() && std::getenv(sw[i].name) ? "ignored" : "default"));
+        text += std::string(sw[i].name) + "\t" + atlas_amd::env_class_name(sw[i].cls) + "\t" + (v ? v : sw[i].default_value) + "\t" + source +
+                "\t" + sw[i].default_value + "\t" + sw[i].what + "\n";
+    }
+    if (buf && capacity > 0) {
+        const size_t k = std::min<size_t>(text.size(), (size_t)capacity - 1);
+        std::memcpy(buf, text.data(), k);
+        buf[k] = 0;
+    }
+    return (long long)text.size() + 1;
+}
 int atlas_amd__device_count(void) {
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) {
+    if (hip_failed(hipGetDeviceCount(&n))) {
         (void)hipGetLastError();
         return 0;
     }
@@ -109,7 +141,7 @@ int atlas_amd__stream_wait_stream(void* waiting_stream, void* signalling_stream)
     AA_TRY
     if (waiting_stream != signalling_stream) {
         hipEvent_t e;
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+        if (hip_failed(hipEventCreateWithFlags(&e, hipEventDisableTiming))) {
             throw std::runtime_error("stream_wait_stream: hipEventCreate failed");
         }
         hipError_t r = hipEventRecord(e, (hipStream_t)signalling_stream);
@@ -117,7 +149,7 @@ int atlas_amd__stream_wait_stream(void* waiting_stream, void* signalling_stream)
             r = hipStreamWaitEvent((hipStream_t)waiting_stream, e, 0);
         }
         (void)hipEventDestroy(e);   // released once the recorded work has completed
-        if (r != hipSuccess) {
+        if (hip_failed(r)) {
             throw std::runtime_error(std::string("stream_wait_stream: ") + hipGetErrorString(r));
         }
     }
@@ -126,7 +158,7 @@ int atlas_amd__stream_wait_stream(void* waiting_stream, void* signalling_stream)
 
 void* atlas_amd__device_malloc(size_t bytes) {
     void* p = nullptr;
-    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+    if (hip_failed(hipMalloc(&p, bytes ? bytes : 1))) {
         (void)hipGetLastError();
         atlas_amd::set_last_error("device_malloc: hipMalloc failed");
         return nullptr;
@@ -135,35 +167,35 @@ void* atlas_amd__device_malloc(size_t bytes) {
 }
 int atlas_amd__device_free(void* ptr) {
     AA_TRY
-    if (ptr && hipFree(ptr) != hipSuccess) {
+    if (ptr && hip_failed(hipFree(ptr))) {
         throw std::runtime_error("device_free: hipFree failed");
     }
     AA_CATCH_INT
 }
 int atlas_amd__device_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes) {
     AA_TRY
-    if (bytes && hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+    if (bytes && hip_failed(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice))) {
         throw std::runtime_error("device_memcpy_h2d failed");
     }
     AA_CATCH_INT
 }
 int atlas_amd__device_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes) {
     AA_TRY
-    if (bytes && hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+    if (bytes && hip_failed(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost))) {
         throw std::runtime_error("device_memcpy_d2h failed");
     }
     AA_CATCH_INT
 }
 int atlas_amd__device_synchronize(void) {
     AA_TRY
-    if (hipDeviceSynchronize() != hipSuccess) {
+    if (hip_failed(hipDeviceSynchronize())) {
         throw std::runtime_error("device_synchronize failed");
     }
     AA_CATCH_INT
 }
 int atlas_amd__set_device(int device) {
     AA_TRY
-    if (hipSetDevice(device) != hipSuccess) {
+    if (hip_failed(hipSetDevice(device))) {
         throw std::runtime_error("set_device failed");
     }
     AA_CATCH_INT
@@ -871,7 +903,7 @@ int atlas_amd__VorDivToUV__execute_device(int truncation, int nb_coeff, int nb_f
     vd2uv_check(truncation, nb_coeff, nb_fields);
     if (nb_fields > 0) {
         hipError_t e = trans::launch_vd2uv(vor, div, U, V, truncation, nb_fields, (hipStream_t)stream);
-        if (e != hipSuccess) {
+        if (hip_failed(e)) {
             throw std::runtime_error(std::string("vd2uv launch: ") + hipGetErrorString(e));
         }
     }
@@ -887,7 +919,7 @@ int atlas_amd__VorDivToUV__execute(int truncation, int nb_coeff, int nb_fields, 
     }
     double* d = nullptr;
     auto ck   = [](hipError_t e) {
-        if (e != hipSuccess) {
+        if (hip_failed(e)) {
             throw std::runtime_error(std::string("VorDivToUV: ") + hipGetErrorString(e));
         }
     };

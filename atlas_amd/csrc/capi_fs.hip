@@ -232,10 +232,12 @@ int atlas_amd__StructuredColumns__fixup_halo_for_vectors(atlas_amd_StructuredCol
         std::vector<int> nodes = fs->impl.pole_row_nodes();
         fs->npole              = (int)nodes.size();
         if (hipMalloc((void**)&fs->d_pole_nodes, std::max<size_t>(nodes.size(), 1) * sizeof(int)) != hipSuccess) {
+            (void)hipGetLastError();
             throw std::runtime_error("hipMalloc failed (no HIP device?)");
         }
         if (!nodes.empty() &&
             hipMemcpy(fs->d_pole_nodes, nodes.data(), nodes.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
             throw std::runtime_error("hipMemcpy failed");
         }
     }

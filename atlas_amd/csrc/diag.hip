@@ -19,6 +19,7 @@ void set_last_error(const std::string& s);
     do {                                                                                                      \
         hipError_t e_ = (call);                                                                               \
         if (e_ != hipSuccess) {                                                                               \
+            (void)hipGetLastError(); /* reported here, once: not left sticky for the next call */ \
             throw std::runtime_error(std::string("HIP error '") + hipGetErrorString(e_) + "' in " #call);     \
         }                                                                                                     \
     } while (0)

@@ -1,4 +1,5 @@
 // See dist_trans.h.
+#include "env.h"
 #include "dist_trans.h"
 
 #include <algorithm>
@@ -166,7 +167,7 @@ std::vector<TransposeMsg> packed_transpose_messages(const PackedTransposePlan& p
 // bound: the default stays the unpadded record; ATLAS_AMD_DIST_PACK_PAD=1 pads.
 static int packed_cols_for(const Trans& trans, int nb_fields) {
     bool pad = false;
-    if (const char* e = std::getenv("ATLAS_AMD_DIST_PACK_PAD")) {
+    if (const char* e = atlas_amd::env_get("ATLAS_AMD_DIST_PACK_PAD")) {
         pad = atoi(e) != 0;
     }
     return pad ? trans.fourier_row_pitch(nb_fields) : 2 * nb_fields;
@@ -288,7 +289,7 @@ double fourier_packed_probe(Trans& trans, int nb_fields, int reps) {
     long long* d_rowbase = nullptr;
     HIP_CHECK(hipMalloc((void**)&d_rowbase, rowbase.size() * sizeof(long long)));
     HIP_CHECK(hipMemcpy(d_rowbase, rowbase.data(), rowbase.size() * sizeof(long long), hipMemcpyHostToDevice));
-    const char* rb_env    = std::getenv("ATLAS_AMD_DIST_ROWBASE");
+    const char* rb_env    = atlas_amd::env_get("ATLAS_AMD_DIST_ROWBASE");
     const bool use_rowbase = !(rb_env && atoi(rb_env) == 0);
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0));
@@ -322,16 +323,16 @@ DistributedTrans::DistributedTrans(Trans& trans, parallel::Comm& comm) : trans_(
     if (trans.nparts() > 1 && trans.fourier_parts() != trans.nparts()) {
         throw std::invalid_argument("DistributedTrans: the Trans must be sharded by wavenumber (shard = m)");
     }
-    if (const char* e = std::getenv("ATLAS_AMD_DIST_POISON")) {
+    if (const char* e = atlas_amd::env_get("ATLAS_AMD_DIST_POISON")) {
         poison_ = atoi(e) != 0;
     }
     // ATLAS_AMD_DIST_CHECK=always (debugging a hang or misplaced rows): the ranks compare (field count, message limit) on EVERY
     // call, not only the first time a pair is used -- ranks that later call with different, individually already-compared field
     // counts are then caught as well; costs a blocking 3-int all-to-all per call, hence not the default
-    if (const char* e = std::getenv("ATLAS_AMD_DIST_CHECK")) {
+    if (const char* e = atlas_amd::env_get("ATLAS_AMD_DIST_CHECK")) {
         check_every_call_ = std::string(e) == "always";
     }
-    if (const char* e = std::getenv("ATLAS_AMD_DIST_ROWBASE")) {   // A/B: 0 = the piece-table walk of round 3
+    if (const char* e = atlas_amd::env_get("ATLAS_AMD_DIST_ROWBASE")) {   // A/B: 0 = the piece-table walk of round 3
         use_rowbase_ = atoi(e) != 0;
     }
     HIP_CHECK(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
+#include "env.h"
 #include "device_structs.h"
 #include "dyn_lds.h"
 #include "fft_device.h"
@@ -496,7 +497,7 @@ hipError_t launch_fourier_coarse(const FourierParams& p, int lds_bytes, hipStrea
     FourierParams q       = p;
     q.nvirt               = nblk;
     // fp64: several fields of a short row per wavefront (fft_rows_coarse_multi_kernel); ATLAS_AMD_FFT_COARSE_MULTI=0: one field per workgroup
-    const char* em = std::getenv("ATLAS_AMD_FFT_COARSE_MULTI");
+    const char* em = atlas_amd::env_get("ATLAS_AMD_FFT_COARSE_MULTI");
     if (!p.f32 && !(em && atoi(em) == 0) && p.coarse_n[0] + p.coarse_n[1] + p.coarse_n[2] == p.nrows && p.nparts <= 1 && !p.packed_cols) {
         if (hipError_t e = ensure_dynamic_lds<&fft_rows_coarse_multi_kernel>(lds_bytes); e != hipSuccess) {
             return e;
@@ -725,7 +726,7 @@ static hipError_t launch_ct_t(FourierParams p, int lds_bytes, unsigned nblk, hip
 #if defined(AA_FFT_LDS_WRAP)
     lds_bytes = std::min(lds_bytes, (AA_FFT_LDS_WRAP + 1) * 16);   // dev probe: see fft_core.h PAD()
 #endif
-    if (const char* e = std::getenv("ATLAS_AMD_FFT_LDS_PAD")) {  // dev tool: occupancy sensitivity (more LDS per workgroup)
+    if (const char* e = atlas_amd::env_get("ATLAS_AMD_FFT_LDS_PAD")) {  // dev tool: occupancy sensitivity (more LDS per workgroup)
         lds_bytes += atoi(e);
         (void)ensure_dynamic_lds<&fft_rows_ct_kernel<S, F32, FAST>>(lds_bytes);
     }
@@ -734,7 +735,7 @@ static hipError_t launch_ct_t(FourierParams p, int lds_bytes, unsigned nblk, hip
     if (FAST && !ct3_prefetch_safe<&fft_rows_ct_kernel<S, F32, FAST>>("one field per job")) {   // fft_ct_rows.h
         p.pf_dist = 0;
     }
-    static const bool debug = std::getenv("ATLAS_AMD_FFT_DEBUG") != nullptr;
+    const bool debug = atlas_amd::env_get("ATLAS_AMD_FFT_DEBUG") != nullptr;
     if (debug) {
         int per_cu = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fft_rows_ct_kernel<S, F32, FAST>, S::NT, lds_bytes);
@@ -751,7 +752,7 @@ static hipError_t launch_ct_t(FourierParams p, int lds_bytes, unsigned nblk, hip
 #endif
 // dev switch ATLAS_AMD_FFT_FAST_M=<M>,<M>,...: only these lengths take the row_ct3 form (A/B runs); unset: every shape that has it
 static bool ct3_enabled_for(int M) {
-    static const char* e = std::getenv("ATLAS_AMD_FFT_FAST_M");
+    const char* e = atlas_amd::env_get("ATLAS_AMD_FFT_FAST_M");
     if (!e) {
         return true;
     }
@@ -768,14 +769,14 @@ template <class S>
 static hipError_t launch_ct(const FourierParams& p, int lds_bytes, unsigned nblk, hipStream_t stream) {
     if constexpr (ct3_fast_path<S>()) {
 #if defined(ATLAS_AMD_EXPERIMENTS)
-        static const bool halfwin = std::getenv("ATLAS_AMD_FFT_HALFWIN") && atoi(std::getenv("ATLAS_AMD_FFT_HALFWIN")) != 0;
+        const bool halfwin = atlas_amd::env_get("ATLAS_AMD_FFT_HALFWIN") && atoi(atlas_amd::env_get("ATLAS_AMD_FFT_HALFWIN")) != 0;
         if (halfwin && !p.f32) {   // LDS as a half-row window: three workgroups per CU (tools/experiments/fft_halfwin_rows.inc)
             return launch_cth<S>(p, nblk, stream);
         }
 #endif
 #if defined(ATLAS_AMD_EXPERIMENTS)
         // two jobs per workgroup in sequence, the second gather behind the first job's tail (tools/experiments/fft_ct_rows_seq.inc)
-        const char* sq = std::getenv("ATLAS_AMD_FFT_SEQ");
+        const char* sq = atlas_amd::env_get("ATLAS_AMD_FFT_SEQ");
         if (sq && atoi(sq) != 0 && !p.f32 && p.nparts <= 1 && !p.packed_cols && p.seq_ok) {
             return launch_ct_seq<S>(p, lds_bytes, stream);
         }

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "env.h"
 #include "device_structs.h"
 #include "dyn_lds.h"
 #include "fft_device.h"
@@ -364,7 +365,7 @@ hipError_t launch_fourier_ct_pairs(const FourierParams& p, int ctf, int ctk, int
 // switches it off.)  The pair's 16 bytes must be one aligned element of a single-piece intermediate: first field even, no m-sharded
 // pieces, no packed runs; the wind fields (scaled by 1 / cos(lat)) must not end inside a pair.
 static bool pairs_usable(const FourierParams& p) {
-    const char* e = std::getenv("ATLAS_AMD_FFT_F32_PAIRS");   // read per launch: the tests switch it between calls
+    const char* e = atlas_amd::env_get("ATLAS_AMD_FFT_F32_PAIRS");   // read per launch: the tests switch it between calls
     const bool on = !(e && atoi(e) == 0);
     return on && p.f32 && p.table_f32 && !(p.f_begin & 1) && !(p.scale_uv_fields & 1) && p.nparts <= 1 && !p.packed_cols && !(p.RP & 3);
 }

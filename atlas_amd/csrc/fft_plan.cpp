@@ -1,4 +1,5 @@
 // See fft_plan.h.  Host-only.
+#include "env.h"
 #include "fft_plan.h"
 
 #include <algorithm>
@@ -77,7 +78,7 @@ int next_bluestein_length(int n) {
         }
     }
     // the three extra lengths with a specialised [R0, 16, 16] instance: 9*256, 15*256, 18*256
-    const bool finer = std::getenv("ATLAS_AMD_FFT_FINER_M") ? atoi(std::getenv("ATLAS_AMD_FFT_FINER_M")) != 0 : true;
+    const bool finer = atlas_amd::env_get("ATLAS_AMD_FFT_FINER_M") ? atoi(atlas_amd::env_get("ATLAS_AMD_FFT_FINER_M")) != 0 : true;
     if (finer) {
         for (int m : {2304, 3840, 4608}) {
             if (m >= n && m < best) {
@@ -189,7 +190,7 @@ int hybrid_dense_radix(int h) {
 FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, bool specialised_shapes) {
     PlanOptions opt;
     opt.specialised_shapes = specialised_shapes;
-    if (const char* e = std::getenv("ATLAS_AMD_FFT_NATIVE")) {   // native mixed-radix rows: experiments build only
+    if (const char* e = atlas_amd::env_get("ATLAS_AMD_FFT_NATIVE")) {   // native mixed-radix rows: experiments build only
 #if defined(ATLAS_AMD_EXPERIMENTS)
         opt.native = atoi(e) != 0;
 #else
@@ -198,7 +199,7 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, bool specialised_
         }
 #endif
     }
-    if (const char* e = std::getenv("ATLAS_AMD_FFT_HYBRID")) {
+    if (const char* e = atlas_amd::env_get("ATLAS_AMD_FFT_HYBRID")) {
 #if defined(ATLAS_AMD_EXPERIMENTS)
         opt.hybrid = atoi(e) != 0;
 #else
@@ -274,7 +275,7 @@ FftPlanSet make_fft_plans(const std::vector<int>& row_lengths, const PlanOptions
                     family      = family || (k >= 0 && ct_supported(f, k));
                 }
             }
-            static const bool old_rule = std::getenv("ATLAS_AMD_FFT_SMOOTH_DIRECT") && atoi(std::getenv("ATLAS_AMD_FFT_SMOOTH_DIRECT")) != 0;
+            const bool old_rule = atlas_amd::env_get("ATLAS_AMD_FFT_SMOOTH_DIRECT") && atoi(atlas_amd::env_get("ATLAS_AMD_FFT_SMOOTH_DIRECT")) != 0;
             if (!family && !old_rule) {
                 const int Mb = next_bluestein_length(2 * h - 1);
                 for (int f : {1, 3, 5, 9, 15}) {

@@ -1,3 +1,4 @@
+#include "env.h"
 #include "host_copy.h"
 
 #include <algorithm>
@@ -8,7 +9,7 @@ namespace atlas_amd {
 
 int host_copy_threads() {
     int n = 8;
-    if (const char* e = std::getenv("ATLAS_AMD_HOST_THREADS")) {
+    if (const char* e = atlas_amd::env_get("ATLAS_AMD_HOST_THREADS")) {
         n = std::max(1, atoi(e));
     }
     return n;

@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <string>
 
+#include "env.h"
 #include "device_structs.h"
 #include "dyn_lds.h"
 
@@ -795,7 +796,7 @@ __global__ void __launch_bounds__(512, 4) legendre_kernel_lean_n(LegendreParamsT
 // workgroups per CU (profiles/r04_legendre_f32_probes.txt)
 template <auto Kernel>
 static int lean_lds_pad(int bytes) {
-    static const int pad = std::getenv("ATLAS_AMD_LEG_LDS_PAD") ? atoi(std::getenv("ATLAS_AMD_LEG_LDS_PAD")) : 0;
+    static const int pad = atlas_amd::env_get("ATLAS_AMD_LEG_LDS_PAD") ? atoi(atlas_amd::env_get("ATLAS_AMD_LEG_LDS_PAD")) : 0;
     if (pad > 0) {
         (void)ensure_dynamic_lds<Kernel>(bytes + pad);
     }
@@ -842,7 +843,7 @@ static hipError_t launch_lean(LegendreParams p, int nitems, int nchunks, int chu
     p.nchunks_run   = nrun;
     p.abl           = 0;
 #if defined(AA_LEG_LAYOUT_PROBE)
-    if (const char* e = std::getenv("ATLAS_AMD_LEG_LAYOUT_PROBE")) {
+    if (const char* e = atlas_amd::env_get("ATLAS_AMD_LEG_LAYOUT_PROBE")) {
         p.abl = atoi(e);
     }
 #endif
@@ -905,7 +906,7 @@ void legendre_tiling(int nf, int& rtw, int& nrg, int& nchunks) {
     nrg          = rt >= 2 ? 2 : 1;
     nchunks      = (rt + 5) / 6;
     rtw          = ((rt + nchunks - 1) / nchunks + nrg - 1) / nrg;
-    if (const char* e = std::getenv("ATLAS_AMD_LEG_CFG")) {  // A/B: "rtw,nrg"
+    if (const char* e = atlas_amd::env_get("ATLAS_AMD_LEG_CFG")) {  // A/B: "rtw,nrg"
         int a = 0, b = 0;
 #if defined(ATLAS_AMD_EXPERIMENTS)
         const int amax = 9, bmax = 3;   // the tilings that lost (round 1 sweep, {9x2, 9x1, 6x1, 5x2, 3x3, ...}): experiments build only
@@ -960,7 +961,7 @@ hipError_t launch_legendre(const LegendreParams& p, int nitems, int chunk0, int 
         // the 96-column workgroup (every field count whose 16-column tiles come in sixes, e.g. 137 levels) has two more
         // implementations of the same arithmetic: "lean" (default) and, in experiment builds only, "split" and "dma"
         // and "lean2" (tools/experiments/legendre_kernel_experiments.inc); ATLAS_AMD_LEG_KERNEL=classic selects the generic template
-        const char* e       = std::getenv("ATLAS_AMD_LEG_KERNEL");
+        const char* e       = atlas_amd::env_get("ATLAS_AMD_LEG_KERNEL");
         const std::string k = e ? e : "lean";
         if (nrun <= 0) {
             chunk0 = 0;
@@ -986,7 +987,7 @@ hipError_t launch_legendre(const LegendreParams& p, int nitems, int chunk0, int 
 #endif
     }
     if (nrg == 2 && (rtw == 1 || rtw == 2)) {
-        const char* e = std::getenv("ATLAS_AMD_LEG_KERNEL");
+        const char* e = atlas_amd::env_get("ATLAS_AMD_LEG_KERNEL");
         if (!e || std::string(e) == "lean") {
             if (nrun <= 0) {
                 chunk0 = 0;
@@ -1008,7 +1009,7 @@ hipError_t launch_legendre_f32(const LegendreParamsF32& p, int nitems, int chunk
     legendre_tiling(p.nf, rtw, nrg, nchunks);
     if (rtw == 3 && nrg == 2) {
         // the 96-column workgroup in its "lean" form for float as well [r3]; ATLAS_AMD_LEG_KERNEL=classic: the generic template
-        const char* e = std::getenv("ATLAS_AMD_LEG_KERNEL");
+        const char* e = atlas_amd::env_get("ATLAS_AMD_LEG_KERNEL");
         if ((!e || std::string(e) == "lean") && lean_kernel_usable<&legendre_kernel_lean_f32>("legendre_kernel_lean_f32")) {
             if (nrun <= 0) {
                 chunk0 = 0;
@@ -1018,7 +1019,7 @@ hipError_t launch_legendre_f32(const LegendreParamsF32& p, int nitems, int chunk
         }
     }
     if (nrg == 2 && (rtw == 1 || rtw == 2)) {
-        const char* e = std::getenv("ATLAS_AMD_LEG_KERNEL");
+        const char* e = atlas_amd::env_get("ATLAS_AMD_LEG_KERNEL");
         if (!e || std::string(e) == "lean") {
             if (nrun <= 0) {
                 chunk0 = 0;

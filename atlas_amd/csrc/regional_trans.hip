@@ -1,4 +1,5 @@
 // See regional_trans.h.
+#include "env.h"
 #include "regional_trans.h"
 
 #include <algorithm>
@@ -20,6 +21,7 @@ namespace {
     do {                                                                                                              \
         hipError_t e_ = (call);                                                                                       \
         if (e_ != hipSuccess) {                                                                                       \
+            (void)hipGetLastError(); /* reported here, once: not left sticky for the next call */ \
             throw std::runtime_error(std::string("HIP error '") + hipGetErrorString(e_) + "' in " #call);              \
         }                                                                                                             \
     } while (0)
@@ -95,7 +97,7 @@ __global__ void __launch_bounds__(256) points_dft_kernel(const double* __restric
 // inner object's Legendre stage covers the row range the target needs; rowsel_ maps target rows / points to its rows
 void RegionalTrans::make_inner(const std::vector<double>& lats_deg, bool clamp_scale) {
     std::vector<double> a;
-    const char* rp_env         = std::getenv("ATLAS_AMD_REFERENCE_POLES");   // read per object
+    const char* rp_env         = atlas_amd::env_get("ATLAS_AMD_REFERENCE_POLES");   // read per object
     const bool reference_poles = rp_env && atoi(rp_env) != 0;
     // ATLAS_AMD_REFERENCE_POLES=1 ("Deviations"): on this branch the reference calls its Legendre routine with the
     // target's own, unmirrored latitudes; within a metre of EITHER pole (sin(colatitude) <= sqrt(epsilon)) that routine sets

@@ -1,5 +1,6 @@
 // See trans.h.  Host code of the MI355X TransLocal replacement: builds the plan, uploads the tables once,
 // launches the two kernels per call on the object's HIP stream.
+#include "env.h"
 #include "trans.h"
 #include "host_copy.h"
 #include "trace.h"
@@ -81,13 +82,14 @@ Trans::Trans(const grid::StructuredGrid& grid, int truncation, const TransConfig
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
         throw std::runtime_error(
             "atlas_amd::Trans needs a HIP device (MI355X / gfx950); there is no CPU fallback for the transform");
     }
-    if (const char* e = std::getenv("ATLAS_AMD_PIPELINE")) {
+    if (const char* e = atlas_amd::env_get("ATLAS_AMD_PIPELINE")) {
         pipeline_ = std::max(1, atoi(e));
     }
-    if (const char* e = std::getenv("ATLAS_AMD_FFT_GENERIC")) {
+    if (const char* e = atlas_amd::env_get("ATLAS_AMD_FFT_GENERIC")) {
         use_ct_ = !(e[0] == '1');
     }
     if (cfg.row_end > cfg.row_begin) {
@@ -132,7 +134,7 @@ Trans::Trans(const grid::StructuredGrid& grid, int truncation, const TransConfig
         fft::PlanOptions po;
         po.specialised_shapes = use_ct_;
         po.max_mode           = geo_.T;
-        if (const char* e = std::getenv("ATLAS_AMD_FFT_HYBRID")) {      // A/B switch: 0 = Bluestein for every awkward row
+        if (const char* e = atlas_amd::env_get("ATLAS_AMD_FFT_HYBRID")) {      // A/B switch: 0 = Bluestein for every awkward row
             po.hybrid = atoi(e) != 0;
 #if !defined(ATLAS_AMD_EXPERIMENTS)
             if (po.hybrid) {   // the dense-stage kernel lives in tools/experiments: fail here, not at the first launch
@@ -140,7 +142,7 @@ Trans::Trans(const grid::StructuredGrid& grid, int truncation, const TransConfig
             }
 #endif
         }
-        if (const char* e = std::getenv("ATLAS_AMD_FFT_NATIVE")) {      // 1: native mixed-radix rows where a stage list exists
+        if (const char* e = atlas_amd::env_get("ATLAS_AMD_FFT_NATIVE")) {      // 1: native mixed-radix rows where a stage list exists
             po.native = atoi(e) != 0;
 #if !defined(ATLAS_AMD_EXPERIMENTS)
             if (po.native) {   // kernel and planner live in tools/experiments since round 5 (at parity with Bluestein, never the default)
@@ -148,7 +150,7 @@ Trans::Trans(const grid::StructuredGrid& grid, int truncation, const TransConfig
             }
 #endif
         }
-        if (const char* e = std::getenv("ATLAS_AMD_FFT_HYB_MAXA")) {    // largest dense radix
+        if (const char* e = atlas_amd::env_get("ATLAS_AMD_FFT_HYB_MAXA")) {    // largest dense radix
             po.hybrid_max_a = atoi(e);
         }
         {
@@ -157,7 +159,7 @@ Trans::Trans(const grid::StructuredGrid& grid, int truncation, const TransConfig
             std::sort(distinct.begin(), distinct.end());
             distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
             po.coarse_classes = !geo_.regular && geo_.nxmax <= 704 && distinct.size() >= 24;
-            if (const char* e = std::getenv("ATLAS_AMD_FFT_COARSE")) {
+            if (const char* e = atlas_amd::env_get("ATLAS_AMD_FFT_COARSE")) {
                 po.coarse_classes = atoi(e) != 0;
             }
             fft_coarse_ = po.coarse_classes;
@@ -354,7 +356,7 @@ void Trans::upload() {
     bool on_device = cfg_.device_tables == 1;
     if (cfg_.device_tables < 0) {
         // measured at TL1279 / O1280 (gpurun_out/r02_first): device generation 0.9 s, host generation + upload 6.7 s
-        const char* e = std::getenv("ATLAS_AMD_TABLES");
+        const char* e = atlas_amd::env_get("ATLAS_AMD_TABLES");
         on_device     = !(e && std::string(e) == "host");
     }
     if (on_device && !cfg_.legendre_cache) {
@@ -473,7 +475,7 @@ void Trans::upload() {
             // small reduced grids: the coarse classes 256 / 512 / 1024 share one launch (fft_kernel.hip: fft_rows_coarse_kernel);
             // ATLAS_AMD_FFT_COARSE_FUSED=0: one launch per class as before (A/B)
             // (read per Trans object, not once per process: the bitwise tests build one object per setting -- ADVICE r4)
-            const bool fuse = !(std::getenv("ATLAS_AMD_FFT_COARSE_FUSED") && atoi(std::getenv("ATLAS_AMD_FFT_COARSE_FUSED")) == 0);
+            const bool fuse = !(atlas_amd::env_get("ATLAS_AMD_FFT_COARSE_FUSED") && atoi(atlas_amd::env_get("ATLAS_AMD_FFT_COARSE_FUSED")) == 0);
             if (fft_coarse_ && fuse && pl.ct_f == 1 && pl.shape.M <= 1024 && pl.shape.M == fft::coarse_bluestein_length(2 * pl.h - 1)) {
                 by_class[{6, 1024}].push_back(j);
                 continue;
@@ -491,7 +493,7 @@ void Trans::upload() {
             // workgroups per CU / prime 17 .. 31: three); launches bucketed by LDS footprint: 40 KiB (four per CU), 52 KiB (three),
             // 80 KiB (two).  ATLAS_AMD_FFT_NATIVE_FPJ=2: two fields per workgroup where two work arrays fit 80 KiB -- measured
             // slower (2.20 against 1.60 ms for the native rows of O1280, profiles/r04_fft_native.txt), bit-identical
-            const int nat_fpj = std::getenv("ATLAS_AMD_FFT_NATIVE_FPJ") ? atoi(std::getenv("ATLAS_AMD_FFT_NATIVE_FPJ")) : 1;
+            const int nat_fpj = atlas_amd::env_get("ATLAS_AMD_FFT_NATIVE_FPJ") ? atoi(atlas_amd::env_get("ATLAS_AMD_FFT_NATIVE_FPJ")) : 1;
             const int bigp  = pl.nat.radix[0] > 15 ? 1 : 0;
             const int one   = native_lds_elems(pl, row_mmax[j]);
             const int fpj   = (nat_fpj >= 2 && 2 * one + 64 <= 5120) ? 2 : 1;
@@ -544,11 +546,11 @@ void Trans::upload() {
         const int M = it->first.second;
         c.lds_bytes = fft::padded_size(M) * 16;
         int ntdiv   = 16;
-        if (const char* e = std::getenv("ATLAS_AMD_FFT_NT_DIV")) {
+        if (const char* e = atlas_amd::env_get("ATLAS_AMD_FFT_NT_DIV")) {
             ntdiv = std::max(1, atoi(e));
         }
         c.nthreads  = std::min(512, std::max(64, (M / ntdiv + 63) / 64 * 64));
-        if (it->first.first == 2 && M >= 256 && !std::getenv("ATLAS_AMD_FFT_NT_DIV")) {
+        if (it->first.first == 2 && M >= 256 && !atlas_amd::env_get("ATLAS_AMD_FFT_NT_DIV")) {
             // specialised direct rows [16, 16, R0]: the load phase has M / R0 = 256 butterflies, give it one sweep
             c.nthreads = std::min(512, std::max(256, c.nthreads));
         }
@@ -579,7 +581,7 @@ void Trans::upload() {
                 nthr = std::max(nthr, std::min(512, (pl.h / 8 + 63) / 64 * 64));
                 nthr = std::max(nthr, 64 * ((pl.hyb_Mt + fft::HYB_UPW - 1) / fft::HYB_UPW));
             }
-            if (const char* e = std::getenv("ATLAS_AMD_FFT_HYB_NT")) {
+            if (const char* e = atlas_amd::env_get("ATLAS_AMD_FFT_HYB_NT")) {
                 nthr = std::max(nthr, atoi(e));
             }
             c.lds_bytes = lds * 16;
@@ -918,17 +920,17 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
     p.pf_sectors      = 1;
     p.row_affinity    = 1;
     p.mid_rot         = 0;
-    if (const char* e = std::getenv("ATLAS_AMD_FFT_MIDROT")) {   // A/B
+    if (const char* e = atlas_amd::env_get("ATLAS_AMD_FFT_MIDROT")) {   // A/B
         p.mid_rot = atoi(e);
     }
     p.job_group_log2  = f32 ? 4 : 3;
-    if (const char* e = std::getenv("ATLAS_AMD_FFT_GROUP_LOG2")) {   // A/B
+    if (const char* e = atlas_amd::env_get("ATLAS_AMD_FFT_GROUP_LOG2")) {   // A/B
         p.job_group_log2 = std::max(3, std::min(4, atoi(e)));
     }
-    if (const char* e = std::getenv("ATLAS_AMD_FFT_ROW_AFFINITY")) {
+    if (const char* e = atlas_amd::env_get("ATLAS_AMD_FFT_ROW_AFFINITY")) {
         p.row_affinity = atoi(e);
     }
-    if (const char* e = std::getenv("ATLAS_AMD_FFT_PREFETCH")) {   // "distance[,requests per line]"
+    if (const char* e = atlas_amd::env_get("ATLAS_AMD_FFT_PREFETCH")) {   // "distance[,requests per line]"
         p.pf_dist = atoi(e);
         if (const char* c = strchr(e, ',')) {
             p.pf_sectors = std::max(1, std::min(4, atoi(c + 1)));
@@ -936,11 +938,11 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
     }
     p.trace           = d_trace_;
     p.trace_cap       = trace_cap_;
-    p.abl             = std::getenv("ATLAS_AMD_FFT_ABLATE") ? atoi(std::getenv("ATLAS_AMD_FFT_ABLATE")) : 0;
+    p.abl             = atlas_amd::env_get("ATLAS_AMD_FFT_ABLATE") ? atoi(atlas_amd::env_get("ATLAS_AMD_FFT_ABLATE")) : 0;
     TraceRange trace(geo_.regular ? "Inverse Fourier Transform (mi355x, RegularGrid)"      // TransLocal.cc:1107
                                   : "Inverse Fourier Transform (mi355x, ReducedGrid)");    // TransLocal.cc:1159
     timed_begin(1, stream);
-    static const int only_m = std::getenv("ATLAS_AMD_FFT_ONLY_M") ? atoi(std::getenv("ATLAS_AMD_FFT_ONLY_M")) : 0;
+    const int only_m = atlas_amd::env_get("ATLAS_AMD_FFT_ONLY_M") ? atoi(atlas_amd::env_get("ATLAS_AMD_FFT_ONLY_M")) : 0;
     // The row-length classes are independent launches.  Run back to back on one stream each ends in a tail (the last
     // workgroups of a class leave CUs idle); dealt round robin to a few streams the tail of one class is filled by the
     // next and workgroups of different LDS footprints share a CU.  Measured on TL1279/O1280/137 levels (25 classes, in
@@ -949,7 +951,7 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
     // ATLAS_AMD_FFT_STREAMS overrides.  All streams fork from and join the caller's stream through events.
     // Small reduced grids (coarse row classes: three or four launches of tens of microseconds): one stream -- forking and joining
     // side streams costs more than the tails (TL159 -> O160, 60 fields: stage 0.133 / 0.110 / 0.100 ms on 4 / 2 / 1 streams).
-    const int nstreams_env = std::getenv("ATLAS_AMD_FFT_STREAMS") ? atoi(std::getenv("ATLAS_AMD_FFT_STREAMS")) : (fft_coarse_ ? 1 : 4);
+    const int nstreams_env = atlas_amd::env_get("ATLAS_AMD_FFT_STREAMS") ? atoi(atlas_amd::env_get("ATLAS_AMD_FFT_STREAMS")) : (fft_coarse_ ? 1 : 4);
     const int nstreams = std::max(1, std::min(nstreams_env, 8));
     while ((int)side_streams_.size() < nstreams - 1) {
         hipStream_t st;
@@ -977,7 +979,7 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
         if (only_m && c.lds_bytes != fft::padded_size(only_m) * 16) {  // dev tool (tools/fft_phase_prof.py): one class
             continue;
         }
-        static const int only_native = std::getenv("ATLAS_AMD_FFT_ONLY_NATIVE") ? atoi(std::getenv("ATLAS_AMD_FFT_ONLY_NATIVE")) : 0;
+        const int only_native = atlas_amd::env_get("ATLAS_AMD_FFT_ONLY_NATIVE") ? atoi(atlas_amd::env_get("ATLAS_AMD_FFT_ONLY_NATIVE")) : 0;
         if (only_native && !c.native) {   // dev tool: the native mixed-radix rows alone
             continue;
         }
@@ -1220,7 +1222,7 @@ void Trans::invtrans(int nb_scalar_fields, const double scalar_spectra[], double
     // transform, one download, strictly serial -- 178 ms at TL1279 / O1280 / 137 levels; profiles/r05_bench_host.txt).  Read per
     // call: round 4's bench toggled a process-wide static and measured the same path twice.
     bool pipe = true;
-    if (const char* e = std::getenv("ATLAS_AMD_HOST_PIPELINE")) {
+    if (const char* e = atlas_amd::env_get("ATLAS_AMD_HOST_PIPELINE")) {
         pipe = atoi(e) != 0;
     }
     if (pipe && nb_scalar_fields >= 32 && ngp * sizeof(double) >= (size_t(256) << 20) && fourier_parts() == 1 && !windowed()) {
@@ -1281,7 +1283,7 @@ bool Trans::ensure_host_pipeline_buffers(size_t up_doubles, size_t down_doubles)
     drop(hp_up_, hp_down_, hp_dsp_, hp_dgp_);
     hp_up_cap_ = hp_down_cap_ = 0;
     double *nu[2] = {nullptr, nullptr}, *nd[2] = {nullptr, nullptr}, *ns[2] = {nullptr, nullptr}, *ng[2] = {nullptr, nullptr};
-    bool ok = std::getenv("ATLAS_AMD_HOST_PIPELINE_FAIL_ALLOC") == nullptr;
+    bool ok = atlas_amd::env_get("ATLAS_AMD_HOST_PIPELINE_FAIL_ALLOC") == nullptr;
     for (int i = 0; i < 2 && ok; ++i) {
         ok = hipHostMalloc((void**)&nu[i], up_cap * sizeof(double), hipHostMallocDefault) == hipSuccess &&
              hipHostMalloc((void**)&nd[i], down_cap * sizeof(double), hipHostMallocDefault) == hipSuccess &&
@@ -1309,7 +1311,7 @@ bool Trans::invtrans_host_pipelined(int nb_scalar, const double* sp_host, int nb
     const size_t ncoef = nb_spectral_coefficients();   // doubles per field
     const size_t npts  = (size_t)nb_gridpoints();
     int C = 16;
-    if (const char* e = std::getenv("ATLAS_AMD_HOST_CHUNK")) {
+    if (const char* e = atlas_amd::env_get("ATLAS_AMD_HOST_CHUNK")) {
         C = std::max(8, atoi(e) / 8 * 8);
     }
     // the chunks: groups of C / 2 vor/div pairs (C output fields: u then v), then groups of C scalar fields; output field order
@@ -1563,7 +1565,7 @@ void Trans::invtrans(int nb_scalar, const double sp[], int nb_vordiv, const doub
     const size_t ngp   = (size_t)nb_gridpoints() * (size_t)(2 * nb_vordiv + nb_scalar);
     {   // large calls: the field-chunked full-duplex pipeline (invtrans_host_pipelined), as for the scalar call
         bool pipe = true;
-        if (const char* e = std::getenv("ATLAS_AMD_HOST_PIPELINE")) {
+        if (const char* e = atlas_amd::env_get("ATLAS_AMD_HOST_PIPELINE")) {
             pipe = atoi(e) != 0;
         }
         if (pipe && 2 * nb_vordiv + nb_scalar >= 32 && ngp * sizeof(double) >= (size_t(256) << 20) && fourier_parts() == 1 && !windowed()) {

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <string>
 
+#include "env.h"
 #include "device_structs.h"
 
 namespace atlas_amd {
@@ -332,7 +333,7 @@ static hipError_t launch_spectra_prepare_t(const Real* vor, const Real* div, con
     PrepareParamsT<Real> p{vor, div, sp, out, T, nvd, ns, fshift, nb};
     // many vor/div fields and enough coefficients to fill the device with its chunks (T >= 255): the streaming form (a lane per field);
     // ATLAS_AMD_PREPARE=rows / stream forces one of the two (same bits either way: tests/test_gpu_vordiv.py)
-    const char* e     = std::getenv("ATLAS_AMD_PREPARE");
+    const char* e     = atlas_amd::env_get("ATLAS_AMD_PREPARE");
     // (the streaming form walks groups of 64 vor/div fields: it has nothing to do -- and divides by the group count -- without any,
     // e.g. the scalar chunks of a pipelined vor/div call, whatever the override says)
     const bool stream_form = nvd > 0 && (e && *e ? std::string(e) == "stream" : (nvd >= 48 && total_n >= PREP_SNB * 2048));
@@ -434,7 +435,7 @@ hipError_t launch_gp_to_field(const double* gp, double* field, long long npts, i
     if (npts <= 0 || nf <= 0) {
         return hipSuccess;
     }
-    const char* e   = std::getenv("ATLAS_AMD_GP_TO_FIELD");
+    const char* e   = atlas_amd::env_get("ATLAS_AMD_GP_TO_FIELD");
     const bool rows = e && *e ? std::string(e) == "rows" : (nf >= 32 && (npts + 63) / 64 >= 1024);
     if (!rows) {
         hipLaunchKernelGGL(gp_to_field_kernel, dim3((unsigned)((npts + 31) / 32), (unsigned)((nf + 31) / 32)), dim3(256), 0, stream,

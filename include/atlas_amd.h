@@ -42,6 +42,15 @@ const char* atlas_amd__last_error(void);
  * src/atlas/option/TransOptions.cc:38-74, TransLocal.cc:61-110) */
 const char* atlas_amd__last_note(void);
 const char* atlas_amd__version(void);
+/* Environment hygiene (a library loaded into Atlas inherits the caller's environment).  Every ATLAS_AMD_* switch the library reads
+ * is listed in ONE table (csrc/env.cpp; INTEGRATION.md section 8 is generated from it).  atlas_amd__set_ignore_env(1) -- what the
+ * adapter plugin calls when it is loaded -- makes every switch read as unset for the rest of the process (0: honour them again);
+ * ATLAS_AMD_IGNORE_ENV=1 in the environment does the same.  Development switches exist only in dev / experiments builds.
+ * atlas_amd__effective_config writes one line per switch, "NAME<TAB>class<TAB>value in effect<TAB>source<TAB>default<TAB>what",
+ * source = default | env | ignored | compiled out, into buf (NUL-terminated, truncated to `capacity`) and returns the number of
+ * bytes the whole text needs (call with capacity 0 to size the buffer).  No reference counterpart. */
+int atlas_amd__set_ignore_env(int on);
+long long atlas_amd__effective_config(char* buf, long long capacity);
 /* number of visible HIP devices (0: the transform cannot run; there is no CPU fallback) */
 int atlas_amd__device_count(void);
 /* stream ordering helper for callers that own their device arrays on another HIP stream: all work submitted to

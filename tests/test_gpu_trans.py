@@ -251,14 +251,22 @@ def test_every_bluestein_row_shape_fp64_and_fp32(f, k):
     assert compute_rms(gp32.cpu().numpy().astype(np.float64), ref32) < 2e-6
 
 
-def test_native_rows_switch_fails_loudly_in_the_product_library(monkeypatch):
-    """ATLAS_AMD_FFT_NATIVE=1 (the native mixed-radix rows, tools/experiments/ since round 5) needs the experiments build:
-    the product library says so when the object is built instead of silently planning something else"""
-    if "exp" in os.environ.get("ATLAS_AMD_LIB", ""):
-        pytest.skip("experiments build")
-    monkeypatch.setenv("ATLAS_AMD_FFT_NATIVE", "1")
-    with pytest.raises(Exception, match="ATLAS_AMD_EXPERIMENTS"):
-        atlas_amd.Trans(atlas_amd.Grid("O320"), 319)
+def test_development_switches_do_not_exist_in_the_product_library(monkeypatch, capfd):
+    """ATLAS_AMD_FFT_NATIVE=1 (the native mixed-radix rows, tools/experiments/ since round 5) and the other switches of class
+    "dev" (csrc/env.cpp) are compiled out of the product library: a process that happens to carry one in its environment gets the
+    default plan -- not an exception out of the Trans constructor (rounds 3 - 5), not another kernel -- and one line on stderr
+    """
+    if "exp" in os.environ.get("ATLAS_AMD_LIB", "") or "dev" in os.environ.get("ATLAS_AMD_LIB", ""):
+        pytest.skip("experiments / dev build")
+    g = atlas_amd.Grid("O320")
+    plan0 = atlas_amd.Trans(g, 319).fourier_launch_plan()
+    for k2, v in (("ATLAS_AMD_FFT_NATIVE", "1"), ("ATLAS_AMD_FFT_HYBRID", "1"), ("ATLAS_AMD_FFT_ONLY_M", "4096"), ("ATLAS_AMD_FFT_LDS_PAD", "40000")):
+        monkeypatch.setenv(k2, v)
+    tr = atlas_amd.Trans(g, 319)
+    assert tr.fourier_launch_plan() == plan0
+    cfg = atlas_amd._lib.effective_config()
+    assert cfg["ATLAS_AMD_FFT_NATIVE"]["source"] == "compiled out" and cfg["ATLAS_AMD_FFT_NATIVE"]["value"] == "0"
+    assert "development switch" in capfd.readouterr().err
 
 
 def test_coarse_row_classes_in_one_launch_are_bitwise_equal_to_one_launch_per_class(monkeypatch):
