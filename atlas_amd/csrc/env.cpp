@@ -19,7 +19,10 @@ const EnvSwitch kSwitches[] = {
     // ---- tuning: selects between implementations of the same arithmetic (bit-identical unless noted) or sizes a resource
     {"ATLAS_AMD_TABLES",            C::tuning,    "device", "host: Legendre tables generated on the host and uploaded (6.7 s at TL1279) instead of on the device (0.9 s); same bits"},
     {"ATLAS_AMD_PIPELINE",          C::tuning,    "1",      "n > 1: a call's fields in n chunks, Fourier stage of chunk i beside the Legendre stage of chunk i+1 on a second stream (measured no gain: one fp64 datapath)"},
-    {"ATLAS_AMD_LEG_KERNEL",        C::tuning,    "lean",   "classic: the generic Legendre template instead of the hand-scheduled lean kernels (same bits); experiments build: lean2 / split / dma"},
+    {"ATLAS_AMD_LEG_KERNEL",        C::tuning,    "lean",   "classic: the generic Legendre template instead of the hand-scheduled lean kernels (same bits); experiments build: stream / lean2 / split / dma"},
+    {"ATLAS_AMD_LEG_STREAM_W",      C::dev,       "auto",   "workgroups per XCD of the persistent (stream) Legendre kernels instead of (workgroups per CU by the occupancy query) x 32, rounded down to a multiple of the column chunks"},
+    {"ATLAS_AMD_LEG_STREAM_DYNAMIC", C::dev,      "1",      "0: static unit assignment (unit = workgroup + k W) of the persistent Legendre kernels instead of the work counter per XCD"},
+    {"ATLAS_AMD_LEG_STREAM_SKEW",   C::dev,       "0",      "n: the second half of the persistent Legendre workgroups of an XCD starts n x 512 cycles late (phase probe)"},
     {"ATLAS_AMD_LEG_CFG",           C::tuning,    "auto",   "rtw,nrg: 16-column tiles per wavefront (1-3) and column groups per workgroup (1-2) of the Legendre tiling instead of the planner's choice"},
     {"ATLAS_AMD_FFT_GENERIC",       C::tuning,    "0",      "1: every row through the run-time shaped Fourier kernel (no compile-time shaped rows)"},
     {"ATLAS_AMD_FFT_STREAMS",       C::tuning,    "4 (1 for coarse classes)", "streams the row-length classes of the Fourier stage are dealt to (1-8)"},
@@ -53,6 +56,8 @@ const EnvSwitch kSwitches[] = {
     {"ATLAS_AMD_FFT_DEBUG",         C::dev,       "unset",  "set: registers / LDS / workgroups per CU of every Fourier launch on stderr"},
     {"ATLAS_AMD_FFT_LDS_PAD",       C::dev,       "0",      "bytes of extra dynamic LDS per Fourier workgroup (occupancy probe)"},
     {"ATLAS_AMD_LEG_LDS_PAD",       C::dev,       "0",      "bytes of extra dynamic LDS per Legendre workgroup (occupancy probe)"},
+    {"ATLAS_AMD_LEG_ABLATE",        C::dev,       "0",      "parts of the role-split / dma Legendre kernels left out (tools/experiments; results wrong)"},
+    {"ATLAS_AMD_LEG_DEBUG",         C::dev,       "unset",  "set: launch geometry of the experimental Legendre kernels on stderr"},
     {"ATLAS_AMD_LEG_LAYOUT_PROBE",  C::dev,       "0",      "store side of intermediate layouts with several wavenumbers per line (results unusable; also needs -DAA_LEG_LAYOUT_PROBE)"},
     {"ATLAS_AMD_FFT_HYBRID",        C::dev,       "0",      "1: dense-stage hybrid rows (tools/experiments)"},
     {"ATLAS_AMD_FFT_HYB_MAXA",      C::dev,       "plan",   "largest dense radix of the hybrid rows"},

@@ -854,6 +854,9 @@ static hipError_t launch_lean(LegendreParams p, int nitems, int nchunks, int chu
 
 
 #if defined(ATLAS_AMD_EXPERIMENTS)
+// [r6] the lean body as one operand stream over the units of a persistent workgroup (ATLAS_AMD_LEG_KERNEL=stream): bit-identical, built
+// to hide a unit's prologue and epilogue -- measured 2.5 % SLOWER than the lean kernels (profiles/r06_legendre_stream.txt): experiments build only
+#include "../../tools/experiments/legendre_stream.inc"
 #include "../../tools/experiments/legendre_kernel_experiments.inc"
 #endif
 
@@ -967,7 +970,12 @@ hipError_t launch_legendre(const LegendreParams& p, int nitems, int chunk0, int 
             chunk0 = 0;
             nrun   = nchunks;
         }
-        if (k == "lean" && lean_kernel_usable<&legendre_kernel_lean>("legendre_kernel_lean")) {
+#if defined(ATLAS_AMD_EXPERIMENTS)
+        if (k == "stream" && lean_kernel_usable<&legendre_kernel_stream>("legendre_kernel_stream")) {
+            return launch_stream_t<&legendre_kernel_stream, 3, double>(p, nitems, nchunks, chunk0, nrun, stream);
+        }
+#endif
+        if ((k == "lean" || k == "stream") && lean_kernel_usable<&legendre_kernel_lean>("legendre_kernel_lean")) {
             return launch_lean(p, nitems, nchunks, chunk0, nrun, stream);
         }
 #if defined(ATLAS_AMD_EXPERIMENTS)
@@ -988,7 +996,21 @@ hipError_t launch_legendre(const LegendreParams& p, int nitems, int chunk0, int 
     }
     if (nrg == 2 && (rtw == 1 || rtw == 2)) {
         const char* e = atlas_amd::env_get("ATLAS_AMD_LEG_KERNEL");
-        if (!e || std::string(e) == "lean") {
+#if defined(ATLAS_AMD_EXPERIMENTS)
+        if (e && std::string(e) == "stream") {
+            if (nrun <= 0) {
+                chunk0 = 0;
+                nrun   = nchunks;
+            }
+            if (rtw == 1 && lean_kernel_usable<&legendre_kernel_stream_n<1, double>>("legendre_kernel_stream_n<1, double>")) {
+                return launch_stream_t<&legendre_kernel_stream_n<1, double>, 1, double>(p, nitems, nchunks, chunk0, nrun, stream);
+            }
+            if (rtw == 2 && lean_kernel_usable<&legendre_kernel_stream_n<2, double>>("legendre_kernel_stream_n<2, double>")) {
+                return launch_stream_t<&legendre_kernel_stream_n<2, double>, 2, double>(p, nitems, nchunks, chunk0, nrun, stream);
+            }
+        }
+#endif
+        if (!e || std::string(e) == "lean" || std::string(e) == "stream") {
             if (nrun <= 0) {
                 chunk0 = 0;
                 nrun   = nchunks;
@@ -1010,7 +1032,16 @@ hipError_t launch_legendre_f32(const LegendreParamsF32& p, int nitems, int chunk
     if (rtw == 3 && nrg == 2) {
         // the 96-column workgroup in its "lean" form for float as well [r3]; ATLAS_AMD_LEG_KERNEL=classic: the generic template
         const char* e = atlas_amd::env_get("ATLAS_AMD_LEG_KERNEL");
-        if ((!e || std::string(e) == "lean") && lean_kernel_usable<&legendre_kernel_lean_f32>("legendre_kernel_lean_f32")) {
+#if defined(ATLAS_AMD_EXPERIMENTS)
+        if (e && std::string(e) == "stream" && lean_kernel_usable<&legendre_kernel_stream_f32>("legendre_kernel_stream_f32")) {
+            if (nrun <= 0) {
+                chunk0 = 0;
+                nrun   = nchunks;
+            }
+            return launch_stream_t<&legendre_kernel_stream_f32, 3, float>(p, nitems, nchunks, chunk0, nrun, stream);
+        }
+#endif
+        if ((!e || std::string(e) == "lean" || std::string(e) == "stream") && lean_kernel_usable<&legendre_kernel_lean_f32>("legendre_kernel_lean_f32")) {
             if (nrun <= 0) {
                 chunk0 = 0;
                 nrun   = nchunks;
@@ -1020,7 +1051,21 @@ hipError_t launch_legendre_f32(const LegendreParamsF32& p, int nitems, int chunk
     }
     if (nrg == 2 && (rtw == 1 || rtw == 2)) {
         const char* e = atlas_amd::env_get("ATLAS_AMD_LEG_KERNEL");
-        if (!e || std::string(e) == "lean") {
+#if defined(ATLAS_AMD_EXPERIMENTS)
+        if (e && std::string(e) == "stream") {
+            if (nrun <= 0) {
+                chunk0 = 0;
+                nrun   = nchunks;
+            }
+            if (rtw == 1 && lean_kernel_usable<&legendre_kernel_stream_n<1, float>>("legendre_kernel_stream_n<1, float>")) {
+                return launch_stream_t<&legendre_kernel_stream_n<1, float>, 1, float>(p, nitems, nchunks, chunk0, nrun, stream);
+            }
+            if (rtw == 2 && lean_kernel_usable<&legendre_kernel_stream_n<2, float>>("legendre_kernel_stream_n<2, float>")) {
+                return launch_stream_t<&legendre_kernel_stream_n<2, float>, 2, float>(p, nitems, nchunks, chunk0, nrun, stream);
+            }
+        }
+#endif
+        if (!e || std::string(e) == "lean" || std::string(e) == "stream") {
             if (nrun <= 0) {
                 chunk0 = 0;
                 nrun   = nchunks;

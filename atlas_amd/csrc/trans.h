@@ -187,6 +187,7 @@ private:
     int nitems2_         = 0;
     int* d_nlat0_        = nullptr;
     long long* d_sp_moff_ = nullptr;   // block offsets of the owned wavenumbers in a sharded spectral array (lazily)
+    int* d_leg_sched_    = nullptr;  // 16 ints: work counters of the persistent Legendre kernels (self-resetting)
     double* d_zero_      = nullptr;  // zeros: load target of padding columns in the Legendre kernel
     float* d_P32_        = nullptr;  // fp32 variant: table, zero target and Fourier intermediate in float (lazily)
     float* d_zero32_     = nullptr;

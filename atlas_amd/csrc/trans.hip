@@ -199,6 +199,7 @@ void Trans::release() noexcept {
     fr(d_sp_moff_);
     fr(d_nlat0_);
     fr(d_zero_);
+    fr(d_leg_sched_);
     fr(d_P32_);
     fr(d_zero32_);
     fr(d_fourier32_);
@@ -433,6 +434,8 @@ void Trans::upload() {
     {
         const double zeros[16] = {0.};
         d_zero_                = dev_upload(zeros, 16);
+        const int izeros[16]   = {0};
+        d_leg_sched_           = dev_upload(izeros, 16);
     }
     // ---- FFT plans / tables ----
     d_fftplans_ = dev_upload(fftplans_.plans.data(), fftplans_.plans.size());
@@ -774,6 +777,8 @@ void Trans::legendre_chunks(int trc_in, int nb_fields, const double* sp_dev, dou
     p.nitems2 = nitems2_;
     p.nlat0  = d_nlat0_;
     p.zero   = d_zero_;
+    // dynamic unit assignment of the persistent kernels: one launch at a time per object (the chunked pipeline overlaps launches of two streams)
+    p.sched  = (chunk0 == 0 && nrun <= 0) ? d_leg_sched_ : nullptr;
     p.T      = geo_.T;
     p.trc_in = trc_in;
     p.nf     = nb_fields;
@@ -1144,6 +1149,7 @@ void Trans::invtrans_uv_device_f32(int trc_in, int nb_fields, int nb_vordiv, con
     p.sp_moff   = nullptr;
     p.nlat0     = d_nlat0_;
     p.zero      = d_zero32_;
+    p.sched     = d_leg_sched_;
     p.T         = geo_.T;
     p.trc_in    = trc_in;
     p.nf        = nb_fields;

@@ -17,7 +17,9 @@ CSRC = os.path.join(ROOT, "atlas_amd", "csrc")
 
 def _names_read_by_the_sources():
     names = set()
-    for p in glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")) + glob.glob(os.path.join(CSRC, "*.h")):
+    exp = os.path.join(ROOT, "tools", "experiments")   # the kernels of the experiments build read (dev) switches too
+    for p in glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")) + glob.glob(os.path.join(CSRC, "*.h")) + \
+            glob.glob(os.path.join(exp, "*.inc")) + glob.glob(os.path.join(exp, "*.hip")) + glob.glob(os.path.join(exp, "*.h")):
         text = open(p).read()
         if os.path.basename(p) != "env.cpp":
             # nothing but env.cpp may call getenv for one of our names

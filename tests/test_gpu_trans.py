@@ -725,7 +725,7 @@ def test_classic_reduced_gaussian_grid_against_oracle():
         assert compute_rms(gp[:, off[r]:off[r + 1]], ref) < 1e-12, r
 
 
-LEG_KERNELS = ("classic", "lean")
+LEG_KERNELS = ("classic", "lean") + (("stream",) if "exp" in os.environ.get("ATLAS_AMD_LIB", "") else ())   # "stream" [r6]: experiments build
 
 
 @pytest.mark.parametrize("case", ["scalar_O160_nf40", "vordiv_F64", "sharded_O160_nf44", "band_O160_nf42", "scalar_O64_nf137",

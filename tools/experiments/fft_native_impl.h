@@ -391,7 +391,7 @@ hipError_t launch_nat_t(FourierParams p, int lds_bytes, hipStream_t stream) {
             return hipErrorInvalidValue;
         }
     }
-    if (const char* e = std::getenv("ATLAS_AMD_FFT_LDS_PAD")) {  // dev tool: occupancy sensitivity (more LDS per workgroup)
+    if (const char* e = atlas_amd::env_get("ATLAS_AMD_FFT_LDS_PAD")) {  // dev tool: occupancy sensitivity (more LDS per workgroup)
         lds_bytes += atoi(e);
     }
     if (hipError_t e = ensure_dynamic_lds<&fft_rows_nat_kernel<F32, BIGP, NF>>(lds_bytes); e != hipSuccess) {   // dyn_lds.h
@@ -400,7 +400,7 @@ hipError_t launch_nat_t(FourierParams p, int lds_bytes, hipStream_t stream) {
     const int ngr         = (p.f_end - p.f_begin + FGROUP - 1) / FGROUP;
     const long long units = (long long)p.nrows * ngr;
     const unsigned nblk   = (unsigned)((units + 7) / 8 * 8 * (FGROUP / NF));
-    static const bool debug = std::getenv("ATLAS_AMD_FFT_DEBUG") != nullptr;
+    static const bool debug = atlas_amd::env_get("ATLAS_AMD_FFT_DEBUG") != nullptr;
     if (debug) {
         int per_cu = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fft_rows_nat_kernel<F32, BIGP, NF>, NAT_NT, lds_bytes);
