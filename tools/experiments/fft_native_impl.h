@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
+#include "../../atlas_amd/csrc/env.h"
 #include "../../atlas_amd/csrc/device_structs.h"
 #include "../../atlas_amd/csrc/dyn_lds.h"
 #include "../../atlas_amd/csrc/fft_device.h"
