@@ -560,5 +560,62 @@ private:
     int nparts_, part_;
 };
 
+// functionspace::NodeColumns, the halo-exchange contract of it (src/atlas/functionspace/NodeColumns.cc:101-113: the halo exchange is
+// set up from mesh.nodes().partition(), mesh.nodes().remote_index() (base REMOTE_IDX_BASE) and the node count including the halo --
+// WITHOUT halo_begin: every node is tested for ghost-ness; :357-459: haloExchange / adjointHaloExchange of a Field of rank 1 .. 4 in
+// int / long / float / double, any other rank is "Rank not supported").  Atlas builds the three arrays from a Mesh (out of this
+// library's scope); here the caller hands them over, as the adapter does.
+class NodeColumns {
+public:
+    static constexpr int REMOTE_IDX_BASE = 0;   // C++ value; the Fortran interface uses 1
+    NodeColumns(const int partition[], const int remote_index[], int nb_nodes, int remote_idx_base = REMOTE_IDX_BASE)
+        : nb_nodes_(nb_nodes) {
+        hx_.setup(partition, remote_index, remote_idx_base, nb_nodes);   // no halo_begin (NodeColumns.cc:110-111)
+    }
+    // several processes: the caller's allToAll / allToAllv between the two phases (HaloExchange.cc:118,156-159)
+    NodeColumns(int nproc, int myproc, const int partition[], const int remote_index[], int nb_nodes,
+                int remote_idx_base = REMOTE_IDX_BASE)
+        : nb_nodes_(nb_nodes) {
+        hx_.setup_begin(nproc, myproc, partition, remote_index, remote_idx_base, nb_nodes);
+    }
+    void setup_finish(const int sendcounts[], const int recv_requests[]) { hx_.setup_finish(sendcounts, recv_requests); }
+    int nb_nodes() const { return nb_nodes_; }
+    const parallel::HaloExchange& halo_exchange() const { return hx_; }
+    parallel::HaloExchange& halo_exchange() { return hx_; }
+
+    // field[nb_nodes][shape[1]]..[shape[rank-1]], C order, nodes first (the layout of NodeColumns fields); host or device memory
+    template <typename T>
+    void haloExchange(T* field, int rank, const int shape[], bool on_device = false) const {
+        exchange<T>(0, field, rank, shape, on_device);
+    }
+    template <typename T>
+    void adjointHaloExchange(T* field, int rank, const int shape[], bool on_device = false) const {
+        exchange<T>(1, field, rank, shape, on_device);
+    }
+
+private:
+    template <typename T>
+    void exchange(int op, T* field, int rank, const int shape[], bool on_device) const {
+        if (rank < 1 || rank > 4) {
+            throw Exception("Rank not supported");   // NodeColumns.cc:417,439
+        }
+        if (shape[0] != nb_nodes_) {
+            throw Exception("NodeColumns::haloExchange: the first dimension of the field must be the node count");
+        }
+        long long strides[4];
+        long long st = 1;
+        for (int d = rank - 1; d >= 0; --d) {
+            strides[d] = st;
+            st *= shape[d];
+        }
+        hx_.field_op<T>(op, field, rank, shape, strides, 0, static_cast<T*>(nullptr), on_device);
+        if (!on_device) {
+            hx_.synchronize();
+        }
+    }
+    parallel::HaloExchange hx_;
+    int nb_nodes_;
+};
+
 }  // namespace functionspace
 }  // namespace atlas_amd

@@ -119,6 +119,63 @@ static void case_halo_index_logic() {
     EXPECT(fhx.recvcnt() == fs.sizeHalo() - fs.sizeOwned());
 }
 
+static void case_node_columns_contract() {
+    // functionspace::NodeColumns (NodeColumns.cc:101-113,357-459): set-up from (partition, remote_index, nb_nodes) WITHOUT halo_begin --
+    // a ghost node in the middle of the array is found -- and the rank / shape checks of haloExchange
+    const int part[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int ridx[10] = {0, 1, 2, 9, 4, 5, 6, 7, 1, 9};   // node 3 is a ghost of node 9, node 8 of node 1
+    functionspace::NodeColumns fs(part, ridx, 10);
+    EXPECT(fs.nb_nodes() == 10 && fs.halo_exchange().recvcnt() == 2 && fs.halo_exchange().sendcnt() == 2);
+    EXPECT((fs.halo_exchange().get("recvmap") == std::vector<int>{3, 8}));
+    EXPECT((fs.halo_exchange().get("sendmap") == std::vector<int>{9, 1}));
+    // Fortran-side base 1
+    int ridx1[10];
+    for (int i = 0; i < 10; ++i) ridx1[i] = ridx[i] + 1;
+    functionspace::NodeColumns fs1(part, ridx1, 10, 1);
+    EXPECT((fs1.halo_exchange().get("sendmap") == std::vector<int>{9, 1}));
+    std::vector<double> f(10 * 3);
+    const int shape5[5] = {10, 1, 1, 1, 3}, shape_bad[2] = {9, 3};
+    bool rank_refused = false, shape_refused = false;
+    try {
+        fs.haloExchange(f.data(), 5, shape5);
+    }
+    catch (const Exception& e) {
+        rank_refused = std::strstr(e.what(), "Rank not supported") != nullptr;
+    }
+    try {
+        fs.haloExchange(f.data(), 2, shape_bad);
+    }
+    catch (const Exception&) {
+        shape_refused = true;
+    }
+    EXPECT(rank_refused && shape_refused);
+}
+
+static void case_node_columns_exchange() {
+    // the exchange itself (needs a device): levels and variables of a ghost node take the owner's values; the adjoint adds the ghost's
+    // contribution to the owner and zeroes the ghost (HaloExchange.h:222-290), int and double, rank 1 .. 3
+    const int part[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int ridx[10] = {0, 1, 2, 9, 4, 5, 6, 7, 1, 9};
+    functionspace::NodeColumns fs(part, ridx, 10);
+    std::vector<double> f(10 * 2 * 3);
+    for (size_t i = 0; i < f.size(); ++i) f[i] = (double)i;
+    const int shape3[3] = {10, 2, 3};
+    fs.haloExchange(f.data(), 3, shape3);
+    bool ok = true;
+    for (int k = 0; k < 6; ++k) {
+        ok = ok && f[3 * 6 + k] == (double)(9 * 6 + k) && f[8 * 6 + k] == (double)(1 * 6 + k);
+    }
+    EXPECT(ok);
+    std::vector<int> g(10);
+    for (int i = 0; i < 10; ++i) g[i] = 100 + i;
+    const int shape1[1] = {10};
+    fs.haloExchange(g.data(), 1, shape1);
+    EXPECT(g[3] == 109 && g[8] == 101 && g[9] == 109);
+    std::vector<double> a(10, 1.0);
+    fs.adjointHaloExchange(a.data(), 1, shape1);
+    EXPECT(a[9] == 2.0 && a[1] == 2.0 && a[3] == 0.0 && a[8] == 0.0 && a[0] == 1.0);
+}
+
 static void case_no_device_no_fallback() {
     StructuredGrid g("O32");
     bool threw = false;
@@ -291,6 +348,8 @@ int main(int argc, char** argv) {
         {"backend_registry", case_backend_registry, false},
         {"grids", case_grids, false},
         {"halo_index_logic", case_halo_index_logic, false},
+        {"node_columns_contract", case_node_columns_contract, false},
+        {"node_columns_exchange", case_node_columns_exchange, true},
         {"invtrans_analytic_F32", [] { case_invtrans_analytic("F32"); }, true},
         {"invtrans_analytic_O32", [] { case_invtrans_analytic("O32"); }, true},
         {"invtrans_domain_analytic", case_invtrans_domain_analytic, true},

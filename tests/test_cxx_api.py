@@ -34,7 +34,7 @@ def _run(binary, *args):
 def test_cxx_interface_host_cases(cxx_binary):
     out = _run(cxx_binary, "--host-only")
     assert "0 failure(s)" in out
-    for case in ("backend_registry", "grids", "halo_index_logic"):
+    for case in ("backend_registry", "grids", "halo_index_logic", "node_columns_contract"):
         assert f"ok     {case}" in out
 
 
