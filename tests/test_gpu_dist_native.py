@@ -403,3 +403,31 @@ def test_field_counts_are_compared_on_every_call_in_debug_mode(monkeypatch):
 
     assert all(run_ranks(nparts, rank))
     assert all(e is not None and "field count" in e for e in errors), errors
+
+
+def test_exchange_timings_of_the_distributed_transform():
+    """[r6] VERDICT r5 item 5b: with profiling on, every rank reports the pack-kernel and send / receive-group times of its transposition
+    (events on the communication stream) and what it moves per transform: bytes to / from other ranks and to the busiest peer -- the
+    figures bench.py lists per rank in the N > 1 line.  What leaves the ranks must be what arrives."""
+    g = atlas_amd.Grid("O160")
+    T, nf, nparts = 159, 6, 4
+
+    def rank(comm):
+        d = DistributedTrans(g, T, comm=comm, mode="alltoall", profile=True)
+        n = d.trans.nb_gridpoints()
+        sps = [torch.from_numpy(red_spectra(T, nf, seed=s)).cuda() for s in (1, 2, 3)]
+        gps = [torch.zeros(nf * n, dtype=torch.float64, device="cuda") for _ in sps]
+        assert d.exchange_timings(reset=True)["transforms"] == 0
+        d.invtrans_many(nf, sps, gps)
+        d.trans.synchronize()
+        x = d.exchange_timings(reset=True)
+        assert x["transforms"] == 3 and x["pack_ms"] > 0 and x["exchange_ms"] > 0
+        assert d.exchange_timings()["transforms"] == 0                      # reset
+        return comm.rank(), x
+
+    outs = run_ranks(nparts, rank)
+    sent = {r: x["bytes_sent"] for r, x in outs}
+    recv = {r: x["bytes_received"] for r, x in outs}
+    assert sum(sent.values()) == sum(recv.values()) > 0                      # what leaves a rank arrives at another
+    for r, x in outs:
+        assert 0 < x["bytes_to_busiest_peer"] <= x["bytes_sent"] and x["peers"] == nparts - 1
