@@ -67,3 +67,69 @@ def test_random_grid_truncation_and_fields_against_the_oracle(seed):
     assert np.isfinite(wgot).all()
     for f in range(ns + 2 * nvd):
         assert compute_rms(wgot[f], wref[f]) < 1e-12, ("vor/div", f, list(nx[:len(nx) // 2]), T, ns, nvd)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ATLAS_AMD_FUZZ_DIST_CASES", "12"))))
+def test_random_distributed_transform_equals_the_single_device_one(seed):
+    """[r6] the same for the distributed transform inside the library (csrc/dist_trans.hip over the "local" communicator: P ranks as host
+    threads on one device): random reduced grids, rank counts 2 .. 6 (more ranks than some grids have rows per hemisphere: empty
+    bands), field counts, message limits that cut the runs into one .. many pieces, replicated and m-sharded input.  Every rank's
+    latitude band must be, bit for bit, the rows of the single-device transform -- which must meet the oracle."""
+    import threading
+    from atlas_amd.comm import CommHub
+    from atlas_amd.dist import DistributedTrans
+    rng = np.random.default_rng(7000 + seed)
+    nx, y = _random_grid(rng)
+    while len(nx) < 8:                       # a few rows at least, so that most ranks own some
+        nx, y = _random_grid(rng)
+    T = int(rng.integers(2, 64))
+    nf = int(rng.choice([1, 2, 5, 9, 48, 49]))
+    P = int(rng.integers(2, 7))
+    maxmsg = int(rng.choice([0, 8, 4096, 1 << 16]))
+    sharded = bool(rng.integers(0, 2))
+    g = atlas_amd.StructuredGrid(nx=nx, y=y)
+    sp = red_spectra(T, nf, seed=seed)
+    sp_d = torch.from_numpy(sp).cuda()
+    tr = atlas_amd.Trans(g, T)
+    gp = torch.full((nf * g.size(),), float("nan"), dtype=torch.float64, device="cuda")
+    tr.invtrans(nf, sp_d, gp)
+    tr.synchronize()
+    ref = gp.cpu().numpy().reshape(nf, -1)
+    assert compute_rms(ref.reshape(-1), oracle.OraclePlan(T, nx, y).invtrans(nf, sp, use_fft=False)) < 1e-13
+    off = np.concatenate([[0], np.cumsum(nx)])
+    hub = CommHub(P)
+    comms = [hub.comm(r) for r in range(P)]
+    out, err = [None] * P, [None] * P
+
+    def rank(r):
+        try:
+            torch.cuda.set_device(0)
+            d = DistributedTrans(g, T, comm=comms[r], mode="alltoall")
+            if maxmsg:
+                d.set_max_message_bytes(max(maxmsg, 8))
+            b = d.trans.bands()
+            n = d.trans.nb_gridpoints()
+            gpr = torch.full((max(nf * n, 1),), float("nan"), dtype=torch.float64, device="cuda")
+            if sharded:
+                sh = torch.from_numpy(d.shard_spectra(nf, sp)).cuda()
+                d.invtrans_many_sharded(nf, [sh], [gpr])
+            else:
+                d.invtrans(nf, sp_d, gpr)
+            d.trans.synchronize()
+            out[r] = (int(b[r]), int(b[r + 1]), gpr.cpu().numpy()[:nf * n].reshape(nf, -1) if n else np.zeros((nf, 0)))
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+    th = [threading.Thread(target=rank, args=(r,)) for r in range(P)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(600)
+    for e in err:
+        if e is not None:
+            raise e
+    rows = 0
+    for b0, b1, band in out:
+        assert band.shape[1] == off[b1] - off[b0]
+        assert np.array_equal(band, ref[:, off[b0]:off[b1]]), (seed, P, T, nf, maxmsg, sharded, b0, b1)
+        rows += b1 - b0
+    assert rows == len(nx)
