@@ -126,3 +126,43 @@ def test_both_forms_of_the_field_transposition_of_the_halo_path(form, monkeypatc
         _lib.check(fn(gp.data_ptr(), out.data_ptr(), npts, nf, 1, C.byref(ms)))
         torch.cuda.synchronize()
         assert torch.equal(out, gp.t().contiguous()), (form, npts, nf)
+
+
+def test_the_device_array_transform_can_be_captured_into_a_hip_graph():
+    """[r6] A caller that replays a fixed sequence (a time step) captures it: after the first call of a shape (buffers, row tables and
+    side streams exist) the device-array entry point issues only kernels and event fork / joins of its side streams from the caller's
+    stream -- no allocation, no synchronisation -- so a stream capture (torch.cuda.CUDAGraph = hipStreamBeginCapture) takes it, and a
+    replay is bit-identical to the direct call (scalar, fp32 and vor/div calls).  tools/probe/graph_probe.py: a replay costs what the
+    direct call costs at TL1279 (15.28 against 15.36 ms) and 4 % less at TL319."""
+    import torch
+    from helpers import red_spectra
+    g = atlas_amd.Grid("O160")
+    T, nf, nvd = 159, 7, 3
+    tr = atlas_amd.Trans(g, T)
+    sp = torch.from_numpy(red_spectra(T, nf, seed=3)).cuda()
+    vor = torch.from_numpy(red_spectra(T, nvd, seed=4)).cuda()
+    div = torch.from_numpy(red_spectra(T, nvd, seed=5)).cuda()
+    gp = torch.zeros(nf * g.size(), dtype=torch.float64, device="cuda")
+    gp32 = torch.zeros(nf * g.size(), dtype=torch.float32, device="cuda")
+    sp32 = sp.float()
+    gpv = torch.zeros((nf + 2 * nvd) * g.size(), dtype=torch.float64, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        tr.use_torch_stream()
+
+        def calls():
+            tr.invtrans(nf, sp, gp)
+            tr.invtrans(nf, sp32, gp32)
+            tr.invtrans(nf, sp, nvd, vor, div, gpv)
+        calls()                                   # first use of every shape: allocations happen here
+        side.synchronize()
+        refs = [t.clone() for t in (gp, gp32, gpv)]
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            calls()
+        for _ in range(2):
+            for t in (gp, gp32, gpv):
+                t.fill_(float("nan"))
+            graph.replay()
+            side.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip((gp, gp32, gpv), refs))
