@@ -137,12 +137,19 @@ def cpu_baseline_blas(sample_fields=8, keep_field=False, one_thread_fields=4):
         avail = os.cpu_count() or 1
     workers = max(1, min(avail, 64))   # one thread per core of a 64-core host; more threads than that only fight over memory
     invtrans_blas(op, 1, np.ascontiguousarray(sp.reshape(-1, sample_fields)[:, :1]).reshape(-1), workers=workers)   # warm-up
-    tm = {}
-    t0 = time.perf_counter()
-    field = invtrans_blas(op, sample_fields, sp, workers=workers, timings=tm)
-    dt = time.perf_counter() - t0
+    # three timed calls (each the whole sample): the MEDIAN is `value`, all three are listed (repeated calls
+    # after a warm-up; one call is 1.5 - 2 s at 137 levels on 64 threads)
+    runs = []
+    for _ in range(3):
+        tm_i = {}
+        t0 = time.perf_counter()
+        field = invtrans_blas(op, sample_fields, sp, workers=workers, timings=tm_i)
+        runs.append((time.perf_counter() - t0, tm_i))
+    runs.sort(key=lambda r_: r_[0])
+    dt, tm = runs[1]
     line = {"value": (sample_fields / NLEV) / dt, "unit": "transforms/s", "cores": workers, "kind": "port",
             "legendre_s": tm.get("legendre_s"), "fourier_s": tm.get("fourier_s"), "layout_s": tm.get("layout_s"),
+            "calls_s": [r_[0] for r_ in runs], "value_is": "median of three timed calls",
             "sample": f"{sample_fields} of {NLEV} levels of one TL{TRUNC}->{GRID} transform in {dt:.2f} s on {workers} threads "
                       f"(of {avail} available): the reference's algorithm with library kernels -- per-m dgemm pairs (numpy/OpenBLAS, "
                       f"one wavenumber per thread) + pocketfft c2r batched per row length (scipy.fft) -- i.e. TransLocal with eckit "
