@@ -84,19 +84,23 @@ struct RealTraits<float> {
     __device__ static __forceinline__ int row_of(int lane, int reg) { return 4 * (lane >> 4) + reg; }
 };
 
+#ifndef AA_LEG_F32_TILES_DEFAULT
+#define AA_LEG_F32_TILES_DEFAULT 2   // latitude tiles per workgroup of the fp32 lean kernel (2: pairs, legendre_kernel_lean_f32_w2)
+#endif
 constexpr int KB   = LEG_KB_DEV;  // 8 total wavenumbers per stage
 constexpr int BN   = LEG_BN_DEV;  // 64 latitudes per item
 constexpr int PSTR = BN + 16;     // LDS row stride of the P stage (== 16 mod 32 doubles: conflict-free ds_read_b64)
 
 // RTW = 16-column tiles per wave, NRG = column groups (of RTW tiles) per workgroup; a workgroup has 4*NRG waves:
 // wave w handles latitude tile (w & 3) and column group (w >> 2).
-template <int RTW, int NRG, class Real = double>
+template <int RTW, int NRG, class Real = double, int LTW = 1>
 struct LegLds {
     static constexpr int NTHR   = 256 * NRG;
     static constexpr int SCOLS  = 16 * RTW * NRG;
     static constexpr int BM     = RealTraits<Real>::BANK_MOD;
     static constexpr int SSTR   = SCOLS + ((16 - SCOLS % BM) + BM) % BM;  // smallest stride >= SCOLS that is == 16 mod BM
-    static constexpr int P_ELEM = 2 * KB * PSTR;
+    static constexpr int PSTRL  = BN * LTW + 16;                          // P rows of 64 LTW latitudes (== 16 mod 32 / 64 as well)
+    static constexpr int P_ELEM = 2 * KB * PSTRL;
     static constexpr int S_ELEM = 2 * KB * SSTR;
     static constexpr int STAGE  = P_ELEM + S_ELEM;
     static constexpr int BYTES  = 2 * STAGE * (int)sizeof(Real);  // double buffered
@@ -361,9 +365,15 @@ __device__ __forceinline__ void lean_static_for(Fn&& fn) {
         lean_static_for<I + 1, N>(fn);
     }
 }
-template <int RTW, class Real>
+// LTW = latitude tiles of 16 per wavefront [r6]: 1 = the 64-latitude workgroup tile described above; 2 (fp32 only: the accumulators of a
+// 32 x 48 register tile are 48 registers in fp32, 96 in fp64) = a PAIR of consecutive 64-latitude tiles of one wavenumber per
+// workgroup (LegendreParams::items2): every spectra fragment read from LDS feeds two MFMAs instead of one and a stage has 24 MFMAs per
+// wavefront between its barriers instead of 12 -- the fp32 MFMA takes half the time of the fp64 one, so the per-stage costs around it
+// (operand wait, LDS writes, barrier) weigh twice as much in the 64-latitude form (profiles/r04_legendre_f32_probes.txt).
+template <int RTW, class Real, int LTW = 1>
 __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p) {
-    using L  = LegLds<RTW, 2, Real>;
+    using L  = LegLds<RTW, 2, Real, LTW>;
+    constexpr int PSTRL = L::PSTRL;   // LDS row stride of the P stage: 64 LTW latitudes + 16
     using RT = RealTraits<Real>;
     using acc_t = typename RT::acc_t;
     constexpr int NTHR = 512;
@@ -379,10 +389,10 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
     const int bq        = blockIdx.x >> 3;
     const int chunk     = p.chunk0 + bq % nchunks;
     const int item_slot = (bq / nchunks) * 8 + bx;
-    if (item_slot >= p.nitems) {
+    if (item_slot >= (LTW == 2 ? p.nitems2 : p.nitems)) {
         return;
     }
-    const LegendreItemDev it = p.items[item_slot];
+    const LegendreItemDev it = (LTW == 2 ? p.items2 : p.items)[item_slot];
     if (it.m < 0) {
         return;
     }
@@ -406,16 +416,19 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
     const int nstage = it.kpad / KB;
     const int ntop_hi = ntop0 > ntop1 ? ntop0 : ntop1, ntop_lo = ntop0 < ntop1 ? ntop0 : ntop1;
 
-    acc_t acc[2][RTW];
+    acc_t acc[2][LTW][RTW];
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int j = 0; j < RTW; ++j) acc[q][j] = acc_t{0, 0, 0, 0};
+        for (int i = 0; i < LTW; ++i)
+#pragma unroll
+            for (int j = 0; j < RTW; ++j) acc[q][i][j] = acc_t{0, 0, 0, 0};
 
     // ---- staging registers of one stage: one 16-byte table load and three spectra elements per thread ----
     typedef int i4_t __attribute__((ext_vector_type(4)));
     typedef int i2_t __attribute__((ext_vector_type(2)));
-    using preg_t = std::conditional_t<F64, i4_t, i2_t>;   // two table elements
+    using preg_t = std::conditional_t<F64 || LTW == 2, i4_t, i2_t>;   // two table elements (four of a tile pair in fp32)
+    static_assert(LTW == 1 || !F64, "the tile pair is the fp32 variant's");
     // register sets: the stage being written to LDS and the ones still in flight = stages of look-ahead of the operand streams.
     // 3 (fp64, 122 registers: a fourth set would cost the fourth wavefront per SIMD).  fp32 [r4]: dev builds -DAA_LEG_F32_NSET=4 / 5
     // measured 5.89 / 6.41 against 5.90 ms on TL1279 -> F1280: the operand streams are not a latency the look-ahead could cover
@@ -428,9 +441,12 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
     preg_t preg[NSET];
     Real sreg[NSET][RTW];
     // table element pair 2 tid of the stage tile [2 parities][8 k][64 latitudes]
-    const int pe = 2 * tid, ppar = pe >> 9, pk = (pe & 511) >> 6, pc = pe & 63;
-    const unsigned pbo = (unsigned)EB * (unsigned)((ppar * it.kpad + pk) * BN + pc);   // bytes from the stage's first table row
-    const int plds     = ppar * (KB * PSTR) + pk * PSTR + pc;
+    // (LTW = 2: element quadruple 4 tid of [2 parities][8 k][128 latitudes]; latitudes 64 .. 127 come from the second tile's block, which
+    // follows the first one's in the table; a workgroup whose item is a single tile reads the first tile twice -- never beyond the table)
+    const int pe = 2 * LTW * tid, ppar = pe / (KB * BN * LTW), pk = (pe % (KB * BN * LTW)) / (BN * LTW), pc = pe % (BN * LTW);
+    const int ptile = (LTW == 2 && it.nrows > BN) ? pc / BN : 0;
+    const unsigned pbo = (unsigned)EB * (unsigned)(((ptile * 2 + ppar) * it.kpad + pk) * BN + (pc % BN));   // bytes from the stage's first table row
+    const int plds     = ppar * (KB * PSTRL) + pk * PSTRL + pc;
     // spectra element q = tid + 512 i of the stage tile [16 rows (parity, k)][96 columns]
     unsigned sbo[RTW];   // bytes from the stage base (lowest wavenumber row of the stage)
     int slds[RTW];
@@ -463,7 +479,7 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
     // stage t travels through register set t % NSET into LDS buffer t & 1; it is requested NSET stages before it is used
     auto load_stage = [&](int s, auto setc) {   // must be called for s = 0, 1, 2, ... in order
         constexpr int SET = decltype(setc)::value;
-        if constexpr (F64) {
+        if constexpr (F64 || LTW == 2) {
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(preg[SET]) : "v"(pbo), "s"(pbase) : "memory");
         }
         else {
@@ -537,7 +553,7 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
         {
             const preg_t pv   = preg[SET];
             const unsigned la = plds_b;
-            if constexpr (F64) {
+            if constexpr (F64 || LTW == 2) {
                 asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(la), "v"(pv), "n"(buf * L::STAGE * EB) : "memory");
             }
             else {
@@ -590,9 +606,9 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
     store_stage(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, (nstage < NSET ? nstage : NSET) - 1);
     __syncthreads();
 
-    const int a_off = (lane >> 4) * PSTR + lt * 16 + (lane & 15);
+    const int a_off = (lane >> 4) * PSTRL + lt * 16 + (lane & 15);
     const int b_off = L::P_ELEM + (lane >> 4) * L::SSTR + rg * RTW * 16 + (lane & 15);
-    const bool lat_active = lt * 16 < it.nrows;
+    const bool lat_active = lt * 16 < it.nrows;   // (LTW = 2: the first tile of the pair; its second tile is multiplied along -- its rows beyond nrows are not stored)
 
     // four steps (parity, 4 wavenumbers) of one A and three B fragments and three MFMAs; the fragments of step t + D are requested
     // before the MFMAs of step t, D = 1.  [r4] In fp32 a step's three MFMAs are 96 cycles of matrix pipe (192 in fp64), shorter than an
@@ -608,8 +624,8 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
 #else
         constexpr int D   = 1;                       // steps of fragment reads in flight
 #endif
-        static_assert(D >= 1 && D < NST && D * (1 + RTW) <= 15, "lgkmcnt is a 4-bit counter");
-        Real a_[D + 1], b_[D + 1][RTW];
+        static_assert(D >= 1 && D < NST && D * (LTW + RTW) <= 15, "lgkmcnt is a 4-bit counter");
+        Real a_[D + 1][LTW], b_[D + 1][RTW];
         // fragment reads as asm with immediate offsets (the compiler pairs them into ds_read2 and pays a VALU add per pair
         // for the base); their completion is counted by hand: 1 + RTW reads per step, D steps in flight
         auto fetch = [&](auto tc) {
@@ -617,13 +633,16 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
             constexpr int slot = t % (D + 1);
             constexpr int par = t / NKS, ks = t % NKS;
             const unsigned ab = a_b, bb = b_b;
-            Real(&a)[D + 1]      = a_;   // (named references: clang does not capture an array that a generic lambda only uses as an
+            Real(&a)[D + 1][LTW] = a_;   // (named references: clang does not capture an array that a generic lambda only uses as an
             Real(&b)[D + 1][RTW] = b_;   //  asm output operand)
-            if constexpr (F64) {
-                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a[slot]) : "v"(ab), "n"((buf * L::STAGE + (par * KB + ks * 4) * PSTR) * EB) : "memory");
-            }
-            else {
-                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(a[slot]) : "v"(ab), "n"((buf * L::STAGE + (par * KB + ks * 4) * PSTR) * EB) : "memory");
+#pragma unroll
+            for (int i = 0; i < LTW; ++i) {
+                if constexpr (F64) {
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a[slot][i]) : "v"(ab), "n"((buf * L::STAGE + (par * KB + ks * 4) * PSTRL + i * BN) * EB) : "memory");
+                }
+                else {
+                    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(a[slot][i]) : "v"(ab), "n"((buf * L::STAGE + (par * KB + ks * 4) * PSTRL + i * BN) * EB) : "memory");
+                }
             }
 #pragma unroll
             for (int j = 0; j < RTW; ++j) {
@@ -649,11 +668,14 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
             }
             // younger steps still in flight behind step t: D, fewer at the end of the stage
             constexpr int younger = (NST - 1 - t) < D ? (NST - 1 - t) : D;
-            __builtin_amdgcn_s_waitcnt((15) | (3 << 14) | (7 << 4) | ((younger * (1 + RTW)) << 8));   // lgkmcnt(younger * (1 + RTW))
+            __builtin_amdgcn_s_waitcnt((15) | (3 << 14) | (7 << 4) | ((younger * (LTW + RTW)) << 8));   // lgkmcnt(younger * (LTW + RTW))
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < RTW; ++j) {
-                acc[t / NKS][j] = RT::mma(a_[t % (D + 1)], b_[t % (D + 1)][j], acc[t / NKS][j]);
+            for (int i = 0; i < LTW; ++i) {
+#pragma unroll
+                for (int j = 0; j < RTW; ++j) {
+                    acc[t / NKS][i][j] = RT::mma(a_[t % (D + 1)][i], b_[t % (D + 1)][j], acc[t / NKS][i][j]);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -718,7 +740,9 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int j = 0; j < RTW; ++j) asm volatile("" ::"v"(acc[q][j]));
+        for (int i = 0; i < LTW; ++i)
+#pragma unroll
+            for (int j = 0; j < RTW; ++j) asm volatile("" ::"v"(acc[q][i][j]));
     return;
 #endif
     // ---- epilogue: merge hemispheres and store (as legendre_kernel) ----
@@ -729,8 +753,10 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
     // (fp32 with the MFMA operands exchanged -- C^T in the accumulators: a lane holds four consecutive columns of one latitude, one
     // 16-byte store per tile and hemisphere instead of four 4-byte stores -- measured 5.98 -> 6.08 ms on TL1279 -> F1280: not kept [r4])
 #pragma unroll
+    for (int ti = 0; ti < LTW; ++ti)
+#pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const int c = lt * 16 + RT::row_of(lane, g);
+        const int c = ti * BN + lt * 16 + RT::row_of(lane, g);
         if (c < it.nrows) {
             const int jn = jleg0 + c;
             const int js = nlats - 1 - jn;
@@ -742,7 +768,7 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
             for (int j = 0; j < RTW; ++j) {
                 const int r = r0 + (rg * RTW + j) * 16 + (lane & 15);
                 if (r < RP) {
-                    Real sy = acc[0][j][g], as = acc[1][j][g];
+                    Real sy = acc[0][ti][j][g], as = acc[1][ti][j][g];
                     if ((m == 0 && (r & 1)) || r >= 2 * nf) {   // n_imag = 1 for m = 0; padding columns hold zeros
                         sy = 0;
                         as = 0;
@@ -787,6 +813,10 @@ __global__ void __launch_bounds__(512, AA_LEAN_WPS) legendre_kernel_lean(Legendr
 __global__ void __launch_bounds__(512, 4) legendre_kernel_lean_f32(LegendreParamsF32 p) {
     legendre_lean_body<3, float>(p);
 }
+// [r6] the same on pairs of latitude tiles (LTW = 2): 128 latitudes x 96 columns per workgroup
+__global__ void __launch_bounds__(512, 4) legendre_kernel_lean_f32_w2(LegendreParamsF32 p) {
+    legendre_lean_body<3, float, 2>(p);
+}
 // the narrower workgroups (field counts whose tiles come in fours or twos per column chunk)
 template <int RTW, class Real>
 __global__ void __launch_bounds__(512, 4) legendre_kernel_lean_n(LegendreParamsT<Real> p) {
@@ -830,6 +860,21 @@ static hipError_t launch_lean_f32(LegendreParamsF32 p, int nitems, int nchunks, 
     p.abl           = 0;
     const int slots = (nitems + 7) / 8;
     hipLaunchKernelGGL(legendre_kernel_lean_f32, dim3(slots * nrun * 8), dim3(L::NTHR), L::BYTES + lean_lds_pad<&legendre_kernel_lean_f32>(L::BYTES), stream, p);
+    return hipGetLastError();
+}
+// [r6] the fp32 lean kernel on pairs of latitude tiles (items2)
+static hipError_t launch_lean_f32_w2(LegendreParamsF32 p, int nchunks, int chunk0, int nrun, hipStream_t stream) {
+    using L = LegLds<3, 2, float, 2>;
+    if (hipError_t e = ensure_dynamic_lds<&legendre_kernel_lean_f32_w2>(L::BYTES); e != hipSuccess) {   // dyn_lds.h
+        return e;
+    }
+    p.nitems        = p.nitems2;
+    p.nchunks       = nchunks;
+    p.chunk0        = chunk0;
+    p.nchunks_run   = nrun;
+    p.abl           = 0;
+    const int slots = (p.nitems2 + 7) / 8;
+    hipLaunchKernelGGL(legendre_kernel_lean_f32_w2, dim3(slots * nrun * 8), dim3(L::NTHR), L::BYTES, stream, p);
     return hipGetLastError();
 }
 static hipError_t launch_lean(LegendreParams p, int nitems, int nchunks, int chunk0, int nrun, hipStream_t stream) {
@@ -1041,6 +1086,19 @@ hipError_t launch_legendre_f32(const LegendreParamsF32& p, int nitems, int chunk
             return launch_stream_t<&legendre_kernel_stream_f32, 3, float>(p, nitems, nchunks, chunk0, nrun, stream);
         }
 #endif
+        // [r6] pairs of latitude tiles per workgroup, the default from T = 400 on (measured, Legendre stage, ms: TL1279 -> F1280 5.66 ->
+        // 5.13, -> O1280 4.57 -> 4.27, -> N1280 5.22 -> 4.77, the 411-field vor/div call 13.55 -> 12.70; TL639 -> O640 0.77 -> 0.75;
+        // TL319 and below: no difference, the 64-latitude form stays).  ATLAS_AMD_LEG_F32_TILES=1 | 2 forces one.  Same bits.
+        const char* w = atlas_amd::env_get("ATLAS_AMD_LEG_F32_TILES");
+        const bool pairs = w ? atoi(w) == 2 : (AA_LEG_F32_TILES_DEFAULT == 2 && p.T >= 400);
+        if (pairs && (!e || std::string(e) == "lean") && p.items2 && p.nitems2 > 0 &&
+            lean_kernel_usable<&legendre_kernel_lean_f32_w2>("legendre_kernel_lean_f32_w2")) {
+            if (nrun <= 0) {
+                chunk0 = 0;
+                nrun   = nchunks;
+            }
+            return launch_lean_f32_w2(p, nchunks, chunk0, nrun, stream);
+        }
         if ((!e || std::string(e) == "lean" || std::string(e) == "stream") && lean_kernel_usable<&legendre_kernel_lean_f32>("legendre_kernel_lean_f32")) {
             if (nrun <= 0) {
                 chunk0 = 0;

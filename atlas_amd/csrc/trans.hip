@@ -394,8 +394,8 @@ void Trans::upload() {
             items[i]               = LegendreItemDev{it.m, it.tile, it.nrows, it.kpad, (long long)it.p_off};
         }
         d_items_ = dev_upload(items.data(), items.size());
-#if defined(ATLAS_AMD_EXPERIMENTS)
-        // paired list (legendre_kernel_lean2): the launch order interleaves eight per-XCD lists (item i belongs to list i % 8);
+        {
+        // paired list (legendre_kernel_lean_f32_w2 [r6]; legendre_kernel_lean2 of the experiments build): the launch order interleaves eight per-XCD lists (item i belongs to list i % 8);
         // inside a list the tiles of one m follow each other, and so do their blocks in the table
         std::vector<std::vector<LegendreItemDev>> lists(8);
         for (size_t i = 0; i < items.size(); ++i) {
@@ -428,7 +428,7 @@ void Trans::upload() {
         }
         nitems2_  = (int)items2.size();
         d_items2_ = items2.empty() ? nullptr : dev_upload(items2.data(), items2.size());
-#endif
+        }
     }
     d_nlat0_ = dev_upload(geo_.nlat0.data(), geo_.nlat0.size());
     {
@@ -1144,8 +1144,8 @@ void Trans::invtrans_uv_device_f32(int trc_in, int nb_fields, int nb_vordiv, con
     p.sp        = sp_dev;
     p.F         = d_fourier32_;
     p.items     = (const LegendreItemDev*)d_items_;
-    p.items2    = nullptr;
-    p.nitems2   = 0;
+    p.items2    = (const LegendreItemDev*)d_items2_;
+    p.nitems2   = nitems2_;
     p.sp_moff   = nullptr;
     p.nlat0     = d_nlat0_;
     p.zero      = d_zero32_;

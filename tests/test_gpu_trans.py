@@ -788,6 +788,20 @@ def test_legendre_kernel_variants_are_bitwise_equal(case, monkeypatch):
     assert float(np.abs(outs["classic"]).max()) > 0
     for kernel in LEG_KERNELS[1:]:
         assert np.array_equal(outs["classic"], outs[kernel]), kernel
+    if case.startswith("f32"):
+        # [r6] the fp32 lean kernel on PAIRS of latitude tiles (128 latitudes x 96 columns per workgroup, 24 MFMAs per wavefront and
+        # stage): the same products in the same order per (latitude, column) -- bit-identical, for field counts that take the
+        # 96-column workgroup (the others do not have the form and must be unaffected by the switch)
+        monkeypatch.setenv("ATLAS_AMD_LEG_KERNEL", "lean")
+        monkeypatch.setenv("ATLAS_AMD_LEG_F32_TILES", "2")
+        gridname, T, nf = {"f32_O160_nf40": ("O160", 159, 40), "f32_O64_nf137": ("O64", 63, 137), "f32_F64_nf44": ("F64", 63, 44),
+                           "f32_O160_nf60": ("O160", 159, 60), "f32_O64_nf10": ("O64", 63, 10)}[case]
+        g, tr = get_trans(gridname, T)
+        sp32 = red_spectra(T, nf, seed=14).astype(np.float32)
+        gp = torch.full((nf * g.size(),), float("nan"), dtype=torch.float32, device="cuda")
+        tr.invtrans(nf, torch.from_numpy(sp32).cuda(), gp)
+        tr.synchronize()
+        assert np.array_equal(outs["classic"], gp.cpu().numpy()), "lean, pairs of latitude tiles"
 
 
 def test_a_constructor_that_throws_releases_its_device_memory():
