@@ -862,6 +862,26 @@ static hipError_t launch_lean_f32(LegendreParamsF32 p, int nitems, int nchunks, 
     hipLaunchKernelGGL(legendre_kernel_lean_f32, dim3(slots * nrun * 8), dim3(L::NTHR), L::BYTES + lean_lds_pad<&legendre_kernel_lean_f32>(L::BYTES), stream, p);
     return hipGetLastError();
 }
+// [r6] ... and the narrower workgroups (one or two 16-column tiles per wavefront) of the fp32 variant on tile pairs
+template <int RTW>
+__global__ void __launch_bounds__(512, 4) legendre_kernel_lean_n_f32_w2(LegendreParamsF32 p) {
+    legendre_lean_body<RTW, float, 2>(p);
+}
+template <int RTW>
+static hipError_t launch_lean_n_f32_w2(LegendreParamsF32 p, int nchunks, int chunk0, int nrun, hipStream_t stream) {
+    using L = LegLds<RTW, 2, float, 2>;
+    if (hipError_t e = ensure_dynamic_lds<&legendre_kernel_lean_n_f32_w2<RTW>>(L::BYTES); e != hipSuccess) {   // dyn_lds.h
+        return e;
+    }
+    p.nitems        = p.nitems2;
+    p.nchunks       = nchunks;
+    p.chunk0        = chunk0;
+    p.nchunks_run   = nrun;
+    p.abl           = 0;
+    const int slots = (p.nitems2 + 7) / 8;
+    hipLaunchKernelGGL(legendre_kernel_lean_n_f32_w2<RTW>, dim3(slots * nrun * 8), dim3(L::NTHR), L::BYTES, stream, p);
+    return hipGetLastError();
+}
 // [r6] the fp32 lean kernel on pairs of latitude tiles (items2)
 static hipError_t launch_lean_f32_w2(LegendreParamsF32 p, int nchunks, int chunk0, int nrun, hipStream_t stream) {
     using L = LegLds<3, 2, float, 2>;
@@ -1127,6 +1147,15 @@ hipError_t launch_legendre_f32(const LegendreParamsF32& p, int nitems, int chunk
             if (nrun <= 0) {
                 chunk0 = 0;
                 nrun   = nchunks;
+            }
+            const char* w    = atlas_amd::env_get("ATLAS_AMD_LEG_F32_TILES");
+            const bool pairs = (w ? atoi(w) == 2 : (AA_LEG_F32_TILES_DEFAULT == 2 && p.T >= 400)) && (!e || std::string(e) == "lean") &&
+                               p.items2 && p.nitems2 > 0;
+            if (pairs && rtw == 1 && lean_kernel_usable<&legendre_kernel_lean_n_f32_w2<1>>("legendre_kernel_lean_n_f32_w2<1>")) {
+                return launch_lean_n_f32_w2<1>(p, nchunks, chunk0, nrun, stream);
+            }
+            if (pairs && rtw == 2 && lean_kernel_usable<&legendre_kernel_lean_n_f32_w2<2>>("legendre_kernel_lean_n_f32_w2<2>")) {
+                return launch_lean_n_f32_w2<2>(p, nchunks, chunk0, nrun, stream);
             }
             if (rtw == 1 && lean_kernel_usable<&legendre_kernel_lean_n<1, float>>("legendre_kernel_lean_n<1, float>")) {
                 return launch_lean_n<1, float>(p, nitems, nchunks, chunk0, nrun, stream);
