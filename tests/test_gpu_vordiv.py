@@ -191,7 +191,10 @@ def test_vordiv_host_pointer_pipeline_is_bitwise_equal_to_the_device_path(monkey
     tr = atlas_amd.Trans(g, T)
     sp, vor, div = red_spectra(T, ns, 51), red_spectra(T, nvd, 52), red_spectra(T, nvd, 53)
     ref = vordiv_device(tr, ns, sp, nvd, vor, div).cpu().numpy()
-    for env in ({"ATLAS_AMD_HOST_PIPELINE": "0"}, {}, {"ATLAS_AMD_HOST_CHUNK": "8"}, {"ATLAS_AMD_HOST_CHUNK": "32"}):
+    # (the last one: the streaming form of the preparation kernel forced; the scalar chunks of the pipeline call it without vor/div
+    # fields, which used to divide by a group count of zero -- ADVICE r5)
+    for env in ({"ATLAS_AMD_HOST_PIPELINE": "0"}, {}, {"ATLAS_AMD_HOST_CHUNK": "8"}, {"ATLAS_AMD_HOST_CHUNK": "32"},
+                {"ATLAS_AMD_PREPARE": "stream"}):
         for k2, v in env.items():
             monkeypatch.setenv(k2, v)
         for rep in range(2):
