@@ -1025,6 +1025,13 @@ static hipError_t launch_legendre_t(const LegendreParamsT<Real>& p, int nitems, 
 hipError_t launch_legendre(const LegendreParams& p, int nitems, int chunk0, int nrun, hipStream_t stream) {
     int rtw, nrg, nchunks;
     legendre_tiling(p.nf, rtw, nrg, nchunks);
+    // [r6] one to eight fields (a single 16-column tile): the two-group lean workgroup with its second column group on padding columns
+    // (never stored: r >= RP) instead of the generic one-group template -- the stage is bound by streaming the table, which the lean
+    // staging does at 4.9 TB/s where the template reaches 2.9: 2.46 -> 1.43 ms at TL1279 / O1280, 0.33 -> 0.19 at TL639, 0.06 -> 0.04 at
+    // TL319 (fp64; the fp32 template is as fast as the lean form there and stays).  Same arithmetic per column: same bits.
+    if (rtw == 1 && nrg == 1 && !atlas_amd::env_get("ATLAS_AMD_LEG_CFG")) {
+        nrg = 2;
+    }
     if (rtw == 3 && nrg == 2) {
         // the 96-column workgroup (every field count whose 16-column tiles come in sixes, e.g. 137 levels) has two more
         // implementations of the same arithmetic: "lean" (default) and, in experiment builds only, "split" and "dma"

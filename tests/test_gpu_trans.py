@@ -730,7 +730,8 @@ LEG_KERNELS = ("classic", "lean") + (("stream",) if "exp" in os.environ.get("ATL
 
 @pytest.mark.parametrize("case", ["scalar_O160_nf40", "vordiv_F64", "sharded_O160_nf44", "band_O160_nf42", "scalar_O64_nf137",
                                   "f32_O160_nf40", "f32_O64_nf137", "f32_F64_nf44",
-                                  "scalar_O160_nf60", "scalar_O64_nf25", "scalar_O64_nf10", "f32_O160_nf60", "f32_O64_nf10"])
+                                  "scalar_O160_nf60", "scalar_O64_nf25", "scalar_O64_nf10", "f32_O160_nf60", "f32_O64_nf10",
+                                  "scalar_O64_nf1", "scalar_O160_nf5"])
 def test_legendre_kernel_variants_are_bitwise_equal(case, monkeypatch):
     """The 96-column workgroup of the Legendre stage (field counts whose 16-column tiles come in sixes: nf 33..48, 81..96,
     129..144, ...) has two implementations of the same arithmetic in the same order: the generic template ("classic") and
@@ -755,7 +756,9 @@ def test_legendre_kernel_variants_are_bitwise_equal(case, monkeypatch):
             # nf = 60: 8 tiles in two column chunks of four (two per wavefront); 25: four tiles in one chunk; 10: two tiles (one per
             # wavefront) -- the narrower instances of the lean body [r3]
             gridname, T, nf = {"scalar_O160_nf40": ("O160", 159, 40), "scalar_O64_nf137": ("O64", 63, 137), "scalar_O160_nf60": ("O160", 159, 60),
-                               "scalar_O64_nf25": ("O64", 63, 25), "scalar_O64_nf10": ("O64", 63, 10)}[case]
+                               "scalar_O64_nf25": ("O64", 63, 25), "scalar_O64_nf10": ("O64", 63, 10),
+                               # [r6] one tile (1 .. 8 fields): the lean two-group workgroup with its second group on padding columns
+                               "scalar_O64_nf1": ("O64", 63, 1), "scalar_O160_nf5": ("O160", 159, 5)}[case]
             g, tr = get_trans(gridname, T)
             outs[kernel] = run_device(tr, nf, red_spectra(T, nf, seed=11))
         elif case == "vordiv_F64":
