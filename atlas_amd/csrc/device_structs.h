@@ -44,6 +44,7 @@ struct LegendreParamsT {
     int nchunks; // column chunks per item (filled in by the launcher)
     int chunk0;  // first column chunk of this launch
     int nchunks_run;  // column chunks computed by this launch (pipelined transform: a subset)
+    int col0;         // first interleaved column of chunk 0 of this launch [r6]: a call may be two launches of different chunk widths
     int* sched;       // [16] ints, zero between launches: unit counters of the persistent ("stream") kernels per XCD [0..7], workgroups
                       // that have finished [8]; the last workgroup to finish zeroes them again.  null: static unit assignment
     int abl;          // dev switch of the role-split kernel (ATLAS_AMD_LEG_ABLATE): parts left out, results then wrong; 0 in production

@@ -24,6 +24,7 @@ const EnvSwitch kSwitches[] = {
     {"ATLAS_AMD_LEG_STREAM_DYNAMIC", C::dev,      "1",      "0: static unit assignment (unit = workgroup + k W) of the persistent Legendre kernels instead of the work counter per XCD"},
     {"ATLAS_AMD_LEG_STREAM_SKEW",   C::dev,       "0",      "n: the second half of the persistent Legendre workgroups of an XCD starts n x 512 cycles late (phase probe)"},
     {"ATLAS_AMD_LEG_F32_TILES",     C::tuning,    "2 from T = 400 on, else 1", "latitude tiles of 64 per workgroup of the fp32 lean Legendre kernel: 2 = pairs (128 latitudes x 96 columns, 24 MFMAs per wavefront and stage), 1 = the 64-latitude form; same bits"},
+    {"ATLAS_AMD_LEG_MIXED",         C::tuning,    "1",      "0: every column chunk of a Legendre call has the same width (round 5) instead of full 96-column chunks + one narrower launch for the remaining tiles where that is cheaper"},
     {"ATLAS_AMD_LEG_CFG",           C::tuning,    "auto",   "rtw,nrg: 16-column tiles per wavefront (1-3) and column groups per workgroup (1-2) of the Legendre tiling instead of the planner's choice"},
     {"ATLAS_AMD_FFT_GENERIC",       C::tuning,    "0",      "1: every row through the run-time shaped Fourier kernel (no compile-time shaped rows)"},
     {"ATLAS_AMD_FFT_STREAMS",       C::tuning,    "4 (1 for coarse classes)", "streams the row-length classes of the Fourier stage are dealt to (1-8)"},

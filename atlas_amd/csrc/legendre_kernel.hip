@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(256 * NRG, (NRG >= 3 ? 6 : 2)) legendre_kernel
     const int T    = p.T;
     const int nf   = p.nf;
     const int trc  = p.trc_in;
-    const int r0   = chunk * L::SCOLS;         // first interleaved column of this chunk
+    const int r0   = p.col0 + chunk * L::SCOLS;         // first interleaved column of this chunk
     const int TL   = T + 1;                    // truncation of the table
     // largest n <= T+1 of each parity (n-m even: sym)
     const int ntop0 = TL - ((TL - m) & 1);
@@ -404,7 +404,7 @@ __device__ __forceinline__ void legendre_lean_body(const LegendreParamsT<Real> p
     const int m    = it.m;
     const int nf   = p.nf;
     const int trc  = p.trc_in;
-    const int r0   = chunk * L::SCOLS;
+    const int r0   = p.col0 + chunk * L::SCOLS;
     const int TL   = p.T + 1;
     const int ntop0 = TL - ((TL - m) & 1);
     const int ntop1 = TL - 1 + ((TL - m) & 1);
@@ -1022,9 +1022,55 @@ static hipError_t launch_legendre_t(const LegendreParamsT<Real>& p, int nitems, 
     return hipErrorInvalidValue;
 }
 
+// [r6] Field counts whose 16-column tiles do not come in sixes.  legendre_tiling() gives every column chunk of a call the same width;
+// with 13 tiles (97 fields) that is three chunks of six -- the stage costs what 144 fields cost.  Where it is cheaper the call becomes
+// TWO launches: the full 96-column chunks, then the remaining one to five tiles with the workgroup width that fits them (LegendreParams::
+// col0 = where they start).  Cost model from the TL1279 sweep (tools/probe/nf_sweep.py; ms per chunk of 1 / 2 / 3 tiles per wavefront:
+// 1.45 / 2.07 / 3.03 -- the narrow chunks are bound by streaming the table once more): e.g. 97 fields 8.08 -> 7.2 ms, 110 fields
+// 8.1 -> 7.2; not for 49 - 64 fields (two chunks of four tiles beat six + two).  Per-column arithmetic does not depend on the chunking.
+static bool legendre_mixed_tiling(int nf, int& nfull, int& rem_rtw) {
+    const int rt = (2 * nf + 15) / 16;
+    nfull        = rt / 6;
+    const int rem = rt - 6 * nfull;
+    if (nfull < 1 || rem < 1 || atlas_amd::env_get("ATLAS_AMD_LEG_CFG")) {
+        return false;
+    }
+    if (const char* e = atlas_amd::env_get("ATLAS_AMD_LEG_MIXED")) {   // A/B: 0 = one width per call
+        if (atoi(e) == 0) {
+            return false;
+        }
+    }
+    static const double cost[4] = {0., 0.48, 0.68, 1.0};
+    int rtw, nrg, nchunks;
+    legendre_tiling(nf, rtw, nrg, nchunks);
+    rem_rtw = (rem + 1) / 2;
+    return nfull * cost[3] + cost[rem_rtw] < nchunks * cost[rtw < 1 ? 1 : (rtw > 3 ? 3 : rtw)] - 1e-9;
+}
+
+static hipError_t launch_legendre_rtw(const LegendreParams& p, int rtw, int nrg, int nchunks, int nitems, int chunk0, int nrun, hipStream_t stream);
+
 hipError_t launch_legendre(const LegendreParams& p, int nitems, int chunk0, int nrun, hipStream_t stream) {
     int rtw, nrg, nchunks;
     legendre_tiling(p.nf, rtw, nrg, nchunks);
+    {
+        const char* e = atlas_amd::env_get("ATLAS_AMD_LEG_KERNEL");
+        int nfull = 0, rem_rtw = 0;
+        if (chunk0 == 0 && nrun <= 0 && (!e || std::string(e) == "lean") && legendre_mixed_tiling(p.nf, nfull, rem_rtw) &&
+            lean_kernel_usable<&legendre_kernel_lean>("legendre_kernel_lean") &&
+            lean_kernel_usable<&legendre_kernel_lean_n<1, double>>("legendre_kernel_lean_n<1, double>") &&
+            lean_kernel_usable<&legendre_kernel_lean_n<2, double>>("legendre_kernel_lean_n<2, double>")) {
+            if (hipError_t err = launch_legendre_rtw(p, 3, 2, nfull, nitems, 0, nfull, stream); err != hipSuccess) {
+                return err;
+            }
+            LegendreParams q = p;
+            q.col0           = nfull * 96;
+            return launch_legendre_rtw(q, rem_rtw, 2, 1, nitems, 0, 1, stream);
+        }
+    }
+    return launch_legendre_rtw(p, rtw, nrg, nchunks, nitems, chunk0, nrun, stream);
+}
+
+static hipError_t launch_legendre_rtw(const LegendreParams& p, int rtw, int nrg, int nchunks, int nitems, int chunk0, int nrun, hipStream_t stream) {
     // [r6] one to eight fields (a single 16-column tile): the two-group lean workgroup with its second column group on padding columns
     // (never stored: r >= RP) instead of the generic one-group template -- the stage is bound by streaming the table, which the lean
     // staging does at 4.9 TB/s where the template reaches 2.9: 2.46 -> 1.43 ms at TL1279 / O1280, 0.33 -> 0.19 at TL639, 0.06 -> 0.04 at
@@ -1098,9 +1144,33 @@ hipError_t launch_legendre(const LegendreParams& p, int nitems, int chunk0, int 
     return launch_legendre_t<double>(p, nitems, chunk0, nrun, stream);
 }
 // fp32 variant: same work list, tiling and table layout (the table converted to float)
+static hipError_t launch_legendre_f32_rtw(const LegendreParamsF32& p, int rtw, int nrg, int nchunks, int nitems, int chunk0, int nrun, hipStream_t stream);
+
 hipError_t launch_legendre_f32(const LegendreParamsF32& p, int nitems, int chunk0, int nrun, hipStream_t stream) {
     int rtw, nrg, nchunks;
     legendre_tiling(p.nf, rtw, nrg, nchunks);
+    {
+        const char* e = atlas_amd::env_get("ATLAS_AMD_LEG_KERNEL");
+        int nfull = 0, rem_rtw = 0;
+        if (chunk0 == 0 && nrun <= 0 && (!e || std::string(e) == "lean") && legendre_mixed_tiling(p.nf, nfull, rem_rtw) &&
+            lean_kernel_usable<&legendre_kernel_lean_f32>("legendre_kernel_lean_f32") &&
+            lean_kernel_usable<&legendre_kernel_lean_f32_w2>("legendre_kernel_lean_f32_w2") &&
+            lean_kernel_usable<&legendre_kernel_lean_n<1, float>>("legendre_kernel_lean_n<1, float>") &&
+            lean_kernel_usable<&legendre_kernel_lean_n<2, float>>("legendre_kernel_lean_n<2, float>") &&
+            lean_kernel_usable<&legendre_kernel_lean_n_f32_w2<1>>("legendre_kernel_lean_n_f32_w2<1>") &&
+            lean_kernel_usable<&legendre_kernel_lean_n_f32_w2<2>>("legendre_kernel_lean_n_f32_w2<2>")) {
+            if (hipError_t err = launch_legendre_f32_rtw(p, 3, 2, nfull, nitems, 0, nfull, stream); err != hipSuccess) {
+                return err;
+            }
+            LegendreParamsF32 q = p;
+            q.col0              = nfull * 96;
+            return launch_legendre_f32_rtw(q, rem_rtw, 2, 1, nitems, 0, 1, stream);
+        }
+    }
+    return launch_legendre_f32_rtw(p, rtw, nrg, nchunks, nitems, chunk0, nrun, stream);
+}
+
+static hipError_t launch_legendre_f32_rtw(const LegendreParamsF32& p, int rtw, int nrg, int nchunks, int nitems, int chunk0, int nrun, hipStream_t stream) {
     if (rtw == 3 && nrg == 2) {
         // the 96-column workgroup in its "lean" form for float as well [r3]; ATLAS_AMD_LEG_KERNEL=classic: the generic template
         const char* e = atlas_amd::env_get("ATLAS_AMD_LEG_KERNEL");

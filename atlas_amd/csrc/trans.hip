@@ -779,6 +779,7 @@ void Trans::legendre_chunks(int trc_in, int nb_fields, const double* sp_dev, dou
     p.zero   = d_zero_;
     // dynamic unit assignment of the persistent kernels: one launch at a time per object (the chunked pipeline overlaps launches of two streams)
     p.sched  = (chunk0 == 0 && nrun <= 0) ? d_leg_sched_ : nullptr;
+    p.col0   = 0;
     p.T      = geo_.T;
     p.trc_in = trc_in;
     p.nf     = nb_fields;
@@ -1150,6 +1151,7 @@ void Trans::invtrans_uv_device_f32(int trc_in, int nb_fields, int nb_vordiv, con
     p.nlat0     = d_nlat0_;
     p.zero      = d_zero32_;
     p.sched     = d_leg_sched_;
+    p.col0      = 0;
     p.T         = geo_.T;
     p.trc_in    = trc_in;
     p.nf        = nb_fields;
