@@ -27,14 +27,14 @@ const EnvSwitch kSwitches[] = {
     {"ATLAS_AMD_LEG_MIXED",         C::tuning,    "1",      "0: every column chunk of a Legendre call has the same width (round 5) instead of full 96-column chunks + one narrower launch for the remaining tiles where that is cheaper"},
     {"ATLAS_AMD_LEG_CFG",           C::tuning,    "auto",   "rtw,nrg: 16-column tiles per wavefront (1-3) and column groups per workgroup (1-2) of the Legendre tiling instead of the planner's choice"},
     {"ATLAS_AMD_FFT_GENERIC",       C::tuning,    "0",      "1: every row through the run-time shaped Fourier kernel (no compile-time shaped rows)"},
-    {"ATLAS_AMD_FFT_STREAMS",       C::tuning,    "4 (1 for coarse classes)", "streams the row-length classes of the Fourier stage are dealt to (1-8)"},
+    {"ATLAS_AMD_FFT_STREAMS",       C::tuning,    "4 (1 for reduced grids with coarse classes of at most 3300 points per row)", "streams the row-length classes of the Fourier stage are dealt to (1-8)"},
     {"ATLAS_AMD_FFT_PREFETCH",      C::tuning,    "2,1",    "distance[,requests per line] of the L2 prefetch of a later job's modes; 0: off"},
     {"ATLAS_AMD_FFT_ROW_AFFINITY",  C::tuning,    "1",      "0: no row -> XCD affinity of the Fourier jobs"},
     {"ATLAS_AMD_FFT_FAST_M",        C::tuning,    "all",    "M,M,..: only these Bluestein lengths take the whole-row-in-one-function form (row_ct3)"},
     {"ATLAS_AMD_FFT_FINER_M",       C::tuning,    "1",      "0: without the extra Bluestein lengths 2304 / 3840 / 4608"},
     {"ATLAS_AMD_FFT_NT_DIV",        C::tuning,    "16",     "elements per worker that size a Fourier workgroup"},
     {"ATLAS_AMD_FFT_SMOOTH_DIRECT", C::tuning,    "0",      "1: the round-2 rule (direct run-time shaped transform for every {2,3,5}-smooth half length)"},
-    {"ATLAS_AMD_FFT_COARSE",        C::tuning,    "auto",   "0 / 1: coarse row classes (a few Bluestein lengths for all rows of a small reduced grid) off / on"},
+    {"ATLAS_AMD_FFT_COARSE",        C::tuning,    "auto",   "0 / 1: coarse row classes (the Bluestein lengths 256 / 512 / 1024 / 2048 for every row short enough, the first three in one launch) off / on; auto = on for reduced grids"},
     {"ATLAS_AMD_FFT_COARSE_FUSED",  C::tuning,    "1",      "0: one launch per coarse class instead of one for all three"},
     {"ATLAS_AMD_FFT_COARSE_MULTI",  C::tuning,    "1",      "0: one field per workgroup in the coarse classes instead of several fields of a short row per wavefront"},
     {"ATLAS_AMD_FFT_GROUP_LOG2",    C::tuning,    "3 (fp32: 4)", "log2 of the fields per job group of the record-less Fourier kernels (3 or 4)"},

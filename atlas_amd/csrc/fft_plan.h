@@ -59,7 +59,7 @@ struct PlanOptions {
     // Small reduced grids are launch-bound: TL159 -> O160 / 60 fields spends 0.15 of its 0.21 ms in 19 row-class launches of a
     // few microseconds of work each.  With `coarse_classes` every even row takes a Bluestein row of one of a few lengths
     // (256, 512, 1024, 2048: any M >= 2h - 1 is a valid convolution length) -- up to 4 x the butterflies of the tight length,
-    // a handful of launches.  Set by Trans for reduced grids of at most 704 points per row (a property of the GLOBAL grid, so
+    // a handful of launches.  Set by Trans for every reduced grid ([r6]; rounds 3 - 5: of at most 704 points per row) -- a property of the GLOBAL grid, so
     // that every decomposition of one grid plans its rows alike); ATLAS_AMD_FFT_COARSE=0/1 overrides.
     bool coarse_classes     = false;
     // native mixed-radix rows (tools/experiments/fft_native.h; experiments build, ATLAS_AMD_FFT_NATIVE=1) for every half length the

@@ -158,7 +158,14 @@ Trans::Trans(const grid::StructuredGrid& grid, int truncation, const TransConfig
             std::vector<int> distinct(lengths);
             std::sort(distinct.begin(), distinct.end());
             distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
-            po.coarse_classes = !geo_.regular && geo_.nxmax <= 704 && distinct.size() >= 24;
+            // [r6] every reduced grid, not only those of at most 704 points per row: the rows short enough for a coarse length share
+            // one launch on every grid (tools/probe/grid_sweep.sh: the Fourier stage of O176 .. O400 spent most of its time in 20 - 25
+            // launches of a few microseconds of work: O200 0.32 -> 0.20 ms at 137 fields, O320 at 20 fields 0.18 -> 0.10; O640 -2.5 %,
+            // O800 -3 %, O1280 -1 %); the rows beyond the coarse lengths keep their tight classes
+            // -- for grids where (nearly) every pair of rows has a length of its own (the octahedral ones: one distinct length per two
+            // rows).  The classic N grids beyond 704 points per row keep their tight classes: a few lengths with many rows each, most of
+            // them lengths of the specialised direct family, which a coarse Bluestein row would replace at a loss (N320: 0.76 -> 0.90 ms)
+            po.coarse_classes = !geo_.regular && distinct.size() >= 24 && (geo_.nxmax <= 704 || distinct.size() * 4 >= (size_t)geo_.nlats);
             if (const char* e = atlas_amd::env_get("ATLAS_AMD_FFT_COARSE")) {
                 po.coarse_classes = atoi(e) != 0;
             }
@@ -957,7 +964,8 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
     // ATLAS_AMD_FFT_STREAMS overrides.  All streams fork from and join the caller's stream through events.
     // Small reduced grids (coarse row classes: three or four launches of tens of microseconds): one stream -- forking and joining
     // side streams costs more than the tails (TL159 -> O160, 60 fields: stage 0.133 / 0.110 / 0.100 ms on 4 / 2 / 1 streams).
-    const int nstreams_env = atlas_amd::env_get("ATLAS_AMD_FFT_STREAMS") ? atoi(atlas_amd::env_get("ATLAS_AMD_FFT_STREAMS")) : (fft_coarse_ ? 1 : 4);
+    const int nstreams_env = atlas_amd::env_get("ATLAS_AMD_FFT_STREAMS") ? atoi(atlas_amd::env_get("ATLAS_AMD_FFT_STREAMS"))
+                                                                         : ((fft_coarse_ && geo_.nxmax <= 3300) ? 1 : 4);   // [r6] one stream up to O800 (tools/probe/coarse_ab.sh)
     const int nstreams = std::max(1, std::min(nstreams_env, 8));
     while ((int)side_streams_.size() < nstreams - 1) {
         hipStream_t st;
