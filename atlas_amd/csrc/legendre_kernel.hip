@@ -1028,7 +1028,10 @@ static hipError_t launch_legendre_t(const LegendreParamsT<Real>& p, int nitems, 
 // col0 = where they start).  Cost model from the TL1279 sweep (tools/probe/nf_sweep.py; ms per chunk of 1 / 2 / 3 tiles per wavefront:
 // 1.45 / 2.07 / 3.03 -- the narrow chunks are bound by streaming the table once more): e.g. 97 fields 8.08 -> 7.2 ms, 110 fields
 // 8.1 -> 7.2; not for 49 - 64 fields (two chunks of four tiles beat six + two).  Per-column arithmetic does not depend on the chunking.
-static bool legendre_mixed_tiling(int nf, int& nfull, int& rem_rtw) {
+static bool legendre_mixed_tiling(int nf, int T, int& nfull, int& rem_rtw) {
+    if (T < 256) {   // small truncations: a launch more costs what the narrower chunk saves (TL159: 0.03 - 0.04 ms either way)
+        return false;
+    }
     const int rt = (2 * nf + 15) / 16;
     nfull        = rt / 6;
     const int rem = rt - 6 * nfull;
@@ -1055,7 +1058,7 @@ hipError_t launch_legendre(const LegendreParams& p, int nitems, int chunk0, int 
     {
         const char* e = atlas_amd::env_get("ATLAS_AMD_LEG_KERNEL");
         int nfull = 0, rem_rtw = 0;
-        if (chunk0 == 0 && nrun <= 0 && (!e || std::string(e) == "lean") && legendre_mixed_tiling(p.nf, nfull, rem_rtw) &&
+        if (chunk0 == 0 && nrun <= 0 && (!e || std::string(e) == "lean") && legendre_mixed_tiling(p.nf, p.T, nfull, rem_rtw) &&
             lean_kernel_usable<&legendre_kernel_lean>("legendre_kernel_lean") &&
             lean_kernel_usable<&legendre_kernel_lean_n<1, double>>("legendre_kernel_lean_n<1, double>") &&
             lean_kernel_usable<&legendre_kernel_lean_n<2, double>>("legendre_kernel_lean_n<2, double>")) {
@@ -1152,7 +1155,7 @@ hipError_t launch_legendre_f32(const LegendreParamsF32& p, int nitems, int chunk
     {
         const char* e = atlas_amd::env_get("ATLAS_AMD_LEG_KERNEL");
         int nfull = 0, rem_rtw = 0;
-        if (chunk0 == 0 && nrun <= 0 && (!e || std::string(e) == "lean") && legendre_mixed_tiling(p.nf, nfull, rem_rtw) &&
+        if (chunk0 == 0 && nrun <= 0 && (!e || std::string(e) == "lean") && legendre_mixed_tiling(p.nf, p.T, nfull, rem_rtw) &&
             lean_kernel_usable<&legendre_kernel_lean_f32>("legendre_kernel_lean_f32") &&
             lean_kernel_usable<&legendre_kernel_lean_f32_w2>("legendre_kernel_lean_f32_w2") &&
             lean_kernel_usable<&legendre_kernel_lean_n<1, float>>("legendre_kernel_lean_n<1, float>") &&

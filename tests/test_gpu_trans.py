@@ -733,7 +733,7 @@ LEG_KERNELS = ("classic", "lean") + (("stream",) if "exp" in os.environ.get("ATL
 @pytest.mark.parametrize("case", ["scalar_O160_nf40", "vordiv_F64", "sharded_O160_nf44", "band_O160_nf42", "scalar_O64_nf137",
                                   "f32_O160_nf40", "f32_O64_nf137", "f32_F64_nf44",
                                   "scalar_O160_nf60", "scalar_O64_nf25", "scalar_O64_nf10", "f32_O160_nf60", "f32_O64_nf10",
-                                  "scalar_O64_nf1", "scalar_O160_nf5", "scalar_O64_nf70", "scalar_O64_nf100", "f32_O64_nf100"])
+                                  "scalar_O64_nf1", "scalar_O160_nf5", "scalar_O320_nf70", "scalar_O320_nf100", "f32_O320_nf100"])
 def test_legendre_kernel_variants_are_bitwise_equal(case, monkeypatch):
     """The 96-column workgroup of the Legendre stage (field counts whose 16-column tiles come in sixes: nf 33..48, 81..96,
     129..144, ...) has two implementations of the same arithmetic in the same order: the generic template ("classic") and
@@ -746,7 +746,7 @@ def test_legendre_kernel_variants_are_bitwise_equal(case, monkeypatch):
         if case.startswith("f32"):
             # the fp32 variant [r3]: legendre_kernel<3, 2, float> ("classic") against the float instantiation of the lean body
             gridname, T, nf = {"f32_O160_nf40": ("O160", 159, 40), "f32_O64_nf137": ("O64", 63, 137), "f32_F64_nf44": ("F64", 63, 44),
-                               "f32_O160_nf60": ("O160", 159, 60), "f32_O64_nf10": ("O64", 63, 10), "f32_O64_nf100": ("O64", 63, 100)}[case]
+                               "f32_O160_nf60": ("O160", 159, 60), "f32_O64_nf10": ("O64", 63, 10), "f32_O320_nf100": ("O320", 319, 100)}[case]
             g, tr = get_trans(gridname, T)
             sp32 = red_spectra(T, nf, seed=14).astype(np.float32)
             gp = torch.full((nf * g.size(),), float("nan"), dtype=torch.float32, device="cuda")
@@ -761,8 +761,9 @@ def test_legendre_kernel_variants_are_bitwise_equal(case, monkeypatch):
                                "scalar_O64_nf25": ("O64", 63, 25), "scalar_O64_nf10": ("O64", 63, 10),
                                # [r6] one tile (1 .. 8 fields): the lean two-group workgroup with its second group on padding columns
                                "scalar_O64_nf1": ("O64", 63, 1), "scalar_O160_nf5": ("O160", 159, 5),
-                               # [r6] tiles that do not come in sixes: full 96-column chunks + one narrower launch (9 = 6 + 3, 13 = 12 + 1)
-                               "scalar_O64_nf70": ("O64", 63, 70), "scalar_O64_nf100": ("O64", 63, 100)}[case]
+                               # [r6] tiles that do not come in sixes: full 96-column chunks + one narrower launch (9 = 6 + 3, 13 = 12 + 1;
+                               # from T = 256 on)
+                               "scalar_O320_nf70": ("O320", 319, 70), "scalar_O320_nf100": ("O320", 319, 100)}[case]
             g, tr = get_trans(gridname, T)
             outs[kernel] = run_device(tr, nf, red_spectra(T, nf, seed=11))
         elif case == "vordiv_F64":
@@ -802,7 +803,7 @@ def test_legendre_kernel_variants_are_bitwise_equal(case, monkeypatch):
         monkeypatch.setenv("ATLAS_AMD_LEG_KERNEL", "lean")
         monkeypatch.setenv("ATLAS_AMD_LEG_F32_TILES", "2")
         gridname, T, nf = {"f32_O160_nf40": ("O160", 159, 40), "f32_O64_nf137": ("O64", 63, 137), "f32_F64_nf44": ("F64", 63, 44),
-                           "f32_O160_nf60": ("O160", 159, 60), "f32_O64_nf10": ("O64", 63, 10), "f32_O64_nf100": ("O64", 63, 100)}[case]
+                           "f32_O160_nf60": ("O160", 159, 60), "f32_O64_nf10": ("O64", 63, 10), "f32_O320_nf100": ("O320", 319, 100)}[case]
         g, tr = get_trans(gridname, T)
         sp32 = red_spectra(T, nf, seed=14).astype(np.float32)
         gp = torch.full((nf * g.size(),), float("nan"), dtype=torch.float32, device="cuda")
