@@ -331,12 +331,12 @@ static hipError_t launch_spectra_prepare_t(const Real* vor, const Real* div, con
     const long long total_n = (long long)(T + 2) * (T + 3) / 2;
     const int nb            = (int)std::max<long long>(2, std::min<long long>(PREP_NB, total_n / 4096));
     PrepareParamsT<Real> p{vor, div, sp, out, T, nvd, ns, fshift, nb};
-    // many vor/div fields and enough coefficients to fill the device with its chunks (T >= 255): the streaming form (a lane per field);
+    // vor/div fields from 20 on and enough coefficients to fill the device with its chunks (T >= 255): the streaming form (a lane per field);
     // ATLAS_AMD_PREPARE=rows / stream forces one of the two (same bits either way: tests/test_gpu_vordiv.py)
     const char* e     = atlas_amd::env_get("ATLAS_AMD_PREPARE");
     // (the streaming form walks groups of 64 vor/div fields: it has nothing to do -- and divides by the group count -- without any,
     // e.g. the scalar chunks of a pipelined vor/div call, whatever the override says)
-    const bool stream_form = nvd > 0 && (e && *e ? std::string(e) == "stream" : (nvd >= 48 && total_n >= PREP_SNB * 2048));
+    const bool stream_form = nvd > 0 && (e && *e ? std::string(e) == "stream" : (nvd >= 20 && total_n >= PREP_SNB * 2048));   // [r6] 20, not 48: tools/probe/prepare_sweep.py (24 - 47 vor/div fields: 1.4 - 2.2 x faster)
     if (stream_form) {
         dim3 grid((T + 2 + PREP_SNB - 1) / PREP_SNB, T + 2);
         hipLaunchKernelGGL(spectra_prepare_stream_kernel<Real>, grid, dim3(256), 0, stream, p);
