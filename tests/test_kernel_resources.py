@@ -29,6 +29,8 @@ HEADLINE = [
     r"trans::legendre_kernel_lean$",
     r"trans::legendre_kernel_lean_f32$",
     r"trans::legendre_kernel_lean_n<[12], (double|float)>$",
+    r"trans::legendre_kernel_lean_f32_w2$",                      # [r6] fp32 stage on pairs of latitude tiles
+    r"trans::legendre_kernel_lean_n_f32_w2<[12]>$",
     r"trans::fft_rows_ct_kernel<fft::CtShape<(1, 12|15, 8|9, 9|5, 10|3, 11)>, (false|true), true>$",     # row_ct3
     r"trans::fft_rows_ct_pair_kernel<fft::CtShape<(1, 12|15, 8|9, 9|5, 10|3, 11)>, true>$",              # row_ct3, fp32 pairs
     r"trans::fft_rows_ct_kernel<fft::CtShape<(3, 10|1, 11|5, 9|9, 8|5, 8|3, 9|1, 10|3, 8|1, 9|5, 7|1, 8|3, 7|5, 6)>, false, false>$",
@@ -54,6 +56,13 @@ def test_headline_kernels_have_no_spills_and_no_scratch(kernels):
                 bad.append((n, k["vgpr_count"], k["vgpr_spill_count"], k["scratch"]))
     assert checked >= 40
     assert not bad, "kernels of the headline path compiled with spills / scratch: " + repr(bad)
+
+
+def test_fp32_tile_pair_legendre_kernels_keep_two_workgroups_per_cu(kernels):
+    # [r6] 105 VGPRs: four wavefronts per SIMD = two 8-wavefront workgroups per CU (the form lost its third workgroup against the 64-latitude
+    # kernel's 73 registers and still wins; a fifth register class -- > 128 -- would halve its occupancy)
+    k = kernels["trans::legendre_kernel_lean_f32_w2"]
+    assert k["vgpr_count"] + k["agpr_count"] <= 128 and k["wg"] == 512
 
 
 def test_row_ct3_instances_fit_two_wavefronts_per_simd(kernels):
