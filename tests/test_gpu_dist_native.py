@@ -43,7 +43,8 @@ def run_ranks(nparts, fn):
 
 
 @pytest.mark.parametrize("gridname,T,nf,nparts,maxmsg", [("O64", 63, 3, 2, None), ("O64", 63, 5, 3, 8192),
-                                                         ("F32", 31, 4, 4, None), ("O160", 159, 9, 8, 1 << 16)])
+                                                         ("F32", 31, 4, 4, None), ("O160", 159, 9, 8, 1 << 16),
+                                                         ("O320", 319, 70, 2, None)])   # [r6] 9 column tiles: 6 + 3 (mixed tiling)
 def test_native_distributed_transform_equals_single_device(gridname, T, nf, nparts, maxmsg):
     g = atlas_amd.Grid(gridname)
     sps = [torch.from_numpy(red_spectra(T, nf, seed=s)).cuda() for s in (1, 2, 3)]
