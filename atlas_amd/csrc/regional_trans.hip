@@ -26,30 +26,136 @@ namespace {
         }                                                                                                             \
     } while (0)
 
-// gp[f][row][lon] = sum_m  C[m][lon] Re F(row, m, f) + S[m][lon] Im F(row, m, f)
-// One workgroup per (target row, field): the row's 2 (T + 1) Fourier coefficients of the field go to LDS once, every
-// thread then owns longitudes i, i + 256, ...  Reads of the table are contiguous in the longitude.
-__global__ void __launch_bounds__(256) regional_dft_kernel(const double* __restrict__ F, const int* __restrict__ rowsel,
-                                                           const double* __restrict__ table, double* __restrict__ gp, int T, int m_cnt,
-                                                           int RP, int nlon, int nlat, const double* __restrict__ rowscale,
-                                                           int nscaled) {
-    extern __shared__ double coef[];   // [T + 1][2]
-    const int row = blockIdx.x, f = blockIdx.y;
-    const double* src = F + (long long)rowsel[row] * m_cnt * RP + 2 * f;
-    for (int m = threadIdx.x; m <= T; m += blockDim.x) {
-        coef[2 * m]     = src[(long long)m * RP];
-        coef[2 * m + 1] = src[(long long)m * RP + 1];
+// gp[f][row][lon] = sum_m  C[m][lon] Re F(row, m, f) + S[m][lon] Im F(row, m, f): ONE matrix product over all target rows and fields
+// (TransLocal.cc:1139-1148 hands exactly this product to its GEMM backend),
+//     out[p][i] = sum_k  A[p][k] B[k][i],   p = row * nf + field,   k = 2 m + (0: real, 1: imaginary),   B = the cos / sin table,
+// on v_mfma_f64_16x16x4_f64.  A workgroup of four wavefronts owns a 128 x 128 tile of (p, i), each wavefront 64 x 64 = 16 accumulator
+// tiles; the contraction runs in stages of 8 wavenumbers (16 rows of B) through two LDS buffers: the loads of stage c + 1 are in
+// flight in registers while stage c is multiplied.  LDS rows have a pitch of 144 doubles, so the four 16-lane groups of an operand
+// read (rows k .. k + 3 of the stage) fall on disjoint banks per half wavefront.  Workgroup -> tile: an XCD (blockIdx & 7) walks a
+// contiguous run of tiles, longitude tiles fastest: the workgroups that run together on it share their A and B panels in its L2.
+constexpr int GT  = 128;       // tile edge
+constexpr int GKM = 8;         // wavenumbers per stage
+constexpr int GLD = GT + 16;   // LDS row pitch in doubles
+typedef double dft_acc_t __attribute__((ext_vector_type(4)));
+typedef double dft_pair_t __attribute__((ext_vector_type(2)));
+
+__global__ void __launch_bounds__(256, 2) regional_dft_mfma_kernel(const double* __restrict__ F, const int* __restrict__ rowsel,
+                                                                   const double* __restrict__ table, double* __restrict__ gp, int T,
+                                                                   int RP, int nlon, int nlat, int nf,
+                                                                   const double* __restrict__ rowscale, int nscaled, int tiles_i,
+                                                                   int total_tiles, int per_xcd) {
+    extern __shared__ double lds[];   // [2 stages][A: 16 x GLD | B: 16 x GLD]
+    const int slot = blockIdx.x >> 3, lin = (blockIdx.x & 7) * per_xcd + slot;
+    if (slot >= per_xcd || lin >= total_tiles) {
+        return;
     }
-    __syncthreads();
-    double* out        = gp + ((long long)f * nlat + row) * nlon;
-    const double scale = f < nscaled ? rowscale[row] : 1.;   // u, v fields of the vor/div path: 1 / cos(lat)
-    for (int i = threadIdx.x; i < nlon; i += blockDim.x) {
-        double acc = 0.;
-        for (int m = 0; m <= T; ++m) {
-            acc += table[(long long)(2 * m) * nlon + i] * coef[2 * m];
-            acc += table[(long long)(2 * m + 1) * nlon + i] * coef[2 * m + 1];
+    const int p0 = (lin / tiles_i) * GT, i0 = (lin % tiles_i) * GT;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int P = nlat * nf, K2 = 2 * (T + 1);
+    // loader roles: element tid & 127 of the tile edge, rows (tid >> 7) + 2 q of the stage
+    const int le = tid & 127, lr = tid >> 7;
+    const int pa     = p0 + le;
+    const bool pa_ok = pa < P;
+    const int row_a  = pa_ok ? pa / nf : 0;
+    const double* asrc = F + (long long)rowsel[row_a] * (T + 1) * RP + 2 * (pa_ok ? pa - row_a * nf : 0);
+    const int ib     = i0 + le;
+    const bool ib_ok = ib < nlon;
+    const double* bsrc = table + (ib_ok ? ib : 0);
+    dft_pair_t ra[GKM / 2];
+    double rb[GKM];
+    // loads are unconditional from clamped (valid) addresses -- straight-line code; what lies outside the problem is zeroed on the
+    // way to LDS
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int q = 0; q < GKM / 2; ++q) {
+            const int m = min(c * GKM + lr + 2 * q, T);
+            ra[q]       = *reinterpret_cast<const dft_pair_t*>(asrc + (long long)m * RP);
         }
-        out[i] = acc * scale;
+#pragma unroll
+        for (int q = 0; q < GKM; ++q) {
+            const int k = min(c * 2 * GKM + lr + 2 * q, K2 - 1);
+            rb[q]       = bsrc[(long long)k * nlon];
+        }
+    };
+    auto stash = [&](int c, double* buf) {
+        double* a = buf;
+        double* b = buf + 2 * GKM * GLD;
+#pragma unroll
+        for (int q = 0; q < GKM / 2; ++q) {
+            const int ml   = lr + 2 * q;
+            const bool ok  = pa_ok && c * GKM + ml <= T;
+            a[(2 * ml) * GLD + le]     = ok ? ra[q].x : 0.;
+            a[(2 * ml + 1) * GLD + le] = ok ? ra[q].y : 0.;
+        }
+#pragma unroll
+        for (int q = 0; q < GKM; ++q) {
+            const int kl = lr + 2 * q;
+            b[kl * GLD + le] = (ib_ok && c * 2 * GKM + kl < K2) ? rb[q] : 0.;
+        }
+    };
+    dft_acc_t acc[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc[t][u] = dft_acc_t{0., 0., 0., 0.};
+        }
+    }
+    const int pw = (w >> 1) * 64, iw = (w & 1) * 64;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int nstage = (T + GKM) / GKM;   // ceil((T + 1) / GKM)
+    constexpr int STAGE = 2 * 2 * GKM * GLD;
+    fetch(0);
+    stash(0, lds);
+    __syncthreads();
+    for (int c = 0; c < nstage; ++c) {
+        const double* a = lds + (c & 1) * STAGE;
+        const double* b = a + 2 * GKM * GLD;
+        if (c + 1 < nstage) {
+            fetch(c + 1);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2 * GKM / 4; ++kk) {
+            double fa[4], fb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                fa[t] = a[(4 * kk + l4) * GLD + pw + 16 * t + l15];
+                fb[t] = b[(4 * kk + l4) * GLD + iw + 16 * t + l15];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc[t][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[t], fb[u], acc[t][u], 0, 0, 0);
+                }
+            }
+        }
+        if (c + 1 < nstage) {
+            stash(c + 1, lds + ((c + 1) & 1) * STAGE);
+        }
+        __syncthreads();
+    }
+    // result element (row of the MFMA tile = (lane >> 4) + 4 reg, column = lane & 15): p = pair, column = longitude
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int p = p0 + pw + 16 * t + l4 + 4 * r;
+            if (p >= P) {
+                continue;
+            }
+            const int row = p / nf, f = p - row * nf;
+            const double scale = f < nscaled ? rowscale[row] : 1.;   // u, v fields of the vor/div path: 1 / cos(lat)
+            double* out        = gp + ((long long)f * nlat + row) * nlon;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + iw + 16 * u + l15;
+                if (i < nlon) {
+                    out[i] = acc[t][u][r] * scale;
+                }
+            }
+        }
     }
 }
 
@@ -268,16 +374,20 @@ void RegionalTrans::dft(int trc_in, int nb_fields, int nb_vordiv, const double* 
         RT_CHECK(hipGetLastError());
         return;
     }
-    const size_t lds = (size_t)2 * (T_ + 1) * sizeof(double);
-    if (lds > 160 * 1024) {
-        throw std::runtime_error("RegionalTrans: truncation too large for the direct Fourier kernel");
-    }
+    const size_t lds = (size_t)2 * 2 * 2 * GKM * GLD * sizeof(double);   // two stages of A and B: 73 728 bytes, two workgroups per CU
     {   // on every launch (cheap): a per-process flag is wrong for a second device and racy between host threads
-        RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&regional_dft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024));
+        RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&regional_dft_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
     }
-    hipLaunchKernelGGL(regional_dft_kernel, dim3(nlat(), nb_fields), dim3(256), lds, inner_->stream(), F, d_rowsel_, d_table_, gp_dev,
-                       T_, T_ + 1, inner_->fourier_row_pitch(nb_fields), nlon_, nlat(), d_scale_, 2 * nb_vordiv);
+    const long long pairs = (long long)nlat() * nb_fields;
+    const long long tiles_p = (pairs + GT - 1) / GT, tiles_i = (nlon_ + GT - 1) / GT, total = tiles_p * tiles_i;
+    if (pairs > std::numeric_limits<int>::max() || total > (1LL << 28)) {
+        throw std::runtime_error("RegionalTrans: target rows x fields beyond the range of the Fourier kernel's indices");
+    }
+    const int per_xcd = (int)((total + 7) / 8);
+    hipLaunchKernelGGL(regional_dft_mfma_kernel, dim3((unsigned)(8 * per_xcd)), dim3(256), lds, inner_->stream(), F, d_rowsel_, d_table_,
+                       gp_dev, T_, inner_->fourier_row_pitch(nb_fields), nlon_, nlat(), nb_fields, d_scale_, 2 * nb_vordiv, (int)tiles_i,
+                       (int)total, per_xcd);
     RT_CHECK(hipGetLastError());
 }
 

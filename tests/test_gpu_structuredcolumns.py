@@ -115,3 +115,30 @@ def test_equal_regions_halo_exchange_emulated(gridname, nparts, halo):
     exchange_emulated(hxs, fields)
     for f, a in zip(fss, fields):
         assert np.array_equal(a.cpu().numpy()[:, 1], f.global_index())
+
+
+def test_full_size_O1280_137_levels_over_eight_parts_emulated():
+    """maximum size (BASELINE config C4's grid and level count): O1280 over eight equal-regions parts, halo 3, a
+    137-level fp64 field per part (0.92 GB each) whose owned entries hold global index + level/256 and whose halo entries
+    hold NaN -- after one exchange (device pack, device copies for the transport, device unpack) every entry of every
+    part holds its owner's value, bit for bit; the index construction itself is compared with the oracle at this size
+    in test_host_structuredcolumns.py."""
+    g = atlas_amd.Grid("O1280")
+    nparts, lev = 8, 137
+    fss = [StructuredColumns(g, halo=3, periodic_points=True, nparts=nparts, part=p, distribution="equal_regions")
+           for p in range(nparts)]
+    assert sum(f.sizeOwned() for f in fss) == g.size()
+    hxs = [f.begin_halo_exchange() for f in fss]
+    HaloExchange.finish_emulated(hxs)
+    levs = torch.arange(lev, dtype=torch.float64, device="cuda") / 256.0
+    fields, wants = [], []
+    for f in fss:
+        gi = torch.from_numpy(f.global_index().astype(np.float64)).cuda()
+        want = gi[:, None] + levs[None, :]
+        a = want.clone()
+        a[torch.from_numpy(f.ghost() == 1).cuda()] = float("nan")
+        fields.append(a)
+        wants.append(want)
+    exchange_emulated(hxs, fields)
+    for a, want in zip(fields, wants):
+        assert torch.equal(a, want)

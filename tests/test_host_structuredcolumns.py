@@ -258,3 +258,26 @@ def test_equal_regions_partition_of_O8_over_five_parts_is_the_reference_vector()
         fs = StructuredColumns(g, halo=0, nparts=fix["nparts"], part=p, distribution="equal_regions")
         assert fs.sizeOwned() == int((want == p).sum())
         assert np.array_equal(np.sort(fs.global_index()[:fs.sizeOwned()]) - 1, np.nonzero(want == p)[0])
+
+
+def test_full_size_O1280_over_eight_equal_regions_parts_matches_oracle():
+    """maximum size of BASELINE config C4: O1280 (6 599 680 points) over eight equal-regions parts with halo 3 -- the
+    partitioner's output for 8 and 64 parts, and the whole index construction of a polar-cap part and of a collar part,
+    equal the oracle's element for element; the eight parts own the grid exactly once."""
+    from atlas_amd.partitioner import EqualRegionsPartitioner
+    from oracle.partitioner import EqualRegionsPartitioner as OraclePartitioner
+    g = atlas_amd.Grid("O1280")
+    for N in (8, 64):
+        part = EqualRegionsPartitioner(N).partition(g)
+        assert np.array_equal(part, OraclePartitioner(N).partition(g))
+        cnt = np.bincount(part, minlength=N)
+        assert cnt.sum() == g.size() and cnt.max() - cnt.min() <= 1
+    part = EqualRegionsPartitioner(8).partition(g)
+    owned = 0
+    for p in range(8):
+        fs = StructuredColumns(g, halo=3, periodic_points=True, nparts=8, part=p, distribution="equal_regions")
+        owned += fs.sizeOwned()
+        if p in (0, 3):
+            compare(fs, StructuredColumnsOracle(g.nx(), g.y(), halo=3, periodic_points=True, nparts=8, part=p,
+                                                distribution=part))
+    assert owned == g.size()
