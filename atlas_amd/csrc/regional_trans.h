@@ -11,7 +11,8 @@
 // polynomials; here the south-pole row is the mirror image of the north-pole row, Pbar_n^m(-x) = (-1)^(n+m) Pbar_n^m(x).
 // Here: the Legendre stage is the same MFMA kernel as for global grids, run on an internal symmetric latitude set (the
 // target's |latitudes| and their mirror images; the rows that are not target rows are computed and not used), the
-// Fourier stage is a direct evaluation kernel over a precomputed cos / sin table.
+// Fourier stage is the matrix product of the reference (:1139-1148) with the precomputed cos / sin table, one fp64-MFMA kernel over all
+// target rows and fields (unstructured targets: a per-point sum).
 #pragma once
 
 #include <hip/hip_runtime.h>

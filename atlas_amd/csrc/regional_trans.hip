@@ -29,7 +29,7 @@ namespace {
 // gp[f][row][lon] = sum_m  C[m][lon] Re F(row, m, f) + S[m][lon] Im F(row, m, f): ONE matrix product over all target rows and fields
 // (TransLocal.cc:1139-1148 hands exactly this product to its GEMM backend),
 //     out[p][i] = sum_k  A[p][k] B[k][i],   p = row * nf + field,   k = 2 m + (0: real, 1: imaginary),   B = the cos / sin table,
-// on v_mfma_f64_16x16x4_f64.  A workgroup of four wavefronts owns a 128 x 128 tile of (p, i), each wavefront 64 x 64 = 16 accumulator
+// on v_mfma_f64_16x16x4_f64.  A workgroup of eight wavefronts owns a 128 x 128 tile of (p, i), each wavefront 64 x 32 = 8 accumulator
 // tiles; the contraction runs in stages of 8 wavenumbers (16 rows of B) through two LDS buffers: the loads of stage c + 1 are in
 // flight in registers while stage c is multiplied.  LDS rows have a pitch of 144 doubles, so the four 16-lane groups of an operand
 // read (rows k .. k + 3 of the stage) fall on disjoint banks per half wavefront.  Workgroup -> tile: an XCD (blockIdx & 7) walks a
@@ -40,7 +40,11 @@ constexpr int GLD = GT + 16;   // LDS row pitch in doubles
 typedef double dft_acc_t __attribute__((ext_vector_type(4)));
 typedef double dft_pair_t __attribute__((ext_vector_type(2)));
 
-__global__ void __launch_bounds__(256, 2) regional_dft_mfma_kernel(const double* __restrict__ F, const int* __restrict__ rowsel,
+// NW = wavefronts per workgroup: 8 (64 x 32 of the tile each, 112 registers, 4 wavefronts per SIMD) is 8 % faster than 4 (64 x 64 each,
+// 200 registers, 2 per SIMD) on a 1000 x 500 target at T1279 / 137 fields: 6.3 against 7.1 ms = 55 TFLOP/s (profiles/r06_regional.txt)
+constexpr int DFT_NW = 8;
+template <int NW>
+__global__ void __launch_bounds__(64 * NW, NW / 2) regional_dft_mfma_kernel(const double* __restrict__ F, const int* __restrict__ rowsel,
                                                                    const double* __restrict__ table, double* __restrict__ gp, int T,
                                                                    int RP, int nlon, int nlat, int nf,
                                                                    const double* __restrict__ rowscale, int nscaled, int tiles_i,
@@ -54,6 +58,8 @@ __global__ void __launch_bounds__(256, 2) regional_dft_mfma_kernel(const double*
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int P = nlat * nf, K2 = 2 * (T + 1);
     // loader roles: element tid & 127 of the tile edge, rows (tid >> 7) + 2 q of the stage
+    constexpr int LR = NW / 2;       // loader rows per pass
+    constexpr int UW = 16 / NW;      // 16-longitude tiles per wavefront: 4 or 2
     const int le = tid & 127, lr = tid >> 7;
     const int pa     = p0 + le;
     const bool pa_ok = pa < P;
@@ -62,19 +68,19 @@ __global__ void __launch_bounds__(256, 2) regional_dft_mfma_kernel(const double*
     const int ib     = i0 + le;
     const bool ib_ok = ib < nlon;
     const double* bsrc = table + (ib_ok ? ib : 0);
-    dft_pair_t ra[GKM / 2];
-    double rb[GKM];
+    dft_pair_t ra[GKM / LR];
+    double rb[2 * GKM / LR];
     // loads are unconditional from clamped (valid) addresses -- straight-line code; what lies outside the problem is zeroed on the
     // way to LDS
     auto fetch = [&](int c) {
 #pragma unroll
-        for (int q = 0; q < GKM / 2; ++q) {
-            const int m = min(c * GKM + lr + 2 * q, T);
+        for (int q = 0; q < GKM / LR; ++q) {
+            const int m = min(c * GKM + lr + LR * q, T);
             ra[q]       = *reinterpret_cast<const dft_pair_t*>(asrc + (long long)m * RP);
         }
 #pragma unroll
-        for (int q = 0; q < GKM; ++q) {
-            const int k = min(c * 2 * GKM + lr + 2 * q, K2 - 1);
+        for (int q = 0; q < 2 * GKM / LR; ++q) {
+            const int k = min(c * 2 * GKM + lr + LR * q, K2 - 1);
             rb[q]       = bsrc[(long long)k * nlon];
         }
     };
@@ -82,27 +88,27 @@ __global__ void __launch_bounds__(256, 2) regional_dft_mfma_kernel(const double*
         double* a = buf;
         double* b = buf + 2 * GKM * GLD;
 #pragma unroll
-        for (int q = 0; q < GKM / 2; ++q) {
-            const int ml   = lr + 2 * q;
+        for (int q = 0; q < GKM / LR; ++q) {
+            const int ml   = lr + LR * q;
             const bool ok  = pa_ok && c * GKM + ml <= T;
             a[(2 * ml) * GLD + le]     = ok ? ra[q].x : 0.;
             a[(2 * ml + 1) * GLD + le] = ok ? ra[q].y : 0.;
         }
 #pragma unroll
-        for (int q = 0; q < GKM; ++q) {
-            const int kl = lr + 2 * q;
+        for (int q = 0; q < 2 * GKM / LR; ++q) {
+            const int kl = lr + LR * q;
             b[kl * GLD + le] = (ib_ok && c * 2 * GKM + kl < K2) ? rb[q] : 0.;
         }
     };
-    dft_acc_t acc[4][4];
+    dft_acc_t acc[4][UW];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < UW; ++u) {
             acc[t][u] = dft_acc_t{0., 0., 0., 0.};
         }
     }
-    const int pw = (w >> 1) * 64, iw = (w & 1) * 64;
+    const int pw = (w / (NW / 2)) * 64, iw = (w % (NW / 2)) * 16 * UW;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int nstage = (T + GKM) / GKM;   // ceil((T + 1) / GKM)
     constexpr int STAGE = 2 * 2 * GKM * GLD;
@@ -117,16 +123,19 @@ __global__ void __launch_bounds__(256, 2) regional_dft_mfma_kernel(const double*
         }
 #pragma unroll
         for (int kk = 0; kk < 2 * GKM / 4; ++kk) {
-            double fa[4], fb[4];
+            double fa[4], fb[UW];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 fa[t] = a[(4 * kk + l4) * GLD + pw + 16 * t + l15];
-                fb[t] = b[(4 * kk + l4) * GLD + iw + 16 * t + l15];
+            }
+#pragma unroll
+            for (int u = 0; u < UW; ++u) {
+                fb[u] = b[(4 * kk + l4) * GLD + iw + 16 * u + l15];
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < UW; ++u) {
                     acc[t][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[t], fb[u], acc[t][u], 0, 0, 0);
                 }
             }
@@ -149,7 +158,7 @@ __global__ void __launch_bounds__(256, 2) regional_dft_mfma_kernel(const double*
             const double scale = f < nscaled ? rowscale[row] : 1.;   // u, v fields of the vor/div path: 1 / cos(lat)
             double* out        = gp + ((long long)f * nlat + row) * nlon;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UW; ++u) {
                 const int i = i0 + iw + 16 * u + l15;
                 if (i < nlon) {
                     out[i] = acc[t][u][r] * scale;
@@ -376,8 +385,8 @@ void RegionalTrans::dft(int trc_in, int nb_fields, int nb_vordiv, const double* 
     }
     const size_t lds = (size_t)2 * 2 * 2 * GKM * GLD * sizeof(double);   // two stages of A and B: 73 728 bytes, two workgroups per CU
     {   // on every launch (cheap): a per-process flag is wrong for a second device and racy between host threads
-        RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&regional_dft_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds));
+        RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&regional_dft_mfma_kernel<DFT_NW>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     const long long pairs = (long long)nlat() * nb_fields;
     const long long tiles_p = (pairs + GT - 1) / GT, tiles_i = (nlon_ + GT - 1) / GT, total = tiles_p * tiles_i;
@@ -385,9 +394,9 @@ void RegionalTrans::dft(int trc_in, int nb_fields, int nb_vordiv, const double* 
         throw std::runtime_error("RegionalTrans: target rows x fields beyond the range of the Fourier kernel's indices");
     }
     const int per_xcd = (int)((total + 7) / 8);
-    hipLaunchKernelGGL(regional_dft_mfma_kernel, dim3((unsigned)(8 * per_xcd)), dim3(256), lds, inner_->stream(), F, d_rowsel_, d_table_,
-                       gp_dev, T_, inner_->fourier_row_pitch(nb_fields), nlon_, nlat(), nb_fields, d_scale_, 2 * nb_vordiv, (int)tiles_i,
-                       (int)total, per_xcd);
+    hipLaunchKernelGGL(regional_dft_mfma_kernel<DFT_NW>, dim3((unsigned)(8 * per_xcd)), dim3(64 * DFT_NW), lds, inner_->stream(), F, d_rowsel_,
+                       d_table_, gp_dev, T_, inner_->fourier_row_pitch(nb_fields), nlon_, nlat(), nb_fields, d_scale_, 2 * nb_vordiv,
+                       (int)tiles_i, (int)total, per_xcd);
     RT_CHECK(hipGetLastError());
 }
 

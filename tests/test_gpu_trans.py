@@ -994,6 +994,33 @@ def test_regional_target_that_is_not_a_crop_of_a_global_grid(case):
     assert compute_rms(gp2.cpu().numpy(), sel.ravel()) < 1e-13
 
 
+@pytest.mark.parametrize("T,nlat,nlon,nf", [(42, 31, 300, 7), (21, 130, 129, 1), (106, 9, 257, 30)])
+def test_regional_target_over_several_tiles_of_the_matrix_product(T, nlat, nlon, nf):
+    """the Fourier part of the no_nest branch is one fp64-MFMA matrix product over (target row, field) pairs x longitudes in 128 x 128
+    tiles, the contraction in stages of 8 wavenumbers (csrc/regional_trans.hip): pair counts, row lengths and truncations that are
+    not multiples of the tile / stage sizes, several tiles each way -- against the oracle's restatement (TransLocal.cc:719-738,
+    1139-1148), scalar and vor/div calls; every element outside the target stays untouched."""
+    rng = np.random.default_rng(T)
+    lats = np.sort(rng.uniform(-80.0, 80.0, nlat))[::-1].copy()
+    west, dlon = -33.0, 360.0 / (nlon + 3)
+    lons = west + dlon * np.arange(nlon)
+    sp = red_spectra(T, nf, seed=T + 1)
+    rt = atlas_amd.RegionalTrans(nlon, west, dlon, lats, T)
+    gp = torch.full((nf * nlon * nlat + 64,), float("nan"), dtype=torch.float64, device="cuda")
+    rt.invtrans(nf, dev(sp), gp[:-64])
+    rt.synchronize()
+    got = gp.cpu().numpy()
+    assert np.all(np.isnan(got[-64:]))
+    want = oracle.invtrans_regional(T, lats, lons, nf, sp)
+    assert compute_rms(got[:-64], want.ravel()) < 1e-13
+    ns, nvd = 1, max(1, nf // 3)
+    s1, vor, div = red_spectra(T, ns, 7), red_spectra(T, nvd, 8), red_spectra(T, nvd, 9)
+    want_vd = oracle.invtrans_regional_vordiv(T, lats, lons, ns, s1, nvd, vor, div)
+    gp_vd = np.zeros((ns + 2 * nvd) * nlon * nlat)
+    rt.invtrans_vordiv(ns, s1, nvd, vor, div, gp_vd)
+    assert compute_rms(gp_vd, want_vd.ravel()) < 1e-12
+
+
 def test_unstructured_target_points():
     """TransLocal's unstructured path (TransLocal.cc:741-790, 1200-1420; compared there with the structured result in
     test_transgeneral.cc:1336-1490): a list of (lon, lat) points.  Against the oracle's per-point restatement, and the points
