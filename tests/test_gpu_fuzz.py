@@ -133,3 +133,39 @@ def test_random_distributed_transform_equals_the_single_device_one(seed):
         assert np.array_equal(band, ref[:, off[b0]:off[b1]]), (seed, P, T, nf, maxmsg, sharded, b0, b1)
         rows += b1 - b0
     assert rows == len(nx)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ATLAS_AMD_FUZZ_REGIONAL_CASES", "12"))))
+def test_random_regional_targets_against_the_oracle(seed):
+    """[r6] the no_nest branch (atlas_amd__RegionalTrans__*, TransLocal.cc:394-406,719-738,1139-1148): random targets -- latitudes in any
+    order with repeats, mirror pairs and the equator, random west / spacing (wrapping past 360 degrees or not), row lengths 1 .. 400,
+    1 .. 60 rows, truncations 1 .. 120, field counts that leave the last tile of the matrix product part-filled; scalar and vor/div
+    calls against the oracle's restatement of the branch."""
+    rng = np.random.default_rng(7000 + seed)
+    nlat = int(rng.integers(1, 61))
+    lats = rng.uniform(-85.0, 85.0, nlat)
+    if nlat > 4:
+        lats[1] = -lats[0]                 # a mirror pair
+        lats[2] = lats[3]                  # a repeated latitude
+        if seed % 3 == 0:
+            lats[4] = 0.0                  # the equator
+    nlon = int(rng.integers(1, 401))
+    west, dlon = float(rng.uniform(-180.0, 360.0)), float(rng.uniform(0.01, 3.0))
+    lons = west + dlon * np.arange(nlon)
+    T = int(rng.integers(1, 121))
+    nf = int(rng.choice([1, 2, 3, 7, 16, 33, 64, 100]))
+    sp = red_spectra(T, nf, seed=seed)
+    rt = atlas_amd.RegionalTrans(nlon, west, dlon, lats, T)
+    gp = torch.full((nf * nlon * nlat,), float("nan"), dtype=torch.float64, device="cuda")
+    rt.invtrans(nf, torch.from_numpy(sp).cuda(), gp)
+    rt.synchronize()
+    got = gp.cpu().numpy()
+    assert np.isfinite(got).all()
+    want = oracle.invtrans_regional(T, lats, lons, nf, sp)
+    assert compute_rms(got, want.ravel()) < 1e-13, ("scalar", nlat, nlon, T, nf)
+    ns, nvd = int(rng.integers(0, 3)), int(rng.integers(1, 5))
+    s, vor, div = red_spectra(T, max(ns, 1), seed + 1), red_spectra(T, nvd, seed + 2), red_spectra(T, nvd, seed + 3)
+    w = np.full((ns + 2 * nvd) * nlon * nlat, np.nan)
+    rt.invtrans_vordiv(ns, s if ns else None, nvd, vor, div, w)
+    wref = oracle.invtrans_regional_vordiv(T, lats, lons, ns, s if ns else None, nvd, vor, div)
+    assert compute_rms(w, wref.ravel()) < 1e-12, ("vor/div", nlat, nlon, T, ns, nvd)
