@@ -44,11 +44,10 @@ typedef double dft_pair_t __attribute__((ext_vector_type(2)));
 // 200 registers, 2 per SIMD) on a 1000 x 500 target at T1279 / 137 fields: 6.3 against 7.1 ms = 55 TFLOP/s (profiles/r06_regional.txt)
 constexpr int DFT_NW = 8;
 template <int NW>
-__global__ void __launch_bounds__(64 * NW, NW / 2) regional_dft_mfma_kernel(const double* __restrict__ F, const int* __restrict__ rowsel,
-                                                                   const double* __restrict__ table, double* __restrict__ gp, int T,
-                                                                   int RP, int nlon, int nlat, int nf,
-                                                                   const double* __restrict__ rowscale, int nscaled, int tiles_i,
-                                                                   int total_tiles, int per_xcd) {
+__global__ void __launch_bounds__(64 * NW, NW / 2)
+    regional_dft_mfma_kernel(const double* __restrict__ F, const int* __restrict__ rowsel, const double* __restrict__ table,
+                             double* __restrict__ gp, int T, int RP, int nlon, int nlat, int nf, const double* __restrict__ rowscale,
+                             int nscaled, int tiles_i, int total_tiles, int per_xcd) {
     extern __shared__ double lds[];   // [2 stages][A: 16 x GLD | B: 16 x GLD]
     const int slot = blockIdx.x >> 3, lin = (blockIdx.x & 7) * per_xcd + slot;
     if (slot >= per_xcd || lin >= total_tiles) {
@@ -57,7 +56,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 2) regional_dft_mfma_kernel(cons
     const int p0 = (lin / tiles_i) * GT, i0 = (lin % tiles_i) * GT;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int P = nlat * nf, K2 = 2 * (T + 1);
-    // loader roles: element tid & 127 of the tile edge, rows (tid >> 7) + 2 q of the stage
+    // loader roles: element tid & 127 of the tile edge, rows (tid >> 7) + LR q of the stage
     constexpr int LR = NW / 2;       // loader rows per pass
     constexpr int UW = 16 / NW;      // 16-longitude tiles per wavefront: 4 or 2
     const int le = tid & 127, lr = tid >> 7;
