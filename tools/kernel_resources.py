@@ -89,8 +89,8 @@ def waves_per_simd(r):
 
 def short(dm):
     dm = re.sub(r"^void ", "", dm)
+    dm = dm.replace("atlas_amd::", "").replace("(anonymous namespace)::", "")   # before the argument list is cut at its "("
     dm = re.sub(r"\(.*$", "", dm)
-    dm = dm.replace("atlas_amd::", "").replace("(anonymous namespace)::", "")
     return dm
 
 
