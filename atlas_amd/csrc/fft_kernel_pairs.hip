@@ -230,6 +230,152 @@ static hipError_t launch_dct_pair(const FourierParams& p, int lds_bytes, hipStre
     }
 }
 
+// ---- run-time shaped direct rows, two fields per job [r6] --------------------------------------------------------------------------
+// The {2,3,5}-smooth half lengths outside the specialised family F 2^K (2^a 25, 2^a 27, 2^a 45, ... : a quarter of the points of the
+// classic N grids) run fft_rows_kernel's direct branch -- fp64 arithmetic on float storage, one field per job -- in the fp32 variant
+// (fft_kernel.hip); this is the same phase list (load + c2r pre-processing into digit-reversed order | DIT stages from the shape record
+// | store) on the pair type: half the jobs, packed fp32 instructions, float tables -- and likewise the ODD branch (odd {3,5}-smooth
+// lengths, a complex transform of the row's own length: the many odd row lengths of the classic N grids, 1.35 of the 5.3 ms of kernel
+// time of TL1279 -> N1280's Fourier stage in round 5).  The launch's row list holds FFT_DIRECT and FFT_ODD rows only (trans.hip splits
+// the run-time shaped classes).
+template <int R>
+__device__ __forceinline__ void dit_stage_pair(fft::cplxp* d, int M, int L, int lsh, fft::PairTable tw, int t, int nt) {
+    fft::dit_stage<R, fft::cplxp, fft::PairTable>(d, M, L, lsh, tw, +1, t, nt);
+}
+__global__ void __launch_bounds__(FFT_MAX_NTHR) fft_rows_pair_kernel(FourierParams p) {
+    using C  = fft::cplxp;
+    using TC = fft::cplxf;
+    using fft::both;
+    extern __shared__ double lds_raw[];
+    C* work = reinterpret_cast<C*>(lds_raw);
+    int row, f;
+    if (!fft_block_to_pair_job(p, blockIdx.x, row, f)) {
+        return;
+    }
+    const fft::FftRowPlan* pl = p.plans + p.row_plan[row];
+    const fft::FftShape& sh   = pl->shape;
+    const long long goff      = (long long)f * p.npts + (p.rowoff[row] - p.rowoff[p.lat0]);
+    const int nx              = (int)(p.rowoff[row + 1] - p.rowoff[row]);
+    const int tid             = threadIdx.x;
+    const int nt              = blockDim.x;
+    const bool has_b          = f + 1 < p.f_end;
+    const float cli           = (float)p.coslatinv[row];
+    const fft::f32x2 scale(f < p.scale_uv_fields ? cli : 1.0f, f + 1 < p.scale_uv_fields ? cli : 1.0f);
+    const int h               = pl->h;
+    const int M               = sh.M;
+    const int mmax0           = p.row_mmax[row];
+    const int mmax            = mmax0 < h ? mmax0 : h;
+    const fft::PairTable tw{p.table_f32 + pl->off_tw};
+    const TC* pre             = p.table_f32 + pl->off_pre;
+    float* ya                 = reinterpret_cast<float*>(p.gp) + goff;
+    float* yb                 = ya + p.npts;
+    const bool al_a           = (goff & 1) == 0;
+    const bool al_b           = ((goff + p.npts) & 1) == 0;
+    const ModeReaderT<1> rd{p, (long long)(row - p.lat0), 2 * f};
+    // mode m of both fields: the 16 bytes (re f, im f, re f + 1, im f + 1) of the float intermediate
+    auto mode = [&](int m) {
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(1))) float* gfloat_ptr;
+        long long o;
+        gfloat_ptr src = (gfloat_ptr)rd.locate(m, o) + o;
+        const v4 q     = *reinterpret_cast<const __attribute__((address_space(1))) v4*>(src);
+        return C{fft::f32x2(q.x, q.z), fft::f32x2(q.y, q.w)};
+    };
+    const bool odd = pl->method == fft::FFT_ODD;   // uniform per workgroup
+    if (odd) {
+        // ---- odd {3,5}-smooth length: complex DIT of length n = h on the Hermitian extension (fft_core.h: row_phase_odd), real parts stored
+        const int n  = pl->n;
+        const int mm = mmax0 < (n - 1) / 2 ? mmax0 : (n - 1) / 2;
+        for (int k = tid; k < n; k += nt) {
+            C z{fft::f32x2(0.f), fft::f32x2(0.f)};
+            if (k <= mm) {
+                z = mode(k);
+                if (k == 0) {
+                    z.im = fft::f32x2(0.f);   // the imaginary part of the mean is dropped
+                }
+            }
+            else if (n - k <= mm) {
+                z = fft::cconj(mode(n - k));
+            }
+            work[fft::PAD(fft::pos_of_freq(sh, k))] = z;
+        }
+    }
+    else {
+        // ---- load + c2r pre-processing: four elements per sweep, their loads issued as one batch (fft_core.h: row_phase)
+        constexpr int NB = 4;
+        for (int k0 = tid; k0 < h; k0 += NB * nt) {
+            C A[NB], B[NB];
+            TC P[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int k  = k0 + i * nt;
+                const int kc = k < h ? k : h - 1;
+                A[i]         = mode(fft::row_mode_index(mmax, kc));
+                B[i]         = mode(fft::row_mode_index(mmax, h - kc));
+                P[i]         = pre[kc];
+            }
+            AA_SCHED_FENCE();
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int k = k0 + i * nt;
+                if (k < h) {
+                    const C a = fft::row_mode_mask(A[i], mmax, k, h);
+                    const C b = fft::cconj(fft::row_mode_mask(B[i], mmax, h - k, h));
+                    work[fft::PAD(fft::pos_of_freq(sh, k))] = fft::c2r_pre(a, b, both(P[i]));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- inverse DIT, stages in reverse order
+    for (int i = sh.nstages - 1; i >= 0; --i) {
+        const int L = fft::stage_L(sh, i), lsh = sh.lsh[i];
+        switch (sh.radix[i]) {
+            case 2: dit_stage_pair<2>(work, M, L, lsh, tw, tid, nt); break;
+            case 3: dit_stage_pair<3>(work, M, L, lsh, tw, tid, nt); break;
+            case 4: dit_stage_pair<4>(work, M, L, lsh, tw, tid, nt); break;
+            case 5: dit_stage_pair<5>(work, M, L, lsh, tw, tid, nt); break;
+            case 8: dit_stage_pair<8>(work, M, L, lsh, tw, tid, nt); break;
+            case 9: dit_stage_pair<9>(work, M, L, lsh, tw, tid, nt); break;
+            case 16: dit_stage_pair<16>(work, M, L, lsh, tw, tid, nt); break;
+        }
+        __syncthreads();
+    }
+    if (odd) {
+        // ---- store: y[j] = Re z[j]
+        for (int j = tid; j < nx; j += nt) {
+            const fft::f32x2 re = work[fft::PAD(j)].re * scale;
+            ya[j]               = re.v.x;
+            if (has_b) {
+                yb[j] = re.v.y;
+            }
+        }
+        return;
+    }
+    // ---- store: y[2 j] = Re z[j], y[2 j + 1] = Im z[j]; lane x to field f, lane y to field f + 1
+    const bool whole = nx == 2 * h;
+    for (int j = tid; j < h; j += nt) {
+        const C z           = work[fft::PAD(j)];
+        const fft::f32x2 re = z.re * scale, im = z.im * scale;
+        if (whole) {
+            store_field_pair(ya, al_a, j, re.v.x, im.v.x);
+            if (has_b) {
+                store_field_pair(yb, al_b, j, re.v.y, im.v.y);
+            }
+        }
+        else {   // a row of which the grid keeps fewer points than the transform has
+            if (2 * j < nx) {
+                ya[2 * j] = re.v.x;
+                if (has_b) yb[2 * j] = re.v.y;
+            }
+            if (2 * j + 1 < nx) {
+                ya[2 * j + 1] = im.v.x;
+                if (has_b) yb[2 * j + 1] = im.v.y;
+            }
+        }
+    }
+}
+
 // ---- specialised Bluestein rows --------------------------------------------------------------------------------------------------
 // workgroup -> (row index of the launch's list, first field of the pair): fft_block_to_job_index (fft_device.h) with the pair as the unit
 __device__ __forceinline__ bool fft_block_to_pair_job_index(const FourierParams& p, int b, int& ri, int& f) {
@@ -379,6 +525,20 @@ bool fourier_pairs_usable(const FourierParams& p, int ctf, int ctk) {   // direc
 }
 bool fourier_ct_pairs_usable(const FourierParams& p) {   // specialised Bluestein rows: every shape
     return pairs_usable(p) && p.desc != nullptr;
+}
+
+// run-time shaped direct rows (fft_kernel.hip: launch_fourier): can the launch take the two-field form, and its launch
+bool fourier_generic_pairs_usable(const FourierParams& p) {
+    return pairs_usable(p);
+}
+hipError_t launch_fourier_generic_pairs(const FourierParams& p, int lds_bytes, int nthreads, hipStream_t stream) {
+    if (hipError_t e = ensure_dynamic_lds<&fft_rows_pair_kernel>(lds_bytes); e != hipSuccess) {   // dyn_lds.h
+        return e;
+    }
+    const int npair     = (p.f_end - p.f_begin + 1) / 2;
+    const unsigned nblk = fft_job_blocks(p.nrows, npair, 3);
+    hipLaunchKernelGGL(fft_rows_pair_kernel, dim3(nblk), dim3(nthreads), lds_bytes, stream, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_fourier_dct_pairs(const FourierParams& p, int ctf, int ctk, int lds_bytes, hipStream_t stream) {

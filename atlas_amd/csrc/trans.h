@@ -215,6 +215,11 @@ private:
         int native_fpj   = 1;       // ... fields per workgroup (1 or 2)
         int nrows;
         int* d_rows;
+        // run-time shaped classes [r6]: the list split into its direct rows (the fp32 variant runs them two fields per job,
+        // fft_kernel_pairs.hip: fft_rows_pair_kernel) and the rest (odd lengths, ...); both null where the class has no such split
+        int nrows_pair = 0, nrows_rest = 0;
+        int* d_rows_pair = nullptr;
+        int* d_rows_rest = nullptr;
         void* d_desc = nullptr;   // FftRowDesc[nrows] for the specialised Bluestein kernels
     };
     std::vector<SizeClass> classes_;

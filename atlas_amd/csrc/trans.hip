@@ -32,6 +32,8 @@ void legendre_tiling(int nf, int& rtw, int& nrg, int& nchunks);
 hipError_t launch_legendre_f32(const LegendreParamsF32& p, int nitems, int chunk0, int nrun, hipStream_t stream);
 hipError_t launch_convert_f64_f32(const double* src, float* dst, size_t n, hipStream_t stream);
 hipError_t launch_fourier(const FourierParams& p, int lds_bytes, int nthreads, hipStream_t stream);
+bool fourier_generic_pairs_usable(const FourierParams& p);   // fft_kernel_pairs.hip
+hipError_t launch_fourier_generic_pairs(const FourierParams& p, int lds_bytes, int nthreads, hipStream_t stream);
 hipError_t launch_fourier_ct(const FourierParams& p, int ctf, int ctk, int lds_bytes, int nthreads,
                              hipStream_t stream);
 hipError_t launch_fourier_hyb(const FourierParams& p, int lds_bytes, int nthreads, hipStream_t stream);
@@ -220,6 +222,8 @@ void Trans::release() noexcept {
     fr(d_coslatinv_);
     for (auto& c : classes_) {
         fr(c.d_rows);
+        fr(c.d_rows_pair);
+        fr(c.d_rows_rest);
         fr(c.d_desc);
     }
     classes_.clear();
@@ -608,6 +612,19 @@ void Trans::upload() {
             return na > nb || (na == nb && a < b);
         });
         c.d_rows = dev_upload(it->second.data(), it->second.size());
+        if (it->first.first == 0) {   // run-time shaped rows: direct and odd-length ones apart (same order), for the fp32 variant's two-field form
+            std::vector<int> direct_rows, rest;
+            for (int j : it->second) {
+                const int method = fftplans_.plans[row_plan[j]].method;
+                (method == fft::FFT_DIRECT || method == fft::FFT_ODD ? direct_rows : rest).push_back(j);
+            }
+            if (!direct_rows.empty()) {
+                c.nrows_pair  = (int)direct_rows.size();
+                c.d_rows_pair = dev_upload(direct_rows.data(), direct_rows.size());
+                c.nrows_rest  = (int)rest.size();
+                c.d_rows_rest = rest.empty() ? nullptr : dev_upload(rest.data(), rest.size());
+            }
+        }
         c.coarse_n[0] = c.coarse_n[1] = c.coarse_n[2] = 0;
         if (c.coarse_fused) {   // rows per Bluestein length 1024 / 512 / 256: contiguous in the list (sorted by descending row length)
             int last = 1024;
@@ -1025,6 +1042,16 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
             }
             else {
                 HIP_CHECK(launch_fourier_ct(p, c.ct_f, c.ct_k, c.lds_bytes, c.nthreads, st));
+            }
+        }
+        else if (c.nrows_pair > 0 && fourier_generic_pairs_usable(p)) {   // fp32 variant: the direct rows two fields per job, then the rest
+            p.rows  = c.d_rows_pair;
+            p.nrows = c.nrows_pair;
+            HIP_CHECK(launch_fourier_generic_pairs(p, c.lds_bytes, c.nthreads, st));
+            if (c.nrows_rest > 0) {
+                p.rows  = c.d_rows_rest;
+                p.nrows = c.nrows_rest;
+                HIP_CHECK(launch_fourier(p, c.lds_bytes, c.nthreads, st));
             }
         }
         else {

@@ -9,7 +9,7 @@ Template: the reference's own benchmark driver, src/sandbox/benchmark_trans/atla
   C3x1      TL639  -> O640,  137 levels on ONE device       (configs[2] is a 4-GPU run; this is its single-device workload)
   C4batch   TL1279 -> O1280, 1370 fields in ONE invtrans    (configs[3]: "10 fields" x 137 levels; single device)
   C5        TL1279 -> F1280 ("N1280 full"), 137 levels, fp32 (configs[4]);  C5f64: the same grid in fp64
-  C5n       TL1279 -> N1280 (classic reduced Gaussian), fp32
+  C5n       TL1279 -> N1280 (classic reduced Gaussian), fp32;  C5nf64: the same grid in fp64
   C4f32     TL1279 -> O1280, 137 levels, fp32 (the headline grid in the precision of C5; not a BASELINE configuration)
   C4vd      TL1279 -> O1280, nscalar 137 + nvordiv 137 in ONE invtrans(nb_scalar, sp, nb_vordiv, vor, div, gp): the other axis of the
             reference's benchmark (atlas-benchmark-trans.cc:66-76,148-149 `--nscalar --nvordiv`; TransLocal.cc:1523-1597): 411 output
@@ -35,6 +35,7 @@ CONFIGS = {
     "C5": ("F1280", 1279, 137, True, 10, 3),
     "C5f64": ("F1280", 1279, 137, False, 10, 3),
     "C5n": ("N1280", 1279, 137, True, 10, 3),
+    "C5nf64": ("N1280", 1279, 137, False, 10, 3),
     "C4f32": ("O1280", 1279, 137, True, 10, 3),
     "C4vd": ("O1280", 1279, 137, False, 8, 2, 137),
     "C2vd": ("O160", 159, 60, False, 200, 20, 60),
