@@ -633,11 +633,12 @@ def test_fp32_variant_against_fp64(gridname, T, nf):
 
 
 @pytest.mark.parametrize("gridname,T,nf", [("F320", 319, 9), ("F64", 63, 1), ("F160", 159, 34), ("O160", 159, 7), ("O320", 319, 19),
-                                           ("N320", 319, 4)])
+                                           ("N320", 319, 4), ("N64", 63, 7), ("N160", 159, 1)])
 def test_fp32_two_field_jobs_against_the_one_field_form(gridname, T, nf, monkeypatch):
     """[r4] The fp32 variant's direct and specialised Bluestein rows take TWO fields per job (csrc/fft_pair.h, fft_kernel_pairs.hip:
     lane x / lane y of packed fp32 instructions, the pair's 16 bytes gathered by one LDS-DMA request): odd field counts (the last
-    job's second lane is not stored), a single field, reduced grids (direct smooth rows, Bluestein rows plain and row_ct3).  Against the fp64 device result of the float-rounded
+    job's second lane is not stored), a single field, reduced grids (direct smooth rows, Bluestein rows plain and row_ct3; [r6] the
+    run-time shaped rows of the classic N grids: odd {3,5}-smooth row lengths).  Against the fp64 device result of the float-rounded
     spectra (2e-6), against the one-field form (ATLAS_AMD_FFT_F32_PAIRS=0; same arithmetic, other instruction selection: 1e-6 of
     the largest value), and the array next to the last field stays untouched."""
     g, tr = get_trans(gridname, T)
@@ -725,6 +726,17 @@ def test_classic_reduced_gaussian_grid_against_oracle():
     off = np.concatenate([[0], np.cumsum(g.nx())])
     for r, ref in zip(rows, op.invtrans_rows(nf, sp, rows, use_fft=True)):
         assert compute_rms(gp[:, off[r]:off[r + 1]], ref) < 1e-12, r
+    # [r6] the same rows in the fp32 variant: the odd {3,5}-smooth row lengths of the classic grids (run-time shaped rows) take two
+    # fields per job there (fft_kernel_pairs.hip: fft_rows_pair_kernel); five fields: the last job's second lane is not stored
+    assert any(int(g.nx()[r]) % 2 == 1 for r in rows)
+    sp32 = sp.astype(np.float32)
+    gp32 = torch.full((nf * g.size() + 8,), float("nan"), dtype=torch.float32, device="cuda")
+    tr.invtrans(nf, torch.from_numpy(sp32).cuda(), gp32[:nf * g.size()])
+    tr.synchronize()
+    assert bool(torch.isnan(gp32[nf * g.size():]).all()) and bool(torch.isfinite(gp32[:nf * g.size()]).all())
+    v = gp32[:nf * g.size()].view(nf, -1)
+    for r, ref in zip(rows, op.invtrans_rows(nf, sp32.astype(np.float64), rows, use_fft=True)):
+        assert compute_rms(v[:, off[r]:off[r + 1]].cpu().numpy().astype(np.float64), ref) < 2e-6, r
 
 
 LEG_KERNELS = ("classic", "lean") + (("stream",) if "exp" in os.environ.get("ATLAS_AMD_LIB", "") else ())   # "stream" [r6]: experiments build
