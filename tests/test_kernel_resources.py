@@ -37,6 +37,8 @@ HEADLINE = [
     r"trans::fft_rows_dct_kernel<fft::CtShape<(5, 9|1, 11|3, 9|1, 9|9, 8|3, 8|1, 10|1, 8|5, 7|5, 8)>, false, false>$",
     r"trans::fft_rows_dct_pair_kernel<.*>$",
     r"trans::fft_rows_coarse(_multi)?_kernel$",
+    r"trans::fft_rows_pair_kernel$",                  # [r6] run-time shaped rows of the fp32 variant, two fields per job
+    r"trans::regional_dft_mfma_kernel<8>$",           # [r6] no_nest targets: the Fourier part as an fp64-MFMA matrix product
     r"trans::pack_rows_kernel.*", r"trans::spectra_prepare_kernel.*", r"trans::vd2uv_kernel.*",
     r"halo::.*",
 ]
@@ -63,6 +65,15 @@ def test_fp32_tile_pair_legendre_kernels_keep_two_workgroups_per_cu(kernels):
     # kernel's 73 registers and still wins; a fifth register class -- > 128 -- would halve its occupancy)
     k = kernels["trans::legendre_kernel_lean_f32_w2"]
     assert k["vgpr_count"] + k["agpr_count"] <= 128 and k["wg"] == 512
+
+
+def test_round6_kernels_keep_their_occupancy(kernels):
+    # the regional matrix-product kernel: 8 wavefronts per workgroup at <= 128 registers = two workgroups per CU (4 per SIMD; measured 8 %
+    # faster than 4 wavefronts at 200 registers); the two-field run-time shaped rows: <= 128 registers as well (the one-field fp64 form: 194)
+    k = kernels["trans::regional_dft_mfma_kernel<8>"]
+    assert k["vgpr_count"] + k["agpr_count"] <= 128 and k["wg"] == 512 and not k["vgpr_spill_count"]
+    k = kernels["trans::fft_rows_pair_kernel"]
+    assert k["vgpr_count"] + k["agpr_count"] <= 128 and not k["vgpr_spill_count"]
 
 
 def test_row_ct3_instances_fit_two_wavefronts_per_simd(kernels):
