@@ -51,6 +51,7 @@ const EnvSwitch kSwitches[] = {
     {"ATLAS_AMD_DIST_POISON",       C::test_hook, "0",      "1: the buffers of the distributed transform are filled with NaN before every transform"},
     {"ATLAS_AMD_DIST_CHECK",        C::test_hook, "first use", "always: the ranks compare (field count, message limit) on every call (a blocking 3-int all-to-all), not only the first time a pair is used"},
     {"ATLAS_AMD_HOST_PIPELINE_FAIL_ALLOC", C::test_hook, "unset", "set: the staging buffers of the host-pointer pipeline fail to allocate (exercises the serial fallback)"},
+    {"ATLAS_AMD_FFT_LDS_ELEMS",     C::test_hook, "10080",  "complex elements of a row transform beyond which a row is evaluated as a matrix product (dft_gemm.hip) instead of an FFT in LDS; read when the object is built: lets small grids exercise the path of O2560's longest rows"},
     // ---- development switches: compiled in only with -DATLAS_AMD_DEV_SWITCHES (make dev, make experiments)
     {"ATLAS_AMD_FFT_ABLATE",        C::dev,       "0",      "access ablations of the Fourier rows (results wrong; also needs -DAA_FFT_ABLATE)"},
     {"ATLAS_AMD_FFT_ONLY_M",        C::dev,       "0",      "M: launch only the Fourier class of this length"},

@@ -223,6 +223,17 @@ private:
         void* d_desc = nullptr;   // FftRowDesc[nrows] for the specialised Bluestein kernels
     };
     std::vector<SizeClass> classes_;
+    // rows whose transform does not fit a CU's LDS (more than 10 080 complex elements: the four longest row lengths of O2560, regular
+    // grids beyond F5040): their c2r sum as a matrix product with a cos / sin table on fp64 MFMA (dft_gemm.h) [r6]; one group per length
+    struct GemmRows {
+        int n = 0, nrows = 0;
+        int* d_rowsel       = nullptr;   // row of the local band
+        long long* d_rowout = nullptr;   // offset of the row inside a field of the band
+        double* d_rowscale  = nullptr;   // 1 / cos(lat)
+        int* d_rowmmax      = nullptr;   // highest kept wavenumber
+        double* d_table     = nullptr;   // [2 (T + 1)][n]
+    };
+    std::vector<GemmRows> gemm_rows_;
 public:
     // launches of one Fourier stage (one per row class) and, of those, launches that take two fields per workgroup (native rows)
     void fourier_launch_plan(int out[3]) const {

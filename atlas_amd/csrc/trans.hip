@@ -2,6 +2,7 @@
 // launches the two kernels per call on the object's HIP stream.
 #include "env.h"
 #include "trans.h"
+#include "dft_gemm.h"
 #include "host_copy.h"
 #include "trace.h"
 
@@ -216,6 +217,13 @@ void Trans::release() noexcept {
     fr(d_ffttable_);
     fr(d_ffttable_f32_);
     fr(d_nat_table_);
+    for (GemmRows& g : gemm_rows_) {
+        fr(g.d_rowsel);
+        fr(g.d_rowout);
+        fr(g.d_rowscale);
+        fr(g.d_rowmmax);
+        fr(g.d_table);
+    }
     fr(d_row_plan_);
     fr(d_row_mmax_);
     fr(d_rowoff_);
@@ -483,8 +491,17 @@ void Trans::upload() {
     // everything else (short rows, {2,3,5}-smooth rows, odd rows) goes to the generic kernel, bucketed by LDS need.
     const int class_M[] = {256, 512, 1024, 1536, 2048, 2560, 3072, 4096, 5120, 6144, 8192, 10080};
     std::map<std::pair<int, int>, std::vector<int>> by_class;  // (specialised ? 1 : 0, M bucket)
+    std::map<int, std::vector<int>> gemm_by_n;   // row length -> rows whose transform does not fit a CU's LDS
+    int lds_max = fft::padded_size(class_M[sizeof(class_M) / sizeof(class_M[0]) - 1]);
+    if (const char* e = atlas_amd::env_get("ATLAS_AMD_FFT_LDS_ELEMS")) {   // test hook: small grids through the matrix-product rows
+        lds_max = std::min(lds_max, fft::padded_size(std::max(1, atoi(e))));
+    }
     for (int j = band_begin(); j < band_end(); ++j) {
         const fft::FftRowPlan& pl = fftplans_.plans[row_plan[j]];
+        if (pl.lds_complex > lds_max) {   // [r6] (the four longest row lengths of O2560: Bluestein length 12 288)
+            gemm_by_n[pl.n].push_back(j);
+            continue;
+        }
         if (pl.method == fft::FFT_BLUESTEIN && pl.ct_k >= 0) {
             // small reduced grids: the coarse classes 256 / 512 / 1024 share one launch (fft_kernel.hip: fft_rows_coarse_kernel);
             // ATLAS_AMD_FFT_COARSE_FUSED=0: one launch per class as before (A/B)
@@ -553,6 +570,48 @@ void Trans::upload() {
             throw std::runtime_error("row length " + std::to_string(pl.n) + " does not fit in LDS (160 KiB)");
         }
         by_class[{0, cls}].push_back(j);
+    }
+    // [r6] rows beyond the LDS: per row length the table of the c2r sum (FFT.h:22-82: out[k] = X_0 + sum_{m >= 1} 2 (Re X_m cos(2 pi m k / n)
+    // - Im X_m sin(2 pi m k / n)), the Nyquist wavenumber with its real part only), unit roots in extended precision, the angle reduced
+    // in integers: table[2 m][k], table[2 m + 1][k] = the factors of Re X_m and Im X_m
+    for (const auto& kv : gemm_by_n) {
+        const int n = kv.first;
+        GemmRows gr;
+        gr.n     = n;
+        gr.nrows = (int)kv.second.size();
+        std::vector<int> sel, mm;
+        std::vector<long long> out;
+        std::vector<double> scl;
+        for (int j : kv.second) {
+            sel.push_back(j - band_begin());
+            out.push_back((long long)(geo_.rowoff[j] - geo_.rowoff[band_begin()]));
+            scl.push_back(coslatinv[j]);
+            mm.push_back(row_mmax[j]);
+        }
+        std::vector<double> rc(n), rs(n);
+        const long double two_pi = 6.283185307179586476925286766559005768L;
+        for (int t = 0; t < n; ++t) {
+            const long double a = two_pi * (long double)t / (long double)n;
+            rc[t] = (double)cosl(a);
+            rs[t] = (double)sinl(a);
+        }
+        std::vector<double> table((size_t)2 * (geo_.T + 1) * n, 0.);
+        for (int m = 0; m <= geo_.T && 2 * m <= n; ++m) {
+            const bool edge = m == 0 || 2 * m == n;   // mean and Nyquist wavenumber: real part only, counted once
+            double* tc = table.data() + (size_t)(2 * m) * n;
+            double* ts = tc + n;
+            for (int k = 0; k < n; ++k) {
+                const int t = (int)(((long long)m * k) % n);
+                tc[k] = edge ? rc[t] : 2. * rc[t];
+                ts[k] = edge ? 0. : -2. * rs[t];
+            }
+        }
+        gr.d_rowsel   = dev_upload(sel.data(), sel.size());
+        gr.d_rowout   = dev_upload(out.data(), out.size());
+        gr.d_rowscale = dev_upload(scl.data(), scl.size());
+        gr.d_rowmmax  = dev_upload(mm.data(), mm.size());
+        gr.d_table    = dev_upload(table.data(), table.size());
+        gemm_rows_.push_back(gr);
     }
     // big classes first (longest blocks start first)
     for (auto it = by_class.rbegin(); it != by_class.rend(); ++it) {
@@ -1057,6 +1116,34 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
         else {
             HIP_CHECK(launch_fourier(p, c.lds_bytes, c.nthreads, st));
         }
+    }
+    for (const GemmRows& gr : gemm_rows_) {   // [r6] rows beyond the LDS: dft_gemm.hip, on the caller's stream beside the classes
+        if (fourier_parts() != 1 || p.packed_cols || p.packed_rowbase) {
+            throw std::logic_error("rows of " + std::to_string(gr.n) + " points (longer than a CU's LDS holds) are not supported by the "
+                                   "distributed transform's intermediate layouts");
+        }
+        if (p.part_cnt0 < geo_.T + 1) {
+            throw std::logic_error("Fourier stage: the intermediate holds fewer wavenumbers than the truncation");
+        }
+        DftGemmArgs ga{};
+        ga.F        = p.part_base0;
+        ga.f32      = f32 ? 1 : 0;
+        ga.rowsel   = gr.d_rowsel;
+        ga.table    = gr.d_table;
+        ga.out      = p.gp;
+        ga.rowout   = gr.d_rowout;
+        ga.fstride  = p.npts;
+        ga.rowscale = gr.d_rowscale;
+        ga.rowmmax  = gr.d_rowmmax;
+        ga.T        = geo_.T;
+        ga.m_cnt    = p.part_cnt0;
+        ga.RP       = p.RP;
+        ga.nlon     = gr.n;
+        ga.nrows    = gr.nrows;
+        ga.f0       = p.f_begin;
+        ga.nf       = p.f_end - p.f_begin;
+        ga.nscaled  = p.scale_uv_fields;
+        HIP_CHECK(launch_dft_gemm(ga, stream));
     }
     for (int si = 1; si < nstreams; ++si) {
         if (used[si]) {

@@ -62,7 +62,8 @@ HOSTILE = {"ATLAS_AMD_LEG_KERNEL": "classic", "ATLAS_AMD_LEG_CFG": "1,1", "ATLAS
            "ATLAS_AMD_FFT_COARSE_FUSED": "0", "ATLAS_AMD_FFT_COARSE_MULTI": "0", "ATLAS_AMD_FFT_NT_DIV": "4", "ATLAS_AMD_FFT_ROW_AFFINITY": "0",
            "ATLAS_AMD_FFT_SMOOTH_DIRECT": "1", "ATLAS_AMD_PREPARE": "rows", "ATLAS_AMD_PIPELINE": "3", "ATLAS_AMD_TABLES": "host",
            "ATLAS_AMD_HOST_PIPELINE": "0", "ATLAS_AMD_FFT_NATIVE": "1", "ATLAS_AMD_FFT_HYBRID": "1", "ATLAS_AMD_FFT_ONLY_M": "4096",
-           "ATLAS_AMD_FFT_ABLATE": "64", "ATLAS_AMD_FFT_DEBUG": "1", "ATLAS_AMD_DIST_POISON": "1", "ATLAS_AMD_HOST_PIPELINE_FAIL_ALLOC": "1"}
+           "ATLAS_AMD_FFT_ABLATE": "64", "ATLAS_AMD_FFT_DEBUG": "1", "ATLAS_AMD_DIST_POISON": "1", "ATLAS_AMD_HOST_PIPELINE_FAIL_ALLOC": "1",
+           "ATLAS_AMD_FFT_LDS_ELEMS": "600"}
 
 
 @pytest.mark.gpu

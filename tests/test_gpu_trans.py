@@ -1009,7 +1009,7 @@ def test_regional_target_that_is_not_a_crop_of_a_global_grid(case):
 @pytest.mark.parametrize("T,nlat,nlon,nf", [(42, 31, 300, 7), (21, 130, 129, 1), (106, 9, 257, 30)])
 def test_regional_target_over_several_tiles_of_the_matrix_product(T, nlat, nlon, nf):
     """the Fourier part of the no_nest branch is one fp64-MFMA matrix product over (target row, field) pairs x longitudes in 128 x 128
-    tiles, the contraction in stages of 8 wavenumbers (csrc/regional_trans.hip): pair counts, row lengths and truncations that are
+    tiles, the contraction in stages of 8 wavenumbers (csrc/dft_gemm.hip): pair counts, row lengths and truncations that are
     not multiples of the tile / stage sizes, several tiles each way -- against the oracle's restatement (TransLocal.cc:719-738,
     1139-1148), scalar and vor/div calls; every element outside the target stays untouched."""
     rng = np.random.default_rng(T)
@@ -1031,6 +1031,53 @@ def test_regional_target_over_several_tiles_of_the_matrix_product(T, nlat, nlon,
     gp_vd = np.zeros((ns + 2 * nvd) * nlon * nlat)
     rt.invtrans_vordiv(ns, s1, nvd, vor, div, gp_vd)
     assert compute_rms(gp_vd, want_vd.ravel()) < 1e-12
+
+
+@pytest.mark.parametrize("gridname,T,nf,limit", [("O64", 63, 5, 150), ("N160", 159, 8, 256), ("F160", 159, 3, 256), ("O160", 159, 33, 300),
+                                                 ("O640", 639, 40, 1200)])
+def test_rows_beyond_the_lds_are_a_matrix_product(gridname, T, nf, limit, monkeypatch):
+    """[r6] A row whose transform needs more than 10 080 complex LDS elements (the four longest row lengths of O2560; regular grids beyond
+    F5040) is evaluated as a matrix product with a cos / sin table on fp64 MFMA (csrc/dft_gemm.hip, the kernel of the no_nest branch) instead
+    of failing the set-up.  The test hook ATLAS_AMD_FFT_LDS_ELEMS lowers that limit (LDS footprints come in blocks of 256 elements) so that the longer rows of
+    small grids take the path:
+    against the oracle, against the same object without the hook (1e-13 of each other: an FFT and a direct sum), fp32 variant, the
+    vor/div call (u, v scaled by 1 / cos(lat) in the product's epilogue), a field subset through the host-pointer pipeline, and what lies
+    behind the last field untouched."""
+    g = atlas_amd.Grid(gridname)
+    sp = red_spectra(T, nf, seed=31)
+    small = g.size() < 200000                              # O640: against the default path only (which the other tests pin)
+    ref = run_device(atlas_amd.Trans(g, T), nf, sp)
+    want = oracle.OraclePlan(T, g.nx(), g.y()).invtrans(nf, sp, use_fft=True) if small else ref
+    monkeypatch.setenv("ATLAS_AMD_FFT_LDS_ELEMS", str(limit))
+    tr = atlas_amd.Trans(g, T)
+    monkeypatch.delenv("ATLAS_AMD_FFT_LDS_ELEMS")          # read when the object is built
+    gp = torch.full((nf * g.size() + 16,), float("nan"), dtype=torch.float64, device="cuda")
+    tr.invtrans(nf, dev(sp), gp[:-16])
+    tr.synchronize()
+    got = gp.cpu().numpy()
+    assert np.all(np.isnan(got[-16:])) and np.isfinite(got[:-16]).all()
+    assert compute_rms(got[:-16], want) < 1e-13
+    assert compute_rms(got[:-16], ref) < 1e-13 and not np.array_equal(got[:-16], ref)     # another algorithm on the long rows
+    # host pointers (O640 / 40 fields: the full-duplex pipeline over chunks of 16 fields -- later chunks start at a field > 0)
+    host = np.full(nf * g.size(), np.nan)
+    tr.invtrans(nf, sp, host)
+    assert np.array_equal(host, got[:-16])
+    if not small:
+        return
+    # fp32 variant
+    sp32 = sp.astype(np.float32)
+    gp32 = torch.full((nf * g.size(),), float("nan"), dtype=torch.float32, device="cuda")
+    tr.invtrans(nf, torch.from_numpy(sp32).cuda(), gp32)
+    tr.synchronize()
+    assert compute_rms(gp32.cpu().numpy().astype(np.float64), run_device(tr, nf, sp32.astype(np.float64))) < 2e-6
+    # vor/div call
+    ns, nvd = 1, 2
+    s1, vor, div = red_spectra(T, ns, 7), red_spectra(T, nvd, 8), red_spectra(T, nvd, 9)
+    w = torch.full(((ns + 2 * nvd) * g.size(),), float("nan"), dtype=torch.float64, device="cuda")
+    tr.invtrans(ns, dev(s1), nvd, dev(vor), dev(div), w)
+    tr.synchronize()
+    wref = oracle.OraclePlan(T, g.nx(), g.y()).invtrans_vordiv(ns, s1, nvd, vor, div, use_fft=True)
+    assert compute_rms(w.cpu().numpy(), wref.ravel()) < 1e-12
 
 
 def test_unstructured_target_points():

@@ -38,7 +38,7 @@ HEADLINE = [
     r"trans::fft_rows_dct_pair_kernel<.*>$",
     r"trans::fft_rows_coarse(_multi)?_kernel$",
     r"trans::fft_rows_pair_kernel$",                  # [r6] run-time shaped rows of the fp32 variant, two fields per job
-    r"trans::regional_dft_mfma_kernel<8>$",           # [r6] no_nest targets: the Fourier part as an fp64-MFMA matrix product
+    r"trans::dft_gemm_kernel<8, (false|true)>$",      # [r6] no_nest targets / rows beyond the LDS: the Fourier sum as an fp64-MFMA matrix product
     r"trans::pack_rows_kernel.*", r"trans::spectra_prepare_kernel.*", r"trans::vd2uv_kernel.*",
     r"halo::.*",
 ]
@@ -70,8 +70,9 @@ def test_fp32_tile_pair_legendre_kernels_keep_two_workgroups_per_cu(kernels):
 def test_round6_kernels_keep_their_occupancy(kernels):
     # the regional matrix-product kernel: 8 wavefronts per workgroup at <= 128 registers = two workgroups per CU (4 per SIMD; measured 8 %
     # faster than 4 wavefronts at 200 registers); the two-field run-time shaped rows: <= 128 registers as well (the one-field fp64 form: 194)
-    k = kernels["trans::regional_dft_mfma_kernel<8>"]
-    assert k["vgpr_count"] + k["agpr_count"] <= 128 and k["wg"] == 512 and not k["vgpr_spill_count"]
+    for name in ("trans::dft_gemm_kernel<8, false>", "trans::dft_gemm_kernel<8, true>"):
+        k = kernels[name]
+        assert k["vgpr_count"] + k["agpr_count"] <= 128 and k["wg"] == 512 and not k["vgpr_spill_count"]
     k = kernels["trans::fft_rows_pair_kernel"]
     assert k["vgpr_count"] + k["agpr_count"] <= 128 and not k["vgpr_spill_count"]
 
