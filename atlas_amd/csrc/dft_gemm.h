@@ -12,8 +12,8 @@ namespace atlas_amd {
 namespace trans {
 
 struct DftGemmArgs {
-    const void* F;             // Fourier intermediate: element (row r, wavenumber m, column c) at (rowsel[r] * m_cnt + m) * RP + c
-    int f32;                   // F and out hold floats (fp32 variant; the product itself is formed in fp64)
+    const double* F;           // Fourier coefficients: element (row r, wavenumber m, column c) at (rowsel[r] * m_cnt + m) * RP + c
+    int f32;                   // out holds floats (fp32 variant; the product itself is formed in fp64)
     const int* rowsel;         // [nrows] row of the intermediate
     const double* table;       // [2 (T + 1)][nlon]
     void* out;                 // out[field * fstride + rowout[r] + lon]
@@ -27,6 +27,12 @@ struct DftGemmArgs {
 };
 
 hipError_t launch_dft_gemm(const DftGemmArgs& a, hipStream_t stream);
+
+// The kept wavenumbers of a few rows of a global grid, read through the Fourier stage's own reader (any layout of the intermediate: single
+// piece, m-sharded pieces, packed runs; double or float storage) into a dense array dense[(r * (T + 1) + m) * RPd + 2 (f - f_begin) + (0 | 1)],
+// zeros above a row's highest kept wavenumber: the A operand of the product for the rows beyond the LDS (trans.hip).
+struct FourierParams;
+hipError_t launch_gather_rows_dense(const FourierParams& p, const int* rows, int nrows, double* dense, int RPd, hipStream_t stream);
 
 }  // namespace trans
 }  // namespace atlas_amd

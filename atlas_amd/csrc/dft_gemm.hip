@@ -9,6 +9,9 @@
 
 #include <limits>
 
+#include "device_structs.h"
+#include "fft_device.h"
+
 namespace atlas_amd {
 namespace trans {
 
@@ -19,7 +22,6 @@ constexpr int GKM = 8;         // wavenumbers per stage
 constexpr int GLD = GT + 16;   // LDS row pitch in doubles
 typedef double dft_acc_t __attribute__((ext_vector_type(4)));
 typedef double dft_pair_t __attribute__((ext_vector_type(2)));
-typedef float dft_pairf_t __attribute__((ext_vector_type(2)));
 
 // NW = wavefronts per workgroup: 8 (64 x 32 of the tile each, 112 registers, 4 wavefronts per SIMD) is 8 % faster than 4 (64 x 64 each,
 // 200 registers, 2 per SIMD) on a 1000 x 500 target at T1279 / 137 fields: 6.3 against 7.1 ms = 55 TFLOP/s (profiles/r06_regional.txt)
@@ -44,9 +46,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 2) dft_gemm_kernel(DftGemmArgs a
     const bool pa_ok = pa < P;
     const int row_a  = pa_ok ? pa / nf : 0;
     const int mtop   = a.rowmmax ? min(T, a.rowmmax[row_a]) : T;   // the highest wavenumber the intermediate holds for this row
-    const long long aoff = ((long long)a.rowsel[row_a] * a.m_cnt) * RP + 2 * (a.f0 + (pa_ok ? pa - row_a * nf : 0));
-    const double* asrc   = reinterpret_cast<const double*>(a.F) + aoff;
-    const float* asrcf   = reinterpret_cast<const float*>(a.F) + aoff;
+    const double* asrc = a.F + ((long long)a.rowsel[row_a] * a.m_cnt) * RP + 2 * (a.f0 + (pa_ok ? pa - row_a * nf : 0));
     const int ib     = i0 + le;
     const bool ib_ok = ib < nlon;
     const double* bsrc = a.table + (ib_ok ? ib : 0);
@@ -58,13 +58,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 2) dft_gemm_kernel(DftGemmArgs a
 #pragma unroll
         for (int q = 0; q < GKM / LR; ++q) {
             const int m = max(0, min(c * GKM + lr + LR * q, mtop));
-            if constexpr (F32) {
-                const dft_pairf_t v = *reinterpret_cast<const dft_pairf_t*>(asrcf + (long long)m * RP);
-                ra[q]               = dft_pair_t{(double)v.x, (double)v.y};
-            }
-            else {
-                ra[q] = *reinterpret_cast<const dft_pair_t*>(asrc + (long long)m * RP);
-            }
+            ra[q]       = *reinterpret_cast<const dft_pair_t*>(asrc + (long long)m * RP);
         }
 #pragma unroll
         for (int q = 0; q < 2 * GKM / LR; ++q) {
@@ -181,7 +175,38 @@ hipError_t launch_t(const DftGemmArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// one workgroup per (row of the list, block of 8 wavenumbers); threads over (wavenumber, field): a wavefront reads consecutive fields of one record
+__global__ void __launch_bounds__(256) gather_rows_dense_kernel(FourierParams p, const int* __restrict__ rows, double* __restrict__ dense,
+                                                                int RPd) {
+    const int r   = blockIdx.x;
+    const int row = rows[r];
+    const int nfs = p.f_end - p.f_begin;
+    const int top = p.row_mmax[row] < p.T ? p.row_mmax[row] : p.T;
+    for (int q = threadIdx.x; q < 8 * nfs; q += blockDim.x) {
+        const int m = blockIdx.y * 8 + q / nfs, f = q % nfs;
+        if (m > p.T) {
+            break;
+        }
+        fft::cplx v{0., 0.};
+        if (m <= top) {
+            const ModeReader rd{p, (long long)(row - p.lat0), 2 * (p.f_begin + f)};
+            v = rd(m);
+        }
+        double* d = dense + ((long long)r * (p.T + 1) + m) * RPd + 2 * f;
+        d[0]      = v.re;
+        d[1]      = v.im;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_gather_rows_dense(const FourierParams& p, const int* rows, int nrows, double* dense, int RPd, hipStream_t stream) {
+    if (nrows <= 0 || p.f_end <= p.f_begin) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(gather_rows_dense_kernel, dim3((unsigned)nrows, (unsigned)((p.T + 8) / 8)), dim3(256), 0, stream, p, rows, dense, RPd);
+    return hipGetLastError();
+}
 
 hipError_t launch_dft_gemm(const DftGemmArgs& a, hipStream_t stream) {
     if (a.nrows <= 0 || a.nf <= 0 || a.nlon <= 0) {

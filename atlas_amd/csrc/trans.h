@@ -227,13 +227,16 @@ private:
     // grids beyond F5040): their c2r sum as a matrix product with a cos / sin table on fp64 MFMA (dft_gemm.h) [r6]; one group per length
     struct GemmRows {
         int n = 0, nrows = 0;
-        int* d_rowsel       = nullptr;   // row of the local band
+        int* d_rows         = nullptr;   // rows (global index)
+        int* d_rowsel       = nullptr;   // 0 .. nrows - 1: row of the dense coefficient array
         long long* d_rowout = nullptr;   // offset of the row inside a field of the band
         double* d_rowscale  = nullptr;   // 1 / cos(lat)
         int* d_rowmmax      = nullptr;   // highest kept wavenumber
         double* d_table     = nullptr;   // [2 (T + 1)][n]
     };
     std::vector<GemmRows> gemm_rows_;
+    double* d_gemm_dense_  = nullptr;    // the kept wavenumbers of a group's rows, gathered from the intermediate (any layout) in front of the product
+    size_t gemm_dense_cap_ = 0;
 public:
     // launches of one Fourier stage (one per row class) and, of those, launches that take two fields per workgroup (native rows)
     void fourier_launch_plan(int out[3]) const {

@@ -217,7 +217,9 @@ void Trans::release() noexcept {
     fr(d_ffttable_);
     fr(d_ffttable_f32_);
     fr(d_nat_table_);
+    fr(d_gemm_dense_);
     for (GemmRows& g : gemm_rows_) {
+        fr(g.d_rows);
         fr(g.d_rowsel);
         fr(g.d_rowout);
         fr(g.d_rowscale);
@@ -582,8 +584,9 @@ void Trans::upload() {
         std::vector<int> sel, mm;
         std::vector<long long> out;
         std::vector<double> scl;
+        gr.d_rows = dev_upload(kv.second.data(), kv.second.size());
         for (int j : kv.second) {
-            sel.push_back(j - band_begin());
+            sel.push_back((int)sel.size());
             out.push_back((long long)(geo_.rowoff[j] - geo_.rowoff[band_begin()]));
             scl.push_back(coslatinv[j]);
             mm.push_back(row_mmax[j]);
@@ -1118,15 +1121,23 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
         }
     }
     for (const GemmRows& gr : gemm_rows_) {   // [r6] rows beyond the LDS: dft_gemm.hip, on the caller's stream beside the classes
-        if (fourier_parts() != 1 || p.packed_cols || p.packed_rowbase) {
-            throw std::logic_error("rows of " + std::to_string(gr.n) + " points (longer than a CU's LDS holds) are not supported by the "
-                                   "distributed transform's intermediate layouts");
+        // their kept wavenumbers through the stage's own reader (whatever the layout of the intermediate) into a dense array, then the product
+        const int nfs    = p.f_end - p.f_begin;
+        const int RPd    = 2 * nfs;
+        const size_t need = (size_t)gr.nrows * (size_t)(geo_.T + 1) * (size_t)RPd;
+        if (need > gemm_dense_cap_) {
+            HIP_CHECK(hipStreamSynchronize(stream));
+            if (d_gemm_dense_) {
+                HIP_CHECK(hipFree(d_gemm_dense_));
+                d_gemm_dense_   = nullptr;
+                gemm_dense_cap_ = 0;
+            }
+            HIP_CHECK(hipMalloc((void**)&d_gemm_dense_, need * sizeof(double)));
+            gemm_dense_cap_ = need;
         }
-        if (p.part_cnt0 < geo_.T + 1) {
-            throw std::logic_error("Fourier stage: the intermediate holds fewer wavenumbers than the truncation");
-        }
+        HIP_CHECK(launch_gather_rows_dense(p, gr.d_rows, gr.nrows, d_gemm_dense_, RPd, stream));
         DftGemmArgs ga{};
-        ga.F        = p.part_base0;
+        ga.F        = d_gemm_dense_;
         ga.f32      = f32 ? 1 : 0;
         ga.rowsel   = gr.d_rowsel;
         ga.table    = gr.d_table;
@@ -1136,13 +1147,13 @@ void Trans::fourier_fields(int nb_fields, int nb_vordiv, const double* const* pa
         ga.rowscale = gr.d_rowscale;
         ga.rowmmax  = gr.d_rowmmax;
         ga.T        = geo_.T;
-        ga.m_cnt    = p.part_cnt0;
-        ga.RP       = p.RP;
+        ga.m_cnt    = geo_.T + 1;
+        ga.RP       = RPd;
         ga.nlon     = gr.n;
         ga.nrows    = gr.nrows;
-        ga.f0       = p.f_begin;
-        ga.nf       = p.f_end - p.f_begin;
-        ga.nscaled  = p.scale_uv_fields;
+        ga.f0       = 0;
+        ga.nf       = nfs;
+        ga.nscaled  = p.scale_uv_fields - p.f_begin;   // fields of the dense array are counted from f_begin
         HIP_CHECK(launch_dft_gemm(ga, stream));
     }
     for (int si = 1; si < nstreams; ++si) {

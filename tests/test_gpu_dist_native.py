@@ -432,3 +432,49 @@ def test_exchange_timings_of_the_distributed_transform():
     assert sum(sent.values()) == sum(recv.values()) > 0                      # what leaves a rank arrives at another
     for r, x in outs:
         assert 0 < x["bytes_to_busiest_peer"] <= x["bytes_sent"] and x["peers"] == nparts - 1
+
+
+@pytest.mark.parametrize("gridname,T,nf,nparts,mode", [("O160", 159, 9, 3, "alltoall"), ("O160", 159, 9, 4, "mirror"), ("O160", 159, 9, 3, "band"),
+                                                       ("O64", 63, 4, 2, "alltoall")])
+def test_rows_beyond_the_lds_in_the_distributed_transform(gridname, T, nf, nparts, mode, monkeypatch):
+    """[r6] the rows whose transform does not fit a CU's LDS (O2560's four longest row lengths -- where a transform is most likely to be
+    distributed) are a matrix product whose coefficients are first gathered through the Fourier stage's own reader: every layout of the
+    intermediate (single piece, packed runs of the m-sharded transposition, latitude bands, mirror bands) must give the bits of the
+    single-device transform.  The test hook ATLAS_AMD_FFT_LDS_ELEMS sends the longer rows of a small grid down that path on every rank."""
+    hook = "300" if gridname == "O160" else "150"
+    g = atlas_amd.Grid(gridname)
+    sp = torch.from_numpy(red_spectra(T, nf, seed=11)).cuda()
+    plain = torch.zeros(nf * g.size(), dtype=torch.float64, device="cuda")
+    t0 = atlas_amd.Trans(g, T)
+    t0.invtrans(nf, sp, plain)
+    t0.synchronize()
+    monkeypatch.setenv("ATLAS_AMD_FFT_LDS_ELEMS", hook)          # read when an object is built: stays set for the ranks' objects
+    tr = atlas_amd.Trans(g, T)
+    ref = torch.zeros(nf * g.size(), dtype=torch.float64, device="cuda")
+    tr.invtrans(nf, sp, ref)
+    tr.synchronize()
+    assert not torch.equal(plain, ref) and float((plain - ref).abs().max()) < 1e-11      # the hook did select another algorithm
+    refv = ref.view(nf, -1)
+    off = np.concatenate([[0], np.cumsum(g.nx())])
+    if mode == "alltoall":
+        def rank(comm):
+            d = DistributedTrans(g, T, comm=comm, mode="alltoall")
+            gp = torch.full((nf * d.trans.nb_gridpoints(),), float("nan"), dtype=torch.float64, device="cuda")
+            d.invtrans(nf, sp, gp)
+            d.trans.synchronize()
+            return d.bands, gp.view(nf, -1).clone()
+
+        for r, (bands, gp) in enumerate(run_ranks(nparts, rank)):
+            assert torch.equal(gp, refv[:, off[bands[r]]:off[bands[r + 1]]]), r
+        return
+    seen = []
+    for part in range(nparts):          # exchange-free decompositions: every rank's object in turn
+        t = atlas_amd.Trans(g, T, nparts=nparts, part=part, shard=mode)
+        rows = t.owned_rows()
+        cols = torch.from_numpy(np.concatenate([np.arange(off[j], off[j + 1]) for j in rows])).cuda()
+        gp = torch.full((nf * cols.numel(),), float("nan"), dtype=torch.float64, device="cuda")
+        t.invtrans(nf, sp, gp)
+        t.synchronize()
+        assert torch.equal(gp.view(nf, -1), refv[:, cols]), part
+        seen.append(rows)
+    assert np.array_equal(np.sort(np.concatenate(seen)), np.arange(g.ny()))
